@@ -1,0 +1,157 @@
+"""CPU: pin the oracle (oracle/mdgen_oracle.py) against golden vectors produced by the reference
+itself (oracle/gen_golden.py).  fp32 tolerances: the reference's own thread-order noise is
+rel-L2 3.3e-7."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, weights_for, rel_l2
+from oracle import mdgen_oracle as O
+
+torch.set_grad_enabled(False)
+
+
+def _fwd_kwargs(g):
+    return dict(
+        x=g["x"], t=g["t"], mask=g["mask"],
+        start_frames=(g["start_rot"], g["start_trans"]), end_frames=(g["end_rot"], g["end_trans"]),
+        x_cond=g["x_cond"], x_cond_mask=g["x_cond_mask"], aatype=g["aatype"])
+
+
+@pytest.mark.parametrize("name", ["fwd_tiny_sim", "fwd_tiny_tps", "fwd_full_sim", "fwd_full_pep",
+                                  "fwd_full_atlas", "fwd_full_tps"])
+def test_forward_matches_reference(name):
+    g = load_golden(name)
+    cfg, sd = weights_for(g)
+    out, tr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **_fwd_kwargs(g))
+    for k in ("ipa_out", "h0", "h1", f"h{cfg.num_layers}"):
+        if k in g:
+            assert rel_l2(tr[k], g[k]) < 2e-5, k
+    assert rel_l2(out, g["out"]) < 2e-5
+    assert (out - g["out"]).abs().max() < 1e-4 * g["out"].pow(2).mean().sqrt() * 10
+
+
+def test_padded_sequences_are_finite():
+    g = load_golden("fwd_full_sim")
+    assert torch.isfinite(g["out"]).all()
+    assert (g["mask"] == 0).any()
+
+
+def test_rigid_ops():
+    g = load_golden("rigid_ops")
+    R, t = O.rigid_compose(g["R1"], g["t1"], g["R2"], g["t2"])
+    assert torch.allclose(R, g["comp_R"], atol=1e-6) and torch.allclose(t, g["comp_t"], atol=1e-5)
+    R, t = O.rigid_invert(g["R1"], g["t1"])
+    assert torch.allclose(R, g["inv_R"], atol=1e-6) and torch.allclose(t, g["inv_t"], atol=1e-5)
+    assert torch.allclose(O.rigid_apply(g["R1"], g["t1"], g["p"]), g["apply"], atol=1e-5)
+    assert torch.allclose(O.rigid_invert_apply(g["R1"], g["t1"], g["p"]), g["invert_apply"], atol=1e-5)
+    t7 = O.to_tensor_7(g["R1"], g["t1"])
+    sgn = torch.sign((t7[:, :4] * g["tensor7"][:, :4]).sum(-1, keepdim=True))   # eigh sign is arbitrary
+    assert torch.allclose(t7[:, :4] * sgn, g["tensor7"][:, :4], atol=1e-5)
+    assert torch.allclose(t7[:, 4:], g["tensor7"][:, 4:])
+    R, t = O.from_tensor_7(g["q7"])
+    assert torch.allclose(R, g["from7_R"], atol=1e-6) and torch.allclose(t, g["from7_t"])
+    off = O.get_offsets((g["R1"][None, :1, None], g["t1"][None, :1, None]), (g["R2"][None, :, None], g["t2"][None, :, None]))
+    sgn = torch.sign((off[..., :4] * g["offsets"][..., :4]).sum(-1, keepdim=True))
+    assert torch.allclose(off[..., :4] * sgn, g["offsets"][..., :4], atol=1e-5)
+    assert torch.allclose(off[..., 4:], g["offsets"][..., 4:], atol=1e-5)
+    R, t = O.from_3_points(g["p3a"], g["p3b"], g["p3c"])
+    assert torch.allclose(R, g["f3_R"], atol=1e-6) and torch.allclose(t, g["f3_t"])
+    # identities: compose with inverse = identity; quat round trip
+    iR, it = O.rigid_invert(g["R1"], g["t1"])
+    cR, ct = O.rigid_compose(g["R1"], g["t1"], iR, it)
+    assert torch.allclose(cR, torch.eye(3).expand_as(cR), atol=1e-5) and ct.abs().max() < 1e-4
+    assert torch.allclose(O.quat_to_rot(O.rot_to_quat(g["R1"])), g["R1"], atol=1e-5)
+
+
+def test_geometry():
+    g = load_golden("geometry")
+    B, T, L = g["atom14"].shape[:3]
+    aat = g["seqres"][:, None].expand(B, T, L)
+    R, t = O.atom14_to_frames(g["atom14"])
+    assert torch.allclose(R, g["frames_R"], atol=1e-5) and torch.allclose(t, g["frames_t"])
+    a37 = O.atom14_to_atom37(g["atom14"], aat)
+    assert torch.allclose(a37, g["atom37"])
+    tors, tm = O.atom37_to_torsions(a37, aat)
+    assert torch.allclose(tors, g["torsions"], atol=1e-5) and torch.allclose(tm, g["torsion_mask"])
+    back = O.frames_torsions_to_atom14(R, t, tors, aat)
+    assert torch.allclose(back, g["atom14_back"], atol=1e-4)
+    # property: atom14_to_frames(frames_torsions_to_atom14(F, tau)) == F
+    R2, t2 = O.atom14_to_frames(back)
+    assert torch.allclose(R2, R, atol=1e-4) and torch.allclose(t2, t, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["prep_sim", "prep_tps"])
+def test_prep_batch(name):
+    g = load_golden(name)
+    batch = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+    prep = O.prep_batch(batch, g["cfg"])
+    assert torch.allclose(prep["latents"], g["latents"], atol=2e-5)
+    assert torch.allclose(prep["model_kwargs"]["x_cond"], g["x_cond"], atol=2e-5)
+    assert torch.equal(prep["model_kwargs"]["x_cond_mask"], g["x_cond_mask"])
+    assert torch.equal(prep["loss_mask"].float(), g["loss_mask"].float())
+    assert torch.equal(prep["model_kwargs"]["mask"], g["mask"])
+    assert torch.allclose(prep["model_kwargs"]["start_frames"][0], g["start_rot"])
+    assert torch.allclose(prep["model_kwargs"]["end_frames"][1], g["end_trans"])
+    # the real part of every offset quaternion is >= 0 (wrapper.py:309)
+    assert (g["latents"][..., 0] >= 0).all()
+    # get_batch restatement reproduces the reference's batch from the raw atom14 array
+    for b in range(g["atom14"].shape[0]):
+        mine = O.get_batch_from_atom14(g["atom14"][b], g["in_seqres"][b])
+        assert torch.allclose(mine["rots"], g["in_rots"][b], atol=1e-5)
+        assert torch.allclose(mine["torsions"], g["in_torsions"][b], atol=1e-5)
+        assert torch.allclose(mine["torsion_mask"], g["in_torsion_mask"][b])
+
+
+@pytest.mark.parametrize("name", ["inference_sim", "inference_tiny"])
+def test_inference_and_rollout(name):
+    g = load_golden(name)
+    cfg, sd = weights_for(g)
+    cd = O.cfg_dict(cfg)
+    batch0 = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+    T = g[f"S{int(g['steps'][0])}_b0_zs"].shape[1]
+    for S in [int(s) for s in g["steps"]]:
+        cur = dict(batch0)
+        blk = 0
+        while f"S{S}_b{blk}_zs" in g:
+            ex = dict(cur)
+            ex["torsions"] = cur["torsions"].expand(-1, T, -1, -1, -1)
+            ex["trans"] = cur["trans"].expand(-1, T, -1, -1)
+            ex["rots"] = cur["rots"].expand(-1, T, -1, -1, -1)
+            atom14, aa, samples = O.inference(sd, cd, ex, g[f"S{S}_b{blk}_zs"], S)
+            assert rel_l2(samples, g[f"S{S}_b{blk}_samples"]) < 5e-5, (S, blk)
+            assert (atom14 - g[f"S{S}_b{blk}_atom14"]).abs().max() < 2e-3, (S, blk)     # Angstrom
+            nxt = O.rollout_glue(g[f"S{S}_b{blk}_atom14"][:, -1], batch0["seqres"])
+            assert torch.allclose(nxt["trans"], g[f"S{S}_b{blk}_next_trans"], atol=1e-5)
+            assert torch.allclose(nxt["rots"], g[f"S{S}_b{blk}_next_rots"], atol=1e-5)
+            assert torch.allclose(nxt["torsions"], g[f"S{S}_b{blk}_next_torsions"], atol=2e-4)
+            cur = dict(cur, trans=g[f"S{S}_b{blk}_next_trans"], rots=g[f"S{S}_b{blk}_next_rots"],
+                       torsions=g[f"S{S}_b{blk}_next_torsions"])
+            blk += 1
+
+
+def test_rope_matches_hf_port():
+    """The fair-esm rotary embedding is not vendored by the reference ("parity unpinned"); cross-check
+    the rotate-half convention of the restatement against the independent HF transformers ESM port."""
+    try:
+        from transformers.models.esm.modeling_esm import apply_rotary_pos_emb, rotate_half
+    except Exception:
+        pytest.skip("transformers ESM port not importable")
+    torch.manual_seed(0)
+    q, k = torch.randn(3, 2, 8, 24), torch.randn(3, 2, 8, 24)
+    cos, sin = O.rope_tables(8, 24)
+    assert torch.equal(rotate_half(q), O.rotate_half(q))
+    hq, hk = apply_rotary_pos_emb(q, k, cos[None], sin[None], unsqueeze_dim=1)
+    assert torch.allclose(hq, q * cos + O.rotate_half(q) * sin, atol=1e-6)
+    assert torch.allclose(hk, k * cos + O.rotate_half(k) * sin, atol=1e-6)
+    # angle table: theta[pos, i] = pos * 10000^(-2 (i mod 12) / 24)
+    ang = torch.arange(8)[:, None] * (10000.0 ** (-2 * (torch.arange(24) % 12) / 24.0))[None]
+    assert torch.allclose(cos, ang.cos(), atol=1e-6) and torch.allclose(sin, ang.sin(), atol=1e-6)
+
+
+def test_euler_grid():
+    """integrators.py:88 linspace(t0,t1,num_steps) -> S = num_steps-1 Euler steps; dt sums to 1."""
+    tg = torch.linspace(0, 1, 50)
+    assert len(tg) - 1 == 49 and abs(float((tg[1:] - tg[:-1]).sum()) - 1) < 1e-6
