@@ -1,0 +1,231 @@
+"""bench.py -- sampled MD frames/sec of the MDGen denoising sampler on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one `NewMDGenWrapper.inference()` call on one batch of synthetic input resident in HBM:
+noise zs (B,T,L,21) -> S fixed Euler steps of the denoiser -> atom14 (B,T,L,14,3)  (the region the
+reference times at sim_inference.py:109-115).  Workload (BASELINE.json configs[1]): tetrapeptide
+forward-sim, crop 4, 1000 frames, batch 16, bf16 MFMA operands, S = 49 Euler steps (the reference's
+hard-coded 50-point grid, wrapper.py:441-442).  Batches shard over ranks with no data-path collective
+(scaling = weak: every rank samples its own 16 x 1000 frames).
+
+The JSON line also carries
+  roofline     -- the dominant kernel (largest share of hipEvent time), its ALGORITHMIC flops per launch
+                  divided by its average hipEvent-measured launch duration, vs the dense bf16 MFMA peak;
+  cpu_baseline -- the CPU oracle (a port of the reference's PyTorch path, oracle/mdgen_oracle.py) timed on
+                  this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md chip table)
+
+WORKLOADS = {
+    # name: (B, T, L, abs_pos_emb, n_pad)
+    "tetrapeptide_fwdsim_crop4_T1000_B16": (16, 1000, 4, True, 0),
+    "atlas_crop256_T250_B1": (1, 250, 256, False, 16),
+    "tetrapeptide_fwdsim_crop4_T100_B1": (1, 100, 4, True, 0),
+}
+
+
+def synth_batch(B, T, L, n_pad, dev, seed):
+    """Self-consistent synthetic conditioning batch: random frames + torsions ->
+    atom14 (sampler post-processing kernel) -> conditioning frame (rollout-glue kernel), first frame
+    expanded over T (sim_inference.py:72-79); trailing `n_pad` residues padded (dataset.py:80-89)."""
+    from mdgen_amd.geometry import atom14_to_cond, samples_to_atom14
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, L, 4, generator=g)
+    q = (q / q.norm(dim=-1, keepdim=True)).to(dev)
+    from mdgen_amd.rigid_utils import Rotation
+    R = Rotation(quats=q).get_rot_mats()
+    tr = torch.cumsum(2.2 * torch.randn(B, L, 3, generator=g), 1).to(dev)
+    ang = 6.283185307 * torch.rand(B, L, 7, generator=g)
+    seqres = torch.randint(0, 20, (B, L), generator=g).to(dev)
+    lat = torch.zeros(B, 1, L, 21, device=dev)
+    lat[..., 0] = 1.0
+    lat[..., 7:21] = torch.stack([ang.sin(), ang.cos()], -1).reshape(B, 1, L, 14).to(dev)
+    atom14 = samples_to_atom14(lat, R, tr, seqres, tps=False)[:, 0]
+    c = atom14_to_cond(atom14, seqres)
+    mask = torch.ones(B, L, device=dev)
+    if n_pad:
+        mask[:, L - n_pad:] = 0
+        seqres[:, L - n_pad:] = 0
+    return {"torsions": c["torsions"][:, None].expand(B, T, L, 7, 2).contiguous(),
+            "torsion_mask": c["torsion_mask"], "trans": c["trans"][:, None].expand(B, T, L, 3).contiguous(),
+            "rots": c["rots"][:, None].expand(B, T, L, 3, 3).contiguous(), "seqres": seqres, "mask": mask}
+
+
+def algorithmic_flops(cls, B, T, L):
+    """Algorithmic flops of ONE launch of a kernel class (SURVEY.md section 8(d) per-token figures x N).
+    dh padding 24->32, masked keys and tile padding are NOT counted."""
+    N, C = B * T * L, 384
+    if cls in ("ln_qkv_L", "ln_qkv_T"):
+        return 2.0 * N * C * 3 * C
+    if cls == "proj_T":
+        return 2.0 * N * C * C
+    if cls == "proj_L":
+        return 2.0 * N * C * C + (4.0 * N * C * (L + 1) if L <= 8 else 0.0)   # + fused micro-attention
+    if cls == "flash_T":
+        return 4.0 * N * C * (T + 1)
+    if cls == "flash_L":
+        return 4.0 * N * C * (L + 1)
+    if cls == "mlp":
+        return 16.0 * N * C * C
+    return None
+
+
+def cpu_baseline(cfg, sd, B, T, L, S, n_pad, budget_s=20.0):
+    """Time the CPU oracle (port of the reference's PyTorch path) on a bounded sample: B=1 of the same
+    (T, L) workload, n NFEs (network evaluations) until ~budget_s is spent, then scale to frames/s at S
+    steps: value = T / (t_nfe * S + t_prepost)."""
+    from oracle import mdgen_oracle as O
+    torch.set_grad_enabled(False)
+    cd = O.cfg_dict(cfg)
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(1, 1, L, 4, generator=g)
+    R = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True)).expand(1, T, L, 3, 3).contiguous()
+    tr = torch.cumsum(2.2 * torch.randn(1, 1, L, 3, generator=g), 2).expand(1, T, L, 3).contiguous()
+    ang = 6.283185307 * torch.rand(1, 1, L, 7, generator=g)
+    tors = torch.stack([ang.sin(), ang.cos()], -1).expand(1, T, L, 7, 2).contiguous()
+    mask = torch.ones(1, L)
+    if n_pad:
+        mask[:, L - n_pad:] = 0
+    batch = {"torsions": tors, "torsion_mask": torch.ones(1, L, 7), "trans": tr, "rots": R,
+             "seqres": torch.randint(0, 20, (1, L), generator=g), "mask": mask}
+    zs = torch.randn(1, T, L, cfg.latent_dim, generator=g)
+    t0 = time.time()
+    prep = O.prep_batch(batch, cd)
+    t_pre = time.time() - t0
+    x, n, t_nfe_total = zs, 0, 0.0
+    while n < S and (n == 0 or t_nfe_total + t_nfe_total / n < budget_s):
+        t0 = time.time()
+        v = O.forward(sd, cd, x, torch.ones(1) * (n / S), **prep["model_kwargs"])
+        x = x + v / S
+        t_nfe_total += time.time() - t0
+        n += 1
+    t0 = time.time()
+    O.postprocess(x, prep["rigids"], batch["seqres"], cd)
+    t_post = time.time() - t0
+    t_nfe = t_nfe_total / n
+    value = T / (t_nfe * S + t_pre + t_post)
+    return {"value": round(value, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (fp32 PyTorch port of the reference path) B=1 T={T} L={L}: {n} network evaluations "
+                      f"timed ({t_nfe:.3f} s each on {torch.get_num_threads()} threads, os.cpu_count()={os.cpu_count()}), "
+                      f"scaled to S={S} Euler steps + pre/post"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="tetrapeptide_fwdsim_crop4_T1000_B16", choices=list(WORKLOADS))
+    ap.add_argument("--euler-steps", type=int, default=49, help="Euler steps S per inference() call (reference: 49)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.set_grad_enabled(False)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist_.init_process_group("nccl", device_id=dev)
+        dist = dist_
+
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict
+    from mdgen_amd.wrapper import NewMDGenWrapper
+
+    B, T, L, abs_pos, n_pad = WORKLOADS[a.workload]
+    S = a.euler_steps
+    cfg = ModelConfig(crop=L, num_frames=T, abs_pos_emb=abs_pos, sim_condition=True)
+    sd = synth_state_dict(cfg, 0)
+    w = NewMDGenWrapper(cfg, device=dev)
+    w.model.load_state_dict(sd)
+    batch = synth_batch(B, T, L, n_pad, dev, seed=100 + rank)      # every rank: its own peptides (weak scaling)
+    zs = torch.randn(B, T, L, cfg.latent_dim, generator=torch.Generator().manual_seed(137 + rank)).to(dev)
+    use_graph = not a.no_graph
+
+    def step():
+        return w.inference(batch, zs=zs, num_steps=S, use_graph=use_graph)
+
+    for _ in range(a.warmup):
+        atom14, _ = step()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        atom14, _ = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(atom14).all()
+    frames = B * T * a.steps * world
+    value = frames / dt
+
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        # per-kernel-class durations measured with hipEvents on the launch stream (eager pass, graphs bypassed)
+        w.model.profile(True)
+        step()
+        rep = w.model.profile_report()
+        w.model.profile(False)
+        tot = sum(v["ms"] for v in rep.values())
+        dom = max((k for k in rep if algorithmic_flops(k, B, T, L)), key=lambda k: rep[k]["ms"])
+        avg_ms = rep[dom]["ms"] / rep[dom]["count"]
+        fl = algorithmic_flops(dom, B, T, L)
+        ach = fl / (avg_ms * 1e-3) / 1e12
+        roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches": rep[dom]["count"],
+                "share_of_event_time": round(rep[dom]["ms"] / tot, 3),
+                "by_kernel_ms_per_call": {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}}
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, sd, B, T, L, S, n_pad)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        out = {
+            "metric": "sampled MD frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (seeded random-init weights, synthetic peptide frames/torsions, CPU-seeded noise)",
+            "config": {"workload": a.workload, "batch_per_gpu": B, "num_frames": T, "crop": L,
+                       "euler_steps": S, "hipgraph": use_graph, "parallelism": f"batch-sharded x{world}, no collective"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,189 @@
+/*
+ * mdgen_amd.h -- C-ABI of the MI355X-native MDGen denoising sampler (libmdgen_amd.so).
+ *
+ * The reference (bjing2016/mdgen) is pure Python/PyTorch and has no FFI of its own; its boundary
+ * for this path is the Python call surface.  Each entry point below
+ * names the reference code it replaces (paths relative to the reference repo).  The Python host
+ * (`mdgen_amd/`) keeps the reference's signatures and calls these through ctypes.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types.  All tensor arguments are DEVICE pointers (row-major,
+ *     contiguous, layouts exactly as the reference's tensors) unless the name ends in `_host`.
+ *   - the caller owns every input/output/workspace buffer; the library owns only the packed
+ *     weights and cached hipGraph handles inside the opaque context.
+ *   - every launch goes on the caller's `stream` (a hipStream_t passed as void*); there are no
+ *     hidden streams and no device synchronisation inside any call (graph-capturable).
+ *   - return 0 on success, negative = invalid argument / state, positive = hipError_t.
+ *     `mdgen_last_error()` returns a thread-local message.  No exceptions cross the ABI.
+ *   - a context is not thread-safe; use one per device per process.
+ *   - compiled for gfx950 only; C = 384, heads = 16, head_dim = 24, ffn = 1536 are compile-time.
+ */
+#ifndef MDGEN_AMD_H
+#define MDGEN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDGEN_ABI_VERSION 1
+
+typedef struct mdgen_ctx mdgen_ctx;
+
+/* Model hyper-parameters (reference argparse flags, mdgen/parsing.py:79-120). */
+typedef struct mdgen_model_desc {
+    int32_t embed_dim;      /* must be 384 */
+    int32_t mha_heads;      /* must be 16  */
+    int32_t num_layers;     /* trunk layers == IPA layers (reference default 5), 1..8 */
+    int32_t latent_dim;     /* 21 (forward-sim) or 28 (TPS); wrapper.py:196 */
+    int32_t ipa_heads;      /* must be 4  */
+    int32_t ipa_head_dim;   /* must be 32 */
+    int32_t ipa_qk;         /* must be 8  */
+    int32_t ipa_v;          /* must be 8  */
+    int32_t abs_pos_emb;    /* 1: add pos_embed[1,crop,C] (latent_model.py:234-235) */
+    int32_t crop;           /* rows of pos_embed (>= L when abs_pos_emb) */
+    int32_t tps_condition;  /* 1: two-stream IPA with relative-frame inputs (latent_model.py:193-207) */
+    float   time_multiplier;/* latent_model.py:243 (100) */
+} mdgen_model_desc;
+
+/* Problem shape of one call: x is (B,T,L,D). */
+typedef struct mdgen_shape {
+    int32_t B, T, L;
+} mdgen_shape;
+
+/* Byte offsets into the caller-provided workspace (for tests / debugging / profiling). */
+typedef struct mdgen_ws_layout {
+    size_t total_bytes;
+    size_t h;          /* fp32 residual stream        [N][384]                         */
+    size_t qf, kf, vf; /* bf16 attention operand fragments (DESIGN.md "fragment layout") */
+    size_t obuf;       /* bf16 attention output       [N][384]                         */
+    size_t mod;        /* fp32 adaLN table            [R][77*384]                      */
+    size_t silu_t;     /* fp32 SiLU(t_embedder(t))    [R][384]                         */
+    size_t ipa_out;    /* fp32 IPA-stack table        [S][B*L][384]                    */
+    size_t h_ipa;      /* fp32 IPA-stack residual     [S*B*L][384] (x2 when TPS)       */
+    size_t ipa_proj;   /* fp32 IPA projections        [S*B*L][672]                     */
+    size_t ipa_feat;   /* bf16 IPA concat features    [S*B*L][256]                     */
+    size_t mask_bl;    /* fp32 compact mask[:,0]      [B][L]                           */
+    size_t rel7;       /* fp32 TPS relative frames    [2][B][L][7]                     */
+    size_t tgrid;      /* fp32 per-step times         [S][B]                           */
+} mdgen_ws_layout;
+
+const char* mdgen_last_error(void);
+int32_t     mdgen_abi_version(void);
+
+/* ---- context / weights -------------------------------------------------------------------
+ * Replaces `NewMDGenWrapper.load_from_checkpoint(...).eval().to('cuda')` (sim_inference.py:129-130)
+ * for the `model.*` sub-tree of the Lightning state_dict.  Weights are handed over one tensor
+ * at a time under the reference's own state_dict key (e.g. "layers.0.mha_t.attn.q_proj.weight");
+ * `data` is an fp32 DEVICE pointer; the library re-packs into its MFMA fragment formats on
+ * `stream`.  `mdgen_ctx_finalize` fails if any required key was not provided. */
+int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* desc);
+int32_t mdgen_ctx_destroy(mdgen_ctx* ctx);
+int32_t mdgen_ctx_set_weight(mdgen_ctx* ctx, const char* key, const float* data,
+                             const int64_t* shape, int32_t ndim, void* stream);
+int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
+/* number of state_dict keys the model needs; name of the i-th (for loaders / tests) */
+int32_t mdgen_ctx_num_weights(const mdgen_ctx* ctx);
+const char* mdgen_ctx_weight_name(const mdgen_ctx* ctx, int32_t i);
+
+/* ---- workspace ---------------------------------------------------------------------------
+ * `n_steps` = number of distinct time rows prepared per call (1 for a single forward, S for an
+ * S-step Euler rollout).  `t_shared` = 1 when all batch elements share t within a step (always true
+ * in sampling, integrators.py:99), which de-duplicates the adaLN table. */
+int32_t mdgen_workspace_layout(const mdgen_ctx* ctx, const mdgen_shape* shape, int32_t n_steps,
+                               int32_t t_shared, mdgen_ws_layout* out);
+
+/* ---- denoiser ----------------------------------------------------------------------------
+ * `LatentMDGenModel.forward` / `.forward_inference` (latent_model.py:212-269), non-design path:
+ *   out[B,T,L,D] = model(x, t, mask, start_frames, end_frames, x_cond, x_cond_mask, aatype)
+ * x, x_cond, out: fp32 (B,T,L,D); t: fp32 (B); mask: fp32 (B,T,L) in {0,1};
+ * x_cond_mask: int64 (B,T,L) in {0,1}; aatype: int64 (B,L) in [0,20];
+ * start/end frames: rot (B,L,3,3) + trans (B,L,3) fp32 (the fields of the reference's `Rigid`);
+ * end_* may be NULL unless tps_condition.  trace_h (nullable): fp32 [(num_layers+1)][N][384],
+ * the residual stream before layer 0 and after every trunk layer; trace_ipa (nullable): fp32
+ * [B*L][384], the IPA-stack output (latent_model.py:245-246). */
+int32_t mdgen_denoiser_forward(mdgen_ctx* ctx, const mdgen_shape* shape,
+                               const float* x, const float* t, const float* mask,
+                               const float* start_rot, const float* start_trans,
+                               const float* end_rot, const float* end_trans,
+                               const float* x_cond, const int64_t* x_cond_mask, const int64_t* aatype,
+                               float* out, float* trace_h, float* trace_ipa,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* `Sampler.sample_ode(sampling_method='euler', num_steps=n_steps+1)` -> `ode.sample` ->
+ * torchdiffeq fixed-grid Euler (transport.py:408-451, integrators.py:95-114) with the velocity
+ * drift (transport.py:242-244): x <- x + (t[i+1]-t[i]) * model(x, t[i]) on t = linspace(0,1,n_steps+1).
+ * `x` holds the noise zs on entry and samples[-1] on exit (the only state the wrapper reads,
+ * wrapper.py:447).  use_graph=1 captures the whole rollout into a hipGraph on first use (keyed on
+ * shape + pointers) and replays it afterwards; `stream` must then be a non-default stream. */
+int32_t mdgen_sample_euler(mdgen_ctx* ctx, const mdgen_shape* shape, int32_t n_steps,
+                           float* x, const float* mask,
+                           const float* start_rot, const float* start_trans,
+                           const float* end_rot, const float* end_trans,
+                           const float* x_cond, const int64_t* x_cond_mask, const int64_t* aatype,
+                           void* workspace, size_t workspace_bytes, int32_t use_graph, void* stream);
+
+/* ---- measurement ----------------------------------------------------------------------------
+ * Per-kernel-class timing with hipEvents recorded on the launch stream (bench.py's roofline leg).
+ * While enabled, launches are bracketed by event pairs and hipGraph capture/replay is bypassed.
+ * `mdgen_profile_report` synchronises `stream`, writes a JSON object
+ *   {"<class>": {"count": n, "ms": total_ms}, ...}   into buf (NUL-terminated) and resets the log. */
+int32_t mdgen_profile_enable(mdgen_ctx* ctx, int32_t on);
+int32_t mdgen_profile_report(mdgen_ctx* ctx, void* stream, char* buf, size_t buflen);
+
+/* Host-only (no GPU): the weight-row / bias permutations behind the attention fragment layout
+ * (DESIGN.md "fragment layout"), each int32[384], for layout tests:
+ *   map_qk[w*96+rho], map_vflash[w*96+col], map_vsmall[w*96+rho] = source feature of a packed weight row;
+ *   perm_qk[((w*2+h)*4+hd)*12+e], perm_vsmall[...] = source feature of lane-ordered bias slot. */
+int32_t mdgen_debug_layout_maps(int32_t* map_qk, int32_t* map_vflash, int32_t* map_vsmall,
+                                int32_t* perm_qk, int32_t* perm_vsmall);
+
+/* ---- SE(3) frame algebra, fp32 (mdgen/rigid_utils.py) --------------------------------------
+ * n = number of frames; rot: [n][3][3]; trans/pts: [n][3]; quat: [n][4] (w,x,y,z). */
+int32_t mdgen_rigid_compose(int64_t n, const float* r1, const float* t1, const float* r2, const float* t2,
+                            float* r_out, float* t_out, void* stream);            /* :1031-1045 */
+int32_t mdgen_rigid_invert(int64_t n, const float* r, const float* t, float* r_out, float* t_out,
+                           void* stream);                                          /* :1075-1085 */
+int32_t mdgen_rigid_apply(int64_t n, int64_t pts_per_frame, const float* r, const float* t,
+                          const float* pts, float* out, int32_t inverse, void* stream); /* :1047-1073 */
+int32_t mdgen_quat_to_rot(int64_t n, const float* quat, int32_t normalize, float* rot, void* stream); /* :168-188, :324 */
+int32_t mdgen_rot_to_quat(int64_t n, const float* rot, float* quat, void* stream); /* :191-210 (sign: w >= 0) */
+
+/* ---- sampler pre/post-processing (mdgen/wrapper.py) ----------------------------------------
+ * `NewMDGenWrapper.prep_batch` latents (wrapper.py:298-327, 339-342, 362) incl. `utils.get_offsets`
+ * (utils.py:7-14): offsets = rigid[b,0]^-1 o rigid[b,t] as [quat(w>=0) | trans], TPS appends the
+ * offsets w.r.t. frame T-1; latents = [offsets | torsions(14)]; cond frames = 0 (and T-1 for TPS).
+ * rots (B,T,L,3,3), trans (B,T,L,3), torsions (B,T,L,7,2) -> latents, x_cond (B,T,L,D),
+ * x_cond_mask int64 (B,T,L). */
+int32_t mdgen_prep_latents(const mdgen_shape* shape, int32_t tps, const float* rots, const float* trans,
+                           const float* torsions, float* latents, float* x_cond, int64_t* x_cond_mask,
+                           void* stream);
+
+/* `NewMDGenWrapper.inference` tail (wrapper.py:456-478) + `geometry.frames_torsions_to_atom14`
+ * (geometry.py:61-79, 236-334): samples (B,T,L,D) + first-frame rigids (rot0 (B,L,3,3), trans0
+ * (B,L,3)) + seqres int64 (B,L) -> atom14 (B,T,L,14,3).  Residue constant tables (device):
+ * default_frames [21][8][4][4], lit_positions [21][14][3], atom14_group int64 [21][14],
+ * atom14_mask [21][14] (mdgen/residue_constants.py:1124-1216). */
+int32_t mdgen_samples_to_atom14(const mdgen_shape* shape, int32_t latent_dim, int32_t tps,
+                                const float* samples, const float* rot0, const float* trans0,
+                                const int64_t* seqres, const float* default_frames,
+                                const float* lit_positions, const int64_t* atom14_group,
+                                const float* atom14_mask, float* atom14, void* stream);
+
+/* Rollout glue (sim_inference.py:91-96): last frame atom14 (B,L,14,3) -> next block's conditioning
+ * frame: `geometry.atom14_to_frames` (geometry.py:218-231) + `atom14_to_atom37` + `atom37_to_torsions`
+ * (geometry.py:9-27, 82-202).  Tables: atom37_to_atom14 int64 [21][37], atom37_mask [21][37],
+ * chi_atom_indices int64 [21][4][4], chi_angles_mask [21][4].  Outputs rots (B,L,3,3),
+ * trans (B,L,3), torsions (B,L,7,2), torsion_mask (B,L,7). */
+int32_t mdgen_atom14_to_cond(int32_t B, int32_t L, const float* atom14, const int64_t* seqres,
+                             const int64_t* atom37_to_atom14, const float* atom37_mask,
+                             const int64_t* chi_atom_indices, const float* chi_angles_mask,
+                             float* rots, float* trans, float* torsions, float* torsion_mask,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDGEN_AMD_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of libmdgen_amd.so (include/mdgen_amd.h).  There is NO fallback: if the HIP
+library is missing or fails to load, importing this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- must be imported first: provides the process-wide libamdhip64.so.7
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdgen_amd.so")
+
+EXPORTS = [
+    "mdgen_last_error", "mdgen_abi_version", "mdgen_ctx_create", "mdgen_ctx_destroy", "mdgen_ctx_set_weight",
+    "mdgen_ctx_finalize", "mdgen_ctx_num_weights", "mdgen_ctx_weight_name", "mdgen_workspace_layout",
+    "mdgen_denoiser_forward", "mdgen_sample_euler", "mdgen_profile_enable", "mdgen_profile_report", "mdgen_debug_layout_maps",
+    "mdgen_rigid_compose", "mdgen_rigid_invert",
+    "mdgen_rigid_apply", "mdgen_quat_to_rot", "mdgen_rot_to_quat", "mdgen_prep_latents",
+    "mdgen_samples_to_atom14", "mdgen_atom14_to_cond",
+]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "embed_dim", "mha_heads", "num_layers", "latent_dim", "ipa_heads", "ipa_head_dim", "ipa_qk", "ipa_v",
+        "abs_pos_emb", "crop", "tps_condition")] + [("time_multiplier", C.c_float)]
+
+
+class Shape(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("L", C.c_int32)]
+
+
+class WsLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in (
+        "total_bytes", "h", "qf", "kf", "vf", "obuf", "mod", "silu_t", "ipa_out", "h_ipa", "ipa_proj",
+        "ipa_feat", "mask_bl", "rel7", "tgrid")]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m mdgen_amd.build` (hipcc, gfx950). "
+            "mdgen_amd has no CPU/PyTorch fallback path.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    lib.mdgen_last_error.restype = C.c_char_p
+    lib.mdgen_abi_version.restype = i32
+    lib.mdgen_ctx_create.argtypes = [C.POINTER(vp), C.POINTER(ModelDesc)]
+    lib.mdgen_ctx_destroy.argtypes = [vp]
+    lib.mdgen_ctx_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(i64), i32, vp]
+    lib.mdgen_ctx_finalize.argtypes = [vp, vp]
+    lib.mdgen_ctx_num_weights.argtypes = [vp]
+    lib.mdgen_ctx_weight_name.argtypes = [vp, i32]
+    lib.mdgen_ctx_weight_name.restype = C.c_char_p
+    lib.mdgen_workspace_layout.argtypes = [vp, C.POINTER(Shape), i32, i32, C.POINTER(WsLayout)]
+    lib.mdgen_denoiser_forward.argtypes = [vp, C.POINTER(Shape)] + [vp] * 14 + [sz, vp]
+    lib.mdgen_sample_euler.argtypes = [vp, C.POINTER(Shape), i32] + [vp] * 10 + [sz, i32, vp]
+    lib.mdgen_profile_enable.argtypes = [vp, i32]
+    lib.mdgen_profile_report.argtypes = [vp, vp, C.c_char_p, sz]
+    lib.mdgen_debug_layout_maps.argtypes = [vp] * 5
+    lib.mdgen_rigid_compose.argtypes = [i64] + [vp] * 7
+    lib.mdgen_rigid_invert.argtypes = [i64] + [vp] * 5
+    lib.mdgen_rigid_apply.argtypes = [i64, i64, vp, vp, vp, vp, i32, vp]
+    lib.mdgen_quat_to_rot.argtypes = [i64, vp, i32, vp, vp]
+    lib.mdgen_rot_to_quat.argtypes = [i64, vp, vp, vp]
+    lib.mdgen_prep_latents.argtypes = [C.POINTER(Shape), i32] + [vp] * 7
+    lib.mdgen_samples_to_atom14.argtypes = [C.POINTER(Shape), i32, i32] + [vp] * 10
+    lib.mdgen_atom14_to_cond.argtypes = [i32, i32] + [vp] * 11
+    for n in EXPORTS:
+        getattr(lib, n)
+        if n not in ("mdgen_last_error", "mdgen_ctx_weight_name"):
+            getattr(lib, n).restype = i32
+    return lib
+
+
+lib = _load()
+
+
+class MdgenError(RuntimeError):
+    pass
+
+
+def check(rc: int):
+    if rc != 0:
+        raise MdgenError(f"libmdgen_amd error {rc}: {lib.mdgen_last_error().decode()}")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MdgenError("mdgen_amd runs on the GPU only (no CPU fallback): got a CPU tensor")
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if dtype is not None and t.dtype != dtype:
+        raise MdgenError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise MdgenError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,1024 @@
+// api.hip -- C-ABI of libmdgen_amd.so (include/mdgen_amd.h): context, weight packing, workspace
+// layout, the denoiser forward / Euler rollout orchestration and hipGraph capture.
+#include "../../include/mdgen_amd.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace mdg;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail((int)e_, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define LAUNCHCHK()                                                                            \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess) return fail((int)e_, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char* mdgen_last_error(void) { return g_err; }
+extern "C" int32_t mdgen_abi_version(void) { return MDGEN_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxPos = 8160;        // positions covered by the rotary table / flash mask table
+constexpr int kKS = 24;              // k-steps at K = 384
+constexpr size_t kPackCC = (size_t)12 * kKS * 64;  // bf16x8 elements of a packed [384][384] matrix
+
+struct MhaW {
+    bf16x8 *wq = nullptr, *wk = nullptr, *wv_flash = nullptr, *wv_small = nullptr, *wo = nullptr;
+    float *bq = nullptr, *bk = nullptr, *bv_flash = nullptr, *bv_small = nullptr, *bo = nullptr;
+    float *bias_k = nullptr, *bias_v = nullptr;
+};
+struct FfnW {
+    bf16x8 *w1 = nullptr, *w2 = nullptr;
+    float *b1 = nullptr, *b2 = nullptr;
+};
+struct TrunkW {
+    MhaW mha_l, mha_t;
+    FfnW ffn;
+};
+struct IpaW {
+    float* gamma_beta = nullptr;  // [gamma(C) | beta(C)]
+    bf16x8* wproj = nullptr;      // [21 ftile][24][64][8]
+    float* bproj = nullptr;       // [672]
+    float* head_w = nullptr;      // [4]
+    bf16x8* wout = nullptr;       // [12 ftile][16][64][8]
+    float* bout = nullptr;
+    MhaW mha_l;
+    FfnW ffn;
+};
+
+struct ProfRec {
+    const char* cls;
+    hipEvent_t a, b;
+};
+
+struct GraphEntry {
+    std::vector<uint64_t> key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+struct mdgen_ctx {
+    mdgen_model_desc d;
+    int nl = 0, D = 0, modrow = 0;
+    std::vector<void*> allocs;
+    std::vector<std::string> names;
+    std::map<std::string, std::function<int(const float*, const int64_t*, int, hipStream_t)>> setters;
+    std::map<std::string, bool> provided;
+    bool finalized = false;
+    // fp32 small weights
+    float *wl = nullptr, *bl = nullptr, *wc = nullptr, *bc = nullptr, *mask_emb = nullptr, *aa_emb = nullptr;
+    float *pos_embed = nullptr, *t_w0 = nullptr, *t_b0 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
+    float *wf7 = nullptr, *bf7 = nullptr, *wr7 = nullptr, *br7 = nullptr;
+    float *ada_w = nullptr, *ada_b = nullptr;
+    float *inv_freq = nullptr, *rope = nullptr;
+    bf16x8* wfin = nullptr;
+    float* bfin = nullptr;
+    std::vector<TrunkW> trunk;
+    std::vector<IpaW> ipa;
+    // device index maps
+    int *map_nat = nullptr, *map_qk = nullptr, *map_vflash = nullptr, *map_vsmall = nullptr, *map_fin = nullptr;
+    int *perm_qk = nullptr, *perm_vsmall = nullptr;
+    std::vector<GraphEntry> graphs;
+    bool inv_freq_set = false;
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+
+    template <typename T>
+    int dalloc(T** p, size_t count) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, count * sizeof(T));
+        if (e != hipSuccess) return fail((int)e, "hipMalloc(%zu) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        allocs.push_back(q);
+        *p = (T*)q;
+        return 0;
+    }
+    int trunk_off(int i) const { return i * 9 * kC; }
+    int ipa_off(int i) const { return nl * 9 * kC + i * 6 * kC; }
+    int final_off() const { return nl * 15 * kC; }
+};
+
+// RAII bracket of one launch with a hipEvent pair on the launch stream (profiling mode only)
+struct ProfScope {
+    mdgen_ctx* c;
+    hipStream_t s;
+    ProfRec r;
+    bool on;
+    ProfScope(mdgen_ctx* c_, const char* cls, hipStream_t s_) : c(c_), s(s_), on(c_->prof_on) {
+        if (on) {
+            r.cls = cls;
+            on = hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess &&
+                 hipEventRecord(r.a, s) == hipSuccess;
+        }
+    }
+    ~ProfScope() {
+        if (on && hipEventRecord(r.b, s) == hipSuccess) c->prof.push_back(r);
+    }
+};
+
+// ---- host-side index maps (DESIGN.md "fragment layout") -------------------------------------
+// Row rho (0..95) of wave-tile w of a TRANSPOSED projection -> (head, lane-half h, slot e):
+//   ft = rho/32, m = rho%32 = b + 8a + 4h, a' = 4ft + a, head = 4w + a'/3, e = 4(a'%3) + b
+static void decode_T(int rho, int& hd, int& h, int& e) {
+    const int ft = rho / 32, m = rho % 32;
+    const int b = m & 3, hh = (m >> 2) & 1, a = m >> 3;
+    const int ap = 4 * ft + a;
+    hd = ap / 3;
+    h = hh;
+    e = 4 * (ap % 3) + b;
+}
+// rotary-pair order for Q/K: slot e of half h is feature 6h + e/2 (+12 for odd e)
+static int feat_qk(int w, int rho) {
+    int hd, h, e;
+    decode_T(rho, hd, h, e);
+    return (4 * w + hd) * kDH + 6 * h + (e >> 1) + 12 * (e & 1);
+}
+// natural order for the SMALL-layout V: slot e of half h is feature 12h + e
+static int feat_vsmall(int w, int rho) {
+    int hd, h, e;
+    decode_T(rho, hd, h, e);
+    return (4 * w + hd) * kDH + 12 * h + e;
+}
+// FLASH-layout V (non-transposed): column col (0..95) of wave-tile w -> head 4w + col/24, V^T row
+// d = col%24 carries feature psi(d) = 12*((d>>2)&1) + 4*(d>>3) + (d&3)
+static int feat_vflash(int w, int col) {
+    const int hd = col / kDH, d = col % kDH;
+    return (4 * w + hd) * kDH + 12 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3);
+}
+
+static void build_maps(std::vector<int>& qk, std::vector<int>& vf, std::vector<int>& vs, std::vector<int>& pqk,
+                       std::vector<int>& pvs) {
+    qk.assign(kC, 0); vf.assign(kC, 0); vs.assign(kC, 0); pqk.assign(kC, 0); pvs.assign(kC, 0);
+    for (int w = 0; w < 4; ++w)
+        for (int r = 0; r < 96; ++r) {
+            qk[w * 96 + r] = feat_qk(w, r);
+            vs[w * 96 + r] = feat_vsmall(w, r);
+            vf[w * 96 + r] = feat_vflash(w, r);
+        }
+    // lane-order bias permutations: index ((w*2+h)*4+hd)*12 + e
+    for (int w = 0; w < 4; ++w)
+        for (int h = 0; h < 2; ++h)
+            for (int hd = 0; hd < 4; ++hd)
+                for (int e = 0; e < 12; ++e) {
+                    const int i = ((w * 2 + h) * 4 + hd) * 12 + e;
+                    pqk[i] = (4 * w + hd) * kDH + 6 * h + (e >> 1) + 12 * (e & 1);
+                    pvs[i] = (4 * w + hd) * kDH + 12 * h + e;
+                }
+}
+
+extern "C" int32_t mdgen_debug_layout_maps(int32_t* map_qk, int32_t* map_vflash, int32_t* map_vsmall,
+                                           int32_t* perm_qk, int32_t* perm_vsmall) {
+    if (!map_qk || !map_vflash || !map_vsmall || !perm_qk || !perm_vsmall) return fail(-1, "null argument");
+    std::vector<int> qk, vf, vs, pqk, pvs;
+    build_maps(qk, vf, vs, pqk, pvs);
+    for (int i = 0; i < kC; ++i) {
+        map_qk[i] = qk[i]; map_vflash[i] = vf[i]; map_vsmall[i] = vs[i]; perm_qk[i] = pqk[i]; perm_vsmall[i] = pvs[i];
+    }
+    return 0;
+}
+
+static int upload_ints(mdgen_ctx* c, int** dst, const std::vector<int>& v) {
+    if (int r = c->dalloc(dst, v.size())) return r;
+    HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static bool shape_is(const int64_t* s, int nd, std::initializer_list<int64_t> want) {
+    // accept exact shape, ignoring leading singleton dims (bias_k is (1,1,C), pos_embed (1,crop,C))
+    std::vector<int64_t> a(s, s + nd), b(want);
+    while (a.size() > b.size() && a.front() == 1) a.erase(a.begin());
+    return a == b;
+}
+
+#define SETTER(key, body)                                                                        \
+    c->names.push_back(key);                                                                     \
+    c->setters[key] = [=](const float* data, const int64_t* shp, int nd, hipStream_t s) -> int { \
+        (void)shp; (void)nd; body; return 0; }
+#define WANT(...) \
+    if (!shape_is(shp, nd, {__VA_ARGS__})) return fail(-3, "unexpected shape for weight")
+
+static int copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
+    HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+static int register_mha(mdgen_ctx* c, const std::string& pre, MhaW* m) {
+    const float qscale = (1.0f / std::sqrt((float)kDH)) * kLog2e;
+    if (int r = c->dalloc(&m->wq, kPackCC)) return r;
+    if (int r = c->dalloc(&m->wk, kPackCC)) return r;
+    if (int r = c->dalloc(&m->wv_flash, kPackCC)) return r;
+    if (int r = c->dalloc(&m->wv_small, kPackCC)) return r;
+    if (int r = c->dalloc(&m->wo, kPackCC)) return r;
+    for (float** p : {&m->bq, &m->bk, &m->bv_flash, &m->bv_small, &m->bo, &m->bias_k, &m->bias_v})
+        if (int r = c->dalloc(p, (size_t)kC)) return r;
+    SETTER(pre + "q_proj.weight", { WANT(kC, kC); launch_pack_rows(data, kC, c->map_qk, 12, kKS, qscale, m->wq, s); });
+    SETTER(pre + "q_proj.bias", { WANT(kC); launch_gather_f32(data, c->perm_qk, qscale, m->bq, kC, s); });
+    SETTER(pre + "k_proj.weight", { WANT(kC, kC); launch_pack_rows(data, kC, c->map_qk, 12, kKS, 1.f, m->wk, s); });
+    SETTER(pre + "k_proj.bias", { WANT(kC); launch_gather_f32(data, c->perm_qk, 1.f, m->bk, kC, s); });
+    SETTER(pre + "v_proj.weight", {
+        WANT(kC, kC);
+        launch_pack_rows(data, kC, c->map_vflash, 12, kKS, 1.f, m->wv_flash, s);
+        launch_pack_rows(data, kC, c->map_vsmall, 12, kKS, 1.f, m->wv_small, s);
+    });
+    SETTER(pre + "v_proj.bias", {
+        WANT(kC);
+        launch_gather_f32(data, c->map_vflash, 1.f, m->bv_flash, kC, s);
+        launch_gather_f32(data, c->perm_vsmall, 1.f, m->bv_small, kC, s);
+    });
+    SETTER(pre + "out_proj.weight", { WANT(kC, kC); launch_pack_rows(data, kC, c->map_nat, 12, kKS, 1.f, m->wo, s); });
+    SETTER(pre + "out_proj.bias", { WANT(kC); if (int r = copy_f32(m->bo, data, kC, s)) return r; });
+    SETTER(pre + "bias_k", { WANT(kC); if (int r = copy_f32(m->bias_k, data, kC, s)) return r; });
+    SETTER(pre + "bias_v", { WANT(kC); if (int r = copy_f32(m->bias_v, data, kC, s)) return r; });
+    SETTER(pre + "rot_emb.inv_freq", {
+        WANT(12);
+        if (int r = copy_f32(c->inv_freq, data, 12, s)) return r;
+        c->inv_freq_set = true;
+    });
+    return 0;
+}
+
+static int register_ffn(mdgen_ctx* c, const std::string& pre, FfnW* f) {
+    if (int r = c->dalloc(&f->w1, (size_t)48 * kKS * 64)) return r;
+    if (int r = c->dalloc(&f->w2, (size_t)12 * 96 * 64)) return r;
+    if (int r = c->dalloc(&f->b1, (size_t)kF)) return r;
+    if (int r = c->dalloc(&f->b2, (size_t)kC)) return r;
+    SETTER(pre + "fc1.weight", { WANT(kF, kC); launch_pack_rows(data, kC, c->map_nat, 48, kKS, 1.f, f->w1, s); });
+    SETTER(pre + "fc1.bias", { WANT(kF); if (int r = copy_f32(f->b1, data, kF, s)) return r; });
+    SETTER(pre + "fc2.weight", { WANT(kC, kF); launch_pack_rows(data, kF, c->map_nat, 12, 96, 1.f, f->w2, s); });
+    SETTER(pre + "fc2.bias", { WANT(kC); if (int r = copy_f32(f->b2, data, kC, s)) return r; });
+    return 0;
+}
+
+extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) {
+    if (!out || !d) return fail(-1, "null argument");
+    if (d->embed_dim != kC || d->mha_heads != kH) return fail(-2, "this build supports embed_dim=384, mha_heads=16 only");
+    if (d->ipa_heads != 4 || d->ipa_head_dim != 32 || d->ipa_qk != 8 || d->ipa_v != 8)
+        return fail(-2, "this build supports ipa_heads=4, ipa_head_dim=32, ipa_qk=ipa_v=8 only");
+    if (d->num_layers < 1 || d->num_layers > 8) return fail(-2, "num_layers must be in 1..8");
+    if (d->latent_dim < 1 || d->latent_dim > 28) return fail(-2, "latent_dim must be in 1..28");
+    if (d->tps_condition && d->latent_dim != 28) return fail(-2, "tps_condition requires latent_dim 28");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(-9, "no HIP device");
+    mdgen_ctx* c = new mdgen_ctx();
+    c->d = *d;
+    c->nl = d->num_layers;
+    c->D = d->latent_dim;
+    c->modrow = (15 * c->nl + 2) * kC;
+    const int D = c->D, nl = c->nl;
+    // index maps
+    std::vector<int> nat(kF), qk, vf, vs, fin(32), pqk, pvs;
+    for (int i = 0; i < kF; ++i) nat[i] = i;
+    build_maps(qk, vf, vs, pqk, pvs);
+    for (int i = 0; i < 32; ++i) fin[i] = i < D ? i : -1;
+#define TRY(x) do { if (int r_ = (x)) { mdgen_ctx_destroy(c); return r_; } } while (0)
+    TRY(upload_ints(c, &c->map_nat, nat));
+    TRY(upload_ints(c, &c->map_qk, qk));
+    TRY(upload_ints(c, &c->map_vflash, vf));
+    TRY(upload_ints(c, &c->map_vsmall, vs));
+    TRY(upload_ints(c, &c->map_fin, fin));
+    TRY(upload_ints(c, &c->perm_qk, pqk));
+    TRY(upload_ints(c, &c->perm_vsmall, pvs));
+    TRY(c->dalloc(&c->wl, (size_t)kC * D));
+    TRY(c->dalloc(&c->bl, (size_t)kC));
+    TRY(c->dalloc(&c->wc, (size_t)kC * D));
+    TRY(c->dalloc(&c->bc, (size_t)kC));
+    TRY(c->dalloc(&c->mask_emb, (size_t)2 * kC));
+    TRY(c->dalloc(&c->aa_emb, (size_t)21 * kC));
+    TRY(c->dalloc(&c->t_w0, (size_t)kC * 256));
+    TRY(c->dalloc(&c->t_b0, (size_t)kC));
+    TRY(c->dalloc(&c->t_w2, (size_t)kC * kC));
+    TRY(c->dalloc(&c->t_b2, (size_t)kC));
+    TRY(c->dalloc(&c->ada_w, (size_t)c->modrow * kC));
+    TRY(c->dalloc(&c->ada_b, (size_t)c->modrow));
+    TRY(c->dalloc(&c->inv_freq, (size_t)12));
+    TRY(c->dalloc(&c->rope, (size_t)(kMaxPos + 1) * 24));
+    TRY(c->dalloc(&c->wfin, (size_t)kKS * 64));
+    TRY(c->dalloc(&c->bfin, (size_t)32));
+    HIPCHK(hipMemset(c->bfin, 0, 32 * sizeof(float)));
+    SETTER("latent_to_emb.weight", { WANT(kC, c->D); if (int r = copy_f32(c->wl, data, (size_t)kC * c->D, s)) return r; });
+    SETTER("latent_to_emb.bias", { WANT(kC); if (int r = copy_f32(c->bl, data, kC, s)) return r; });
+    SETTER("cond_to_emb.weight", { WANT(kC, c->D); if (int r = copy_f32(c->wc, data, (size_t)kC * c->D, s)) return r; });
+    SETTER("cond_to_emb.bias", { WANT(kC); if (int r = copy_f32(c->bc, data, kC, s)) return r; });
+    SETTER("mask_to_emb.weight", { WANT(2, kC); if (int r = copy_f32(c->mask_emb, data, 2 * kC, s)) return r; });
+    SETTER("aatype_to_emb.weight", { WANT(21, kC); if (int r = copy_f32(c->aa_emb, data, 21 * kC, s)) return r; });
+    SETTER("t_embedder.mlp.0.weight", { WANT(kC, 256); if (int r = copy_f32(c->t_w0, data, (size_t)kC * 256, s)) return r; });
+    SETTER("t_embedder.mlp.0.bias", { WANT(kC); if (int r = copy_f32(c->t_b0, data, kC, s)) return r; });
+    SETTER("t_embedder.mlp.2.weight", { WANT(kC, kC); if (int r = copy_f32(c->t_w2, data, (size_t)kC * kC, s)) return r; });
+    SETTER("t_embedder.mlp.2.bias", { WANT(kC); if (int r = copy_f32(c->t_b2, data, kC, s)) return r; });
+    if (d->abs_pos_emb) {
+        if (d->crop < 1) { mdgen_ctx_destroy(c); return fail(-2, "abs_pos_emb requires crop >= 1"); }
+        TRY(c->dalloc(&c->pos_embed, (size_t)d->crop * kC));
+        SETTER("pos_embed", { WANT(c->d.crop, kC); if (int r = copy_f32(c->pos_embed, data, (size_t)c->d.crop * kC, s)) return r; });
+    }
+    if (d->tps_condition) {
+        TRY(c->dalloc(&c->wf7, (size_t)kC * 7));
+        TRY(c->dalloc(&c->bf7, (size_t)kC));
+        TRY(c->dalloc(&c->wr7, (size_t)kC * 7));
+        TRY(c->dalloc(&c->br7, (size_t)kC));
+        SETTER("latent_to_emb_f.weight", { WANT(kC, 7); if (int r = copy_f32(c->wf7, data, kC * 7, s)) return r; });
+        SETTER("latent_to_emb_f.bias", { WANT(kC); if (int r = copy_f32(c->bf7, data, kC, s)) return r; });
+        SETTER("latent_to_emb_r.weight", { WANT(kC, 7); if (int r = copy_f32(c->wr7, data, kC * 7, s)) return r; });
+        SETTER("latent_to_emb_r.bias", { WANT(kC); if (int r = copy_f32(c->br7, data, kC, s)) return r; });
+    }
+    SETTER("emb_to_latent.linear.weight",
+           { WANT(c->D, kC); launch_pack_rows(data, kC, c->map_fin, 1, kKS, 1.f, c->wfin, s); });
+    SETTER("emb_to_latent.linear.bias", { WANT(c->D); if (int r = copy_f32(c->bfin, data, c->D, s)) return r; });
+    SETTER("emb_to_latent.adaLN_modulation.1.weight", {
+        WANT(2 * kC, kC);
+        if (int r = copy_f32(c->ada_w + (size_t)c->final_off() * kC, data, (size_t)2 * kC * kC, s)) return r;
+    });
+    SETTER("emb_to_latent.adaLN_modulation.1.bias",
+           { WANT(2 * kC); if (int r = copy_f32(c->ada_b + c->final_off(), data, 2 * kC, s)) return r; });
+    c->trunk.resize(nl);
+    c->ipa.resize(nl);
+    for (int i = 0; i < nl; ++i) {
+        const std::string p = "layers." + std::to_string(i) + ".";
+        TrunkW* t = &c->trunk[i];
+        SETTER(p + "adaLN_modulation.1.weight", {
+            WANT(9 * kC, kC);
+            if (int r = copy_f32(c->ada_w + (size_t)c->trunk_off(i) * kC, data, (size_t)9 * kC * kC, s)) return r;
+        });
+        SETTER(p + "adaLN_modulation.1.bias",
+               { WANT(9 * kC); if (int r = copy_f32(c->ada_b + c->trunk_off(i), data, 9 * kC, s)) return r; });
+        TRY(register_mha(c, p + "mha_t.attn.", &t->mha_t));
+        TRY(register_mha(c, p + "mha_l.attn.", &t->mha_l));
+        TRY(register_ffn(c, p, &t->ffn));
+    }
+    for (int i = 0; i < nl; ++i) {
+        const std::string p = "ipa_layers." + std::to_string(i) + ".";
+        IpaW* w = &c->ipa[i];
+        TRY(c->dalloc(&w->gamma_beta, (size_t)2 * kC));
+        TRY(c->dalloc(&w->wproj, (size_t)21 * kKS * 64));
+        TRY(c->dalloc(&w->bproj, (size_t)kIpaProj));
+        TRY(c->dalloc(&w->head_w, (size_t)4));
+        TRY(c->dalloc(&w->wout, (size_t)12 * 16 * 64));
+        TRY(c->dalloc(&w->bout, (size_t)kC));
+        SETTER(p + "adaLN_modulation.1.weight", {
+            WANT(6 * kC, kC);
+            if (int r = copy_f32(c->ada_w + (size_t)c->ipa_off(i) * kC, data, (size_t)6 * kC * kC, s)) return r;
+        });
+        SETTER(p + "adaLN_modulation.1.bias",
+               { WANT(6 * kC); if (int r = copy_f32(c->ada_b + c->ipa_off(i), data, 6 * kC, s)) return r; });
+        SETTER(p + "ipa_norm.weight", { WANT(kC); if (int r = copy_f32(w->gamma_beta, data, kC, s)) return r; });
+        SETTER(p + "ipa_norm.bias", { WANT(kC); if (int r = copy_f32(w->gamma_beta + kC, data, kC, s)) return r; });
+        SETTER(p + "ipa.head_weights", { WANT(4); if (int r = copy_f32(w->head_w, data, 4, s)) return r; });
+        SETTER(p + "ipa.linear_q.weight", { WANT(128, kC); launch_pack_rows(data, kC, c->map_nat, 4, kKS, 1.f, w->wproj, s); });
+        SETTER(p + "ipa.linear_q.bias", { WANT(128); if (int r = copy_f32(w->bproj, data, 128, s)) return r; });
+        SETTER(p + "ipa.linear_kv.weight",
+               { WANT(256, kC); launch_pack_rows(data, kC, c->map_nat, 8, kKS, 1.f, w->wproj + (size_t)4 * kKS * 64, s); });
+        SETTER(p + "ipa.linear_kv.bias", { WANT(256); if (int r = copy_f32(w->bproj + 128, data, 256, s)) return r; });
+        SETTER(p + "ipa.linear_q_points.weight",
+               { WANT(96, kC); launch_pack_rows(data, kC, c->map_nat, 3, kKS, 1.f, w->wproj + (size_t)12 * kKS * 64, s); });
+        SETTER(p + "ipa.linear_q_points.bias", { WANT(96); if (int r = copy_f32(w->bproj + 384, data, 96, s)) return r; });
+        SETTER(p + "ipa.linear_kv_points.weight",
+               { WANT(192, kC); launch_pack_rows(data, kC, c->map_nat, 6, kKS, 1.f, w->wproj + (size_t)15 * kKS * 64, s); });
+        SETTER(p + "ipa.linear_kv_points.bias", { WANT(192); if (int r = copy_f32(w->bproj + 480, data, 192, s)) return r; });
+        SETTER(p + "ipa.linear_out.weight",
+               { WANT(kC, kIpaFeat); launch_pack_rows(data, kIpaFeat, c->map_nat, 12, 16, 1.f, w->wout, s); });
+        SETTER(p + "ipa.linear_out.bias", { WANT(kC); if (int r = copy_f32(w->bout, data, kC, s)) return r; });
+        TRY(register_mha(c, p + "mha_l.attn.", &w->mha_l));
+        TRY(register_ffn(c, p, &w->ffn));
+    }
+#undef TRY
+    *out = c;
+    return 0;
+}
+
+extern "C" int32_t mdgen_ctx_destroy(mdgen_ctx* c) {
+    if (!c) return 0;
+    for (auto& g : c->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    for (void* p : c->allocs) (void)hipFree(p);
+    delete c;
+    return 0;
+}
+
+extern "C" int32_t mdgen_ctx_num_weights(const mdgen_ctx* c) { return c ? (int32_t)c->names.size() : 0; }
+extern "C" const char* mdgen_ctx_weight_name(const mdgen_ctx* c, int32_t i) {
+    if (!c || i < 0 || i >= (int32_t)c->names.size()) return nullptr;
+    return c->names[i].c_str();
+}
+
+extern "C" int32_t mdgen_ctx_set_weight(mdgen_ctx* c, const char* key, const float* data, const int64_t* shape,
+                                        int32_t ndim, void* stream) {
+    if (!c || !key || !data || !shape) return fail(-1, "null argument");
+    auto it = c->setters.find(key);
+    if (it == c->setters.end()) return fail(-4, "unknown weight key '%s'", key);
+    const int r = it->second(data, shape, ndim, (hipStream_t)stream);
+    if (r) {
+        if (r == -3) {
+            char buf[160] = "";
+            int o = 0;
+            for (int i = 0; i < ndim && o < 140; ++i) o += snprintf(buf + o, sizeof(buf) - o, "%lld,", (long long)shape[i]);
+            return fail(-3, "unexpected shape (%s) for weight '%s'", buf, key);
+        }
+        return r;
+    }
+    LAUNCHCHK();
+    c->provided[key] = true;
+    c->finalized = false;
+    return 0;
+}
+
+extern "C" int32_t mdgen_ctx_finalize(mdgen_ctx* c, void* stream) {
+    if (!c) return fail(-1, "null context");
+    for (const auto& n : c->names)
+        if (!c->provided.count(n)) return fail(-5, "weight '%s' was not provided", n.c_str());
+    if (!c->inv_freq_set) return fail(-5, "rot_emb.inv_freq was not provided");
+    launch_rope_table(c->rope, c->inv_freq, kMaxPos + 1, (hipStream_t)stream);
+    LAUNCHCHK();
+    c->finalized = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t frag_bytes(long nseq, int len) { return (size_t)nseq * kH * (len / 32 + 1) * kFragBytes; }
+
+static int check_shape(const mdgen_ctx* c, const mdgen_shape* sh, int S) {
+    if (!c || !sh) return fail(-1, "null argument");
+    if (sh->B < 1 || sh->T < 1 || sh->L < 1 || S < 1) return fail(-2, "B, T, L, n_steps must be >= 1");
+    if (sh->T > kMaxPos - 1 || sh->L > kMaxPos - 1) return fail(-2, "T and L must be < %d", kMaxPos - 1);
+    if ((long)sh->B * sh->T * sh->L > 1500000000L || (long)S * sh->B * sh->L > 1500000000L)
+        return fail(-2, "token count too large");
+    if (c->d.abs_pos_emb && sh->L > c->d.crop) return fail(-2, "L=%d exceeds pos_embed crop=%d", sh->L, c->d.crop);
+    return 0;
+}
+
+extern "C" int32_t mdgen_workspace_layout(const mdgen_ctx* c, const mdgen_shape* sh, int32_t S, int32_t t_shared,
+                                          mdgen_ws_layout* o) {
+    if (!o) return fail(-1, "null argument");
+    if (int r = check_shape(c, sh, S)) return r;
+    const long B = sh->B, T = sh->T, L = sh->L;
+    const long N = B * T * L, Mp = (long)S * B * L, R = t_shared ? S : (long)S * B;
+    const long maxrows = N > Mp ? N : Mp;
+    size_t fq = (size_t)maxrows * 3 * kC * 2;  // SMALL layout lives in the q region
+    size_t fkv = 0;
+    auto upd = [&](size_t b) { if (b > fq) fq = b; if (b > fkv) fkv = b; };
+    upd(frag_bytes(B * L, (int)T));
+    if (L > 8) {
+        upd(frag_bytes(B * T, (int)L));
+        upd(frag_bytes((long)S * B, (int)L));
+    }
+    if (fkv == 0) fkv = 256;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t a = off; off += align256(bytes); return a; };
+    o->h = take((size_t)N * kC * 4);
+    o->qf = take(fq);
+    o->kf = take(fkv);
+    o->vf = take(fkv);
+    o->obuf = take((size_t)maxrows * kC * 2);
+    o->mod = take((size_t)R * c->modrow * 4);
+    o->silu_t = take((size_t)R * kC * 4);
+    o->ipa_out = take((size_t)Mp * kC * 4);
+    o->h_ipa = take((size_t)Mp * kC * 4 * (c->d.tps_condition ? 2 : 1));
+    o->ipa_proj = take((size_t)Mp * kIpaProj * 4);
+    o->ipa_feat = take((size_t)Mp * kIpaFeat * 2);
+    o->mask_bl = take((size_t)B * L * 4);
+    o->rel7 = take((size_t)2 * B * L * 7 * 4);
+    o->tgrid = take((size_t)S * B * 4);
+    o->total_bytes = off;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// orchestration
+// ---------------------------------------------------------------------------------------------
+// MDGEN_DEBUG_SKIP (tests only): bit0/1/2 skip the trunk's residue-attention / temporal-attention / MLP
+// sub-layers, bit3/4/5 skip the IPA layer's point-attention / residue-attention / MLP sub-layers.
+static int debug_skip() {
+    const char* e = getenv("MDGEN_DEBUG_SKIP");
+    return e ? atoi(e) : 0;
+}
+
+struct Run {
+    mdgen_ctx* c;
+    int B, T, L, D, S;
+    long N, Mp;
+    int t_shared;
+    long mod_step_stride, mod_group_stride;
+    unsigned char* ws;
+    mdgen_ws_layout lay;
+    const float *mask, *start_rot, *start_trans, *end_rot, *end_trans, *x_cond;
+    const int64_t *x_cond_mask, *aatype;
+    hipStream_t s;
+    float* h() const { return (float*)(ws + lay.h); }
+    float* mod() const { return (float*)(ws + lay.mod); }
+};
+
+static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, const AxisMap& ax, const ModMap& mm,
+                         int shift, int scale, int gate, const MaskMap& mk, bool residue_axis, bool trunk) {
+    const char* c_qkv = !trunk ? "ipa.ln_qkv" : residue_axis ? "ln_qkv_L" : "ln_qkv_T";
+    const char* c_att = !trunk ? "ipa.flash" : residue_axis ? "flash_L" : "flash_T";
+    const char* c_prj = !trunk ? "ipa.proj" : residue_axis ? "proj_L" : "proj_T";
+    QkvParams q{};
+    q.h = h;
+    q.nrows = nrows;
+    q.ax = ax;
+    q.mm = mm;
+    q.shift_chunk = shift;
+    q.scale_chunk = scale;
+    q.wq = m.wq;
+    q.wk = m.wk;
+    q.bq = m.bq;
+    q.bk = m.bk;
+    q.rope = r.c->rope;
+    q.qf = r.ws + r.lay.qf;
+    q.kf = r.ws + r.lay.kf;
+    q.vf = r.ws + r.lay.vf;
+    q.qkv_small = (__bf16*)(r.ws + r.lay.qf);
+    q.panels_per_seq = (ax.len + kPanel - 1) / kPanel;
+    ProjParams p{};
+    p.h = h;
+    p.nrows = nrows;
+    p.mm = mm;
+    p.gate_chunk = gate;
+    p.gated = 1;
+    p.w = m.wo;
+    p.bias = m.bo;
+    const bool small = residue_axis && ax.len <= 8;
+    if (small) {
+        q.wv = m.wv_small;
+        q.bv = m.bv_small;
+        { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv(q, true, r.s); }
+        LAUNCHCHK();
+        p.qkv_small = q.qkv_small;
+        p.ax = ax;
+        p.mk = mk;
+        p.bias_k = m.bias_k;
+        p.bias_v = m.bias_v;
+        p.rope = r.c->rope;
+        { ProfScope ps(r.c, c_prj, r.s); launch_proj(p, 2, r.s); }
+        LAUNCHCHK();
+    } else {
+        q.wv = m.wv_flash;
+        q.bv = m.bv_flash;
+        { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv(q, false, r.s); }
+        LAUNCHCHK();
+        FlashParams f{};
+        f.ax = ax;
+        f.mk = mk;
+        f.qf = q.qf;
+        f.kf = q.kf;
+        f.vf = q.vf;
+        f.bias_k = m.bias_k;
+        f.bias_v = m.bias_v;
+        f.rope = r.c->rope;
+        f.obuf = (__bf16*)(r.ws + r.lay.obuf);
+        { ProfScope ps(r.c, c_att, r.s); launch_flash(f, r.s); }
+        LAUNCHCHK();
+        p.a_bf16 = f.obuf;
+        { ProfScope ps(r.c, c_prj, r.s); launch_proj(p, 0, r.s); }
+        LAUNCHCHK();
+    }
+    return 0;
+}
+
+static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const ModMap& mm, int shift, int scale,
+                        int gate, bool trunk) {
+    MlpParams p{};
+    p.h = h;
+    p.nrows = nrows;
+    p.mm = mm;
+    p.shift_chunk = shift;
+    p.scale_chunk = scale;
+    p.gate_chunk = gate;
+    p.w1 = f.w1;
+    p.w2 = f.w2;
+    p.b1 = f.b1;
+    p.b2 = f.b2;
+    { ProfScope ps(r.c, trunk ? "mlp" : "ipa.mlp", r.s); launch_mlp(p, r.s); }
+    LAUNCHCHK();
+    return 0;
+}
+
+// IPA stack for all prepared steps at once (latent_model.py:175-210): tokens (step, b, l).
+static int ipa_stack(const Run& r, float* hbuf, const float* rel7, const float* w7, const float* b7, const float* rot,
+                     const float* trans) {
+    mdgen_ctx* c = r.c;
+    const int G = r.S * r.B;
+    launch_ipa_init(c->aa_emb, r.aatype, rel7, w7, b7, hbuf, G, r.B, r.L, r.s);
+    LAUNCHCHK();
+    AxisMap ax{G, r.L, G, 0, r.L, 1};
+    MaskMap mk{(const float*)(r.ws + r.lay.mask_bl), (long)r.B * r.L};
+    const int skip = debug_skip();
+    for (int i = 0; i < c->nl; ++i) {
+        const IpaW& w = c->ipa[i];
+        ModMap mm{r.mod() + c->ipa_off(i), r.L, r.B, r.mod_step_stride, r.mod_group_stride};
+        if (!(skip & 8)) {
+        LnLinearParams lp{};
+        lp.h = hbuf;
+        lp.nrows = r.Mp;
+        lp.mm = ModMap{w.gamma_beta, 1, 1, 0, 0};
+        lp.w = w.wproj;
+        lp.bias = w.bproj;
+        lp.out = (float*)(r.ws + r.lay.ipa_proj);
+        lp.nout = kIpaProj;
+        { ProfScope ps(c, "ipa.ln_linear", r.s); launch_ln_linear(lp, r.s); }
+        LAUNCHCHK();
+        IpaAttnParams ap{};
+        ap.proj = lp.out;
+        ap.rot = rot;
+        ap.trans = trans;
+        ap.mask_bl = (const float*)(r.ws + r.lay.mask_bl);
+        ap.head_w = w.head_w;
+        ap.feat = (__bf16*)(r.ws + r.lay.ipa_feat);
+        ap.ngroups = G;
+        ap.B = r.B;
+        ap.L = r.L;
+        { ProfScope ps(c, "ipa.point_attn", r.s); launch_ipa_attn(ap, r.s); }
+        LAUNCHCHK();
+        ProjParams pp{};
+        pp.h = hbuf;
+        pp.nrows = r.Mp;
+        pp.mm = mm;
+        pp.gated = 0;
+        pp.w = w.wout;
+        pp.bias = w.bout;
+        pp.a_bf16 = ap.feat;
+        { ProfScope ps(c, "ipa.linear_out", r.s); launch_proj(pp, 1, r.s); }
+        LAUNCHCHK();
+        }
+        if (!(skip & 16))
+            if (int e = attn_sublayer(r, w.mha_l, hbuf, r.Mp, ax, mm, 0, 1, 2, mk, true, false)) return e;
+        if (!(skip & 32))
+            if (int e = mlp_sublayer(r, w.ffn, hbuf, r.Mp, mm, 3, 4, 5, false)) return e;
+    }
+    return 0;
+}
+
+// Step-invariant work: adaLN table for every prepared time row, compact mask, IPA table.
+// t values: t_dev (device, [S][B]) when non-null, else t_host[step] baked into the launch.
+static int prepare(const Run& r, const float* t_dev, const float* t_host) {
+    mdgen_ctx* c = r.c;
+    float* silu = (float*)(r.ws + r.lay.silu_t);
+    const int R = r.t_shared ? r.S : r.S * r.B;
+    if (t_dev) {
+        if (r.t_shared && r.B > 1) return fail(-2, "device t rows require t_shared == 0 or B == 1");
+        launch_temb(t_dev, R, c->d.time_multiplier, c->t_w0, c->t_b0, c->t_w2, c->t_b2, silu, r.s);
+        LAUNCHCHK();
+    } else {
+        // the (tiny) host time grid travels as memset nodes: capturable, no host buffer lifetime issue
+        float* tg = (float*)(r.ws + r.lay.tgrid);
+        for (int i = 0; i < r.S; ++i) {
+            uint32_t bits;
+            std::memcpy(&bits, &t_host[i], 4);
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(tg + i), (int)bits, 1, r.s));
+        }
+        launch_temb(tg, r.S, c->d.time_multiplier, c->t_w0, c->t_b0, c->t_w2, c->t_b2, silu, r.s);
+        LAUNCHCHK();
+    }
+    { ProfScope ps(c, "adaln_table", r.s); launch_adaln(silu, R, c->ada_w, c->ada_b, c->modrow, r.mod(), r.s); }
+    LAUNCHCHK();
+    // mask_bl[b][l] = mask[b][0][l]  (latent_model.py:246 passes mask[:,0])
+    HIPCHK(hipMemcpy2DAsync(r.ws + r.lay.mask_bl, (size_t)r.L * 4, r.mask, (size_t)r.T * r.L * 4, (size_t)r.L * 4, r.B,
+                            hipMemcpyDeviceToDevice, r.s));
+    float* ipa_out = (float*)(r.ws + r.lay.ipa_out);
+    if (!c->d.tps_condition) {
+        if (int e = ipa_stack(r, ipa_out, nullptr, nullptr, nullptr, r.start_rot, r.start_trans)) return e;
+    } else {
+        if (!r.end_rot || !r.end_trans) return fail(-2, "tps_condition requires end frames");
+        float* rel = (float*)(r.ws + r.lay.rel7);
+        const long BL = (long)r.B * r.L;
+        // x_f = (start^-1 o end).to_tensor_7(), x_r = (end^-1 o start).to_tensor_7()   (latent_model.py:194-195)
+        launch_rel7(r.start_rot, r.start_trans, r.end_rot, r.end_trans, rel, BL, r.s);
+        launch_rel7(r.end_rot, r.end_trans, r.start_rot, r.start_trans, rel + BL * 7, BL, r.s);
+        LAUNCHCHK();
+        float* h2 = (float*)(r.ws + r.lay.h_ipa);
+        // x_r stream runs on the start frames, x_f stream on the end frames (latent_model.py:203-205)
+        if (int e = ipa_stack(r, ipa_out, rel + BL * 7, c->wr7, c->br7, r.start_rot, r.start_trans)) return e;
+        if (int e = ipa_stack(r, h2, rel, c->wf7, c->bf7, r.end_rot, r.end_trans)) return e;
+        launch_add_inplace(ipa_out, h2, r.Mp * kC, r.s);
+        LAUNCHCHK();
+    }
+    return 0;
+}
+
+// One network evaluation at prepared step `step`: x -> velocity (out) or Euler update of x in place.
+static int denoise_step(const Run& r, int step, float* x, float* out, int euler, float dt, float* trace_h) {
+    mdgen_ctx* c = r.c;
+    float* h = r.h();
+    EmbedParams e{};
+    e.x = x;
+    e.x_cond = r.x_cond;
+    e.x_cond_mask = r.x_cond_mask;
+    e.wl = c->wl;
+    e.bl = c->bl;
+    e.wc = c->wc;
+    e.bc = c->bc;
+    e.mask_emb = c->mask_emb;
+    e.pos_embed = c->d.abs_pos_emb ? c->pos_embed : nullptr;
+    e.ipa_out = (const float*)(r.ws + r.lay.ipa_out) + (long)step * r.B * r.L * kC;
+    e.h = h;
+    e.N = r.N;
+    e.T = r.T;
+    e.L = r.L;
+    e.D = r.D;
+    { ProfScope ps(c, "embed", r.s); launch_embed(e, r.s); }
+    LAUNCHCHK();
+    const size_t hbytes = (size_t)r.N * kC * 4;
+    if (trace_h) HIPCHK(hipMemcpyAsync(trace_h, h, hbytes, hipMemcpyDeviceToDevice, r.s));
+    const float* modstep = r.mod() + (long)step * r.mod_step_stride;
+    AxisMap axL{r.B * r.T, r.L, r.B * r.T, 0, r.L, 1};
+    AxisMap axT{r.B * r.L, r.T, r.L, r.T * r.L, 1, r.L};
+    MaskMap mk{r.mask, 0};
+    const int skip = debug_skip();
+    for (int i = 0; i < c->nl; ++i) {
+        const TrunkW& w = c->trunk[i];
+        ModMap mm{modstep + c->trunk_off(i), r.T * r.L, r.B, 0, r.mod_group_stride};
+        if (!(skip & 1))
+            if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true)) return er;
+        if (!(skip & 2))
+            if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true)) return er;
+        if (!(skip & 4))
+            if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true)) return er;
+        if (trace_h) HIPCHK(hipMemcpyAsync(trace_h + (size_t)(i + 1) * r.N * kC, h, hbytes, hipMemcpyDeviceToDevice, r.s));
+    }
+    FinalParams f{};
+    f.h = h;
+    f.nrows = r.N;
+    f.mm = ModMap{modstep + c->final_off(), r.T * r.L, r.B, 0, r.mod_group_stride};
+    f.shift_chunk = 0;
+    f.scale_chunk = 1;
+    f.w = c->wfin;
+    f.bias = c->bfin;
+    f.D = r.D;
+    f.euler = euler;
+    f.dt = dt;
+    f.x = x;
+    f.out = out;
+    { ProfScope ps(c, "final_euler", r.s); launch_final(f, r.s); }
+    LAUNCHCHK();
+    return 0;
+}
+
+static int make_run(Run* r, mdgen_ctx* c, const mdgen_shape* sh, int S, int t_shared, void* ws, size_t ws_bytes,
+                    void* stream) {
+    if (int e = check_shape(c, sh, S)) return e;
+    if (!c->finalized) return fail(-6, "context not finalized (mdgen_ctx_finalize)");
+    if (!ws) return fail(-1, "null workspace");
+    if (int e = mdgen_workspace_layout(c, sh, S, t_shared, &r->lay)) return e;
+    if (ws_bytes < r->lay.total_bytes)
+        return fail(-7, "workspace too small: %zu < %zu bytes", ws_bytes, r->lay.total_bytes);
+    if (((uintptr_t)ws & 255) != 0) return fail(-7, "workspace must be 256-byte aligned");
+    r->c = c;
+    r->B = sh->B;
+    r->T = sh->T;
+    r->L = sh->L;
+    r->D = c->D;
+    r->S = S;
+    r->N = (long)sh->B * sh->T * sh->L;
+    r->Mp = (long)S * sh->B * sh->L;
+    r->t_shared = t_shared;
+    r->mod_step_stride = t_shared ? c->modrow : (long)sh->B * c->modrow;
+    r->mod_group_stride = t_shared ? 0 : c->modrow;
+    r->ws = (unsigned char*)ws;
+    r->s = (hipStream_t)stream;
+    return 0;
+}
+
+extern "C" int32_t mdgen_denoiser_forward(mdgen_ctx* c, const mdgen_shape* sh, const float* x, const float* t,
+                                          const float* mask, const float* start_rot, const float* start_trans,
+                                          const float* end_rot, const float* end_trans, const float* x_cond,
+                                          const int64_t* x_cond_mask, const int64_t* aatype, float* out,
+                                          float* trace_h, float* trace_ipa, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !t || !mask || !start_rot || !start_trans || !x_cond || !x_cond_mask || !aatype || !out)
+        return fail(-1, "null tensor argument");
+    Run r{};
+    const int t_shared = (sh && sh->B == 1) ? 1 : 0;
+    if (int e = make_run(&r, c, sh, 1, t_shared, ws, ws_bytes, stream)) return e;
+    r.mask = mask;
+    r.start_rot = start_rot;
+    r.start_trans = start_trans;
+    r.end_rot = end_rot;
+    r.end_trans = end_trans;
+    r.x_cond = x_cond;
+    r.x_cond_mask = x_cond_mask;
+    r.aatype = aatype;
+    if (int e = prepare(r, t, nullptr)) return e;
+    if (trace_ipa)
+        HIPCHK(hipMemcpyAsync(trace_ipa, r.ws + r.lay.ipa_out, (size_t)r.B * r.L * kC * 4, hipMemcpyDeviceToDevice, r.s));
+    return denoise_step(r, 0, const_cast<float*>(x), out, 0, 0.f, trace_h);
+}
+
+// torch.linspace(0, 1, n) in fp32 (ATen RangeFactories: symmetric evaluation around the midpoint)
+static void linspace01(int n, std::vector<float>* out) {
+    out->resize(n);
+    const float step = 1.0f / (float)(n - 1);
+    const int half = n / 2;
+    for (int i = 0; i < n; ++i) (*out)[i] = i < half ? 0.0f + step * (float)i : 1.0f - step * (float)(n - 1 - i);
+}
+
+static int euler_body(const Run& r, const std::vector<float>& tg, float* x) {
+    if (int e = prepare(r, nullptr, tg.data())) return e;
+    for (int i = 0; i < r.S; ++i) {
+        const float dt = tg[i + 1] - tg[i];
+        if (int e = denoise_step(r, i, x, nullptr, 1, dt, nullptr)) return e;
+    }
+    return 0;
+}
+
+extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32_t S, float* x, const float* mask,
+                                      const float* start_rot, const float* start_trans, const float* end_rot,
+                                      const float* end_trans, const float* x_cond, const int64_t* x_cond_mask,
+                                      const int64_t* aatype, void* ws, size_t ws_bytes, int32_t use_graph,
+                                      void* stream) {
+    if (!x || !mask || !start_rot || !start_trans || !x_cond || !x_cond_mask || !aatype)
+        return fail(-1, "null tensor argument");
+    Run r{};
+    if (int e = make_run(&r, c, sh, S, 1, ws, ws_bytes, stream)) return e;
+    r.mask = mask;
+    r.start_rot = start_rot;
+    r.start_trans = start_trans;
+    r.end_rot = end_rot;
+    r.end_trans = end_trans;
+    r.x_cond = x_cond;
+    r.x_cond_mask = x_cond_mask;
+    r.aatype = aatype;
+    std::vector<float> tg;
+    linspace01(S + 1, &tg);   // integrators.py:88  th.linspace(t0, t1, num_steps)
+    if (!use_graph || c->prof_on) return euler_body(r, tg, x);
+    if (!stream) return fail(-8, "use_graph requires a non-default stream");
+    std::vector<uint64_t> key = {(uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
+                                 (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
+                                 (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
+                                 (uint64_t)ws};
+    for (auto& g : c->graphs)
+        if (g.key == key) {
+            HIPCHK(hipGraphLaunch(g.exec, r.s));
+            return 0;
+        }
+    GraphEntry ge;
+    ge.key = key;
+    HIPCHK(hipStreamBeginCapture(r.s, hipStreamCaptureModeThreadLocal));
+    const int e = euler_body(r, tg, x);
+    hipError_t ce = hipStreamEndCapture(r.s, &ge.graph);
+    if (e) {
+        if (ge.graph) (void)hipGraphDestroy(ge.graph);
+        return e;
+    }
+    if (ce != hipSuccess) return fail((int)ce, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    HIPCHK(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+    if (c->graphs.size() >= 8) {
+        (void)hipGraphExecDestroy(c->graphs.front().exec);
+        (void)hipGraphDestroy(c->graphs.front().graph);
+        c->graphs.erase(c->graphs.begin());
+    }
+    c->graphs.push_back(ge);
+    HIPCHK(hipGraphLaunch(ge.exec, r.s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t mdgen_profile_enable(mdgen_ctx* c, int32_t on) {
+    if (!c) return fail(-1, "null context");
+    c->prof_on = on != 0;
+    return 0;
+}
+
+extern "C" int32_t mdgen_profile_report(mdgen_ctx* c, void* stream, char* buf, size_t buflen) {
+    if (!c || !buf || buflen < 8) return fail(-1, "null argument");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    std::map<std::string, std::pair<long, double>> agg;
+    for (auto& r : c->prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto& a = agg[r.cls];
+            a.first += 1;
+            a.second += ms;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    c->prof.clear();
+    std::string js = "{";
+    bool first = true;
+    for (auto& kv : agg) {
+        char tmp[160];
+        snprintf(tmp, sizeof(tmp), "%s\"%s\": {\"count\": %ld, \"ms\": %.6f}", first ? "" : ", ", kv.first.c_str(),
+                 kv.second.first, kv.second.second);
+        js += tmp;
+        first = false;
+    }
+    js += "}";
+    if (js.size() + 1 > buflen) return fail(-7, "profile buffer too small");
+    std::memcpy(buf, js.c_str(), js.size() + 1);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SE(3) / pre / post
+// ---------------------------------------------------------------------------------------------
+static bool any_null(std::initializer_list<const void*> ps) {
+    for (const void* p : ps)
+        if (!p) return true;
+    return false;
+}
+#define NONNULL(...) \
+    if (any_null({__VA_ARGS__})) return fail(-1, "null tensor argument")
+
+extern "C" int32_t mdgen_rigid_compose(int64_t n, const float* r1, const float* t1, const float* r2, const float* t2,
+                                       float* ro, float* to, void* stream) {
+    NONNULL(r1, t1, r2, t2, ro, to);
+    if (n <= 0) return 0;
+    launch_rigid_compose(n, r1, t1, r2, t2, ro, to, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}
+extern "C" int32_t mdgen_rigid_invert(int64_t n, const float* r, const float* t, float* ro, float* to, void* stream) {
+    NONNULL(r, t, ro, to);
+    if (n <= 0) return 0;
+    launch_rigid_invert(n, r, t, ro, to, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}
+extern "C" int32_t mdgen_rigid_apply(int64_t n, int64_t ppf, const float* r, const float* t, const float* pts,
+                                     float* out, int32_t inverse, void* stream) {
+    NONNULL(r, t, pts, out);
+    if (n <= 0 || ppf <= 0) return 0;
+    launch_rigid_apply(n, ppf, r, t, pts, out, inverse, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}
+extern "C" int32_t mdgen_quat_to_rot(int64_t n, const float* q, int32_t normalize, float* rot, void* stream) {
+    NONNULL(q, rot);
+    if (n <= 0) return 0;
+    launch_quat_to_rot(n, q, normalize, rot, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}
+extern "C" int32_t mdgen_rot_to_quat(int64_t n, const float* rot, float* q, void* stream) {
+    NONNULL(rot, q);
+    if (n <= 0) return 0;
+    launch_rot_to_quat(n, rot, q, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}
+extern "C" int32_t mdgen_prep_latents(const mdgen_shape* sh, int32_t tps, const float* rots, const float* trans,
+                                      const float* torsions, float* latents, float* x_cond, int64_t* x_cond_mask,
+                                      void* stream) {
+    if (!sh) return fail(-1, "null shape");
+    NONNULL(rots, trans, torsions, latents, x_cond, x_cond_mask);
+    if (sh->B < 1 || sh->T < 1 || sh->L < 1) return fail(-2, "B, T, L must be >= 1");
+    launch_prep_latents(sh->B, sh->T, sh->L, tps, rots, trans, torsions, latents, x_cond, x_cond_mask,
+                        (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}
+extern "C" int32_t mdgen_samples_to_atom14(const mdgen_shape* sh, int32_t D, int32_t tps, const float* samples,
+                                           const float* rot0, const float* trans0, const int64_t* seqres,
+                                           const float* default_frames, const float* lit_positions,
+                                           const int64_t* atom14_group, const float* atom14_mask, float* atom14,
+                                           void* stream) {
+    if (!sh) return fail(-1, "null shape");
+    NONNULL(samples, rot0, trans0, seqres, default_frames, lit_positions, atom14_group, atom14_mask, atom14);
+    if (sh->B < 1 || sh->T < 1 || sh->L < 1) return fail(-2, "B, T, L must be >= 1");
+    if (D < (tps ? 28 : 21)) return fail(-2, "latent_dim too small");
+    launch_samples_to_atom14(sh->B, sh->T, sh->L, D, tps, samples, rot0, trans0, seqres, default_frames, lit_positions,
+                             atom14_group, atom14_mask, atom14, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}
+extern "C" int32_t mdgen_atom14_to_cond(int32_t B, int32_t L, const float* atom14, const int64_t* seqres,
+                                        const int64_t* a37to14, const float* a37mask, const int64_t* chi_idx,
+                                        const float* chi_mask, float* rots, float* trans, float* tors, float* tmask,
+                                        void* stream) {
+    NONNULL(atom14, seqres, a37to14, a37mask, chi_idx, chi_mask, rots, trans, tors, tmask);
+    if (B < 1 || L < 1) return fail(-2, "B, L must be >= 1");
+    launch_atom14_to_cond(B, L, atom14, seqres, a37to14, a37mask, chi_idx, chi_mask, rots, trans, tors, tmask,
+                          (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}

@@ -1,0 +1,90 @@
+// common.h -- shared types/constants for the gfx950 kernels of libmdgen_amd.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace mdg {
+
+// ---- compile-time model geometry (reference defaults, parsing.py:79-90) ------------------
+constexpr int kC = 384;        // embed_dim
+constexpr int kH = 16;         // mha_heads
+constexpr int kDH = 24;        // head_dim
+constexpr int kF = 1536;       // ffn dim (4C)
+constexpr int kIpaProj = 672;  // linear_q(128) | linear_kv(256) | linear_q_points(96) | linear_kv_points(192)
+constexpr int kIpaFeat = 256;  // o(128) | o_pt.x(32) | o_pt.y(32) | o_pt.z(32) | |o_pt|(32)
+constexpr int kFragBytes = 1536;  // one (seq, head, 32-position tile) of Q, K or V^T fragments
+constexpr int kPanel = 64;     // token rows per GEMM panel (workgroup)
+constexpr float kLog2e = 1.4426950408889634f;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// (seq, pos) -> token row of the [B][T][L] token block.  Used by both attention axes:
+//   residue axis : seq = b*T + t, pos = l  -> token = seq*L + pos
+//   temporal axis: seq = b*L + l, pos = t  -> token = b*T*L + pos*L + l
+struct AxisMap {
+    int nseq, len;
+    int inner;          // seq = outer*inner + in
+    int outer_stride;   // token stride of `outer`
+    int inner_stride;   // token stride of `in`
+    int pos_stride;     // token stride of `pos`
+    __host__ __device__ inline long token(int seq, int pos) const {
+        return (long)(seq / inner) * outer_stride + (long)(seq % inner) * inner_stride + (long)pos * pos_stride;
+    }
+    __host__ __device__ inline int ntile() const { return len / 32 + 1; }   // tiles covering len+1 keys
+};
+
+// Per-row modulation lookup: group g = token / tokens_per_group;
+// vector = mod + (g / groups_per_step) * step_stride + (g % groups_per_step) * group_stride + chunk*kC
+struct ModMap {
+    const float* mod;
+    int tokens_per_group;
+    int groups_per_step;
+    long step_stride;
+    long group_stride;
+    __device__ inline long row_off(long token) const {
+        long g = token / tokens_per_group;
+        return (g / groups_per_step) * step_stride + (g % groups_per_step) * group_stride;
+    }
+};
+
+// key-padding mask lookup: mask[token % period]
+struct MaskMap {
+    const float* mask;
+    long period;
+    // period == 0: mask is indexed by the token itself (trunk); else token % period (IPA stack: (b,l))
+    __device__ inline float at(long token) const {
+        return mask[period ? (long)((unsigned)token % (unsigned)period) : token];
+    }
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// D-layout row of accumulator register r for lane-half h of a 32x32 MFMA tile
+__host__ __device__ constexpr int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+}  // namespace mdg

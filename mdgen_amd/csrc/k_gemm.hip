@@ -1,0 +1,435 @@
+// k_gemm.hip -- the resident-panel GEMM family: LN+QKV(+RoPE), out-proj(+micro-attention),
+// fused MLP, IPA projections, final layer.  gfx950 only (MFMA 32x32x16 bf16, wave64).
+#include "kernels.h"
+#include "panel.h"
+
+namespace mdg {
+
+constexpr int kRowB = kC * 2;            // panel row bytes at K = 384
+constexpr int kPanelBytes = kPanel * kRowB;
+
+// =================================================================================================
+// LN + modulate + QKV projection + bias + (q scale folded) + RoPE -> attention operand fragments.
+// Replaces latent_model.py:457-461 / 465-475 (modulate(LN(x))) + mha.py:258-263 (q/k/v proj, q scaling)
+// + mha.py:356-357 (rotary).  One workgroup = 64 positions of one sequence (FLASH layout) or 64
+// consecutive tokens (SMALL layout, residue axis with L <= 8).
+// Wave w owns heads 4w..4w+3.  Q and K are computed TRANSPOSED (D[feature][token]) so that a lane
+// holds, for its token, 12 features of each head = six rotary pairs (i, i+12): RoPE is lane-local
+// and the accumulators ARE the attention MFMA fragments (DESIGN.md "fragment layout").
+// =================================================================================================
+template <bool ROPE>
+__device__ __forceinline__ void epilogue_heads_T(const f32x16* acc /*[3 ft][2 tt]*/, const PanelRows* pr, int w,
+                                                 const float* __restrict__ bias_perm, const float* __restrict__ rope,
+                                                 bool small, int pos0, int len, int seq, int ntile, int tile0,
+                                                 unsigned char* __restrict__ frag, __bf16* __restrict__ small_dst,
+                                                 int which) {
+    const int lane = lane_id(), hh = lane >> 5, tk = lane & 31;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int row = tt * 32 + tk;
+        const int token = pr->tok[row];
+        const bool valid = token >= 0;
+        int pos = small ? (valid ? token % len : 0) : pos0 + row;
+        if (pos > len) pos = len;  // padding rows: any in-table position (values are never used)
+        float cs[6], sn[6];
+        if (ROPE) {
+            const float* rc = rope + (long)pos * 24 + 6 * hh;
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                cs[p] = rc[p];
+                sn[p] = rc[12 + p];
+            }
+        }
+        const int tile = tile0 + tt;
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) {
+            float e[12];
+            const float* bp = bias_perm + ((w * 2 + hh) * 4 + hd) * 12;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) e[4 * c + b] = acc[ft * 2 + tt][4 * a + b] + bp[4 * c + b];
+            }
+            if (ROPE) {
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                    const float x1 = e[2 * p], x2 = e[2 * p + 1];
+                    e[2 * p] = x1 * cs[p] - x2 * sn[p];
+                    e[2 * p + 1] = x2 * cs[p] + x1 * sn[p];
+                }
+            }
+            uint32_t u[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) u[i] = pack_bf16(e[2 * i], e[2 * i + 1]);
+            const int head = 4 * w + hd;
+            if (small) {
+                if (valid) {
+                    u32x2* d = reinterpret_cast<u32x2*>(small_dst + (long)token * (3 * kC) + which * kC + head * kDH + hh * 12);
+                    d[0] = u32x2{u[0], u[1]};
+                    d[1] = u32x2{u[2], u[3]};
+                    d[2] = u32x2{u[4], u[5]};
+                }
+            } else if (tile < ntile) {
+                unsigned char* base = frag + ((long)(seq * kH + head) * ntile + tile) * kFragBytes;
+                *reinterpret_cast<u32x4*>(base + lane * 16) = u32x4{u[0], u[1], u[2], u[3]};
+                *reinterpret_cast<u32x2*>(base + 1024 + lane * 8) = u32x2{u[4], u[5]};
+            }
+        }
+    }
+}
+
+// V for the FLASH layout: non-transposed D[token][feature]; the accumulators are the V^T
+// fragments of the P.V MFMA (lane = (d, half), register r = key slot) -- no data movement.
+__device__ __forceinline__ void epilogue_v_flash(const f32x16* acc /*[2 tt][3 ft]*/, int w,
+                                                 const float* __restrict__ bias_perm, int seq, int ntile, int tile0,
+                                                 unsigned char* __restrict__ vf) {
+    const int lane = lane_id(), hh = lane >> 5, n = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int col = 32 * j + n;
+        const int hd = col / kDH, d = col - hd * kDH;
+        const float b = bias_perm[w * 96 + col];
+        const int head = 4 * w + hd;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int tile = tile0 + tt;
+            if (tile < ntile) {
+                unsigned char* base = vf + ((long)(seq * kH + head) * ntile + tile) * kFragBytes + hh * 384 + d * 16;
+                const f32x16 a = acc[tt * 3 + j];
+                *reinterpret_cast<u32x4*>(base) = u32x4{pack_bf16(a[0] + b, a[1] + b), pack_bf16(a[2] + b, a[3] + b),
+                                                         pack_bf16(a[4] + b, a[5] + b), pack_bf16(a[6] + b, a[7] + b)};
+                *reinterpret_cast<u32x4*>(base + 768) =
+                    u32x4{pack_bf16(a[8] + b, a[9] + b), pack_bf16(a[10] + b, a[11] + b),
+                          pack_bf16(a[12] + b, a[13] + b), pack_bf16(a[14] + b, a[15] + b)};
+            }
+        }
+    }
+}
+
+template <bool SMALL>
+__global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
+    PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
+    unsigned char* panel = smem + sizeof(PanelRows);
+    int seq = 0, pos0 = 0, tile0 = 0;
+    if (SMALL) {
+        setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
+    } else {
+        seq = blockIdx.x / p.panels_per_seq;
+        const int pn = blockIdx.x - seq * p.panels_per_seq;
+        pos0 = pn * kPanel;
+        tile0 = pn * 2;
+        setup_rows_axis(pr, p.ax, seq, pos0, p.mm);
+    }
+    __syncthreads();
+    prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    const int ntile = p.ax.ntile();
+    const int len = p.ax.len;
+    f32x16 acc[6];
+    // ---- Q (heads 4w..4w+3), transposed
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    epilogue_heads_T<true>(acc, pr, w, p.bq, p.rope, SMALL, pos0, len, seq, ntile, tile0, p.qf, p.qkv_small, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- K
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    epilogue_heads_T<true>(acc, pr, w, p.bk, p.rope, SMALL, pos0, len, seq, ntile, tile0, p.kf, p.qkv_small, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- V
+    zero_acc<6>(acc);
+    if (SMALL) {
+        wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        epilogue_heads_T<false>(acc, pr, w, p.bv, nullptr, true, pos0, len, seq, ntile, tile0, nullptr, p.qkv_small, 2);
+    } else {
+        wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        epilogue_v_flash(acc, w, p.bv, seq, ntile, tile0, p.vf);
+    }
+}
+
+// =================================================================================================
+// Attention output projection + gate + residual:  h += gate * (Wo o + bo)
+// (mha.py:397 out_proj; latent_model.py:462,476 gated residual).  A-operand sources:
+//   MODE 0: bf16 rows [token][384] written by the flash kernel
+//   MODE 1: bf16 rows [token][256] (IPA concat features; gate = 1; ipa.py:250-254 + latent_model.py:373)
+//   MODE 2: residue-axis micro-attention computed in the prologue from the SMALL q/k/v layout
+//           (L <= 8: five keys incl. the learned bias key; mha.py:265-268, 359-396)
+// =================================================================================================
+template <int MAXL>
+__device__ __forceinline__ void prologue_micro_attn(unsigned char* panel, const PanelRows* pr, const ProjParams& p) {
+    const int L = p.ax.len;
+    for (int item = threadIdx.x; item < kPanel * kH; item += 256) {
+        const int row = item >> 4, head = item & 15;
+        const int token = pr->tok[row];
+        u32x4 o4[3] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+        if (token >= 0) {
+            const int seq = token / L;
+            const u32x4* qp = reinterpret_cast<const u32x4*>(p.qkv_small + (long)token * (3 * kC) + head * kDH);
+            float q[24];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const u32x4 v = qp[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    q[8 * i + 2 * j] = bf16_lo(v[j]);
+                    q[8 * i + 2 * j + 1] = bf16_hi(v[j]);
+                }
+            }
+            float s[MAXL + 1];
+            float mx = -1e30f;
+#pragma unroll
+            for (int j = 0; j < MAXL; ++j) {
+                s[j] = -1e30f;
+                if (j < L) {
+                    const long kt = (long)seq * L + j;
+                    if (p.mk.at(kt) != 0.f) {
+                        const u32x4* kp = reinterpret_cast<const u32x4*>(p.qkv_small + kt * (3 * kC) + kC + head * kDH);
+                        float d = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const u32x4 v = kp[i];
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+                                d += q[8 * i + 2 * jj] * bf16_lo(v[jj]) + q[8 * i + 2 * jj + 1] * bf16_hi(v[jj]);
+                        }
+                        s[j] = d;
+                    }
+                }
+                mx = fmaxf(mx, s[j]);
+            }
+            {   // learned bias key at position L, rotated there (mha.py:265-268 before :356-357); never masked
+                const float* bk = p.bias_k + head * kDH;
+                const float* rc = p.rope + (long)L * 24;
+                float d = 0.f;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int pp = 0; pp < 6; ++pp) {
+                        const int i = 6 * hh + pp;
+                        const float x1 = bk[i], x2 = bk[i + 12], c = rc[i], sn = rc[12 + i];
+                        const float k1 = bf16_lo(pack_bf16(x1 * c - x2 * sn, 0.f));
+                        const float k2 = bf16_lo(pack_bf16(x2 * c + x1 * sn, 0.f));
+                        d += q[hh * 12 + 2 * pp] * k1 + q[hh * 12 + 2 * pp + 1] * k2;
+                    }
+                s[MAXL] = d;
+                mx = fmaxf(mx, d);
+            }
+            float o[24];
+#pragma unroll
+            for (int i = 0; i < 24; ++i) o[i] = 0.f;
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXL; ++j) {
+                if (j < L && s[j] > -1e29f) {
+                    const float pj = __builtin_amdgcn_exp2f(s[j] - mx);
+                    den += pj;
+                    const long kt = (long)seq * L + j;
+                    const u32x4* vp = reinterpret_cast<const u32x4*>(p.qkv_small + kt * (3 * kC) + 2 * kC + head * kDH);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const u32x4 v = vp[i];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            o[8 * i + 2 * jj] += pj * bf16_lo(v[jj]);
+                            o[8 * i + 2 * jj + 1] += pj * bf16_hi(v[jj]);
+                        }
+                    }
+                }
+            }
+            {
+                const float pj = __builtin_amdgcn_exp2f(s[MAXL] - mx);
+                den += pj;
+                const float* bv = p.bias_v + head * kDH;
+#pragma unroll
+                for (int i = 0; i < 24; ++i) o[i] += pj * bf16_lo(pack_bf16(bv[i], 0.f));
+            }
+            const float inv = 1.0f / den;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                o4[i] = u32x4{pack_bf16(o[8 * i] * inv, o[8 * i + 1] * inv), pack_bf16(o[8 * i + 2] * inv, o[8 * i + 3] * inv),
+                              pack_bf16(o[8 * i + 4] * inv, o[8 * i + 5] * inv), pack_bf16(o[8 * i + 6] * inv, o[8 * i + 7] * inv)};
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            *reinterpret_cast<u32x4*>(panel + panel_off(row, head * 48 + i * 16, kRowB)) = o4[i];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_proj(const ProjParams p) {
+    constexpr int K = (MODE == 1) ? kIpaFeat : kC;
+    constexpr int ROWB = K * 2;
+    constexpr int KS = K / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanel * ROWB];
+    PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
+    unsigned char* panel = smem + sizeof(PanelRows);
+    setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
+    __syncthreads();
+    if (MODE == 2)
+        prologue_micro_attn<8>(panel, pr, p);
+    else
+        prologue_bf16<K>(panel, pr, p.a_bf16);
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    f32x16 acc[6];
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, KS, false>(panel, ROWB, 0, 0, p.w + (size_t)(3 * w) * KS * 64 + lane, KS * 64, acc);
+    epilogue_gate_residual<2, 3>(acc, pr, 96 * w, p.bias, p.mm, p.gate_chunk, p.gated != 0, p.h);
+}
+
+// =================================================================================================
+// Fused MLP block:  h += gate_m * ( W2 gelu_erf( W1 (LN(h)(1+scale)+shift) + b1 ) + b2 )
+// (latent_model.py:478-481, layers.py:77-84).  The 1536-wide hidden activation never leaves the CU:
+// six chunks of 256 hidden units are produced (transposed MFMA -> 4 consecutive hidden units per
+// lane -> exact-erf GELU -> bf16 -> LDS) and immediately consumed by the fc2 MFMAs.
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
+    constexpr int HC = 256, HROWB = HC * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kPanelBytes + kPanel * HROWB];
+    unsigned char* panel = smem;
+    unsigned char* hbuf = smem + kPanelBytes;
+    PanelRows* pr = reinterpret_cast<PanelRows*>(hbuf);  // aliases hbuf: live only outside the chunk loop
+    setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
+    __syncthreads();
+    prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id(), hh = lane >> 5, tk = lane & 31;
+    f32x16 y[6];
+    zero_acc<6>(y);
+    for (int c = 0; c < kF / HC; ++c) {
+        f32x16 a1[4];
+        zero_acc<4>(a1);
+        wave_gemm<2, 2, 24, true>(panel, kRowB, 0, 0, p.w1 + (size_t)(8 * c + 2 * w) * 24 * 64 + lane, 24 * 64, a1);
+        if (c > 0) __syncthreads();  // previous chunk's fc2 reads of hbuf are complete
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int hid_local = 64 * w + 32 * ft + 8 * a + 4 * hh;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.b1 + c * HC + hid_local);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    float g[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = a1[ft * 2 + tt][4 * a + i] + b[i];
+                        g[i] = v * 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+                    }
+                    *reinterpret_cast<u32x2*>(hbuf + panel_off(tt * 32 + tk, hid_local * 2, HROWB)) =
+                        u32x2{pack_bf16(g[0], g[1]), pack_bf16(g[2], g[3])};
+                }
+            }
+        }
+        __syncthreads();
+        wave_gemm<2, 3, 16, false>(hbuf, HROWB, 0, 0, p.w2 + ((size_t)(3 * w) * 96 + 16 * c) * 64 + lane, 96 * 64, y);
+    }
+    __syncthreads();
+    setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
+    __syncthreads();
+    epilogue_gate_residual<2, 3>(y, pr, 96 * w, p.b2, p.mm, p.gate_chunk, true, p.h);
+}
+
+// =================================================================================================
+// Affine LayerNorm (eps 1e-5) + the four IPA input projections in one GEMM:
+//   out[token][672] = LN_affine(h) @ [linear_q | linear_kv | linear_q_points | linear_kv_points]^T + b
+// (latent_model.py:373 ipa_norm; ipa.py:113-138).  fp32 output, row-major.
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void k_ln_linear(const LnLinearParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
+    PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
+    unsigned char* panel = smem + sizeof(PanelRows);
+    setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
+    __syncthreads();
+    prologue_ln<true>(panel, pr, p.h, p.mm, 1, 0, 1e-5f);   // mm.mod = [gamma(C) | beta(C)]: scale chunk 0, shift chunk 1
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id(), hh = lane >> 5, n = lane & 31;
+    const int ngroups = p.nout / 96;
+    for (int g = w; g < ngroups; g += 4) {
+        f32x16 acc[6];
+        zero_acc<6>(acc);
+        wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.w + (size_t)(3 * g) * 24 * 64 + lane, 24 * 64, acc);
+        float b[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) b[f] = p.bias[96 * g + 32 * f + n];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tk = pr->tok[t * 32 + mfma_row(r, hh)];
+                if (tk >= 0) {
+                    float* op = p.out + (long)tk * p.nout + 96 * g + n;
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) op[32 * f] = acc[t * 3 + f][r] + b[f];
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// =================================================================================================
+// FinalLayer (layers.py:70-74): v = Linear_{C->D}( LN(h)(1+scale)+shift ) fused with the Euler
+// update x += dt*v (integrators.py:106, torchdiffeq fixed-grid Euler) when p.euler != 0.
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void k_final(const FinalParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
+    PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
+    unsigned char* panel = smem + sizeof(PanelRows);
+    setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
+    __syncthreads();
+    prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id(), hh = lane >> 5, n = lane & 31;
+    if (w < 2) {
+        f32x16 acc[1];
+        zero_acc<1>(acc);
+        wave_gemm<1, 1, 24, false>(panel, kRowB, w, 0, p.w + lane, 24 * 64, acc);
+        if (n < p.D) {
+            const float b = p.bias[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tk = pr->tok[w * 32 + mfma_row(r, hh)];
+                if (tk >= 0) {
+                    const float v = acc[0][r] + b;
+                    const long o = (long)tk * p.D + n;
+                    if (p.euler)
+                        p.x[o] = p.x[o] + p.dt * v;
+                    else
+                        p.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------
+void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s) {
+    if (small) {
+        const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
+        hipLaunchKernelGGL(k_ln_qkv<true>, dim3(grid), dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(k_ln_qkv<false>, dim3(p.ax.nseq * p.panels_per_seq), dim3(256), 0, s, p);
+    }
+}
+void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
+    const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
+    if (mode == 0) hipLaunchKernelGGL(k_proj<0>, dim3(grid), dim3(256), 0, s, p);
+    else if (mode == 1) hipLaunchKernelGGL(k_proj<1>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_proj<2>, dim3(grid), dim3(256), 0, s, p);
+}
+void launch_mlp(const MlpParams& p, hipStream_t s) {
+    const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
+    hipLaunchKernelGGL(k_mlp, dim3(grid), dim3(256), 0, s, p);
+}
+void launch_ln_linear(const LnLinearParams& p, hipStream_t s) {
+    const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
+    hipLaunchKernelGGL(k_ln_linear, dim3(grid), dim3(256), 0, s, p);
+}
+void launch_final(const FinalParams& p, hipStream_t s) {
+    const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
+    hipLaunchKernelGGL(k_final, dim3(grid), dim3(256), 0, s, p);
+}
+
+}  // namespace mdg

@@ -1,0 +1,308 @@
+// k_small.hip -- step-invariant / token-embedding / IPA kernels (HBM- or latency-bound, fp32).
+#include "kernels.h"
+
+namespace mdg {
+
+// -------------------------------------------------------------------------------------------------
+// TimestepEmbedder (layers.py:17-55) followed by the SiLU that opens every adaLN_modulation
+// (latent_model.py:349-352, 408-411; layers.py:66-69):  out[r] = SiLU(W2 SiLU(W0 emb(t_r*mult) + b0) + b2)
+// emb = [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(1e4) i / 128).  One block per time row.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(384) void k_temb(const float* __restrict__ t_rows, float tmul,
+                                              const float* __restrict__ w0, const float* __restrict__ b0,
+                                              const float* __restrict__ w2, const float* __restrict__ b2,
+                                              float* __restrict__ out) {
+    __shared__ float emb[256];
+    __shared__ float h1[kC];
+    const int r = blockIdx.x, c = threadIdx.x;
+    const float t = t_rows[r] * tmul;
+    if (c < 256) {
+        const int i = c & 127;
+        const float f = expf(-9.210340371976184f * (float)i / 128.0f);
+        const float a = t * f;
+        emb[c] = (c < 128) ? cosf(a) : sinf(a);
+    }
+    __syncthreads();
+    float acc = b0[c];
+    const float* wr = w0 + (long)c * 256;
+    for (int i = 0; i < 256; ++i) acc += wr[i] * emb[i];
+    h1[c] = acc / (1.0f + expf(-acc));
+    __syncthreads();
+    float acc2 = b2[c];
+    const float* wr2 = w2 + (long)c * kC;
+    for (int i = 0; i < kC; ++i) acc2 += wr2[i] * h1[i];
+    out[(long)r * kC + c] = acc2 / (1.0f + expf(-acc2));
+}
+
+// adaLN table: mod[r][o] = b[o] + sum_c W[o][c] st[r][c]  (all adaLN_modulation Linears of the model
+// concatenated along o).  One wave per output feature; lanes split K = 384.
+__global__ __launch_bounds__(256) void k_adaln(const float* __restrict__ st, int nrows, const float* __restrict__ w,
+                                               const float* __restrict__ b, int nout, float* __restrict__ mod) {
+    const int o = blockIdx.x * 4 + wave_id();
+    if (o >= nout) return;
+    const int lane = lane_id();
+    float wv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wv[i] = w[(long)o * kC + lane + 64 * i];
+    const float bo = b[o];
+    for (int r = 0; r < nrows; ++r) {
+        const float* s = st + (long)r * kC;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a += wv[i] * s[lane + 64 * i];
+        a = wave_sum(a);
+        if (lane == 0) mod[(long)r * nout + o] = a + bo;
+    }
+}
+
+// rotary table rope[pos] = [cos(pos*f_i) (12) | sin(pos*f_i) (12)], f = rot_emb.inv_freq (mha.py:130,356)
+__global__ void k_rope_table(float* __restrict__ rope, const float* __restrict__ inv_freq, int npos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npos * 12) return;
+    const int pos = i / 12, k = i % 12;
+    const float a = (float)pos * inv_freq[k];
+    rope[(long)pos * 24 + k] = cosf(a);
+    rope[(long)pos * 24 + 12 + k] = sinf(a);
+}
+
+__global__ void k_gather_f32(const float* __restrict__ src, const int* __restrict__ idx, float scale,
+                             float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = idx[i] >= 0 ? scale * src[idx[i]] : 0.f;
+}
+
+// Weight re-pack into MFMA fragment order: dst[(ft*ksteps + ks)*64 + lane] = 8 bf16 of
+// W[rowmap[ft*32 + (lane&31)]][ks*16 + (lane>>5)*8 .. +7] * scale   (rowmap < 0 -> zeros)
+__global__ void k_pack_rows(const float* __restrict__ w, int ld, const int* __restrict__ rowmap, int nft, int ksteps,
+                            float scale, bf16x8* __restrict__ dst) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)nft * ksteps * 64;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const long fk = i >> 6;
+    const int ks = (int)(fk % ksteps), ft = (int)(fk / ksteps);
+    const int row = rowmap[ft * 32 + (lane & 31)];
+    const int k0 = ks * 16 + (lane >> 5) * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)(row >= 0 && k0 + j < ld ? w[(long)row * ld + k0 + j] * scale : 0.f);
+    dst[i] = v;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Token embedding (latent_model.py:233-246):
+//   h = latent_to_emb(x) [+ pos_embed[l]] + cond_to_emb(x_cond) + mask_to_emb[x_cond_mask] + ipa_out[b,l]
+// block = 384 threads (one per channel), 32 tokens per block; the D<=28 wide weight rows live in VGPRs.
+// -------------------------------------------------------------------------------------------------
+constexpr int kEmbTok = 32;
+__global__ __launch_bounds__(384) void k_embed(const EmbedParams p) {
+    __shared__ float xs[kEmbTok][28];
+    __shared__ float cs[kEmbTok][28];
+    __shared__ int ms[kEmbTok];
+    const int c = threadIdx.x;
+    const long tok0 = (long)blockIdx.x * kEmbTok;
+    for (int i = threadIdx.x; i < kEmbTok * 28; i += 384) {
+        const int tk = i / 28, d = i % 28;
+        const long t = tok0 + tk;
+        float a = 0.f, b = 0.f;
+        if (t < p.N && d < p.D) {
+            a = p.x[t * p.D + d];
+            b = p.x_cond[t * p.D + d];
+        }
+        xs[tk][d] = a;
+        cs[tk][d] = b;
+    }
+    if (threadIdx.x < kEmbTok) {
+        const long t = tok0 + threadIdx.x;
+        ms[threadIdx.x] = (t < p.N) ? (int)p.x_cond_mask[t] : 0;
+    }
+    float wl[28], wc[28];
+#pragma unroll
+    for (int d = 0; d < 28; ++d) {
+        wl[d] = d < p.D ? p.wl[(long)c * p.D + d] : 0.f;
+        wc[d] = d < p.D ? p.wc[(long)c * p.D + d] : 0.f;
+    }
+    const float b0 = p.bl[c] + p.bc[c];
+    const float me0 = p.mask_emb[c], me1 = p.mask_emb[kC + c];
+    __syncthreads();
+    const long TL = (long)p.T * p.L;
+    for (int tk = 0; tk < kEmbTok; ++tk) {
+        const long t = tok0 + tk;
+        if (t >= p.N) break;
+        float a = b0;
+#pragma unroll
+        for (int d = 0; d < 28; ++d) a += wl[d] * xs[tk][d];
+        float a2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 28; ++d) a2 += wc[d] * cs[tk][d];
+        const int l = (int)(t % p.L);
+        const int b = (int)(t / TL);
+        a += a2 + (ms[tk] ? me1 : me0);
+        if (p.pos_embed) a += p.pos_embed[(long)l * kC + c];
+        if (p.ipa_out) a += p.ipa_out[((long)b * p.L + l) * kC + c];
+        p.h[t * kC + c] = a;
+    }
+}
+
+// IPA-stack input (latent_model.py:184-187 / 193-201): h[g,l] = aatype_emb[aatype[b,l]]
+// (+ latent_to_emb_{f,r}(rel7[b,l]) for the two-sided model); g = step*B + b.
+__global__ __launch_bounds__(384) void k_ipa_init(const float* __restrict__ aa_emb, const int64_t* __restrict__ aatype,
+                                                  const float* __restrict__ rel7, const float* __restrict__ w7,
+                                                  const float* __restrict__ b7, float* __restrict__ h, int B, int L) {
+    const long row = blockIdx.x;  // (g, l)
+    const int c = threadIdx.x;
+    const int l = (int)(row % L);
+    const int b = (int)((row / L) % B);
+    const long bl = (long)b * L + l;
+    float a = aa_emb[(long)aatype[bl] * kC + c];
+    if (rel7) {
+        a += b7[c];
+#pragma unroll
+        for (int d = 0; d < 7; ++d) a += w7[c * 7 + d] * rel7[bl * 7 + d];
+    }
+    h[row * kC + c] = a;
+}
+
+__global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+// -------------------------------------------------------------------------------------------------
+// Invariant point attention core, c_z = 0, H=4, c=32, Pq=Pv=8 (ipa.py:126-234), fp32.
+// One thread per (group, query residue, head); keys streamed with an online softmax.
+//   logit = q.k sqrt(1/96) - 0.5 softplus(w_h) sqrt(1/108) sum_p |R_i qp + t_i - R_j kp - t_j|^2
+//           + 1e5 (m_i m_j - 1)
+// out[token] = [ o(128) | o_pt.x(32) | o_pt.y(32) | o_pt.z(32) | |o_pt|(32) ] as bf16 (ipa.py:250-254)
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rot_apply(const float* R, const float* t, float x, float y, float z, float& ox,
+                                          float& oy, float& oz) {
+    ox = R[0] * x + R[1] * y + R[2] * z + t[0];
+    oy = R[3] * x + R[4] * y + R[5] * z + t[1];
+    oz = R[6] * x + R[7] * y + R[8] * z + t[2];
+}
+
+__global__ __launch_bounds__(256) void k_ipa_attn(const IpaAttnParams p) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)p.ngroups * p.L * 4;
+    if (idx >= total) return;
+    const int hd = (int)(idx & 3);
+    const long gi = idx >> 2;
+    const int i = (int)(gi % p.L);
+    const long g = gi / p.L;
+    const int b = (int)(g % p.B);
+    const float* pi = p.proj + gi * kIpaProj;
+    float Ri[9], ti[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ri[k] = p.rot[((long)b * p.L + i) * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ti[k] = p.trans[((long)b * p.L + i) * 3 + k];
+    const float mi = p.mask_bl[(long)b * p.L + i];
+    float q[32], qp[8][3];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) q[c] = pi[hd * 32 + c];
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt)
+        rot_apply(Ri, ti, pi[384 + hd * 8 + pt], pi[416 + hd * 8 + pt], pi[448 + hd * 8 + pt], qp[pt][0], qp[pt][1],
+                  qp[pt][2]);
+    const float hwraw = p.head_w[hd];
+    const float sp = (hwraw > 20.f) ? hwraw : log1pf(expf(hwraw));  // torch softplus (threshold 20)
+    const float hw = sp * 0.09622504486493763f;                     // sqrt(1/(3*(8*9/2))) = sqrt(1/108)
+    const float qk_scale = 0.10206207261596575f;                    // sqrt(1/(3*32))
+    float o[32], op[8][3];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) op[pt][0] = op[pt][1] = op[pt][2] = 0.f;
+    float mrun = -3.0e38f, den = 0.f;
+    for (int j = 0; j < p.L; ++j) {
+        const float* pj = p.proj + (g * p.L + j) * kIpaProj;
+        float Rj[9], tj[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rj[k] = p.rot[((long)b * p.L + j) * 9 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tj[k] = p.trans[((long)b * p.L + j) * 3 + k];
+        const float mj = p.mask_bl[(long)b * p.L + j];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) dot += q[c] * pj[128 + hd * 64 + c];
+        float d2 = 0.f;
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt) {
+            float kx, ky, kz;
+            rot_apply(Rj, tj, pj[480 + hd * 16 + pt], pj[544 + hd * 16 + pt], pj[608 + hd * 16 + pt], kx, ky, kz);
+            const float dx = qp[pt][0] - kx, dy = qp[pt][1] - ky, dz = qp[pt][2] - kz;
+            d2 += dx * dx + dy * dy + dz * dz;
+        }
+        const float logit = dot * qk_scale - 0.5f * hw * d2 + 1e5f * (mi * mj - 1.0f);
+        const float mnew = fmaxf(mrun, logit);
+        const float alpha = expf(mrun - mnew);
+        const float pw = expf(logit - mnew);
+        mrun = mnew;
+        den = den * alpha + pw;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) o[c] = o[c] * alpha + pw * pj[128 + hd * 64 + 32 + c];
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt) {
+            float vx, vy, vz;
+            rot_apply(Rj, tj, pj[480 + hd * 16 + 8 + pt], pj[544 + hd * 16 + 8 + pt], pj[608 + hd * 16 + 8 + pt], vx, vy,
+                      vz);
+            op[pt][0] = op[pt][0] * alpha + pw * vx;
+            op[pt][1] = op[pt][1] * alpha + pw * vy;
+            op[pt][2] = op[pt][2] * alpha + pw * vz;
+        }
+    }
+    const float inv = 1.0f / den;
+    __bf16* f = p.feat + gi * kIpaFeat;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) f[hd * 32 + c] = (__bf16)(o[c] * inv);
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {
+        const float gx = op[pt][0] * inv - ti[0], gy = op[pt][1] * inv - ti[1], gz = op[pt][2] * inv - ti[2];
+        const float lx = Ri[0] * gx + Ri[3] * gy + Ri[6] * gz;   // R^T (p - t)  (rigid_utils.py:1061-1073)
+        const float ly = Ri[1] * gx + Ri[4] * gy + Ri[7] * gz;
+        const float lz = Ri[2] * gx + Ri[5] * gy + Ri[8] * gz;
+        f[128 + hd * 8 + pt] = (__bf16)lx;
+        f[160 + hd * 8 + pt] = (__bf16)ly;
+        f[192 + hd * 8 + pt] = (__bf16)lz;
+        f[224 + hd * 8 + pt] = (__bf16)sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------
+void launch_temb(const float* t_rows, int nrows, float tmul, const float* w0, const float* b0, const float* w2,
+                 const float* b2, float* silu_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_temb, dim3(nrows), dim3(384), 0, s, t_rows, tmul, w0, b0, w2, b2, silu_out);
+}
+void launch_adaln(const float* st, int nrows, const float* w, const float* b, int nout, float* mod, hipStream_t s) {
+    hipLaunchKernelGGL(k_adaln, dim3((nout + 3) / 4), dim3(256), 0, s, st, nrows, w, b, nout, mod);
+}
+void launch_rope_table(float* rope, const float* inv_freq, int npos, hipStream_t s) {
+    hipLaunchKernelGGL(k_rope_table, dim3((npos * 12 + 255) / 256), dim3(256), 0, s, rope, inv_freq, npos);
+}
+void launch_gather_f32(const float* src, const int* idx, float scale, float* dst, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_f32, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, scale, dst, n);
+}
+void launch_pack_rows(const float* w, int ld, const int* rowmap, int nft, int ksteps, float scale, bf16x8* dst,
+                      hipStream_t s) {
+    const long total = (long)nft * ksteps * 64;
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, ld, rowmap, nft, ksteps,
+                       scale, dst);
+}
+void launch_embed(const EmbedParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(k_embed, dim3((unsigned)((p.N + kEmbTok - 1) / kEmbTok)), dim3(384), 0, s, p);
+}
+void launch_ipa_init(const float* aa_emb, const int64_t* aatype, const float* rel7, const float* w7, const float* b7,
+                     float* h, int ngroups, int B, int L, hipStream_t s) {
+    hipLaunchKernelGGL(k_ipa_init, dim3((unsigned)((long)ngroups * L)), dim3(384), 0, s, aa_emb, aatype, rel7, w7, b7, h,
+                       B, L);
+}
+void launch_add_inplace(float* dst, const float* src, long n, hipStream_t s) {
+    hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n);
+}
+void launch_ipa_attn(const IpaAttnParams& p, hipStream_t s) {
+    const long total = (long)p.ngroups * p.L * 4;
+    hipLaunchKernelGGL(k_ipa_attn, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+}
+
+}  // namespace mdg

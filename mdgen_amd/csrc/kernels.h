@@ -1,0 +1,141 @@
+// kernels.h -- parameter blocks and launchers shared between the kernels (*.hip) and api.cpp
+#pragma once
+#include "common.h"
+
+namespace mdg {
+
+struct QkvParams {
+    const float* h;        // residual stream [N][384] fp32
+    long nrows;            // N (SMALL layout: natural-order panels)
+    AxisMap ax;            // attention axis
+    ModMap mm;
+    int shift_chunk, scale_chunk;
+    const bf16x8 *wq, *wk, *wv;   // packed fragments [12 ftile][24 kstep][64 lane][8]
+    const float *bq, *bk, *bv;    // permuted biases [384]
+    const float* rope;     // [P][24] = 12 cos | 12 sin per position
+    unsigned char *qf, *kf, *vf;  // FLASH layout fragment buffers
+    __bf16* qkv_small;     // SMALL layout [token][3][16 head][2 half][12]
+    int panels_per_seq;
+};
+
+struct ProjParams {
+    float* h;
+    long nrows;
+    ModMap mm;
+    int gate_chunk;
+    int gated;
+    const bf16x8* w;       // packed [12 ftile][K/16][64][8]
+    const float* bias;
+    const __bf16* a_bf16;  // MODE 0/1 A rows
+    // MODE 2 (micro attention)
+    const __bf16* qkv_small;
+    AxisMap ax;
+    MaskMap mk;
+    const float *bias_k, *bias_v;
+    const float* rope;
+};
+
+struct MlpParams {
+    float* h;
+    long nrows;
+    ModMap mm;
+    int shift_chunk, scale_chunk, gate_chunk;
+    const bf16x8 *w1, *w2;  // w1 [48 ftile][24][64][8]; w2 [12 ftile][96][64][8]
+    const float *b1, *b2;
+};
+
+struct LnLinearParams {
+    const float* h;
+    long nrows;
+    ModMap mm;              // mm.mod = [gamma | beta]
+    const bf16x8* w;        // packed [nout/32][24][64][8]
+    const float* bias;
+    float* out;             // [nrows][nout] fp32
+    int nout;               // multiple of 96
+};
+
+struct FinalParams {
+    const float* h;
+    long nrows;
+    ModMap mm;
+    int shift_chunk, scale_chunk;
+    const bf16x8* w;        // packed [1 ftile][24][64][8] (rows >= D are zero)
+    const float* bias;      // [32]
+    int D;
+    int euler;
+    float dt;
+    float* x;               // euler: state updated in place
+    float* out;             // !euler: velocity
+};
+
+struct FlashParams {
+    AxisMap ax;
+    MaskMap mk;
+    const unsigned char *qf, *kf, *vf;
+    const float *bias_k, *bias_v;  // natural fp32 [384]
+    const float* rope;
+    __bf16* obuf;           // [N][384]
+};
+
+struct EmbedParams {
+    const float *x, *x_cond;
+    const int64_t* x_cond_mask;
+    const float *wl, *bl, *wc, *bc;  // latent_to_emb / cond_to_emb fp32 [C][D], [C]
+    const float* mask_emb;           // [2][C]
+    const float* pos_embed;          // [crop][C] or nullptr
+    const float* ipa_out;            // [B*L][C] for this step
+    float* h;
+    long N;
+    int T, L, D;
+};
+
+struct IpaAttnParams {
+    const float* proj;      // [M][672]
+    const float *rot, *trans;  // [B][L][3][3], [B][L][3]
+    const float* mask_bl;   // [B][L]
+    const float* head_w;    // [4]
+    __bf16* feat;           // [M][256]
+    int ngroups, B, L;
+};
+
+void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s);
+void launch_proj(const ProjParams& p, int mode, hipStream_t s);
+void launch_mlp(const MlpParams& p, hipStream_t s);
+void launch_ln_linear(const LnLinearParams& p, hipStream_t s);
+void launch_final(const FinalParams& p, hipStream_t s);
+void launch_flash(const FlashParams& p, hipStream_t s);
+void launch_embed(const EmbedParams& p, hipStream_t s);
+void launch_ipa_attn(const IpaAttnParams& p, hipStream_t s);
+
+// small kernels (k_small.hip)
+void launch_temb(const float* t_rows, int nrows, float tmul, const float* w0, const float* b0, const float* w2,
+                 const float* b2, float* silu_out, hipStream_t s);
+void launch_adaln(const float* st, int nrows, const float* w, const float* b, int nout, float* mod, hipStream_t s);
+void launch_rope_table(float* rope, const float* inv_freq, int npos, hipStream_t s);
+void launch_gather_f32(const float* src, const int* idx, float scale, float* dst, int n, hipStream_t s);
+void launch_pack_rows(const float* w, int ld, const int* rowmap, int nft, int ksteps, float scale, bf16x8* dst,
+                      hipStream_t s);
+void launch_ipa_init(const float* aa_emb, const int64_t* aatype, const float* rel7, const float* w7, const float* b7,
+                     float* h, int ngroups, int B, int L, hipStream_t s);
+void launch_add_inplace(float* dst, const float* src, long n, hipStream_t s);
+void launch_rel7(const float* r1, const float* t1, const float* r2, const float* t2, float* out7, long n, hipStream_t s);
+
+// SE(3) / pre / post (k_se3.hip)
+void launch_rigid_compose(long n, const float* r1, const float* t1, const float* r2, const float* t2, float* ro,
+                          float* to, hipStream_t s);
+void launch_rigid_invert(long n, const float* r, const float* t, float* ro, float* to, hipStream_t s);
+void launch_rigid_apply(long n, long ppf, const float* r, const float* t, const float* pts, float* out, int inverse,
+                        hipStream_t s);
+void launch_quat_to_rot(long n, const float* q, int normalize, float* rot, hipStream_t s);
+void launch_rot_to_quat(long n, const float* rot, float* q, hipStream_t s);
+void launch_prep_latents(int B, int T, int L, int tps, const float* rots, const float* trans, const float* tors,
+                         float* latents, float* x_cond, int64_t* x_cond_mask, hipStream_t s);
+void launch_samples_to_atom14(int B, int T, int L, int D, int tps, const float* samples, const float* rot0,
+                              const float* trans0, const int64_t* seqres, const float* default_frames,
+                              const float* lit_positions, const int64_t* atom14_group, const float* atom14_mask,
+                              float* atom14, hipStream_t s);
+void launch_atom14_to_cond(int B, int L, const float* atom14, const int64_t* seqres, const int64_t* a37to14,
+                           const float* a37mask, const int64_t* chi_idx, const float* chi_mask, float* rots,
+                           float* trans, float* tors, float* tmask, hipStream_t s);
+
+}  // namespace mdg

@@ -1,0 +1,204 @@
+// panel.h -- device building blocks of the "resident A-panel" GEMM family (gfx950).
+//
+// Design (DESIGN.md "GEMM family"): a workgroup owns a panel of 64 token rows.  The panel's
+// activations are normalised/modulated once and kept in LDS as bf16 [64][K] with an XOR swizzle
+// that makes the MFMA fragment reads (ds_read_b128) bank-conflict free.  Weights are pre-packed
+// at load time into MFMA fragment order, so each wave streams its own weight slab straight from
+// L2 into VGPRs with fully coalesced 1 KiB loads -- no LDS staging and no barriers in the K loop.
+#pragma once
+#include "common.h"
+
+namespace mdg {
+
+// ---- LDS panel addressing -----------------------------------------------------------------
+// Row r holds K bf16 (ROWB = 2K bytes, a multiple of 256).  Byte offset b within the row is
+// stored at b ^ ((r & 15) << 4): the 16 rows a ds_read_b128 lane-group touches land on 16
+// distinct 16-byte slots of the 256-byte bank row (MI355X_MICROARCH LDS table).
+__device__ __forceinline__ int panel_off(int row, int byte_in_row, int rowb) {
+    return row * rowb + (byte_in_row ^ ((row & 15) << 4));
+}
+
+// MFMA operand fragment (32 rows x 16 k) for k-step ks from the panel: lane -> row (lane&31),
+// k = ks*16 + (lane>>5)*8 .. +7  (the same k mapping the packed weights use).
+__device__ __forceinline__ bf16x8 panel_frag(const unsigned char* panel, const int rowb, int tile, int ks) {
+    const int lane = lane_id();
+    const int row = tile * 32 + (lane & 31);
+    return *reinterpret_cast<const bf16x8*>(panel + panel_off(row, ks * 32 + (lane >> 5) * 16, rowb));
+}
+
+// ---- wave-level GEMM ------------------------------------------------------------------------
+// TT token tiles (32 rows of the panel each) x FT feature tiles (32 weight rows each), K = 16*KSTEPS.
+// wfrag points at this lane's 16 bytes of the first feature tile's first k-step; feature tile f,
+// k-step k lives (f*wtile_stride + k*64) bf16x8 further (packed layout [ftile][kstep][lane][8]).
+// TRANS = false: acc[tt*FT+ft] = D[token][feature]  (A = activations, B = weights)
+// TRANS = true : acc[ft*TT+tt] = D[feature][token]  (A = weights,      B = activations)
+template <int TT, int FT, int KSTEPS, bool TRANS, int PF = 3>
+__device__ __forceinline__ void wave_gemm(const unsigned char* panel, const int rowb, const int tile0, const int ks0,
+                                          const bf16x8* __restrict__ wfrag, const int wtile_stride,
+                                          f32x16* acc) {
+    bf16x8 wring[PF + 1][FT];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int f = 0; f < FT; ++f) wring[p][f] = wfrag[(size_t)f * wtile_stride + p * 64];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        if (ks + PF < KSTEPS) {
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+                wring[(ks + PF) % (PF + 1)][f] = wfrag[(size_t)f * wtile_stride + (ks + PF) * 64];
+        }
+        bf16x8 a[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) a[t] = panel_frag(panel, rowb, tile0 + t, ks0 + ks);
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int f = 0; f < FT; ++f) {
+                if (TRANS)
+                    acc[f * TT + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[ks % (PF + 1)][f], a[t],
+                                                                             acc[f * TT + t], 0, 0, 0);
+                else
+                    acc[t * FT + f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], wring[ks % (PF + 1)][f],
+                                                                             acc[t * FT + f], 0, 0, 0);
+            }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void zero_acc(f32x16* acc) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+}
+
+// ---- panel row table (LDS) ----------------------------------------------------------------------
+// tok[r]  = global token row of panel row r, or -1 for padding rows
+// moff[r] = offset (floats) of that token's adaLN table row inside ModMap::mod
+struct PanelRows {
+    int tok[kPanel];
+    int moff[kPanel];
+};
+
+// rows = positions pos0 .. pos0+63 of sequence `seq` along an attention axis
+__device__ __forceinline__ void setup_rows_axis(PanelRows* pr, const AxisMap ax, int seq, int pos0, const ModMap mm) {
+    if (threadIdx.x < kPanel) {
+        const int pos = pos0 + threadIdx.x;
+        long t = -1, mo = 0;
+        if (pos < ax.len) {
+            t = ax.token(seq, pos);
+            mo = mm.row_off(t);
+        }
+        pr->tok[threadIdx.x] = (int)t;
+        pr->moff[threadIdx.x] = (int)mo;
+    }
+}
+
+// rows = natural token order row0 .. row0+63 (clipped at nrows)
+__device__ __forceinline__ void setup_rows_linear(PanelRows* pr, long row0, long nrows, const ModMap mm) {
+    if (threadIdx.x < kPanel) {
+        long t = row0 + threadIdx.x, mo = 0;
+        if (t < nrows) mo = mm.row_off(t); else t = -1;
+        pr->tok[threadIdx.x] = (int)t;
+        pr->moff[threadIdx.x] = (int)mo;
+    }
+}
+
+// ---- panel prologues --------------------------------------------------------------------------
+// LayerNorm (no affine, eps) + adaLN modulate  y = LN(x)*(1+scale)+shift   (layers.py:14-15), or
+// affine LayerNorm y = LN(x)*gamma+beta (AFFINE; nn.LayerNorm of IPALayer.ipa_norm, eps 1e-5).
+// 256 threads; wave w normalises rows w, w+4, ...; a row is 384 fp32 = 6 per lane as 3 float2.
+// `tok[r]` (in LDS) = global token row of panel row r, or -1 for padding rows (written as zeros).
+template <bool AFFINE>
+__device__ __forceinline__ void prologue_ln(unsigned char* panel, const PanelRows* pr, const float* __restrict__ x,
+                                            const ModMap mm, int shift_chunk, int scale_chunk, float eps) {
+    const int lane = lane_id(), w = wave_id();
+    constexpr int ROWB = kC * 2;
+    for (int r = w; r < kPanel; r += 4) {
+        const long t = pr->tok[r];
+        f32x2 v[3];
+        if (t >= 0) {
+            const f32x2* xr = reinterpret_cast<const f32x2*>(x + t * kC);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[i] = xr[lane + 64 * i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[i] = f32x2{0.f, 0.f};
+        }
+        float s = (v[0][0] + v[0][1]) + (v[1][0] + v[1][1]) + (v[2][0] + v[2][1]);
+        const float mean = wave_sum(s) * (1.0f / kC);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            v[i][0] -= mean;
+            v[i][1] -= mean;
+            q += v[i][0] * v[i][0] + v[i][1] * v[i][1];
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kC) + eps);
+        if (t >= 0) {
+            const float* mrow = AFFINE ? mm.mod : mm.mod + pr->moff[r];
+            const f32x2* sh = reinterpret_cast<const f32x2*>(mrow + shift_chunk * kC);
+            const f32x2* sc = reinterpret_cast<const f32x2*>(mrow + scale_chunk * kC);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const f32x2 a = sc[lane + 64 * i], b = sh[lane + 64 * i];
+                const float m0 = AFFINE ? a[0] : 1.0f + a[0];
+                const float m1 = AFFINE ? a[1] : 1.0f + a[1];
+                const float y0 = v[i][0] * rstd * m0 + b[0];
+                const float y1 = v[i][1] * rstd * m1 + b[1];
+                *reinterpret_cast<uint32_t*>(panel + panel_off(r, 4 * lane + 256 * i, ROWB)) = pack_bf16(y0, y1);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                *reinterpret_cast<uint32_t*>(panel + panel_off(r, 4 * lane + 256 * i, ROWB)) = 0u;
+        }
+    }
+}
+
+// Plain bf16 rows [token][K] -> panel (K = 384 or 256).  16-byte chunks, 256 threads.
+template <int K>
+__device__ __forceinline__ void prologue_bf16(unsigned char* panel, const PanelRows* pr, const __bf16* __restrict__ src) {
+    constexpr int ROWB = K * 2;
+    constexpr int CPR = ROWB / 16;  // 16-byte chunks per row
+    for (int i = threadIdx.x; i < kPanel * CPR; i += 256) {
+        const int r = i / CPR, c = i % CPR;
+        const long t = pr->tok[r];
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (t >= 0) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(src) + t * ROWB + c * 16);
+        *reinterpret_cast<u32x4*>(panel + panel_off(r, c * 16, ROWB)) = v;
+    }
+}
+
+// Epilogue: residual update  h[token][col] += gate[col] * (acc + bias[col])   (latent_model.py:462,476,481)
+// acc tile is D[token][feature] (non-transposed).  gate == nullptr -> 1 (IPA linear_out residual).
+template <int TT, int FT>
+__device__ __forceinline__ void epilogue_gate_residual(const f32x16* acc, const PanelRows* pr, int col0,
+                                                       const float* __restrict__ bias, const ModMap mm,
+                                                       int gate_chunk, bool gated, float* __restrict__ h) {
+    const int lane = lane_id();
+    const int hh = lane >> 5, n = lane & 31;
+    float b[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) b[f] = bias[col0 + f * 32 + n];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = t * 32 + mfma_row(r, hh);
+            const int tk = pr->tok[row];
+            if (tk >= 0) {
+                float* hp = h + (long)tk * kC + col0 + n;
+                const float* gp = mm.mod + pr->moff[row] + gate_chunk * kC + col0 + n;
+#pragma unroll
+                for (int f = 0; f < FT; ++f) {
+                    const float g = gated ? gp[f * 32] : 1.0f;
+                    hp[f * 32] = hp[f * 32] + g * (acc[t * FT + f][r] + b[f]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace mdg

@@ -1,0 +1,226 @@
+"""`LatentMDGenModel` -- drop-in for `mdgen.model.latent_model.LatentMDGenModel` (inference path).
+
+`forward` / `forward_inference` keep the reference signature (latent_model.py:212-216, 263-269) and
+dispatch to `mdgen_denoiser_forward`; `sample_euler` runs the whole S-step Euler rollout
+(`mdgen_sample_euler`, optionally replayed from a hipGraph).  All arithmetic is in libmdgen_amd.so;
+this class owns the opaque context, the workspaces and persistent staging buffers (stable pointers
+are what make hipGraph replay possible).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import lib, check, ptr, require_cuda
+from .config import ModelConfig
+from .rigid_utils import Rigid
+
+
+def _frames(fr):
+    """Rigid | (rot, trans) | None -> (rot [B,L,3,3], trans [B,L,3]) contiguous fp32."""
+    if fr is None:
+        return None, None
+    if isinstance(fr, Rigid):
+        r, t = fr.get_rots().get_rot_mats(), fr.get_trans()
+    else:
+        r, t = fr
+    return r.to(torch.float32).contiguous(), t.to(torch.float32).contiguous()
+
+
+class LatentMDGenModel:
+    def __init__(self, cfg: ModelConfig, device: Optional[torch.device] = None):
+        if isinstance(cfg, ModelConfig) is False:
+            cfg = ModelConfig.from_args(cfg)
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise L.MdgenError("mdgen_amd.LatentMDGenModel needs a GPU (gfx950); there is no CPU path")
+        d = L.ModelDesc(cfg.embed_dim, cfg.mha_heads, cfg.num_layers, cfg.latent_dim, cfg.ipa_heads,
+                        cfg.ipa_head_dim, cfg.ipa_qk, cfg.ipa_v, int(cfg.abs_pos_emb), cfg.crop,
+                        int(cfg.tps_condition), float(cfg.time_multiplier))
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.mdgen_ctx_create(C.byref(self._ctx), C.byref(d)))
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._stage: Dict[tuple, dict] = {}
+        self._side = None
+        self._loaded = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                lib.mdgen_ctx_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    # ---- weights ----------------------------------------------------------------------------
+    def weight_names(self):
+        n = lib.mdgen_ctx_num_weights(self._ctx)
+        return [lib.mdgen_ctx_weight_name(self._ctx, i).decode() for i in range(n)]
+
+    def load_state_dict(self, sd, strict: bool = True):
+        """`sd`: the reference's `LatentMDGenModel.state_dict()` (keys of SURVEY.md section 8(b))."""
+        names = set(self.weight_names())
+        missing = [k for k in names if k not in sd]
+        unexpected = [k for k in sd if k not in names]
+        if strict and (missing or unexpected):
+            raise L.MdgenError(f"state_dict mismatch: missing={missing[:5]} unexpected={unexpected[:5]}")
+        keep = []
+        with torch.cuda.device(self.device):
+            s = L.stream_ptr()
+            for k in names:
+                if k not in sd:
+                    continue
+                t = sd[k].detach().to(device=self.device, dtype=torch.float32).contiguous()
+                keep.append(t)
+                shp = (C.c_int64 * t.dim())(*t.shape)
+                check(lib.mdgen_ctx_set_weight(self._ctx, k.encode(), ptr(t), shp, t.dim(), s))
+            check(lib.mdgen_ctx_finalize(self._ctx, s))
+            torch.cuda.current_stream().synchronize()   # packing kernels read `keep` asynchronously
+        self._loaded = True
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        if torch.device(device).type != "cuda":
+            raise L.MdgenError("mdgen_amd has no CPU path")
+        return self
+
+    # ---- measurement ------------------------------------------------------------------------
+    def profile(self, on: bool):
+        check(lib.mdgen_profile_enable(self._ctx, int(on)))
+
+    def profile_report(self) -> dict:
+        """{"kernel class": {"count": n, "ms": total}} measured with hipEvents on the launch stream."""
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        with torch.cuda.device(self.device):
+            check(lib.mdgen_profile_report(self._ctx, L.stream_ptr(), buf, len(buf)))
+        return json.loads(buf.value.decode())
+
+    # ---- workspace --------------------------------------------------------------------------
+    def workspace_layout(self, B, T, L_, S, t_shared):
+        lay = L.WsLayout()
+        sh = L.Shape(B, T, L_)
+        check(lib.mdgen_workspace_layout(self._ctx, C.byref(sh), S, int(t_shared), C.byref(lay)))
+        return lay
+
+    def _workspace(self, B, T, L_, S, t_shared):
+        key = (B, T, L_, S, int(t_shared))
+        ws = self._ws.get(key)
+        if ws is None:
+            lay = self.workspace_layout(B, T, L_, S, t_shared)
+            ws = torch.empty(lay.total_bytes, dtype=torch.uint8, device=self.device)
+            self._ws.clear()           # one live workspace (they are large)
+            self._stage.clear()
+            self._ws[key] = ws
+        return ws
+
+    # ---- forward ----------------------------------------------------------------------------
+    def _check_inputs(self, x, mask, x_cond, x_cond_mask, aatype):
+        if x_cond is None or x_cond_mask is None or aatype is None:
+            raise L.MdgenError("x_cond, x_cond_mask and aatype are required (conditional models only)")
+        if x.dim() != 4 or x.shape[-1] != self.cfg.latent_dim:
+            raise L.MdgenError(f"x must be (B,T,L,{self.cfg.latent_dim}), got {tuple(x.shape)}")
+        B, T, L_, _ = x.shape
+        if tuple(mask.shape) != (B, T, L_):
+            raise L.MdgenError(f"mask must be (B,T,L)={B, T, L_}, got {tuple(mask.shape)}")
+        return B, T, L_
+
+    def forward(self, x, t, mask, start_frames=None, end_frames=None, x_cond=None, x_cond_mask=None, aatype=None,
+                return_trace: bool = False):
+        """latent_model.py:212-260 (non-design path).  Returns the velocity (B,T,L,D) fp32."""
+        B, T, L_ = self._check_inputs(x, mask, x_cond, x_cond_mask, aatype)
+        require_cuda(x, t, mask, x_cond, x_cond_mask, aatype)
+        sr, st = _frames(start_frames)
+        er, et = _frames(end_frames)
+        if sr is None:
+            raise L.MdgenError("start_frames is required (prepend_ipa models)")
+        x = x.to(torch.float32).contiguous()
+        t = t.to(torch.float32).contiguous()
+        mask = mask.to(torch.float32).contiguous()
+        x_cond = x_cond.to(torch.float32).contiguous()
+        x_cond_mask = x_cond_mask.to(torch.int64).contiguous()
+        aatype = aatype.to(torch.int64).contiguous()
+        out = torch.empty_like(x)
+        ws = self._workspace(B, T, L_, 1, B == 1)
+        nl = self.cfg.num_layers
+        tr_h = torch.empty(nl + 1, B * T * L_, self.cfg.embed_dim, device=x.device) if return_trace else None
+        tr_i = torch.empty(B * L_, self.cfg.embed_dim, device=x.device) if return_trace else None
+        sh = L.Shape(B, T, L_)
+        with torch.cuda.device(self.device):
+            check(lib.mdgen_denoiser_forward(self._ctx, C.byref(sh), ptr(x), ptr(t), ptr(mask), ptr(sr), ptr(st),
+                                             ptr(er), ptr(et), ptr(x_cond), ptr(x_cond_mask), ptr(aatype), ptr(out),
+                                             ptr(tr_h), ptr(tr_i), ptr(ws), ws.numel(), L.stream_ptr()))
+        if return_trace:
+            C_ = self.cfg.embed_dim
+            trace = {"ipa_out": tr_i.view(B, L_, C_)}
+            for i in range(nl + 1):
+                trace[f"h{i}"] = tr_h[i].view(B, T, L_, C_)
+            return out, trace
+        return out
+
+    forward_inference = forward
+    __call__ = forward
+
+    # ---- Euler rollout ----------------------------------------------------------------------
+    def sample_euler(self, zs, num_steps: int, mask=None, start_frames=None, end_frames=None, x_cond=None,
+                     x_cond_mask=None, aatype=None, use_graph: bool = True):
+        """x <- zs; for i < S: x += (t[i+1]-t[i]) * model(x, t[i]) on t = linspace(0,1,S+1); returns x.
+        (transport.py:408-451 + integrators.py:95-114 + torchdiffeq fixed-grid Euler.)"""
+        B, T, L_ = self._check_inputs(zs, mask, x_cond, x_cond_mask, aatype)
+        require_cuda(zs, mask, x_cond, x_cond_mask, aatype)
+        S = int(num_steps)
+        sr, st = _frames(start_frames)
+        er, et = _frames(end_frames)
+        if sr is None:
+            raise L.MdgenError("start_frames is required")
+        ws = self._workspace(B, T, L_, S, True)
+        key = (B, T, L_, S)
+        stg = self._stage.get(key)
+        if stg is None:   # persistent staging buffers: stable device pointers => hipGraph replay
+            dev = self.device
+            stg = dict(
+                x=torch.empty(B, T, L_, self.cfg.latent_dim, device=dev), mask=torch.empty(B, T, L_, device=dev),
+                sr=torch.empty(B, L_, 3, 3, device=dev), st=torch.empty(B, L_, 3, device=dev),
+                er=torch.empty(B, L_, 3, 3, device=dev), et=torch.empty(B, L_, 3, device=dev),
+                x_cond=torch.empty(B, T, L_, self.cfg.latent_dim, device=dev),
+                x_cond_mask=torch.empty(B, T, L_, dtype=torch.int64, device=dev),
+                aatype=torch.empty(B, L_, dtype=torch.int64, device=dev))
+            self._stage[key] = stg
+        stg["x"].copy_(zs)
+        stg["mask"].copy_(mask)
+        stg["sr"].copy_(sr)
+        stg["st"].copy_(st)
+        if er is not None:
+            stg["er"].copy_(er)
+            stg["et"].copy_(et)
+        stg["x_cond"].copy_(x_cond)
+        stg["x_cond_mask"].copy_(x_cond_mask)
+        stg["aatype"].copy_(aatype)
+        has_end = er is not None
+        sh = L.Shape(B, T, L_)
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream()
+            if use_graph:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                self._side.wait_stream(cur)
+                stream = self._side
+            else:
+                stream = cur
+            check(lib.mdgen_sample_euler(
+                self._ctx, C.byref(sh), S, ptr(stg["x"]), ptr(stg["mask"]), ptr(stg["sr"]), ptr(stg["st"]),
+                ptr(stg["er"]) if has_end else None, ptr(stg["et"]) if has_end else None, ptr(stg["x_cond"]),
+                ptr(stg["x_cond_mask"]), ptr(stg["aatype"]), ptr(ws), ws.numel(), int(use_graph),
+                C.c_void_p(stream.cuda_stream)))
+            if use_graph:
+                cur.wait_stream(self._side)
+        return stg["x"].clone()

@@ -1,0 +1,136 @@
+"""`NewMDGenWrapper` -- drop-in for the inference surface of `mdgen.wrapper.NewMDGenWrapper`
+(wrapper.py:175-221 `__init__`, :283-365 `prep_batch`, :405-484 `inference`) plus
+`load_from_checkpoint` for Lightning-format checkpoints (SURVEY.md section 5 "Checkpoint / resume"),
+without Lightning.  Training hooks / EMA / logging are out of scope."""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+from functools import partial
+
+import torch
+
+from . import _lib as L
+from ._lib import lib, check, ptr, require_cuda
+from .config import ModelConfig
+from .geometry import samples_to_atom14
+from .model import LatentMDGenModel
+from .rigid_utils import Rigid, Rotation
+from .transport import Sampler, create_transport
+
+_BACKFILL = ["inpainting", "no_torsion", "hyena", "no_aa_emb", "supervise_all_torsions", "supervise_no_torsions",
+             "design_key_frames", "no_design_torsion", "cond_interval", "mpnn", "dynamic_mpnn", "no_offsets",
+             "no_frames", "design", "tps_condition", "sim_condition", "abs_pos_emb", "prepend_ipa", "oracle"]
+_UNSUPPORTED = ["inpainting", "hyena", "no_aa_emb", "design_key_frames", "mpnn", "dynamic_mpnn", "no_offsets",
+                "no_frames", "design", "no_torsion", "no_design_torsion", "cond_interval", "interleave_ipa",
+                "abs_time_emb", "oracle", "no_rope"]
+
+
+def default_args(cfg: ModelConfig) -> argparse.Namespace:
+    a = argparse.Namespace(**cfg.to_dict())
+    a.path_type, a.prediction, a.sampling_method = "GVP", "velocity", "euler"
+    return a
+
+
+class NewMDGenWrapper:
+    def __init__(self, args, device="cuda"):
+        if isinstance(args, ModelConfig):
+            args = default_args(args)
+        for k in _BACKFILL:                       # wrapper.py:178-194: newer flags default to False
+            if not hasattr(args, k):
+                setattr(args, k, False)
+        bad = [k for k in _UNSUPPORTED if getattr(args, k, False)]
+        if bad:
+            raise L.MdgenError(f"flags outside the accelerated sampler path: {bad}")
+        if not getattr(args, "prepend_ipa", False):
+            raise L.MdgenError("the accelerated path implements the prepend_ipa models (README.md:48,60)")
+        self.args = args
+        self.cfg = ModelConfig.from_args(args)
+        self.latent_dim = self.cfg.latent_dim
+        self.device = torch.device(device)
+        self.model = LatentMDGenModel(self.cfg, self.device)
+        self.transport = create_transport(args, getattr(args, "path_type", "GVP"), getattr(args, "prediction", "velocity"))
+        self.transport_sampler = Sampler(self.transport)
+
+    # Lightning surface used by the drivers (sim_inference.py:129-130)
+    @classmethod
+    def load_from_checkpoint(cls, path, device="cuda"):
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        args = ckpt["hyper_parameters"]["args"]
+        w = cls(args, device=device)
+        sd = {k[len("model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("model.")}
+        w.model.load_state_dict(sd)
+        return w
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        self.model.to(device)
+        return self
+
+    # ---------------------------------------------------------------------------------------------
+    def prep_batch(self, batch):
+        """wrapper.py:283-365 (sim_condition / tps_condition paths)."""
+        trans = batch["trans"].to(torch.float32).contiguous()
+        rots = batch["rots"].to(torch.float32).contiguous()
+        tors = batch["torsions"].to(torch.float32).contiguous()
+        require_cuda(trans, rots, tors)
+        B, T, L_ = trans.shape[:3]
+        tps = bool(self.args.tps_condition)
+        D = self.latent_dim
+        dev = trans.device
+        latents = torch.empty(B, T, L_, D, device=dev)
+        x_cond = torch.empty(B, T, L_, D, device=dev)
+        cond_mask = torch.empty(B, T, L_, dtype=torch.int64, device=dev)
+        sh = L.Shape(B, T, L_)
+        check(lib.mdgen_prep_latents(C.byref(sh), int(tps), ptr(rots), ptr(trans), ptr(tors), ptr(latents), ptr(x_cond),
+                                     ptr(cond_mask), L.stream_ptr()))
+        rigids = Rigid(Rotation(rot_mats=rots), trans)
+        mask = batch["mask"].to(torch.float32)
+        frame_lm = mask.unsqueeze(-1).expand(-1, -1, 7)
+        if tps:
+            frame_lm = torch.cat([frame_lm, frame_lm], -1)
+        tors_lm = batch["torsion_mask"].unsqueeze(-1).expand(-1, -1, -1, 2).reshape(B, L_, 14)
+        if getattr(self.args, "supervise_all_torsions", False):
+            tors_lm = torch.ones_like(tors_lm)
+        elif getattr(self.args, "supervise_no_torsions", False):
+            tors_lm = torch.zeros_like(tors_lm)
+        loss_mask = torch.cat([frame_lm, tors_lm.to(frame_lm.dtype)], -1).unsqueeze(1).expand(-1, T, -1, -1)
+        return {
+            "rigids": rigids,
+            "latents": latents,
+            "loss_mask": loss_mask,
+            "model_kwargs": {
+                "start_frames": rigids[:, 0],
+                "end_frames": rigids[:, -1],
+                "mask": mask.unsqueeze(1).expand(-1, T, -1),
+                "aatype": batch["seqres"],
+                "x_cond": x_cond,
+                "x_cond_mask": cond_mask,
+            },
+        }
+
+    def inference(self, batch, zs=None, num_steps=None, use_graph=True):
+        """wrapper.py:405-484.  Extra keywords (defaults reproduce the reference): `zs` explicit noise
+        (reference: device randn, wrapper.py:439), `num_steps` Euler steps S (reference: 50 grid points = 49
+        steps, wrapper.py:441-442 / transport.py:412)."""
+        prep = self.prep_batch(batch)
+        rigids = prep["rigids"]
+        B, T, L_ = rigids.shape
+        dev = prep["latents"].device
+        if zs is None:
+            zs = torch.randn(B, T, L_, self.latent_dim, device=dev)
+        S = 49 if num_steps is None else int(num_steps)
+        kw = dict(prep["model_kwargs"])
+        kw["mask"] = kw["mask"].contiguous()
+        if not self.args.tps_condition:
+            kw["end_frames"] = None
+        sample_fn = self.transport_sampler.sample_ode(sampling_method="euler", num_steps=S + 1)
+        samples = sample_fn(zs, partial(self.model.forward_inference, **kw))[-1]
+        r0 = rigids[:, 0]
+        atom14 = samples_to_atom14(samples, r0.get_rots().get_rot_mats(), r0.get_trans(), batch["seqres"],
+                                   bool(self.args.tps_condition))
+        aa_out = batch["seqres"][:, None].expand(B, T, L_)
+        self.last_samples = samples
+        return atom14, aa_out

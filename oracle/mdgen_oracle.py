@@ -315,39 +315,50 @@ def ipa(P, pre, s, R, t, mask, H=4, c=32, Pq=8, Pv=8, inf=1e5, eps=1e-8):
     return linear(P, pre + "linear_out", cat)
 
 
-def ipa_layer(P, pre, x, t, mask, R, tr, heads):
-    """IPALayer.forward (latent_model.py:369-384)."""
+def ipa_layer(P, pre, x, t, mask, R, tr, heads, skip=0):
+    """IPALayer.forward (latent_model.py:369-384).  `skip` (tests only) drops sub-layers, mirroring the
+    library's MDGEN_DEBUG_SKIP bits 3/4/5."""
     C = x.shape[-1]
     mod = linear(P, pre + "adaLN_modulation.1", F.silu(t))
     sh_l, sc_l, g_l, sh_m, sc_m, g_m = mod.chunk(6, dim=-1)
-    xn = F.layer_norm(x, (C,), P[pre + "ipa_norm.weight"], P[pre + "ipa_norm.bias"], 1e-5)
-    x = x + ipa(P, pre + "ipa.", xn, R, tr, mask)
-    y = mha_rope(P, pre + "mha_l.attn.", modulate(ln(x), sh_l, sc_l), mask, heads)
-    x = x + g_l.unsqueeze(1) * y
-    y = linear(P, pre + "fc2", gelu(linear(P, pre + "fc1", modulate(ln(x), sh_m, sc_m))))
-    return x + g_m.unsqueeze(1) * y
+    if not skip & 8:
+        xn = F.layer_norm(x, (C,), P[pre + "ipa_norm.weight"], P[pre + "ipa_norm.bias"], 1e-5)
+        x = x + ipa(P, pre + "ipa.", xn, R, tr, mask)
+    if not skip & 16:
+        y = mha_rope(P, pre + "mha_l.attn.", modulate(ln(x), sh_l, sc_l), mask, heads)
+        x = x + g_l.unsqueeze(1) * y
+    if not skip & 32:
+        y = linear(P, pre + "fc2", gelu(linear(P, pre + "fc1", modulate(ln(x), sh_m, sc_m))))
+        x = x + g_m.unsqueeze(1) * y
+    return x
 
 
-def trunk_layer(P, pre, x, t, mask, heads):
-    """LatentMDGenLayer.forward (latent_model.py:446-483).  x [B,T,L,C]; t [B,1,C]; mask [B,T,L]."""
+def trunk_layer(P, pre, x, t, mask, heads, skip=0):
+    """LatentMDGenLayer.forward (latent_model.py:446-483).  x [B,T,L,C]; t [B,1,C]; mask [B,T,L].
+    `skip` (tests only) mirrors MDGEN_DEBUG_SKIP bits 0/1/2."""
     B, T, L, C = x.shape
     mod = linear(P, pre + "adaLN_modulation.1", F.silu(t))               # [B,1,9C]
     sh_l, sc_l, g_l, sh_t, sc_t, g_t, sh_m, sc_m, g_m = mod.chunk(9, dim=-1)
-    y = modulate(ln(x), sh_l, sc_l)
-    y = mha_rope(P, pre + "mha_l.attn.", y.reshape(B * T, L, C), mask.reshape(B * T, L), heads).reshape(B, T, L, C)
-    x = x + g_l.unsqueeze(1) * y
-    y = modulate(ln(x), sh_t, sc_t)
-    y = mha_rope(P, pre + "mha_t.attn.", y.transpose(1, 2).reshape(B * L, T, C),
-                 mask.transpose(1, 2).reshape(B * L, T), heads).reshape(B, L, T, C).transpose(1, 2)
-    x = x + g_t.unsqueeze(1) * y
-    y = linear(P, pre + "fc2", gelu(linear(P, pre + "fc1", modulate(ln(x), sh_m, sc_m))))
-    return x + g_m.unsqueeze(1) * y
+    if not skip & 1:
+        y = modulate(ln(x), sh_l, sc_l)
+        y = mha_rope(P, pre + "mha_l.attn.", y.reshape(B * T, L, C), mask.reshape(B * T, L), heads).reshape(B, T, L, C)
+        x = x + g_l.unsqueeze(1) * y
+    if not skip & 2:
+        y = modulate(ln(x), sh_t, sc_t)
+        y = mha_rope(P, pre + "mha_t.attn.", y.transpose(1, 2).reshape(B * L, T, C),
+                     mask.transpose(1, 2).reshape(B * L, T), heads).reshape(B, L, T, C).transpose(1, 2)
+        x = x + g_t.unsqueeze(1) * y
+    if not skip & 4:
+        y = linear(P, pre + "fc2", gelu(linear(P, pre + "fc1", modulate(ln(x), sh_m, sc_m))))
+        x = x + g_m.unsqueeze(1) * y
+    return x
 
 
 def run_ipa(P, cfg, temb, mask_bl, start, end, aatype):
     """LatentMDGenModel.run_ipa (latent_model.py:175-210).  start/end = (R [B,L,3,3], t [B,L,3])."""
     H = cfg["mha_heads"]
     nl = cfg["num_layers"]
+    sk = cfg.get("debug_skip", 0)
     aa = P["aatype_to_emb.weight"][aatype]
     if cfg.get("tps_condition", False):
         iR, it = rigid_invert(*start)
@@ -357,12 +368,12 @@ def run_ipa(P, cfg, temb, mask_bl, start, end, aatype):
         x_f = linear(P, "latent_to_emb_f", x_f) + aa
         x_r = linear(P, "latent_to_emb_r", x_r) + aa
         for i in range(nl):
-            x_r = ipa_layer(P, f"ipa_layers.{i}.", x_r, temb, mask_bl, start[0], start[1], H)
-            x_f = ipa_layer(P, f"ipa_layers.{i}.", x_f, temb, mask_bl, end[0], end[1], H)
+            x_r = ipa_layer(P, f"ipa_layers.{i}.", x_r, temb, mask_bl, start[0], start[1], H, sk)
+            x_f = ipa_layer(P, f"ipa_layers.{i}.", x_f, temb, mask_bl, end[0], end[1], H, sk)
         return x_r + x_f
     x = aa
     for i in range(nl):
-        x = ipa_layer(P, f"ipa_layers.{i}.", x, temb, mask_bl, start[0], start[1], H)
+        x = ipa_layer(P, f"ipa_layers.{i}.", x, temb, mask_bl, start[0], start[1], H, sk)
     return x
 
 
@@ -381,7 +392,7 @@ def forward(P, cfg, x, t, mask, start_frames, end_frames, x_cond, x_cond_mask, a
         h = h + ipa_out[:, None]                                         # :245-246
     trace["h0"] = h
     for i in range(cfg["num_layers"]):
-        h = trunk_layer(P, f"layers.{i}.", h, temb, mask, H)             # :248-249
+        h = trunk_layer(P, f"layers.{i}.", h, temb, mask, H, cfg.get("debug_skip", 0))   # :248-249
         trace[f"h{i + 1}"] = h
     mod = linear(P, "emb_to_latent.adaLN_modulation.1", F.silu(temb))    # layers.py:70-74
     shift, scale = mod.chunk(2, dim=-1)

@@ -1,0 +1,132 @@
+"""CPU emulation of the attention fragment pipeline (DESIGN.md "fragment layout").
+
+The kernels never shuffle data between lanes: the weight-row permutations chosen at pack time make the
+MFMA accumulators of the QKV GEMM *be* the operand fragments of the attention MFMAs.  This test replays
+that index algebra in numpy with the documented gfx950 32x32x16 lane maps
+(A: row = lane&31, k = 8*(lane>>5)+j;  B: col = lane&31, same k;  C/D: col = lane&31,
+row = (r&3) + 8*(r>>2) + 4*(lane>>5)) using the REAL permutation tables exported by the library, and
+checks the result against a plain attention computed from the un-permuted weights."""
+import ctypes
+
+import numpy as np
+
+
+def mfma(a, b, c):
+    """a, b: [64 lanes][8]; c: [64][16] -> d [64][16] (v_mfma_f32_32x32x16 semantics)."""
+    A = np.zeros((32, 16)); B = np.zeros((16, 32))
+    for l in range(64):
+        A[l & 31, 8 * (l >> 5):8 * (l >> 5) + 8] = a[l]
+        B[8 * (l >> 5):8 * (l >> 5) + 8, l & 31] = b[l]
+    D = A @ B
+    d = c.copy()
+    for l in range(64):
+        for r in range(16):
+            d[l, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+    return d
+
+
+def panel_frag(X, tile, ks):
+    return np.stack([X[tile * 32 + (l & 31), ks * 16 + (l >> 5) * 8: ks * 16 + (l >> 5) * 8 + 8] for l in range(64)])
+
+
+def wfrag(W, rowmap, ft, ks):
+    return np.stack([W[rowmap[ft * 32 + (l & 31)], ks * 16 + (l >> 5) * 8: ks * 16 + (l >> 5) * 8 + 8] for l in range(64)])
+
+
+def maps():
+    import mdgen_amd._lib as L
+    arrs = [(ctypes.c_int32 * 384)() for _ in range(5)]
+    assert L.lib.mdgen_debug_layout_maps(*arrs) == 0
+    return [np.array(a) for a in arrs]
+
+
+def test_maps_are_permutations_with_rotary_pairs():
+    qk, vf, vs, pqk, pvs = maps()
+    for m in (qk, vf, vs, pqk, pvs):
+        assert sorted(m.tolist()) == list(range(384))
+    # lane-order slots (2p, 2p+1) of half h are the rotary pair (6h+p, 6h+p+12) of the same head
+    for i in range(0, 384, 2):
+        e = i % 12
+        h = (i // 48) % 2
+        assert pqk[i + 1] == pqk[i] + 12 and pqk[i] % 24 == 6 * h + e // 2
+
+
+def test_fragment_pipeline_reproduces_attention():
+    qk, vf, vs, pqk, pvs = maps()
+    rng = np.random.default_rng(0)
+    C, KS = 384, 24
+    X = rng.standard_normal((64, C))
+    Wq, Wk, Wv = (rng.standard_normal((C, C)) / 20 for _ in range(3))
+    w = 2                                   # wave 2: heads 8..11
+    def gemm_T(W, rowmap):                  # acc[ft][tt] = D[feature][token]
+        acc = [[np.zeros((64, 16)) for _ in range(2)] for _ in range(3)]
+        for ks in range(KS):
+            for ft in range(3):
+                for tt in range(2):
+                    acc[ft][tt] = mfma(wfrag(W, rowmap, 3 * w + ft, ks), panel_frag(X, tt, ks), acc[ft][tt])
+        return acc
+    def heads_T(acc):                       # epilogue_heads_T without bias/rope -> frag[hd][tt] = (ks0 [64][8], ks1 [64][8])
+        out = {}
+        for tt in range(2):
+            for hd in range(4):
+                e = np.zeros((64, 12))
+                for c in range(3):
+                    ap = 3 * hd + c
+                    ft, a = ap >> 2, ap & 3
+                    for b in range(4):
+                        e[:, 4 * c + b] = acc[ft][tt][:, 4 * a + b]
+                k1 = np.zeros((64, 8)); k1[:, :4] = e[:, 8:12]
+                out[hd, tt] = (e[:, :8].copy(), k1)
+        return out
+    qf, kf = heads_T(gemm_T(Wq, qk)), heads_T(gemm_T(Wk, qk))
+    accv = [[np.zeros((64, 16)) for _ in range(3)] for _ in range(2)]   # V non-transposed: acc[tt][j]
+    for ks in range(KS):
+        for tt in range(2):
+            for j in range(3):
+                accv[tt][j] = mfma(panel_frag(X, tt, ks), wfrag(Wv, vf, 3 * w + j, ks), accv[tt][j])
+    vfrag = {}                              # epilogue_v_flash: [hd][tt][ks][half][d] = 8 values
+    for j in range(3):
+        for l in range(64):
+            col = 32 * j + (l & 31)
+            hd, d, hh = col // 24, col % 24, l >> 5
+            for tt in range(2):
+                vfrag[hd, tt, 0, hh, d] = accv[tt][j][l, :8].copy()
+                vfrag[hd, tt, 1, hh, d] = accv[tt][j][l, 8:].copy()
+    q, k, v = X @ Wq.T, X @ Wk.T, X @ Wv.T
+    for hd in range(4):
+        head = 4 * w + hd
+        sl = slice(head * 24, head * 24 + 24)
+        for qt in range(2):
+            o_ref = np.zeros((32, 24))
+            O = np.zeros((64, 16))
+            for kt in range(2):
+                S = mfma(kf[hd, kt][0], qf[hd, qt][0], np.zeros((64, 16)))
+                S = mfma(kf[hd, kt][1], qf[hd, qt][1], S)
+                v0 = np.zeros((64, 8)); v1 = np.zeros((64, 8))
+                for l in range(64):
+                    if (l & 31) < 24:
+                        v0[l] = vfrag[hd, kt, 0, l >> 5, l & 31]
+                        v1[l] = vfrag[hd, kt, 1, l >> 5, l & 31]
+                O = mfma(v0, S[:, :8], O)
+                O = mfma(v1, S[:, 8:], O)
+                s_ref = q[qt * 32:(qt + 1) * 32, sl] @ k[kt * 32:(kt + 1) * 32, sl].T
+                o_ref += s_ref @ v[kt * 32:(kt + 1) * 32, sl]
+            got = np.zeros((32, 24))
+            for l in range(64):
+                got[l & 31, (l >> 5) * 12:(l >> 5) * 12 + 12] = O[l, :12]       # flash epilogue store
+                assert np.allclose(O[l, 12:], 0)
+            assert np.allclose(got, o_ref, rtol=1e-9, atol=1e-9), (hd, qt)
+    # SMALL layout: per-token slots [head][half][12]; q.k over the 24 slots == true dot product,
+    # V slots are the natural feature order
+    accs = gemm_T(Wv, vs)
+    vsm = heads_T(accs)
+    for hd in range(4):
+        head = 4 * w + hd
+        for tt in range(2):
+            for l in range(64):
+                tok, hh = tt * 32 + (l & 31), l >> 5
+                val = np.concatenate([vsm[hd, tt][0][l], vsm[hd, tt][1][l, :4]])
+                assert np.allclose(val, v[tok, head * 24 + 12 * hh: head * 24 + 12 * hh + 12])
+                qq = np.concatenate([qf[hd, tt][0][l], qf[hd, tt][1][l, :4]])
+                feats = pqk[((w * 2 + hh) * 4 + hd) * 12: ((w * 2 + hh) * 4 + hd) * 12 + 12]
+                assert np.allclose(qq, q[tok, feats])
