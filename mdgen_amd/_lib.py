@@ -8,7 +8,7 @@ import os
 import torch  # noqa: F401  -- must be imported first: provides the process-wide libamdhip64.so.7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdgen_amd.so")
+LIB_PATH = os.environ.get("MDGEN_AMD_LIB", os.path.join(_HERE, "libmdgen_amd.so"))   # override: debugging builds only
 
 EXPORTS = [
     "mdgen_last_error", "mdgen_abi_version", "mdgen_ctx_create", "mdgen_ctx_destroy", "mdgen_ctx_set_weight",

@@ -16,8 +16,12 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmdgen_amd.so")
 SOURCES = ["api.hip", "k_gemm.hip", "k_flash.hip", "k_small.hip", "k_se3.hip"]
 HEADERS = ["common.h", "panel.h", "kernels.h", os.path.join("..", "..", "include", "mdgen_amd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-         "-Wno-pass-failed"]
+# -fno-slp-vectorize: keeps hipcc from fusing scalar fp32 math into v_pk_{mul,add,fma}_f32.  On MI355X those
+# packed ops (a) are an anti-lever beside MFMAs (MI355X_MICROARCH "price of one filler") and (b) produced
+# intermittently wrong results in lanes 48-63 when two waves shared a SIMD (DESIGN.md "packed-fp32 hazard").
+# check_isa() fails the build if a v_pk_*_f32 or an MFMA with dst overlapping a source is emitted.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall",
+         "-Wno-unused-function", "-Wno-pass-failed"]
 
 
 def hipcc() -> str:
@@ -25,6 +29,35 @@ def hipcc() -> str:
         if c and os.path.exists(c):
             return c
     raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+_MFMA_RE = None
+
+
+def check_isa(cc: str, src: str) -> None:
+    """Fail the build if hipcc emitted an MFMA whose destination overlaps its A/B sources (see
+    csrc/common.h `opaque_zero`): such code runs, but corrupts accumulators intermittently."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        r = subprocess.run([cc] + [f for f in FLAGS if f not in ("-fPIC",)] + ["-S", "--cuda-device-only", src, "-o", out],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("ISA check failed to compile " + src + "\n" + r.stderr)
+        pat = re.compile(r"v_mfma_\w+ [va]\[(\d+):(\d+)\], [va]\[(\d+):(\d+)\], [va]\[(\d+):(\d+)\], (.*)$")
+        n = 0
+        for line in open(out):
+            if re.search(r"\bv_pk_(mul|add|fma)_f32\b", line):
+                raise RuntimeError(f"{os.path.basename(src)}: packed fp32 VALU op emitted: {line.strip()}")
+            m = pat.search(line)
+            if not m:
+                continue
+            n += 1
+            d0, d1, a0, a1, b0, b1 = map(int, m.groups()[:6])
+            if not (a1 < d0 or a0 > d1) or not (b1 < d0 or b0 > d1):
+                raise RuntimeError(f"{os.path.basename(src)}: MFMA destination overlaps a source operand: {line.strip()}")
+    return n
 
 
 def _stale(target, deps):
@@ -53,6 +86,13 @@ def build(force: bool = False, jobs: int = 8, verbose: bool = True) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if os.path.basename(s).startswith("k_"):
+            try:
+                check_isa(cc, s)
+            except Exception:
+                if os.path.exists(o):
+                    os.remove(o)
+                raise
         return s, r.stderr
 
     if todo:

@@ -316,7 +316,7 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     TRY(c->dalloc(&c->ada_w, (size_t)c->modrow * kC));
     TRY(c->dalloc(&c->ada_b, (size_t)c->modrow));
     TRY(c->dalloc(&c->inv_freq, (size_t)12));
-    TRY(c->dalloc(&c->rope, (size_t)(kMaxPos + 1) * 24));
+    TRY(c->dalloc(&c->rope, (size_t)(kMaxPos + 1) * kRopeRow));
     TRY(c->dalloc(&c->wfin, (size_t)kKS * 64));
     TRY(c->dalloc(&c->bfin, (size_t)32));
     HIPCHK(hipMemset(c->bfin, 0, 32 * sizeof(float)));

@@ -14,6 +14,7 @@ constexpr int kF = 1536;       // ffn dim (4C)
 constexpr int kIpaProj = 672;  // linear_q(128) | linear_kv(256) | linear_q_points(96) | linear_kv_points(192)
 constexpr int kIpaFeat = 256;  // o(128) | o_pt.x(32) | o_pt.y(32) | o_pt.z(32) | |o_pt|(32)
 constexpr int kFragBytes = 1536;  // one (seq, head, 32-position tile) of Q, K or V^T fragments
+constexpr int kRopeRow = 32;   // floats per position of the rotary table: [2 halves][cos 6 | pad 2 | sin 6 | pad 2]
 constexpr int kPanel = 64;     // token rows per GEMM panel (workgroup)
 constexpr float kLog2e = 1.4426950408889634f;
 
@@ -82,6 +83,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// A zero the compiler cannot constant-fold.  hipcc (ROCm 7.2) folds a zero-initialised accumulator
+// into the MFMA's inline-constant C operand and then allocates the 16-register destination ON TOP of
+// the A/B source registers (no early-clobber on v_mfma_f32_32x32x16_bf16 ... , 0).  With two waves per
+// SIMD that corrupts results intermittently.  Accumulators are therefore always zeroed with real
+// v_mov instructions, which forces the tied (dst == C) form whose destination never overlaps A/B;
+// mdgen_amd/build.py scans the generated ISA and fails the build if such an overlap is emitted.
+__device__ __forceinline__ float opaque_zero() {
+    float z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
 }
 
 // D-layout row of accumulator register r for lane-half h of a 32x32 MFMA tile

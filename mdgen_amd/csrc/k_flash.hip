@@ -67,12 +67,12 @@ __global__ __launch_bounds__(256, 2) void k_flash(const FlashParams p) {
     bf16x8 kb0, kb1;
     {
         const float* bk = p.bias_k + head * kDH;
-        const float* rc = p.rope + (long)len * 24;
+        const float* rc = p.rope + (long)len * kRopeRow + 16 * hh;
         float e[12];
 #pragma unroll
         for (int pp = 0; pp < 6; ++pp) {
             const int i = 6 * hh + pp;
-            const float x1 = bk[i], x2 = bk[i + 12], c = rc[i], sn = rc[12 + i];
+            const float x1 = bk[i], x2 = bk[i + 12], c = rc[pp], sn = rc[8 + pp];
             e[2 * pp] = x1 * c - x2 * sn;
             e[2 * pp + 1] = x2 * c + x1 * sn;
         }
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256, 2) void k_flash(const FlashParams p) {
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        o0[r] = 0.f;
-        o1[r] = 0.f;
+        o0[r] = opaque_zero();
+        o1[r] = opaque_zero();
     }
     float m0 = -1e30f, m1 = -1e30f, l0 = 0.f, l1 = 0.f;
 
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256, 2) void k_flash(const FlashParams p) {
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = 0.f;
-            s1[r] = 0.f;
+            s0[r] = opaque_zero();   // see common.h: never let C fold to the inline constant
+            s1[r] = opaque_zero();
         }
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q00, s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q10, s1, 0, 0, 0);

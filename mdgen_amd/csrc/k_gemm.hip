@@ -2,6 +2,7 @@
 // fused MLP, IPA projections, final layer.  gfx950 only (MFMA 32x32x16 bf16, wave64).
 #include "kernels.h"
 #include "panel.h"
+#include <cstdlib>
 
 namespace mdg {
 
@@ -33,11 +34,11 @@ __device__ __forceinline__ void epilogue_heads_T(const f32x16* acc /*[3 ft][2 tt
         if (pos > len) pos = len;  // padding rows: any in-table position (values are never used)
         float cs[6], sn[6];
         if (ROPE) {
-            const float* rc = rope + (long)pos * 24 + 6 * hh;
+            const float* rc = rope + (long)pos * kRopeRow + 16 * hh;
 #pragma unroll
             for (int p = 0; p < 6; ++p) {
                 cs[p] = rc[p];
-                sn[p] = rc[12 + p];
+                sn[p] = rc[8 + p];
             }
         }
         const int tile = tile0 + tt;
@@ -202,14 +203,14 @@ __device__ __forceinline__ void prologue_micro_attn(unsigned char* panel, const 
             }
             {   // learned bias key at position L, rotated there (mha.py:265-268 before :356-357); never masked
                 const float* bk = p.bias_k + head * kDH;
-                const float* rc = p.rope + (long)L * 24;
+                const float* rc = p.rope + (long)L * kRopeRow;
                 float d = 0.f;
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                     for (int pp = 0; pp < 6; ++pp) {
                         const int i = 6 * hh + pp;
-                        const float x1 = bk[i], x2 = bk[i + 12], c = rc[i], sn = rc[12 + i];
+                        const float x1 = bk[i], x2 = bk[i + 12], c = rc[16 * hh + pp], sn = rc[16 * hh + 8 + pp];
                         const float k1 = bf16_lo(pack_bf16(x1 * c - x2 * sn, 0.f));
                         const float k2 = bf16_lo(pack_bf16(x2 * c + x1 * sn, 0.f));
                         d += q[hh * 12 + 2 * pp] * k1 + q[hh * 12 + 2 * pp + 1] * k2;
@@ -406,11 +407,13 @@ __global__ __launch_bounds__(256, 2) void k_final(const FinalParams p) {
 
 // ---- launchers ----------------------------------------------------------------------------------
 void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s) {
+    const char* e = getenv("MDGEN_DEBUG_DYNLDS");   // debugging only: extra dynamic LDS limits WGs per CU
+    const unsigned dyn = e ? (unsigned)atoi(e) : 0u;
     if (small) {
         const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-        hipLaunchKernelGGL(k_ln_qkv<true>, dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_ln_qkv<true>, dim3(grid), dim3(256), dyn, s, p);
     } else {
-        hipLaunchKernelGGL(k_ln_qkv<false>, dim3(p.ax.nseq * p.panels_per_seq), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_ln_qkv<false>, dim3(p.ax.nseq * p.panels_per_seq), dim3(256), dyn, s, p);
     }
 }
 void launch_proj(const ProjParams& p, int mode, hipStream_t s) {

@@ -3,6 +3,11 @@
 // (rigid_utils.py:24-86 "written out by hand to avoid AMP downcasting"); here each is one launch.
 #include "kernels.h"
 
+// Bit-faithful fp32: no FMA contraction, so each expression rounds exactly like the reference's
+// sequence of element-wise torch ops (matters where the reference relies on exact cancellation,
+// e.g. the masked pre-omega torsion of residue 0 evaluates to exactly (0, 0); geometry.py:171-192).
+#pragma clang fp contract(off)
+
 namespace mdg {
 
 struct Rig {
@@ -425,10 +430,11 @@ __global__ void k_atom14_to_cond(int B, int L, const float* atom14, const int64_
     }
     for (int k = 0; k < 7; ++k) {
         const Rig f = from3(P[k][1], P[k][2], P[k][0]);
-        float d[3], rel[3];
+        float it[3], rel[3];
+        matTvec3(f.r, f.t, it);          // Rigid.invert(): (R^T, -(R^T t))
+        matTvec3(f.r, P[k][3], rel);     // .apply(p): R^T p + (-(R^T t))
 #pragma unroll
-        for (int a = 0; a < 3; ++a) d[a] = P[k][3][a] - f.t[a];
-        matTvec3(f.r, d, rel);
+        for (int a = 0; a < 3; ++a) rel[a] = rel[a] + (-it[a]);
         float sn = rel[2], cs = rel[1];
         const float den = sqrtf(sn * sn + cs * cs + 1e-8f);
         sn /= den;

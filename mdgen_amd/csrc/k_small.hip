@@ -55,14 +55,22 @@ __global__ __launch_bounds__(256) void k_adaln(const float* __restrict__ st, int
     }
 }
 
-// rotary table rope[pos] = [cos(pos*f_i) (12) | sin(pos*f_i) (12)], f = rot_emb.inv_freq (mha.py:130,356)
+// rotary table, 128 B per position: rope[pos][h][16] = cos(pos f_i) i=6h..6h+5 | 2 pad | sin(...) | 2 pad,
+// f = rot_emb.inv_freq (mha.py:130,356).  Each lane-half's six (cos, sin) pairs are 16-byte aligned and never
+// straddle a cache line (DESIGN.md "misaligned line-crossing loads").
 __global__ void k_rope_table(float* __restrict__ rope, const float* __restrict__ inv_freq, int npos) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npos * 12) return;
-    const int pos = i / 12, k = i % 12;
-    const float a = (float)pos * inv_freq[k];
-    rope[(long)pos * 24 + k] = cosf(a);
-    rope[(long)pos * 24 + 12 + k] = sinf(a);
+    if (i >= npos * 16) return;
+    const int pos = i / 16, k = i % 16;
+    const int h = k >> 3, j = k & 7;
+    float c = 0.f, sn = 0.f;
+    if (j < 6) {
+        const float a = (float)pos * inv_freq[6 * h + j];
+        c = cosf(a);
+        sn = sinf(a);
+    }
+    rope[(long)pos * kRopeRow + h * 16 + j] = c;
+    rope[(long)pos * kRopeRow + h * 16 + 8 + j] = sn;
 }
 
 __global__ void k_gather_f32(const float* __restrict__ src, const int* __restrict__ idx, float scale,
@@ -278,7 +286,7 @@ void launch_adaln(const float* st, int nrows, const float* w, const float* b, in
     hipLaunchKernelGGL(k_adaln, dim3((nout + 3) / 4), dim3(256), 0, s, st, nrows, w, b, nout, mod);
 }
 void launch_rope_table(float* rope, const float* inv_freq, int npos, hipStream_t s) {
-    hipLaunchKernelGGL(k_rope_table, dim3((npos * 12 + 255) / 256), dim3(256), 0, s, rope, inv_freq, npos);
+    hipLaunchKernelGGL(k_rope_table, dim3((npos * 16 + 255) / 256), dim3(256), 0, s, rope, inv_freq, npos);
 }
 void launch_gather_f32(const float* src, const int* idx, float scale, float* dst, int n, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_f32, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, scale, dst, n);

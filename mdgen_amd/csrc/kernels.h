@@ -12,7 +12,7 @@ struct QkvParams {
     int shift_chunk, scale_chunk;
     const bf16x8 *wq, *wk, *wv;   // packed fragments [12 ftile][24 kstep][64 lane][8]
     const float *bq, *bk, *bv;    // permuted biases [384]
-    const float* rope;     // [P][24] = 12 cos | 12 sin per position
+    const float* rope;     // [P][kRopeRow]: per half h: cos(6) | pad | sin(6) | pad
     unsigned char *qf, *kf, *vf;  // FLASH layout fragment buffers
     __bf16* qkv_small;     // SMALL layout [token][3][16 head][2 half][12]
     int panels_per_seq;

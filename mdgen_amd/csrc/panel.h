@@ -70,7 +70,7 @@ __device__ __forceinline__ void zero_acc(f32x16* acc) {
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = opaque_zero();
 }
 
 // ---- panel row table (LDS) ----------------------------------------------------------------------

@@ -237,9 +237,11 @@ def test_graph_replay_matches_eager_bitwise():
 
 def test_full_size_properties_cfg2():
     """BASELINE cfg-2 size (B16 T1000 L4): properties that do not need the (slow) oracle:
-    (1) batch elements are independent: permuting the batch permutes the output exactly;
-    (2) a fully padded residue does not change the other residues' velocity;
-    (3) the output is finite and deterministic."""
+    (1) the output is finite and bit-for-bit reproducible run to run (this caught two gfx950 code-generation
+        hazards, DESIGN.md "hardware findings");
+    (2) batch elements are independent: permuting the batch permutes the output (to fp32-rounding level:
+        a token's row position inside an MFMA tile changes, which moves last-bit rounding and very rarely a
+        bf16 rounding of an intermediate -- not bit-exact by construction, like any BLAS)."""
     from mdgen_amd.config import ModelConfig
     from mdgen_amd.synthetic import synth_state_dict
     dev = _cuda()
@@ -268,4 +270,4 @@ def test_full_size_properties_cfg2():
     kwp = dict(t=t[perm], mask=mask[perm], start_frames=(R[perm].contiguous(), tr_[perm].contiguous()),
                x_cond=xc[perm].contiguous(), x_cond_mask=cm[perm].contiguous(), aatype=aat[perm].contiguous())
     yp = m.forward(x[perm].contiguous(), **kwp)
-    assert torch.equal(yp, y1[perm])
+    assert rel_l2(yp, y1[perm]) < 1e-3 and (yp - y1[perm]).abs().max() < 2e-2
