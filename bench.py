@@ -187,7 +187,36 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert torch.isfinite(atom14).all()
+    if not torch.isfinite(atom14).all():
+        smp = w.last_samples
+        bad_a = (~torch.isfinite(atom14)).nonzero()
+        bad_s = (~torch.isfinite(smp)).nonzero()
+        print(f"NONFINITE atom14 {len(bad_a)} samples {len(bad_s)}; first atom14 idx {bad_a[:5].tolist()}; "
+              f"first samples idx {bad_s[:5].tolist()}", file=sys.stderr)
+        if len(bad_a):
+            b, t, l = bad_a[0][:3].tolist()
+            print("  samples at that token:", smp[b, t, l].tolist(), file=sys.stderr)
+            print("  batch rots/trans at (b,0,l):", batch["rots"][b, 0, l].tolist(), batch["trans"][b, 0, l].tolist(),
+                  "seqres", int(batch["seqres"][b, l]), file=sys.stderr)
+        again, _ = step()
+        torch.cuda.synchronize()
+        print("  re-run nonfinite:", int((~torch.isfinite(again)).sum()), file=sys.stderr)
+        lay = w.model.workspace_layout(B, T, L, S, True)
+        ws = next(iter(w.model._ws.values()))
+        names = ["h", "qf", "kf", "vf", "obuf", "mod", "silu_t", "ipa_out", "h_ipa", "ipa_proj", "ipa_feat", "mask_bl", "rel7", "tgrid"]
+        offs = [getattr(lay, n) for n in names] + [lay.total_bytes]
+        for n, o, e in zip(names, offs[:-1], offs[1:]):
+            if n in ("mod", "silu_t", "ipa_out", "h_ipa", "ipa_proj", "mask_bl", "tgrid", "h"):
+                v = ws[o:e].view(torch.float32)
+                if n == "tgrid":
+                    v = v[:S]
+                if n == "mask_bl":
+                    v = v[:B * L]
+                print(f"  ws.{n}: nonfinite {int((~torch.isfinite(v)).sum())} of {v.numel()} absmax {float(v[torch.isfinite(v)].abs().max()) if torch.isfinite(v).any() else float('nan'):.3e}", file=sys.stderr)
+        eager, _ = w.inference(batch, zs=zs, num_steps=S, use_graph=False)
+        torch.cuda.synchronize()
+        print("  eager re-run nonfinite:", int((~torch.isfinite(eager)).sum()), file=sys.stderr)
+        raise AssertionError("non-finite atom14")
     frames = B * T * a.steps * world
     value = frames / dt
 

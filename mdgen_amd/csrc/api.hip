@@ -688,13 +688,10 @@ static int prepare(const Run& r, const float* t_dev, const float* t_host) {
         launch_temb(t_dev, R, c->d.time_multiplier, c->t_w0, c->t_b0, c->t_w2, c->t_b2, silu, r.s);
         LAUNCHCHK();
     } else {
-        // the (tiny) host time grid travels as memset nodes: capturable, no host buffer lifetime issue
+        // the (tiny) host time grid travels as kernel arguments: capturable, no host buffer lifetime issue
         float* tg = (float*)(r.ws + r.lay.tgrid);
-        for (int i = 0; i < r.S; ++i) {
-            uint32_t bits;
-            std::memcpy(&bits, &t_host[i], 4);
-            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(tg + i), (int)bits, 1, r.s));
-        }
+        launch_write_floats(t_host, r.S, tg, r.s);
+        LAUNCHCHK();
         launch_temb(tg, r.S, c->d.time_multiplier, c->t_w0, c->t_b0, c->t_w2, c->t_b2, silu, r.s);
         LAUNCHCHK();
     }

@@ -171,6 +171,13 @@ __global__ __launch_bounds__(384) void k_ipa_init(const float* __restrict__ aa_e
     h[row * kC + c] = a;
 }
 
+// Host float values travel as kernel arguments (captured by value in a hipGraph).  Replaces a train of
+// 4-byte hipMemsetD32Async calls, which intermittently lost writes on ROCm 7 (DESIGN.md "hardware findings").
+__global__ void k_write_floats(FloatChunk c, float* __restrict__ dst) {
+    const int i = threadIdx.x;
+    if (i < c.n) dst[i] = c.v[i];
+}
+
 __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += src[i];
@@ -304,6 +311,14 @@ void launch_ipa_init(const float* aa_emb, const int64_t* aatype, const float* re
                      float* h, int ngroups, int B, int L, hipStream_t s) {
     hipLaunchKernelGGL(k_ipa_init, dim3((unsigned)((long)ngroups * L)), dim3(384), 0, s, aa_emb, aatype, rel7, w7, b7, h,
                        B, L);
+}
+void launch_write_floats(const float* host_vals, int n, float* dst, hipStream_t s) {
+    for (int o = 0; o < n; o += 128) {
+        FloatChunk c;
+        c.n = n - o < 128 ? n - o : 128;
+        for (int i = 0; i < c.n; ++i) c.v[i] = host_vals[o + i];
+        hipLaunchKernelGGL(k_write_floats, dim3(1), dim3(128), 0, s, c, dst + o);
+    }
 }
 void launch_add_inplace(float* dst, const float* src, long n, hipStream_t s) {
     hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n);

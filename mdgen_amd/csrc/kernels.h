@@ -98,6 +98,11 @@ struct IpaAttnParams {
     int ngroups, B, L;
 };
 
+struct FloatChunk {
+    float v[128];
+    int n;
+};
+
 void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
 void launch_mlp(const MlpParams& p, hipStream_t s);
@@ -118,6 +123,7 @@ void launch_pack_rows(const float* w, int ld, const int* rowmap, int nft, int ks
 void launch_ipa_init(const float* aa_emb, const int64_t* aatype, const float* rel7, const float* w7, const float* b7,
                      float* h, int ngroups, int B, int L, hipStream_t s);
 void launch_add_inplace(float* dst, const float* src, long n, hipStream_t s);
+void launch_write_floats(const float* host_vals, int n, float* dst, hipStream_t s);
 void launch_rel7(const float* r1, const float* t1, const float* r2, const float* t2, float* out7, long n, hipStream_t s);
 
 // SE(3) / pre / post (k_se3.hip)

@@ -9,6 +9,7 @@ are what make hipGraph replay possible).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -118,6 +119,8 @@ class LatentMDGenModel:
         if ws is None:
             lay = self.workspace_layout(B, T, L_, S, t_shared)
             ws = torch.empty(lay.total_bytes, dtype=torch.uint8, device=self.device)
+            if os.environ.get("MDGEN_POISON_WORKSPACE"):      # tests: every byte 0xFF = NaN in fp32 and bf16
+                ws.fill_(255)
             self._ws.clear()           # one live workspace (they are large)
             self._stage.clear()
             self._ws[key] = ws
