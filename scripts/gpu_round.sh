@@ -7,6 +7,6 @@ timeout 900 python -m pytest tests -m gpu -q -rA -s -p no:cacheprovider 2>&1 | g
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids > gpurun_out/smoke.log
 timeout 900 python bench.py --steps 3 --warmup 1 2>&1 | grep -v amdgpu.ids > gpurun_out/bench.log
 R=$PWD
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o ktrace -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $R/gpurun_out/rocprof.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o ktrace -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $R/gpurun_out/rocprof.log 2>&1)
 ls -R gpurun_out/prof | head -20
 tail -3 gpurun_out/pytest_gpu.log; cat gpurun_out/smoke.log | tail -2; tail -2 gpurun_out/bench.log
