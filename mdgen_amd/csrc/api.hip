@@ -95,7 +95,7 @@ struct mdgen_ctx {
     float *pos_embed = nullptr, *t_w0 = nullptr, *t_b0 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
     float *wf7 = nullptr, *bf7 = nullptr, *wr7 = nullptr, *br7 = nullptr;
     float *ada_w = nullptr, *ada_b = nullptr;
-    float *inv_freq = nullptr, *rope = nullptr;
+    float *inv_freq = nullptr, *rope = nullptr, *zero_page = nullptr;
     bf16x8* wfin = nullptr;
     float* bfin = nullptr;
     std::vector<TrunkW> trunk;
@@ -317,6 +317,8 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     TRY(c->dalloc(&c->ada_b, (size_t)c->modrow));
     TRY(c->dalloc(&c->inv_freq, (size_t)12));
     TRY(c->dalloc(&c->rope, (size_t)(kMaxPos + 1) * kRopeRow));
+    TRY(c->dalloc(&c->zero_page, (size_t)64));
+    HIPCHK(hipMemset(c->zero_page, 0, 256));
     TRY(c->dalloc(&c->wfin, (size_t)kKS * 64));
     TRY(c->dalloc(&c->bfin, (size_t)32));
     HIPCHK(hipMemset(c->bfin, 0, 32 * sizeof(float)));
@@ -566,6 +568,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
     p.gated = 1;
     p.w = m.wo;
     p.bias = m.bo;
+    { const char* e = getenv("MDGEN_DEBUG_KPROJ"); p.dbg = e ? atoi(e) : 0; }
     const bool small = residue_axis && ax.len <= 8;
     if (small) {
         q.wv = m.wv_small;
@@ -595,6 +598,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         f.bias_v = m.bias_v;
         f.rope = r.c->rope;
         f.obuf = (__bf16*)(r.ws + r.lay.obuf);
+        f.zero_page = (const unsigned char*)r.c->zero_page;
         { ProfScope ps(r.c, c_att, r.s); launch_flash(f, r.s); }
         LAUNCHCHK();
         p.a_bf16 = f.obuf;
@@ -617,6 +621,8 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
     p.w2 = f.w2;
     p.b1 = f.b1;
     p.b2 = f.b2;
+    { const char* e = getenv("MDGEN_DEBUG_KMLP"); p.dbg = e ? atoi(e) : 0; }
+    { const char* e = getenv("MDGEN_STAGGER_MLP"); p.stagger = e ? atoi(e) : 0; }
     { ProfScope ps(r.c, trunk ? "mlp" : "ipa.mlp", r.s); launch_mlp(p, r.s); }
     LAUNCHCHK();
     return 0;

@@ -102,13 +102,19 @@ __global__ void k_pack_rows(const float* __restrict__ w, int ld, const int* __re
 //   h = latent_to_emb(x) [+ pos_embed[l]] + cond_to_emb(x_cond) + mask_to_emb[x_cond_mask] + ipa_out[b,l]
 // block = 384 threads (one per channel), 32 tokens per block; the D<=28 wide weight rows live in VGPRs.
 // -------------------------------------------------------------------------------------------------
-constexpr int kEmbTok = 32;
+// 64 tokens per block; thread = channel (384 threads).  The per-channel weight rows (2 x D <= 56 floats)
+// live in VGPRs; token inputs are broadcast from LDS as float4 (7 x ds_read_b128 per dot product); the
+// cond_to_emb product is skipped for tokens whose x_cond row is all zero (every non-conditioning frame);
+// each store is a fully coalesced 1.5 KB row.
+constexpr int kEmbTok = 64;
 __global__ __launch_bounds__(384) void k_embed(const EmbedParams p) {
-    __shared__ float xs[kEmbTok][28];
-    __shared__ float cs[kEmbTok][28];
-    __shared__ int ms[kEmbTok];
+    __shared__ __attribute__((aligned(16))) float xs[kEmbTok][28];
+    __shared__ __attribute__((aligned(16))) float cs[kEmbTok][28];
+    __shared__ int ms[kEmbTok];     // bit0: x_cond_mask, bit1: x_cond row has a non-zero
     const int c = threadIdx.x;
     const long tok0 = (long)blockIdx.x * kEmbTok;
+    if (threadIdx.x < kEmbTok) ms[threadIdx.x] = 0;
+    __syncthreads();
     for (int i = threadIdx.x; i < kEmbTok * 28; i += 384) {
         const int tk = i / 28, d = i % 28;
         const long t = tok0 + tk;
@@ -119,10 +125,12 @@ __global__ __launch_bounds__(384) void k_embed(const EmbedParams p) {
         }
         xs[tk][d] = a;
         cs[tk][d] = b;
+        if (b != 0.f) atomicOr(&ms[tk], 2);
     }
+    __syncthreads();
     if (threadIdx.x < kEmbTok) {
         const long t = tok0 + threadIdx.x;
-        ms[threadIdx.x] = (t < p.N) ? (int)p.x_cond_mask[t] : 0;
+        if (t < p.N && p.x_cond_mask[t]) ms[threadIdx.x] |= 1;
     }
     float wl[28], wc[28];
 #pragma unroll
@@ -134,18 +142,30 @@ __global__ __launch_bounds__(384) void k_embed(const EmbedParams p) {
     const float me0 = p.mask_emb[c], me1 = p.mask_emb[kC + c];
     __syncthreads();
     const long TL = (long)p.T * p.L;
-    for (int tk = 0; tk < kEmbTok; ++tk) {
+    const int ntok = (p.N - tok0 < kEmbTok) ? (int)(p.N - tok0) : kEmbTok;
+    for (int tk = 0; tk < ntok; ++tk) {
         const long t = tok0 + tk;
-        if (t >= p.N) break;
         float a = b0;
+        const f32x4* xr = reinterpret_cast<const f32x4*>(&xs[tk][0]);
 #pragma unroll
-        for (int d = 0; d < 28; ++d) a += wl[d] * xs[tk][d];
-        float a2 = 0.f;
+        for (int d4 = 0; d4 < 7; ++d4) {
+            const f32x4 v = xr[d4];
+            a += wl[4 * d4] * v[0] + wl[4 * d4 + 1] * v[1] + wl[4 * d4 + 2] * v[2] + wl[4 * d4 + 3] * v[3];
+        }
+        const int m = ms[tk];
+        if (m & 2) {
+            const f32x4* cr = reinterpret_cast<const f32x4*>(&cs[tk][0]);
+            float a2 = 0.f;
 #pragma unroll
-        for (int d = 0; d < 28; ++d) a2 += wc[d] * cs[tk][d];
+            for (int d4 = 0; d4 < 7; ++d4) {
+                const f32x4 v = cr[d4];
+                a2 += wc[4 * d4] * v[0] + wc[4 * d4 + 1] * v[1] + wc[4 * d4 + 2] * v[2] + wc[4 * d4 + 3] * v[3];
+            }
+            a += a2;
+        }
+        a += (m & 1) ? me1 : me0;
         const int l = (int)(t % p.L);
         const int b = (int)(t / TL);
-        a += a2 + (ms[tk] ? me1 : me0);
         if (p.pos_embed) a += p.pos_embed[(long)l * kC + c];
         if (p.ipa_out) a += p.ipa_out[((long)b * p.L + l) * kC + c];
         p.h[t * kC + c] = a;

@@ -32,15 +32,26 @@ __device__ __forceinline__ bf16x8 panel_frag(const unsigned char* panel, const i
 // k-step k lives (f*wtile_stride + k*64) bf16x8 further (packed layout [ftile][kstep][lane][8]).
 // TRANS = false: acc[tt*FT+ft] = D[token][feature]  (A = activations, B = weights)
 // TRANS = true : acc[ft*TT+tt] = D[feature][token]  (A = weights,      B = activations)
-template <int TT, int FT, int KSTEPS, bool TRANS, int PF = 3>
+// ---- wave-level GEMM, software-pipelined --------------------------------------------------------------
+// hipcc's scheduler sinks loads down to their first use (prefetch distance 0: every k-step then eats a full
+// L2 round trip).  The pipeline below is therefore pinned with sched_barrier(0) fences: the weight fragments of
+// k-step ks+PF are requested (L2 -> VGPR) and the activation fragments of k-step ks+1 are read from LDS in a
+// scheduling region that precedes the MFMAs of k-step ks.  The loads stay ordinary loads, so hipcc itself
+// inserts exact counted waits (vmcnt(PF*FT)) -- no hand-counted asm waits, no stale-register hazards.
+template <int TT, int FT, int KSTEPS, bool TRANS, int PF = 4>
 __device__ __forceinline__ void wave_gemm(const unsigned char* panel, const int rowb, const int tile0, const int ks0,
                                           const bf16x8* __restrict__ wfrag, const int wtile_stride,
                                           f32x16* acc) {
+    static_assert(PF < KSTEPS, "prefetch depth");
     bf16x8 wring[PF + 1][FT];
+    bf16x8 aring[2][TT];
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
         for (int f = 0; f < FT; ++f) wring[p][f] = wfrag[(size_t)f * wtile_stride + p * 64];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) aring[0][t] = panel_frag(panel, rowb, tile0 + t, ks0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
         if (ks + PF < KSTEPS) {
@@ -48,20 +59,23 @@ __device__ __forceinline__ void wave_gemm(const unsigned char* panel, const int 
             for (int f = 0; f < FT; ++f)
                 wring[(ks + PF) % (PF + 1)][f] = wfrag[(size_t)f * wtile_stride + (ks + PF) * 64];
         }
-        bf16x8 a[TT];
+        if (ks + 1 < KSTEPS) {
 #pragma unroll
-        for (int t = 0; t < TT; ++t) a[t] = panel_frag(panel, rowb, tile0 + t, ks0 + ks);
+            for (int t = 0; t < TT; ++t) aring[(ks + 1) & 1][t] = panel_frag(panel, rowb, tile0 + t, ks0 + ks + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < TT; ++t)
 #pragma unroll
             for (int f = 0; f < FT; ++f) {
                 if (TRANS)
-                    acc[f * TT + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[ks % (PF + 1)][f], a[t],
+                    acc[f * TT + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[ks % (PF + 1)][f], aring[ks & 1][t],
                                                                              acc[f * TT + t], 0, 0, 0);
                 else
-                    acc[t * FT + f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], wring[ks % (PF + 1)][f],
+                    acc[t * FT + f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[ks & 1][t], wring[ks % (PF + 1)][f],
                                                                              acc[t * FT + f], 0, 0, 0);
             }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -71,6 +85,16 @@ __device__ __forceinline__ void zero_acc(f32x16* acc) {
     for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = opaque_zero();
+}
+
+// Phase de-synchronisation: workgroups that share a CU start together and run identical phase sequences, so
+// their HBM-bound prologue/epilogue phases and their MFMA phases coincide instead of overlapping.  Delaying
+// every second "dispatch round" (blocks b and b+256 land on the same CU) by a fraction of a workgroup's
+// lifetime keeps one workgroup's memory phase under the other's MFMA phase for the rest of the launch.
+__device__ __forceinline__ void stagger_start(int units) {
+    if (units > 0 && ((blockIdx.x >> 8) & 1)) {
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);   // 127 x 64 cycles ~ 3.4 us
+    }
 }
 
 // ---- panel row table (LDS) ----------------------------------------------------------------------
@@ -195,6 +219,50 @@ __device__ __forceinline__ void epilogue_gate_residual(const f32x16* acc, const 
                 for (int f = 0; f < FT; ++f) {
                     const float g = gated ? gp[f * 32] : 1.0f;
                     hp[f * 32] = hp[f * 32] + g * (acc[t * FT + f][r] + b[f]);
+                }
+            }
+        }
+    }
+}
+
+// Same update, staged through a wave-private 12 KiB LDS slab so that the read-modify-write of h uses 16-byte
+// accesses on whole 384-byte row segments: the direct form above issues 288 dword memory instructions per
+// lane and measured 100 of the 128 us of the out-projection kernel; this one issues 32 loads + 32 stores.
+// `stage` = this wave's slab ([32 rows][96 cols] fp32); the caller guarantees the panel is no longer read.
+template <int FT>
+__device__ __forceinline__ void epilogue_gate_residual_lds(const f32x16* acc, const PanelRows* pr, float* stage, int col0,
+                                                           const float* __restrict__ bias, const ModMap mm,
+                                                           int gate_chunk, bool gated, float* __restrict__ h) {
+    static_assert(FT == 3, "slab is [32][96]");
+    const int lane = lane_id();
+    const int hh = lane >> 5, n = lane & 31;
+    const int q = lane % 24, r2 = lane / 24;
+    const bool active = lane < 48;
+    f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active) b4 = *reinterpret_cast<const f32x4*>(bias + col0 + 4 * q);
+    const f32x4* stage4 = reinterpret_cast<const f32x4*>(stage);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[mfma_row(r, hh) * 96 + f * 32 + n] = acc[t * FT + f][r];
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int row = t * 32 + 2 * i + r2;
+            if (active) {
+                const int tk = pr->tok[row];
+                if (tk >= 0) {
+                    const f32x4 v = stage4[i * 48 + lane];
+                    f32x4 g = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (gated) g = *reinterpret_cast<const f32x4*>(mm.mod + pr->moff[row] + gate_chunk * kC + col0 + 4 * q);
+                    f32x4* hp = reinterpret_cast<f32x4*>(h + (long)tk * kC + col0 + 4 * q);
+                    f32x4 hv = *hp;
+                    hv[0] += g[0] * (v[0] + b4[0]);
+                    hv[1] += g[1] * (v[1] + b4[1]);
+                    hv[2] += g[2] * (v[2] + b4[2]);
+                    hv[3] += g[3] * (v[3] + b4[3]);
+                    *hp = hv;
                 }
             }
         }
