@@ -183,10 +183,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    from mdgen_amd.sharding import max_over_ranks
+    dt = max_over_ranks(dt, dist, dev)
     if not torch.isfinite(atom14).all():
         smp = w.last_samples
         bad_a = (~torch.isfinite(atom14)).nonzero()
