@@ -11,8 +11,10 @@
  *     contiguous, layouts exactly as the reference's tensors) unless the name ends in `_host`.
  *   - the caller owns every input/output/workspace buffer; the library owns only the packed
  *     weights and cached hipGraph handles inside the opaque context.
- *   - every launch goes on the caller's `stream` (a hipStream_t passed as void*); there are no
- *     hidden streams and no device synchronisation inside any call (graph-capturable).
+ *   - every launch goes on the caller's `stream` (a hipStream_t passed as void*) and nothing inside a
+ *     call synchronises the device (graph-capturable).  One exception, documented: `mdgen_sample_euler`
+ *     forks the second half of the batch onto one context-owned stream and joins it back onto `stream`
+ *     before returning (event fork/join, no host wait; MDGEN_DUAL_STREAM=0 disables it).
  *   - return 0 on success, negative = invalid argument / state, positive = hipError_t.
  *     `mdgen_last_error()` returns a thread-local message.  No exceptions cross the ABI.
  *   - a context is not thread-safe; use one per device per process.

@@ -107,6 +107,9 @@ struct mdgen_ctx {
     bool inv_freq_set = false;
     bool prof_on = false;
     std::vector<ProfRec> prof;
+    static constexpr int kMaxSide = 7;
+    hipStream_t side[kMaxSide] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
 
     template <typename T>
     int dalloc(T** p, size_t count) {
@@ -317,6 +320,11 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     TRY(c->dalloc(&c->ada_b, (size_t)c->modrow));
     TRY(c->dalloc(&c->inv_freq, (size_t)12));
     TRY(c->dalloc(&c->rope, (size_t)(kMaxPos + 1) * kRopeRow));
+    for (int i = 0; i < mdgen_ctx::kMaxSide; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     TRY(c->dalloc(&c->zero_page, (size_t)64));
     HIPCHK(hipMemset(c->zero_page, 0, 256));
     TRY(c->dalloc(&c->wfin, (size_t)kKS * 64));
@@ -416,6 +424,11 @@ extern "C" int32_t mdgen_ctx_destroy(mdgen_ctx* c) {
     for (auto& g : c->graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int i = 0; i < mdgen_ctx::kMaxSide; ++i) {
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+        if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
     }
     for (void* p : c->allocs) (void)hipFree(p);
     delete c;
@@ -534,9 +547,45 @@ struct Run {
     const float *mask, *start_rot, *start_trans, *end_rot, *end_trans, *x_cond;
     const int64_t *x_cond_mask, *aatype;
     hipStream_t s;
-    float* h() const { return (float*)(ws + lay.h); }
-    float* mod() const { return (float*)(ws + lay.mod); }
+    // trunk buffers (a sub-batch view shifts these; see sub_run)
+    float* hp;
+    unsigned char *qfp, *kfp, *vfp;
+    __bf16* obufp;
+    float* modp;                 // adaLN table row of (step 0, first batch element of this view)
+    const float* ipa_out_p;      // IPA table of (step 0, first batch element of this view)
+    long ipa_step_stride;        // floats between consecutive steps of the IPA table
+    float* h() const { return hp; }
+    float* mod() const { return modp; }
 };
+
+// View of the contiguous sub-batch [b0, b0+Bs) of a prepared call: every trunk buffer is per-token (or per
+// sequence) and batch-major, so a sub-batch is a pointer shift.  Used to run two halves of the batch on two
+// streams: their kernels are in different phases (HBM-bound prologues/epilogues, VALU-bound attention,
+// MFMA-bound GEMMs) and overlap on the CUs instead of queueing behind each other.
+static Run sub_run(const Run& r, int b0, int Bs, hipStream_t stream) {
+    Run v = r;
+    const long tl = (long)r.T * r.L;
+    v.B = Bs;
+    v.N = (long)Bs * tl;
+    v.s = stream;
+    v.mask = r.mask + b0 * tl;
+    v.x_cond = r.x_cond + b0 * tl * r.D;
+    v.x_cond_mask = r.x_cond_mask + b0 * tl;
+    v.hp = r.hp + b0 * tl * kC;
+    v.obufp = r.obufp + b0 * tl * kC;
+    // q region: max(SMALL layout, fragment layouts) per batch element; k/v regions: fragment layouts
+    const size_t per_b_small = (size_t)tl * 3 * kC * 2;
+    const size_t per_b_fragT = (size_t)r.L * kH * (r.T / 32 + 1) * kFragBytes;
+    const size_t per_b_fragL = r.L > 8 ? (size_t)r.T * kH * (r.L / 32 + 1) * kFragBytes : 0;
+    const size_t per_b_kv = per_b_fragT > per_b_fragL ? per_b_fragT : per_b_fragL;
+    const size_t per_b_q = per_b_small > per_b_kv ? per_b_small : per_b_kv;
+    v.qfp = r.qfp + (size_t)b0 * per_b_q;
+    v.kfp = r.kfp + (size_t)b0 * per_b_kv;
+    v.vfp = r.vfp + (size_t)b0 * per_b_kv;
+    v.modp = r.modp + (long)b0 * r.mod_group_stride;
+    v.ipa_out_p = r.ipa_out_p + (long)b0 * r.L * kC;
+    return v;
+}
 
 static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, const AxisMap& ax, const ModMap& mm,
                          int shift, int scale, int gate, const MaskMap& mk, bool residue_axis, bool trunk) {
@@ -555,10 +604,10 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
     q.bq = m.bq;
     q.bk = m.bk;
     q.rope = r.c->rope;
-    q.qf = r.ws + r.lay.qf;
-    q.kf = r.ws + r.lay.kf;
-    q.vf = r.ws + r.lay.vf;
-    q.qkv_small = (__bf16*)(r.ws + r.lay.qf);
+    q.qf = r.qfp;
+    q.kf = r.kfp;
+    q.vf = r.vfp;
+    q.qkv_small = (__bf16*)r.qfp;
     q.panels_per_seq = (ax.len + kPanel - 1) / kPanel;
     ProjParams p{};
     p.h = h;
@@ -597,7 +646,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         f.bias_k = m.bias_k;
         f.bias_v = m.bias_v;
         f.rope = r.c->rope;
-        f.obuf = (__bf16*)(r.ws + r.lay.obuf);
+        f.obuf = r.obufp;
         f.zero_page = (const unsigned char*)r.c->zero_page;
         { ProfScope ps(r.c, c_att, r.s); launch_flash(f, r.s); }
         LAUNCHCHK();
@@ -741,7 +790,7 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
     e.bc = c->bc;
     e.mask_emb = c->mask_emb;
     e.pos_embed = c->d.abs_pos_emb ? c->pos_embed : nullptr;
-    e.ipa_out = (const float*)(r.ws + r.lay.ipa_out) + (long)step * r.B * r.L * kC;
+    e.ipa_out = r.ipa_out_p + (long)step * r.ipa_step_stride;
     e.h = h;
     e.N = r.N;
     e.T = r.T;
@@ -807,6 +856,14 @@ static int make_run(Run* r, mdgen_ctx* c, const mdgen_shape* sh, int S, int t_sh
     r->mod_group_stride = t_shared ? 0 : c->modrow;
     r->ws = (unsigned char*)ws;
     r->s = (hipStream_t)stream;
+    r->hp = (float*)(r->ws + r->lay.h);
+    r->qfp = r->ws + r->lay.qf;
+    r->kfp = r->ws + r->lay.kf;
+    r->vfp = r->ws + r->lay.vf;
+    r->obufp = (__bf16*)(r->ws + r->lay.obuf);
+    r->modp = (float*)(r->ws + r->lay.mod);
+    r->ipa_out_p = (const float*)(r->ws + r->lay.ipa_out);
+    r->ipa_step_stride = (long)sh->B * sh->L * kC;
     return 0;
 }
 
@@ -842,13 +899,47 @@ static void linspace01(int n, std::vector<float>* out) {
     for (int i = 0; i < n; ++i) (*out)[i] = i < half ? 0.0f + step * (float)i : 1.0f - step * (float)(n - 1 - i);
 }
 
-static int euler_body(const Run& r, const std::vector<float>& tg, float* x) {
-    if (int e = prepare(r, nullptr, tg.data())) return e;
-    for (int i = 0; i < r.S; ++i) {
+// Number of concurrent sub-batch streams for the Euler rollout (MDGEN_STREAMS, default 2; 1 disables).
+static int n_streams(const Run& r) {
+    const char* e = getenv("MDGEN_DUAL_STREAM");
+    if (e && atoi(e) == 0) return 1;
+    int n = 2;
+    if (const char* e2 = getenv("MDGEN_STREAMS")) n = atoi(e2);
+    if (n > mdgen_ctx::kMaxSide + 1) n = mdgen_ctx::kMaxSide + 1;
+    if (n > r.B) n = r.B;
+    if (n < 2 || r.c->prof_on || r.N < 4096) return 1;
+    return n;
+}
+
+static int euler_steps(const Run& v, const std::vector<float>& tg, float* x) {
+    for (int i = 0; i < v.S; ++i) {
         const float dt = tg[i + 1] - tg[i];
-        if (int e = denoise_step(r, i, x, nullptr, 1, dt, nullptr)) return e;
+        if (int e = denoise_step(v, i, x, nullptr, 1, dt, nullptr)) return e;
     }
     return 0;
+}
+
+static int euler_body(const Run& r, const std::vector<float>& tg, float* x) {
+    if (int e = prepare(r, nullptr, tg.data())) return e;
+    const int ns = n_streams(r);
+    if (ns == 1) return euler_steps(r, tg, x);
+    // contiguous sub-batches on `ns` streams (fork after the shared preparation, join at the end)
+    mdgen_ctx* c = r.c;
+    HIPCHK(hipEventRecord(c->ev_fork, r.s));
+    int e = 0, b0 = 0;
+    for (int i = 0; i < ns; ++i) {
+        const int Bs = r.B / ns + (i < r.B % ns ? 1 : 0);
+        hipStream_t st = i == 0 ? r.s : c->side[i - 1];
+        if (i > 0) HIPCHK(hipStreamWaitEvent(st, c->ev_fork, 0));
+        const Run v = sub_run(r, b0, Bs, st);
+        if (!e) e = euler_steps(v, tg, x + (long)b0 * r.T * r.L * r.D);
+        if (i > 0) {
+            HIPCHK(hipEventRecord(c->ev_join[i - 1], st));
+            HIPCHK(hipStreamWaitEvent(r.s, c->ev_join[i - 1], 0));
+        }
+        b0 += Bs;
+    }
+    return e;
 }
 
 extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32_t S, float* x, const float* mask,
@@ -875,7 +966,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {(uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws};
+                                 (uint64_t)ws, (uint64_t)n_streams(r)};
     for (auto& g : c->graphs)
         if (g.key == key) {
             HIPCHK(hipGraphLaunch(g.exec, r.s));

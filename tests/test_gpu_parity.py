@@ -235,6 +235,39 @@ def test_graph_replay_matches_eager_bitwise():
     assert torch.equal(a, b) and torch.equal(b, c)
 
 
+def test_dual_stream_split_matches_single_stream():
+    """The Euler rollout runs the two halves of the batch on two streams; the result
+    must match the single-stream run to rounding level (panel boundaries move, arithmetic does not)."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict
+    dev = _cuda()
+    cfg = ModelConfig.forward_sim(num_frames=300, crop=4)
+    sd = synth_state_dict(cfg, 3)
+    m = get_model(cfg, sd, ("dual", 4))
+    B, T, L = 5, 300, 4
+    gen = torch.Generator().manual_seed(6)
+    zs = torch.randn(B, T, L, 21, generator=gen).to(dev)
+    mask = torch.ones(B, T, L, device=dev)
+    R = torch.eye(3, device=dev).expand(B, L, 3, 3).contiguous()
+    tr_ = torch.randn(B, L, 3, generator=gen).to(dev)
+    cm = torch.zeros(B, T, L, dtype=torch.long, device=dev)
+    cm[:, 0] = 1
+    xc = torch.where(cm.unsqueeze(-1).bool(), torch.randn(B, T, L, 21, generator=gen).to(dev), torch.zeros((), device=dev))
+    aat = torch.randint(0, 20, (B, L), generator=gen).to(dev)
+    kw = dict(mask=mask, start_frames=(R, tr_), x_cond=xc, x_cond_mask=cm, aatype=aat)
+    outs = {}
+    for dual in ("0", "1"):
+        os.environ["MDGEN_DUAL_STREAM"] = dual
+        for g in (False, True):
+            outs[dual, g] = m.sample_euler(zs, 4, use_graph=g, **kw)
+    os.environ.pop("MDGEN_DUAL_STREAM")
+    torch.cuda.synchronize()
+    ref = outs["0", False]
+    assert torch.isfinite(ref).all()
+    assert torch.equal(outs["0", True], ref) and torch.equal(outs["1", True], outs["1", False])
+    assert rel_l2(outs["1", False], ref) < 1e-3
+
+
 def test_full_size_properties_cfg2():
     """BASELINE cfg-2 size (B16 T1000 L4): properties that do not need the (slow) oracle:
     (1) the output is finite and bit-for-bit reproducible run to run (this caught two gfx950 code-generation
