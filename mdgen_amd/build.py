@@ -22,6 +22,13 @@ HEADERS = ["common.h", "panel.h", "kernels.h", os.path.join("..", "..", "include
 # check_isa() fails the build if a v_pk_*_f32 or an MFMA with dst overlapping a source is emitted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall",
          "-Wno-unused-function", "-Wno-pass-failed"]
+# per-file extras.  k_flash: no NaN-aware code in it, and without this every fmaxf on an MFMA result gets a
+# canonicalising v_max(x, x) in front (15 extra VALU per key tile in a VALU-bound loop).
+EXTRA = {"k_flash.hip": ["-fno-honor-nans"]}
+
+
+def flags_for(src: str):
+    return FLAGS + EXTRA.get(os.path.basename(src), [])
 
 
 def hipcc() -> str:
@@ -41,7 +48,7 @@ def check_isa(cc: str, src: str) -> None:
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
-        r = subprocess.run([cc] + [f for f in FLAGS if f not in ("-fPIC",)] + ["-S", "--cuda-device-only", src, "-o", out],
+        r = subprocess.run([cc] + [f for f in flags_for(src) if f not in ("-fPIC",)] + ["-S", "--cuda-device-only", src, "-o", out],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("ISA check failed to compile " + src + "\n" + r.stderr)
@@ -82,7 +89,7 @@ def build(force: bool = False, jobs: int = 8, verbose: bool = True) -> str:
 
     def compile_one(so):
         s, o = so
-        cmd = [cc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [cc] + flags_for(s) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)

@@ -327,6 +327,10 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     TRY(c->dalloc(&c->zero_page, (size_t)64));
     HIPCHK(hipMemset(c->zero_page, 0, 256));
+    {   // bytes 128..143: eight bf16 1.0 (the all-ones V^T row that accumulates the softmax denominator)
+        const uint16_t ones[8] = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+        HIPCHK(hipMemcpy((unsigned char*)c->zero_page + 128, ones, sizeof(ones), hipMemcpyHostToDevice));
+    }
     TRY(c->dalloc(&c->wfin, (size_t)kKS * 64));
     TRY(c->dalloc(&c->bfin, (size_t)32));
     HIPCHK(hipMemset(c->bfin, 0, 32 * sizeof(float)));
@@ -738,6 +742,9 @@ static int prepare(const Run& r, const float* t_dev, const float* t_host) {
     mdgen_ctx* c = r.c;
     float* silu = (float*)(r.ws + r.lay.silu_t);
     const int R = r.t_shared ? r.S : r.S * r.B;
+    // K/V fragment regions: key slots past a sequence's end are never written by k_ln_qkv but are read (and
+    // masked to P = 0) by k_flash, so they must hold FINITE values: zero them once per call.
+    HIPCHK(hipMemsetAsync(r.ws + r.lay.kf, 0, r.lay.obuf - r.lay.kf, r.s));
     if (t_dev) {
         if (r.t_shared && r.B > 1) return fail(-2, "device t rows require t_shared == 0 or B == 1");
         launch_temb(t_dev, R, c->d.time_multiplier, c->t_w0, c->t_b0, c->t_w2, c->t_b2, silu, r.s);

@@ -25,50 +25,60 @@ __device__ __forceinline__ bf16x8 frag8(const unsigned char* p) {  // 4 real bf1
     return __builtin_bit_cast(bf16x8, w);
 }
 
-// K / V^T fragments of one 32-key tile.  They are fetched one tile ahead with ORDINARY loads (so hipcc counts
-// them and inserts exact vmcnt waits) and pinned in place by sched_barrier(0) fences: without the fence the
-// scheduler sinks each load to its first use and every tile pays a full L2 round trip.  (Inline-asm loads are
-// not an option here: across the loop back-edge hipcc copies the asm outputs before the data lands.)
-struct KVTile {
+// K / V^T fragments of one 32-key tile.  They are fetched ahead with ORDINARY loads (so hipcc counts them and
+// inserts exact vmcnt waits) and pinned in place by sched_barrier(0) fences: without the fence the scheduler
+// sinks each load to its first use and every tile pays a full L2 round trip.  (Inline-asm loads are not an
+// option here: across the loop back-edge hipcc copies the asm outputs before the data lands.)
+struct KTile {
     u32x4 k0;   // K k-step 0: 8 bf16
-    u32x2 k1;   // K k-step 1: 4 bf16 (+4 implicit zeros)
+    u32x2 k1;   // K k-step 1: 4 bf16 (+ the constant-one slot and 3 implicit zeros)
+};
+struct VTile {
     u32x4 v0;   // V^T k-step 0
     u32x4 v1;   // V^T k-step 1
 };
 
+// Running softmax state of the wave's two 32-query tiles.  The row sum is NOT kept here: V^T row 24 (a padding
+// row, d >= 24) is all ones, so the PV MFMA accumulates l = sum_k P[k][q] into O^T[24][q] (register 12 of the
+// lanes with hh == 0) and every rescale of O rescales l with it.
 struct FlashState {
     f32x16 o0, o1;
-    float m0, m1, l0, l1;
+    float m0, m1;        // applied shift (exactly representable in bf16; rides in a spare K-dim slot of Q)
+    bool anch0, anch1;   // the shift has been anchored to a finite score at least once
+    bool settled;        // wave-uniform: every lane is anchored -> only "max moved up" needs checking
 };
 
-// one 32-key tile against the wave's two 32-query tiles
-__device__ __forceinline__ void flash_tile(FlashState& st, const KVTile& t, const bf16x8 q00, const bf16x8 q01,
-                                           const bf16x8 q10, const bf16x8 q11, const f32x16& zc, uint32_t vm, bool last,
-                                           int kl_last, const bf16x8 kb0, const bf16x8 kb1, __bf16 bvd, int hh, int ql) {
-    bf16x8 k0 = __builtin_bit_cast(bf16x8, t.k0);
-    const u32x4 k1w = u32x4{t.k1[0], t.k1[1], 0u, 0u};
-    bf16x8 k1 = __builtin_bit_cast(bf16x8, k1w);
-    bf16x8 v0 = __builtin_bit_cast(bf16x8, t.v0);
-    bf16x8 v1 = __builtin_bit_cast(bf16x8, t.v1);
-    if (last) {  // wave-uniform: splice in the learned bias key/value, zero anything beyond it
-        if (ql == kl_last) {
-            k0 = kb0;
-            k1 = kb1;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int key0 = (j & 3) + 8 * (j >> 2) + 4 * hh;        // k-step 0 slot j
-            const int key1 = (j & 3) + 8 * (2 + (j >> 2)) + 4 * hh;  // k-step 1 slot j
-            if (key0 == kl_last) v0[j] = bvd; else if (key0 > kl_last) v0[j] = (__bf16)0.f;
-            if (key1 == kl_last) v1[j] = bvd; else if (key1 > kl_last) v1[j] = (__bf16)0.f;
-        }
-    }
-    // C is a LIVE all-zero register tuple (never the inline constant, common.h): dst != C, and the build's
-    // ISA check guarantees dst does not overlap A/B.
-    f32x16 s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q00, zc, 0, 0, 0);
-    f32x16 s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q10, zc, 0, 0, 0);
-    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q01, s0, 0, 0, 0);
-    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q11, s1, 0, 0, 0);
+__device__ __forceinline__ float half_max(float x) {   // max over the two half-waves (lane, lane^32)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+__device__ __forceinline__ float round_bf16(float x) { return __uint_as_float(pack_bf16(x, 0.f) << 16); }
+
+// How far the running shift may lag the true row max before O is rescaled (log2 units: P <= 2^kDefer).
+constexpr float kDefer = 8.f;
+
+struct QFrags {
+    bf16x8 q00, q01, q10, q11;   // [q-tile][k-step]; k-step-1 slot 4 of the lanes hh == 0 carries -m
+    f32x16 zc;                   // all-zero accumulator input of the score MFMAs (opaque to the compiler)
+};
+
+// S^T - m for one 32-key tile against both q-tiles.  C is a LIVE all-zero register tuple (QFrags::zc), never the
+// inline constant 0: with the constant hipcc lets the destination overlap A (caught by build.py check_isa).
+__device__ __forceinline__ void scores(const KTile& t, const QFrags& q, f32x16& s0, f32x16& s1) {
+    const f32x16& zc = q.zc;
+    const bf16x8 k0 = __builtin_bit_cast(bf16x8, t.k0);
+    const u32x4 k1w = u32x4{t.k1[0], t.k1[1], 0x00003f80u, 0u};   // slot 4 = 1.0: picks up -m from Q
+    const bf16x8 k1 = __builtin_bit_cast(bf16x8, k1w);
+    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q.q00, zc, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q.q10, zc, 0, 0, 0);
+    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q.q01, s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q.q11, s1, 0, 0, 0);
+}
+
+// Softmax bookkeeping of the current tile (everything except exp): key-padding mask, row max, and -- rarely --
+// moving the shift.  Must run BEFORE the next tile's scores are issued, because it may rewrite Q's -m slot.
+__device__ __forceinline__ void softmax_stats(FlashState& st, f32x16& s0, f32x16& s1, QFrags& q, uint32_t vm, int hh) {
     if (vm != 0xffffffffu) {
         const uint32_t vmh = vm >> (4 * hh);
 #pragma unroll
@@ -78,56 +88,87 @@ __device__ __forceinline__ void flash_tile(FlashState& st, const KVTile& t, cons
             s1[r] = ok ? s1[r] : -1e30f;
         }
     }
-    // ---- online softmax (log2 domain: q carries dh^-1/2 * log2(e))
-    float t0 = s0[0], t1 = s1[0];
+    float t0 = fmaxf(s0[0], s0[1]), t1 = fmaxf(s1[0], s1[1]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) {
-        t0 = fmaxf(t0, s0[r]);
-        t1 = fmaxf(t1, s1[r]);
+    for (int r = 2; r < 16; r += 2) {
+        t0 = fmaxf(fmaxf(t0, s0[r]), s0[r + 1]);   // v_max3_f32
+        t1 = fmaxf(fmaxf(t1, s1[r]), s1[r + 1]);
     }
-    t0 = fmaxf(t0, __shfl_xor(t0, 32, 64));
-    t1 = fmaxf(t1, __shfl_xor(t1, 32, 64));
-    const bool grow = (t0 > st.m0) | (t1 > st.m1);
-    if (__builtin_amdgcn_ballot_w64(grow) != 0) {   // wave-uniform: some query's running max moved -> rescale
-        const float n0 = fmaxf(st.m0, t0), n1 = fmaxf(st.m1, t1);
-        const float a0 = __builtin_amdgcn_exp2f(st.m0 - n0), a1 = __builtin_amdgcn_exp2f(st.m1 - n1);
-        st.m0 = n0;
-        st.m1 = n1;
-        st.l0 *= a0;
-        st.l1 *= a1;
+    t0 = half_max(t0);
+    t1 = half_max(t1);
+    const bool up = fmaxf(t0, t1) > kDefer;
+    if (!st.settled || __builtin_amdgcn_ballot_w64(up) != 0) {   // wave-uniform and rare after the first tiles
+        // Re-anchor when the shift lags the tile max by more than kDefer, or (first finite tile of a query
+        // only) leads it by more than kDefer.  Both half-waves of a query see the same t -> same decision.
+        const bool fin0 = t0 > -1e29f, fin1 = t1 > -1e29f;
+        const bool mv0 = (t0 > kDefer) | (!st.anch0 & fin0 & (t0 < -kDefer));
+        const bool mv1 = (t1 > kDefer) | (!st.anch1 & fin1 & (t1 < -kDefer));
+        st.anch0 |= fin0;
+        st.anch1 |= fin1;
+        st.settled = __builtin_amdgcn_ballot_w64(st.anch0 & st.anch1) == ~0ull;
+        // new shift = bf16(m + tile max); e = what this tile's already-shifted scores still have to lose
+        const float r0 = mv0 ? round_bf16(st.m0 + t0) : st.m0, r1 = mv1 ? round_bf16(st.m1 + t1) : st.m1;
+        const float e0 = r0 - st.m0, e1 = r1 - st.m1;
+        st.m0 = r0;
+        st.m1 = r1;
+        // e < 0 only while nothing has been accumulated yet (first anchoring): O is still zero, keep it so
+        const float a0 = __builtin_amdgcn_exp2f(fminf(-e0, 0.f)), a1 = __builtin_amdgcn_exp2f(fminf(-e1, 0.f));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             st.o0[r] *= a0;
             st.o1[r] *= a1;
+            s0[r] -= e0;
+            s1[r] -= e1;
+        }
+        if (hh == 0) {   // -m into Q's spare slot (k-step 1, slot 4)
+            q.q01[4] = (__bf16)(-r0);
+            q.q11[4] = (__bf16)(-r1);
         }
     }
-    float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        s0[r] = __builtin_amdgcn_exp2f(s0[r] - st.m0);
-        s1[r] = __builtin_amdgcn_exp2f(s1[r] - st.m1);
-        ps0 += s0[r];
-        ps1 += s1[r];
-    }
-    st.l0 += ps0;
-    st.l1 += ps1;
+}
+
+// The MFMA-dense block of one tile: P^T = exp2(S^T - m) packed in place, O^T += V^T P^T, and the scores of the
+// FOLLOWING tile issued into the same straight-line block so its MFMAs run under this tile's exps.  It is one
+// unconditional block on purpose (after the last tile the "next" scores are computed from stale K registers
+// and dropped): with a branch hipcc hoists the exps above it and the overlap is lost.
+__device__ __forceinline__ void exp_pv(FlashState& st, const f32x16& s0, const f32x16& s1, const bf16x8 v0, const bf16x8 v1,
+                                       const KTile& kn, const QFrags& q, f32x16& n0, f32x16& n1) {
+    scores(kn, q, n0, n1);
     bf16x8 p00, p01, p10, p11;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        p00[j] = (__bf16)s0[j];
-        p01[j] = (__bf16)s0[8 + j];
-        p10[j] = (__bf16)s1[j];
-        p11[j] = (__bf16)s1[8 + j];
+        p00[j] = (__bf16)__builtin_amdgcn_exp2f(s0[j]);
+        p10[j] = (__bf16)__builtin_amdgcn_exp2f(s1[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        p01[j] = (__bf16)__builtin_amdgcn_exp2f(s0[8 + j]);
+        p11[j] = (__bf16)__builtin_amdgcn_exp2f(s1[8 + j]);
     }
     st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p00, st.o0, 0, 0, 0);
     st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p10, st.o1, 0, 0, 0);
     st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p01, st.o0, 0, 0, 0);
     st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p11, st.o1, 0, 0, 0);
+    {   // interleave: 4 score MFMAs under the first 32 exp/cvt, then the PV MFMAs as their P arrives
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x402, 8, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x402, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void k_flash(const FlashParams p) {
     const int lane = lane_id(), w = wave_id(), hh = lane >> 5, ql = lane & 31;
-    const int len = p.ax.len, ntile = p.ax.ntile();
+    const int len = p.ax.len, ntile = p.ax.ntile();   // ntile: tiles per (seq, head) in the fragment LAYOUT
+    const int nreal = (len + 31) >> 5;                // tiles that hold real keys
     const int nqc = (len + 63) / 64;
     const int hg = blockIdx.x & 3;
     const int rest = blockIdx.x >> 2;
@@ -138,14 +179,12 @@ __global__ __launch_bounds__(256, 2) void k_flash(const FlashParams p) {
     const long seq_base = p.ax.token(seq, 0);
     const int pstride = p.ax.pos_stride;
 
-    // ---- per-tile key validity bitmasks (key-padding mask; the bias key is always valid), shared
-    //      by the 4 waves (same sequence): wave w fills tiles w, w+4, ...
+    // ---- per-tile key validity bitmasks (key-padding mask; positions >= len are invalid), shared by the
+    //      4 waves (same sequence): wave w fills tiles w, w+4, ...
     __shared__ uint32_t vmask[256];
-    for (int kt = w; kt < ntile; kt += 4) {
+    for (int kt = w; kt < nreal; kt += 4) {
         const int pos = kt * 32 + ql;
-        bool ok = false;
-        if (pos < len) ok = p.mk.at(seq_base + (long)pos * pstride) != 0.f;
-        else if (pos == len) ok = true;
+        const bool ok = pos < len && p.mk.at(seq_base + (long)pos * pstride) != 0.f;
         const uint32_t vm = (uint32_t)__ballot(ok && hh == 0);
         if (lane == 0) vmask[kt] = vm;
     }
@@ -155,15 +194,96 @@ __global__ __launch_bounds__(256, 2) void k_flash(const FlashParams p) {
     const int qt0 = 2 * qc;
     const bool has2 = (qt0 + 1) * 32 < len;
     const int qt1 = has2 ? qt0 + 1 : qt0;
-    const bf16x8 q00 = frag16(qb + (long)qt0 * kFragBytes + lane * 16);
-    const bf16x8 q01 = frag8(qb + (long)qt0 * kFragBytes + 1024 + lane * 8);
-    const bf16x8 q10 = frag16(qb + (long)qt1 * kFragBytes + lane * 16);
-    const bf16x8 q11 = frag8(qb + (long)qt1 * kFragBytes + 1024 + lane * 8);
+    QFrags q;
+    q.q00 = frag16(qb + (long)qt0 * kFragBytes + lane * 16);
+    q.q01 = frag8(qb + (long)qt0 * kFragBytes + 1024 + lane * 8);
+    q.q10 = frag16(qb + (long)qt1 * kFragBytes + lane * 16);
+    q.q11 = frag8(qb + (long)qt1 * kFragBytes + 1024 + lane * 8);
 
-    // ---- learned bias key/value (mha.py:265-268): key index `len`, rotated at position `len`
-    const int kt_last = len >> 5, kl_last = len & 31;
-    bf16x8 kb0, kb1;
+    // per-lane fragment streams: K rows are lanes; V^T rows d > 24 read a zero page, row 24 a ones page (stride
+    // 0): row 24 is the all-ones row that accumulates the softmax denominator
+    const bool vreal = ql < kDH;
+    const unsigned char* vp = vreal ? p.vf + fbase + hh * 384 + ql * 16 : p.zero_page + (ql == kDH ? 128 : 0);
+    const long vstep = vreal ? kFragBytes : 0;
+    const long v1off = vreal ? 768 : 0;
+    // K fragment: k-step 0 at +lane*16, k-step 1 at +1024+lane*8 -> two base pointers
+    const unsigned char* k0p = p.kf + fbase + lane * 16;
+    const unsigned char* k1p = p.kf + fbase + 1024 + lane * 8;
+
+    FlashState st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        st.o0[r] = opaque_zero();
+        st.o1[r] = opaque_zero();
+        q.zc[r] = opaque_zero();
+    }
+    st.m0 = st.m1 = 0.f;
+    st.anch0 = st.anch1 = false;
+    st.settled = false;
+
+    // Loads are UNCONDITIONAL (the tile index wraps instead): a load under `if` makes hipcc merge old and new
+    // register values right behind it, i.e. wait for the data it has just requested.
+    auto issue_k = [&](KTile& t, int kt) {
+        t.k0 = *reinterpret_cast<const u32x4*>(k0p + (long)kt * kFragBytes);
+        t.k1 = *reinterpret_cast<const u32x2*>(k1p + (long)kt * kFragBytes);
+    };
+    auto issue_v = [&](VTile& t, int kt) {
+        t.v0 = *reinterpret_cast<const u32x4*>(vp + (long)kt * vstep);
+        t.v1 = *reinterpret_cast<const u32x4*>(vp + (long)kt * vstep + v1off);
+    };
+    // One tile: `s` holds its shifted scores (issued during the previous tile), `vt` its V^T, `kn` the NEXT
+    // tile's K.  Order: stats (may move the shift in Q) -> [next scores || exp || PV].
+    // The two score tuples ping-pong between "current" and "next" so nothing is copied.
+    f32x16 sa0, sa1, sb0, sb1;
+    auto step = [&](const KTile& kn, const VTile& vt, uint32_t vm, f32x16& s0, f32x16& s1, f32x16& n0, f32x16& n1) {
+        softmax_stats(st, s0, s1, q, vm, hh);
+        exp_pv(st, s0, s1, __builtin_bit_cast(bf16x8, vt.v0), __builtin_bit_cast(bf16x8, vt.v1), kn, q, n0, n1);
+    };
+
+    // Key tiles are visited in ROTATED order, starting at a q-chunk dependent tile (softmax does not care), so
+    // that the workgroups sharing one sequence's K/V stream are not all first-touching the same lines.
+    const int start = (qc * nreal) / nqc;
+    auto tile = [&](int i) {   // i <= nreal + 2
+        int t = start + i;
+        t = t >= nreal ? t - nreal : t;
+        t = t >= nreal ? t - nreal : t;
+        return t >= nreal ? 0 : t;
+    };
+
+    KTile ka, kb;
+    VTile va, vb;
+    issue_k(ka, tile(0));
+    issue_v(va, tile(0));
+    issue_k(kb, tile(1));
+    __builtin_amdgcn_sched_barrier(0);
+    scores(ka, q, sa0, sa1);
+    // Positions >= len of the last real tile hold finite leftovers (the K/V fragment regions are zeroed once per
+    // call and only ever receive finite bf16), masked to P = 0.  After the last real tile the "next" scores are
+    // computed from wrapped-around K and dropped.
+    // The loop body is a PAIR of steps with a single exit (an exit between the two steps makes hipcc keep O in
+    // different registers in the two halves and copy it mid-chain); an odd tile count gets a tail step.
+    int i = 0;
+    for (; i + 1 < nreal; i += 2) {
+        // even step: V in va, next K in kb; refill vb <- V(i+1), ka <- K(i+2)
+        issue_v(vb, tile(i + 1));
+        issue_k(ka, tile(i + 2));
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch AHEAD of the tile that is about to be computed
+        step(kb, va, vmask[tile(i)], sa0, sa1, sb0, sb1);
+        __builtin_amdgcn_sched_barrier(0);
+        // odd step: V in vb, next K in ka; refill va <- V(i+2), kb <- K(i+3)
+        issue_v(va, tile(i + 2));
+        issue_k(kb, tile(i + 3));
+        __builtin_amdgcn_sched_barrier(0);
+        step(ka, vb, vmask[tile(i + 1)], sb0, sb1, sa0, sa1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (i < nreal) step(kb, va, vmask[tile(i)], sa0, sa1, sb0, sb1);
+
+    // ---- the learned bias key/value (mha.py:265-268): one extra key at index `len`, rotated at position `len`,
+    //      always valid.  It is processed as a virtual tile built in registers: every K row is the bias key, only
+    //      key slot 0 is unmasked, V^T column 0 is the bias value.
     {
+        KTile kbias;
         const float* bk = p.bias_k + head * kDH;
         const float* rc = p.rope + (long)len * kRopeRow + 16 * hh;
         float e[12];
@@ -174,57 +294,20 @@ __global__ __launch_bounds__(256, 2) void k_flash(const FlashParams p) {
             e[2 * pp] = x1 * c - x2 * sn;
             e[2 * pp + 1] = x2 * c + x1 * sn;
         }
-        const u32x4 a = u32x4{pack_bf16(e[0], e[1]), pack_bf16(e[2], e[3]), pack_bf16(e[4], e[5]), pack_bf16(e[6], e[7])};
-        const u32x4 b = u32x4{pack_bf16(e[8], e[9]), pack_bf16(e[10], e[11]), 0u, 0u};
-        kb0 = __builtin_bit_cast(bf16x8, a);
-        kb1 = __builtin_bit_cast(bf16x8, b);
+        kbias.k0 = u32x4{pack_bf16(e[0], e[1]), pack_bf16(e[2], e[3]), pack_bf16(e[4], e[5]), pack_bf16(e[6], e[7])};
+        kbias.k1 = u32x2{pack_bf16(e[8], e[9]), pack_bf16(e[10], e[11])};
+        // V^T fragment row d = lane&31 (24 = ones row, 25.. = zero); feature of row d = psi(d)
+        const int dpsi = 12 * ((ql >> 2) & 1) + 4 * (ql >> 3) + (ql & 3);
+        const float bvf = (ql < kDH) ? p.bias_v[head * kDH + dpsi] : (ql == kDH ? 1.f : 0.f);
+        VTile vbias;
+        vbias.v0 = u32x4{hh == 0 ? pack_bf16(bvf, 0.f) : 0u, 0u, 0u, 0u};   // key slot 0 = k-step 0, hh 0, j 0
+        vbias.v1 = u32x4{0u, 0u, 0u, 0u};
+        f32x16 c0, c1, d0, d1;
+        scores(kbias, q, c0, c1);
+        step(kbias, vbias, 0x1u, c0, c1, d0, d1);
     }
-    // V^T fragment row d = lane&31 (rows >= 24 are zero padding); feature of row d = psi(d)
-    const int dpsi = 12 * ((ql >> 2) & 1) + 4 * (ql >> 3) + (ql & 3);
-    const __bf16 bvd = (ql < kDH) ? (__bf16)p.bias_v[head * kDH + dpsi] : (__bf16)0.f;
-
-    // per-lane fragment streams: K rows are lanes; V^T rows d >= 24 read a zero page with stride 0
-    const bool vreal = ql < kDH;
-    const unsigned char* vp = vreal ? p.vf + fbase + hh * 384 + ql * 16 : p.zero_page;
-    const long vstep = vreal ? kFragBytes : 0;
-
-    FlashState st;
-    f32x16 zc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        st.o0[r] = opaque_zero();
-        st.o1[r] = opaque_zero();
-        zc[r] = opaque_zero();
-    }
-    st.m0 = st.m1 = -1e30f;
-    st.l0 = st.l1 = 0.f;
-
-    // K fragment: k-step 0 at +lane*16, k-step 1 at +1024+lane*8 -> two base pointers
-    const unsigned char* k0p = p.kf + fbase + lane * 16;
-    KVTile ta, tb;
-    const unsigned char* k1p = p.kf + fbase + 1024 + lane * 8;
-    const long v1off = vreal ? 768 : 0;
-    auto issue = [&](KVTile& t, int kt) {
-        t.k0 = *reinterpret_cast<const u32x4*>(k0p + (long)kt * kFragBytes);
-        t.k1 = *reinterpret_cast<const u32x2*>(k1p + (long)kt * kFragBytes);
-        t.v0 = *reinterpret_cast<const u32x4*>(vp + (long)kt * vstep);
-        t.v1 = *reinterpret_cast<const u32x4*>(vp + (long)kt * vstep + v1off);
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch AHEAD of the tile that is about to be computed
-    };
-    issue(ta, 0);
-    int kt = 0;
-    for (; kt + 1 < ntile; kt += 2) {
-        issue(tb, kt + 1);
-        flash_tile(st, ta, q00, q01, q10, q11, zc, vmask[kt], kt == kt_last, kl_last, kb0, kb1, bvd, hh, ql);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < ntile) issue(ta, kt + 2);
-        flash_tile(st, tb, q00, q01, q10, q11, zc, vmask[kt + 1], kt + 1 == kt_last, kl_last, kb0, kb1, bvd, hh, ql);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (kt < ntile)   // odd tile count: the last tile was requested in the final loop iteration (or before the loop)
-        flash_tile(st, ta, q00, q01, q10, q11, zc, vmask[kt], kt == kt_last, kl_last, kb0, kb1, bvd, hh, ql);
-    float l0 = st.l0 + __shfl_xor(st.l0, 32, 64);
-    float l1 = st.l1 + __shfl_xor(st.l1, 32, 64);
+    const float l0 = __shfl(st.o0[12], ql, 64);   // O^T row 24 = softmax denominator, held by lanes hh == 0
+    const float l1 = __shfl(st.o1[12], ql, 64);
     const f32x16 o0 = st.o0, o1 = st.o1;
     // ---- epilogue: registers 0..11 of lane-half hh are features 12*hh .. 12*hh+11 of this head
     {

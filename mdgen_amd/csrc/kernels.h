@@ -78,7 +78,7 @@ struct FlashParams {
     const float *bias_k, *bias_v;  // natural fp32 [384]
     const float* rope;
     __bf16* obuf;           // [N][384]
-    const unsigned char* zero_page;   // >= 16 zero bytes (V^T padding rows d >= 24)
+    const unsigned char* zero_page;   // 16 zero bytes (V^T padding rows d > 24); +128: eight bf16 1.0 (row 24)
 };
 
 struct EmbedParams {
