@@ -79,10 +79,22 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
+// v + (v moved by a DPP lane pattern inside each row of 16 lanes): one full-rate VALU op, no LDS round trip.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// All-lanes sum of a wave64: 4 DPP steps inside rows of 16 (quad xor 1, quad xor 2, half-row mirror, row mirror),
+// one cross-row exchange (lane ^ 16) and one half-wave swap.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x140>(v);   // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // A zero the compiler cannot constant-fold.  hipcc (ROCm 7.2) folds a zero-initialised accumulator

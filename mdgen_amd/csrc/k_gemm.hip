@@ -159,103 +159,116 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
 //   MODE 2: residue-axis micro-attention computed in the prologue from the SMALL q/k/v layout
 //           (L <= 8: five keys incl. the learned bias key; mha.py:265-268, 359-396)
 // =================================================================================================
+// Every global load is unconditional (padding rows read token 0, key slots j >= L re-read key L-1 and are
+// masked afterwards) and the loads of one (row, head) item are issued together: with loads under
+// `if (token >= 0)` / `if (mask)` each key paid its own memory round trip (~13 in sequence per item).
 template <int MAXL>
 __device__ __forceinline__ void prologue_micro_attn(unsigned char* panel, const PanelRows* pr, const ProjParams& p) {
     const int L = p.ax.len;
     for (int item = threadIdx.x; item < kPanel * kH; item += 256) {
         const int row = item >> 4, head = item & 15;
         const int token = pr->tok[row];
-        u32x4 o4[3] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
-        if (token >= 0) {
-            const int seq = token / L;
-            const u32x4* qp = reinterpret_cast<const u32x4*>(p.qkv_small + (long)token * (3 * kC) + head * kDH);
-            float q[24];
+        const int tkc = token < 0 ? 0 : token;
+        const int seq = tkc / L;
+        const __bf16* sbase = p.qkv_small + (long)seq * L * (3 * kC) + head * kDH;   // key/value j: + j*3C + {C, 2C}
+        const u32x4* qp = reinterpret_cast<const u32x4*>(p.qkv_small + (long)tkc * (3 * kC) + head * kDH);
+        u32x4 qv[3], kk[MAXL][3], vv[MAXL][3];
+        float mk[MAXL];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const u32x4 v = qp[i];
+        for (int i = 0; i < 3; ++i) qv[i] = qp[i];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    q[8 * i + 2 * j] = bf16_lo(v[j]);
-                    q[8 * i + 2 * j + 1] = bf16_hi(v[j]);
-                }
-            }
-            float s[MAXL + 1];
-            float mx = -1e30f;
+        for (int j = 0; j < MAXL; ++j) {
+            const int jc = j < L ? j : L - 1;
+            mk[j] = p.mk.at((long)seq * L + jc);
+            const u32x4* kp = reinterpret_cast<const u32x4*>(sbase + (long)jc * (3 * kC) + kC);
 #pragma unroll
-            for (int j = 0; j < MAXL; ++j) {
-                s[j] = -1e30f;
-                if (j < L) {
-                    const long kt = (long)seq * L + j;
-                    if (p.mk.at(kt) != 0.f) {
-                        const u32x4* kp = reinterpret_cast<const u32x4*>(p.qkv_small + kt * (3 * kC) + kC + head * kDH);
-                        float d = 0.f;
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            const u32x4 v = kp[i];
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj)
-                                d += q[8 * i + 2 * jj] * bf16_lo(v[jj]) + q[8 * i + 2 * jj + 1] * bf16_hi(v[jj]);
-                        }
-                        s[j] = d;
-                    }
-                }
-                mx = fmaxf(mx, s[j]);
-            }
-            {   // learned bias key at position L, rotated there (mha.py:265-268 before :356-357); never masked
-                const float* bk = p.bias_k + head * kDH;
-                const float* rc = p.rope + (long)L * kRopeRow;
-                float d = 0.f;
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                    for (int pp = 0; pp < 6; ++pp) {
-                        const int i = 6 * hh + pp;
-                        const float x1 = bk[i], x2 = bk[i + 12], c = rc[16 * hh + pp], sn = rc[16 * hh + 8 + pp];
-                        const float k1 = bf16_lo(pack_bf16(x1 * c - x2 * sn, 0.f));
-                        const float k2 = bf16_lo(pack_bf16(x2 * c + x1 * sn, 0.f));
-                        d += q[hh * 12 + 2 * pp] * k1 + q[hh * 12 + 2 * pp + 1] * k2;
-                    }
-                s[MAXL] = d;
-                mx = fmaxf(mx, d);
-            }
-            float o[24];
-#pragma unroll
-            for (int i = 0; i < 24; ++i) o[i] = 0.f;
-            float den = 0.f;
-#pragma unroll
-            for (int j = 0; j < MAXL; ++j) {
-                if (j < L && s[j] > -1e29f) {
-                    const float pj = __builtin_amdgcn_exp2f(s[j] - mx);
-                    den += pj;
-                    const long kt = (long)seq * L + j;
-                    const u32x4* vp = reinterpret_cast<const u32x4*>(p.qkv_small + kt * (3 * kC) + 2 * kC + head * kDH);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const u32x4 v = vp[i];
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            o[8 * i + 2 * jj] += pj * bf16_lo(v[jj]);
-                            o[8 * i + 2 * jj + 1] += pj * bf16_hi(v[jj]);
-                        }
-                    }
-                }
-            }
-            {
-                const float pj = __builtin_amdgcn_exp2f(s[MAXL] - mx);
-                den += pj;
-                const float* bv = p.bias_v + head * kDH;
-#pragma unroll
-                for (int i = 0; i < 24; ++i) o[i] += pj * bf16_lo(pack_bf16(bv[i], 0.f));
-            }
-            const float inv = 1.0f / den;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                o4[i] = u32x4{pack_bf16(o[8 * i] * inv, o[8 * i + 1] * inv), pack_bf16(o[8 * i + 2] * inv, o[8 * i + 3] * inv),
-                              pack_bf16(o[8 * i + 4] * inv, o[8 * i + 5] * inv), pack_bf16(o[8 * i + 6] * inv, o[8 * i + 7] * inv)};
+            for (int i = 0; i < 3; ++i) kk[j][i] = kp[i];
         }
+        if (MAXL <= 4) {   // few keys: the values fit in registers too -> one round trip for everything
+#pragma unroll
+            for (int j = 0; j < MAXL; ++j) {
+                const int jc = j < L ? j : L - 1;
+                const u32x4* vp = reinterpret_cast<const u32x4*>(sbase + (long)jc * (3 * kC) + 2 * kC);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) vv[j][i] = vp[i];
+            }
+        }
+        float q[24];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            *reinterpret_cast<u32x4*>(panel + panel_off(row, head * 48 + i * 16, kRowB)) = o4[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                q[8 * i + 2 * j] = bf16_lo(qv[i][j]);
+                q[8 * i + 2 * j + 1] = bf16_hi(qv[i][j]);
+            }
+        float s[MAXL + 1];
+        float mx = -1e30f;
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    d += q[8 * i + 2 * jj] * bf16_lo(kk[j][i][jj]) + q[8 * i + 2 * jj + 1] * bf16_hi(kk[j][i][jj]);
+            s[j] = (j < L && mk[j] != 0.f) ? d : -1e30f;
+            mx = fmaxf(mx, s[j]);
+        }
+        if (MAXL > 4) {
+#pragma unroll
+            for (int j = 0; j < MAXL; ++j) {
+                const int jc = j < L ? j : L - 1;
+                const u32x4* vp = reinterpret_cast<const u32x4*>(sbase + (long)jc * (3 * kC) + 2 * kC);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) vv[j][i] = vp[i];
+            }
+        }
+        {   // learned bias key at position L, rotated there (mha.py:265-268 before :356-357); never masked
+            const float* bk = p.bias_k + head * kDH;
+            const float* rc = p.rope + (long)L * kRopeRow;
+            float d = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int pp = 0; pp < 6; ++pp) {
+                    const int i = 6 * hh + pp;
+                    const float x1 = bk[i], x2 = bk[i + 12], c = rc[16 * hh + pp], sn = rc[16 * hh + 8 + pp];
+                    const float k1 = bf16_lo(pack_bf16(x1 * c - x2 * sn, 0.f));
+                    const float k2 = bf16_lo(pack_bf16(x2 * c + x1 * sn, 0.f));
+                    d += q[hh * 12 + 2 * pp] * k1 + q[hh * 12 + 2 * pp + 1] * k2;
+                }
+            s[MAXL] = d;
+            mx = fmaxf(mx, d);
+        }
+        float o[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) o[i] = 0.f;
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j) {
+            const float pj = s[j] > -1e29f ? __builtin_amdgcn_exp2f(s[j] - mx) : 0.f;
+            den += pj;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    o[8 * i + 2 * jj] += pj * bf16_lo(vv[j][i][jj]);
+                    o[8 * i + 2 * jj + 1] += pj * bf16_hi(vv[j][i][jj]);
+                }
+        }
+        {
+            const float pj = __builtin_amdgcn_exp2f(s[MAXL] - mx);
+            den += pj;
+            const float* bv = p.bias_v + head * kDH;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) o[i] += pj * bf16_lo(pack_bf16(bv[i], 0.f));
+        }
+        const float inv = token >= 0 ? 1.0f / den : 0.f;   // padding rows are written as zeros
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            *reinterpret_cast<u32x4*>(panel + panel_off(row, head * 48 + i * 16, kRowB)) =
+                u32x4{pack_bf16(o[8 * i] * inv, o[8 * i + 1] * inv), pack_bf16(o[8 * i + 2] * inv, o[8 * i + 3] * inv),
+                      pack_bf16(o[8 * i + 4] * inv, o[8 * i + 5] * inv), pack_bf16(o[8 * i + 6] * inv, o[8 * i + 7] * inv)};
     }
 }
 
@@ -270,9 +283,10 @@ __global__ __launch_bounds__(256, 2) void k_proj(const ProjParams p) {
     setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
     __syncthreads();
     if (!(p.dbg & 1)) {
-        if (MODE == 2)
-            prologue_micro_attn<8>(panel, pr, p);
-        else
+        if (MODE == 2) {
+            if (p.ax.len <= 4) prologue_micro_attn<4>(panel, pr, p);
+            else prologue_micro_attn<8>(panel, pr, p);
+        } else
             prologue_bf16<K>(panel, pr, p.a_bf16);
     }
     __syncthreads();
@@ -430,21 +444,26 @@ __global__ __launch_bounds__(256, 2) void k_final(const FinalParams p) {
         f32x16 acc[1];
         zero_acc<1>(acc);
         wave_gemm<1, 1, 24, false>(panel, kRowB, w, 0, p.w + lane, 24 * 64, acc);
-        if (n < p.D) {
-            const float b = p.bias[n];
+        // Euler read-modify-write of x: all 16 loads unconditional and issued together (see prologue_ln)
+        const bool col_ok = n < p.D;
+        const int nc = col_ok ? n : 0;
+        const float b = p.bias[nc];
+        int tks[16];
+        float xv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tk = pr->tok[w * 32 + mfma_row(r, hh)];
-                if (tk >= 0) {
-                    const float v = acc[0][r] + b;
-                    const long o = (long)tk * p.D + n;
-                    if (p.euler)
-                        p.x[o] = p.x[o] + p.dt * v;
-                    else
-                        p.out[o] = v;
-                }
-            }
+        for (int r = 0; r < 16; ++r) {
+            tks[r] = pr->tok[w * 32 + mfma_row(r, hh)];
+            xv[r] = 0.f;
         }
+        if (p.euler) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = p.x[(long)(tks[r] < 0 ? 0 : tks[r]) * p.D + nc];
+        }
+        float* dst = p.euler ? p.x : p.out;
+        const float dt = p.euler ? p.dt : 1.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (col_ok && tks[r] >= 0) dst[(long)tks[r] * p.D + n] = xv[r] + dt * (acc[0][r] + b);
     }
 }
 

@@ -134,49 +134,66 @@ __device__ __forceinline__ void setup_rows_linear(PanelRows* pr, long row0, long
 // affine LayerNorm y = LN(x)*gamma+beta (AFFINE; nn.LayerNorm of IPALayer.ipa_norm, eps 1e-5).
 // 256 threads; wave w normalises rows w, w+4, ...; a row is 384 fp32 = 6 per lane as 3 float2.
 // `tok[r]` (in LDS) = global token row of panel row r, or -1 for padding rows (written as zeros).
+// Memory-level parallelism: each wave normalises FOUR rows per iteration and every global load is
+// UNCONDITIONAL (padding rows read token 0 and are written as zeros).  A load under `if (t >= 0)` makes hipcc
+// merge old and new register values right behind it, i.e. wait for the data it has just requested -- with one
+// row per iteration that exposed a full HBM round trip per row, 16 times per wave.
 template <bool AFFINE>
 __device__ __forceinline__ void prologue_ln(unsigned char* panel, const PanelRows* pr, const float* __restrict__ x,
                                             const ModMap mm, int shift_chunk, int scale_chunk, float eps) {
     const int lane = lane_id(), w = wave_id();
     constexpr int ROWB = kC * 2;
-    for (int r = w; r < kPanel; r += 4) {
-        const long t = pr->tok[r];
-        f32x2 v[3];
-        if (t >= 0) {
-            const f32x2* xr = reinterpret_cast<const f32x2*>(x + t * kC);
+    constexpr int RB = 4;
+    for (int r0 = w * RB; r0 < kPanel; r0 += 4 * RB) {
+        int t[RB];
+        f32x2 v[RB][3], sc[RB][3], sh[RB][3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) v[i] = xr[lane + 64 * i];
-        } else {
+        for (int j = 0; j < RB; ++j) t[j] = pr->tok[r0 + j];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) v[i] = f32x2{0.f, 0.f};
+        for (int j = 0; j < RB; ++j) {
+            const f32x2* xr = reinterpret_cast<const f32x2*>(x + (long)(t[j] < 0 ? 0 : t[j]) * kC);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[j][i] = xr[lane + 64 * i];
         }
-        float s = (v[0][0] + v[0][1]) + (v[1][0] + v[1][1]) + (v[2][0] + v[2][1]);
-        const float mean = wave_sum(s) * (1.0f / kC);
-        float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            v[i][0] -= mean;
-            v[i][1] -= mean;
-            q += v[i][0] * v[i][0] + v[i][1] * v[i][1];
-        }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kC) + eps);
-        if (t >= 0) {
-            const float* mrow = AFFINE ? mm.mod : mm.mod + pr->moff[r];
-            const f32x2* sh = reinterpret_cast<const f32x2*>(mrow + shift_chunk * kC);
-            const f32x2* sc = reinterpret_cast<const f32x2*>(mrow + scale_chunk * kC);
+        for (int j = 0; j < RB; ++j) {
+            const float* mrow = AFFINE ? mm.mod : mm.mod + pr->moff[r0 + j];   // moff == 0 for padding rows
+            const f32x2* shp = reinterpret_cast<const f32x2*>(mrow + shift_chunk * kC);
+            const f32x2* scp = reinterpret_cast<const f32x2*>(mrow + scale_chunk * kC);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const f32x2 a = sc[lane + 64 * i], b = sh[lane + 64 * i];
-                const float m0 = AFFINE ? a[0] : 1.0f + a[0];
-                const float m1 = AFFINE ? a[1] : 1.0f + a[1];
-                const float y0 = v[i][0] * rstd * m0 + b[0];
-                const float y1 = v[i][1] * rstd * m1 + b[1];
-                *reinterpret_cast<uint32_t*>(panel + panel_off(r, 4 * lane + 256 * i, ROWB)) = pack_bf16(y0, y1);
+                sc[j][i] = scp[lane + 64 * i];
+                sh[j][i] = shp[lane + 64 * i];
             }
-        } else {
+        }
+        float mean[RB], rstd[RB];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                *reinterpret_cast<uint32_t*>(panel + panel_off(r, 4 * lane + 256 * i, ROWB)) = 0u;
+        for (int j = 0; j < RB; ++j) {
+            const float s = (v[j][0][0] + v[j][0][1]) + (v[j][1][0] + v[j][1][1]) + (v[j][2][0] + v[j][2][1]);
+            mean[j] = wave_sum(s) * (1.0f / kC);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                v[j][i][0] -= mean[j];
+                v[j][i][1] -= mean[j];
+                q += v[j][i][0] * v[j][i][0] + v[j][i][1] * v[j][i][1];
+            }
+            rstd[j] = 1.0f / sqrtf(wave_sum(q) * (1.0f / kC) + eps);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float m0 = AFFINE ? sc[j][i][0] : 1.0f + sc[j][i][0];
+                const float m1 = AFFINE ? sc[j][i][1] : 1.0f + sc[j][i][1];
+                const float y0 = v[j][i][0] * rstd[j] * m0 + sh[j][i][0];
+                const float y1 = v[j][i][1] * rstd[j] * m1 + sh[j][i][1];
+                *reinterpret_cast<uint32_t*>(panel + panel_off(r0 + j, 4 * lane + 256 * i, ROWB)) =
+                    t[j] >= 0 ? pack_bf16(y0, y1) : 0u;
+            }
         }
     }
 }
@@ -186,12 +203,24 @@ template <int K>
 __device__ __forceinline__ void prologue_bf16(unsigned char* panel, const PanelRows* pr, const __bf16* __restrict__ src) {
     constexpr int ROWB = K * 2;
     constexpr int CPR = ROWB / 16;  // 16-byte chunks per row
-    for (int i = threadIdx.x; i < kPanel * CPR; i += 256) {
+    constexpr int NIT = kPanel * CPR / 256;
+    static_assert(kPanel * CPR % 256 == 0, "whole iterations");
+    // all of a thread's loads are issued back to back and unconditionally (padding rows read token 0)
+    u32x4 v[NIT];
+    int tk[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + 256 * it;
         const int r = i / CPR, c = i % CPR;
-        const long t = pr->tok[r];
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (t >= 0) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(src) + t * ROWB + c * 16);
-        *reinterpret_cast<u32x4*>(panel + panel_off(r, c * 16, ROWB)) = v;
+        tk[it] = pr->tok[r];
+        v[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(src) +
+                                                (long)(tk[it] < 0 ? 0 : tk[it]) * ROWB + c * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + 256 * it;
+        const int r = i / CPR, c = i % CPR;
+        *reinterpret_cast<u32x4*>(panel + panel_off(r, c * 16, ROWB)) = tk[it] >= 0 ? v[it] : u32x4{0u, 0u, 0u, 0u};
     }
 }
 
@@ -238,32 +267,40 @@ __device__ __forceinline__ void epilogue_gate_residual_lds(const f32x16* acc, co
     const int hh = lane >> 5, n = lane & 31;
     const int q = lane % 24, r2 = lane / 24;
     const bool active = lane < 48;
-    f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (active) b4 = *reinterpret_cast<const f32x4*>(bias + col0 + 4 * q);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + col0 + 4 * q);
     const f32x4* stage4 = reinterpret_cast<const f32x4*>(stage);
+    const int slot = active ? lane : 0;   // lanes 48..63 idle along: keep their LDS/global addresses in range
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
         for (int f = 0; f < FT; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) stage[mfma_row(r, hh) * 96 + f * 32 + n] = acc[t * FT + f][r];
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int row = t * 32 + 2 * i + r2;
-            if (active) {
-                const int tk = pr->tok[row];
-                if (tk >= 0) {
-                    const f32x4 v = stage4[i * 48 + lane];
-                    f32x4 g = f32x4{1.f, 1.f, 1.f, 1.f};
-                    if (gated) g = *reinterpret_cast<const f32x4*>(mm.mod + pr->moff[row] + gate_chunk * kC + col0 + 4 * q);
-                    f32x4* hp = reinterpret_cast<f32x4*>(h + (long)tk * kC + col0 + 4 * q);
-                    f32x4 hv = *hp;
-                    hv[0] += g[0] * (v[0] + b4[0]);
-                    hv[1] += g[1] * (v[1] + b4[1]);
-                    hv[2] += g[2] * (v[2] + b4[2]);
-                    hv[3] += g[3] * (v[3] + b4[3]);
-                    *hp = hv;
-                }
+        // The read-modify-write of h runs in two batches of 8 rows whose loads are all UNCONDITIONAL (padding
+        // rows and idle lanes read token 0) and issued back to back; only the stores are predicated.  With a
+        // load under `if (tk >= 0)` every row paid its own HBM round trip, 32 in sequence per wave.
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x4 hv[8], g[8];
+            int tk[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = active ? t * 32 + 2 * (8 * b + k) + r2 : 0;
+                tk[k] = active ? pr->tok[row] : -1;
+                const long tc = tk[k] < 0 ? 0 : tk[k];
+                hv[k] = *reinterpret_cast<const f32x4*>(h + tc * kC + col0 + 4 * q);
+                g[k] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (gated) g[k] = *reinterpret_cast<const f32x4*>(mm.mod + pr->moff[row] + gate_chunk * kC + col0 + 4 * q);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f32x4 v = stage4[(8 * b + k) * 48 + slot];
+                f32x4 o = hv[k];
+                o[0] += g[k][0] * (v[0] + b4[0]);
+                o[1] += g[k][1] * (v[1] + b4[1]);
+                o[2] += g[k][2] * (v[2] + b4[2]);
+                o[3] += g[k][3] * (v[3] + b4[3]);
+                if (tk[k] >= 0) *reinterpret_cast<f32x4*>(h + (long)tk[k] * kC + col0 + 4 * q) = o;
             }
         }
     }

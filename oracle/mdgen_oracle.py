@@ -103,9 +103,17 @@ def rot_to_quat(R):
     return vectors[..., -1]
 
 
-def to_tensor_7(R, t):
-    """rigid_utils.py:1143-1155  [quat(4) | trans(3)]."""
-    return torch.cat([rot_to_quat(R), t], -1)
+def to_tensor_7(R, t, quat_sign="eigh"):
+    """rigid_utils.py:1143-1155  [quat(4) | trans(3)].
+
+    quat_sign: the reference takes whatever sign LAPACK's eigh returns (arbitrary, rigid_utils.py:208-210).
+    "eigh" reproduces that (same torch build -> same signs; this is what the reference goldens pin);
+    "w_nonneg" flips each quaternion so that w >= 0, the convention the HIP kernel (k_se3.hip rot2quat) uses,
+    so that device parity can be asserted on the TPS relative-frame path where the sign reaches a Linear."""
+    q = rot_to_quat(R)
+    if quat_sign == "w_nonneg":
+        q = torch.where(q[..., :1] < 0, -q, q)
+    return torch.cat([q, t], -1)
 
 
 def from_tensor_7(x, normalize_quats=True):
@@ -362,9 +370,10 @@ def run_ipa(P, cfg, temb, mask_bl, start, end, aatype):
     aa = P["aatype_to_emb.weight"][aatype]
     if cfg.get("tps_condition", False):
         iR, it = rigid_invert(*start)
-        x_f = to_tensor_7(*rigid_compose(iR, it, *end))                  # :194
+        qs = cfg.get("quat_sign", "eigh")
+        x_f = to_tensor_7(*rigid_compose(iR, it, *end), quat_sign=qs)    # :194
         iR, it = rigid_invert(*end)
-        x_r = to_tensor_7(*rigid_compose(iR, it, *start))                # :195
+        x_r = to_tensor_7(*rigid_compose(iR, it, *start), quat_sign=qs)  # :195
         x_f = linear(P, "latent_to_emb_f", x_f) + aa
         x_r = linear(P, "latent_to_emb_r", x_r) + aa
         for i in range(nl):

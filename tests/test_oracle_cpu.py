@@ -155,3 +155,19 @@ def test_euler_grid():
     """integrators.py:88 linspace(t0,t1,num_steps) -> S = num_steps-1 Euler steps; dt sums to 1."""
     tg = torch.linspace(0, 1, 50)
     assert len(tg) - 1 == 49 and abs(float((tg[1:] - tg[:-1]).sum()) - 1) < 1e-6
+
+
+def test_quat_sign_option_is_only_a_sign():
+    """to_tensor_7(quat_sign="w_nonneg") (the convention the HIP kernel uses) differs from the eigh-signed
+    reference restatement by per-quaternion sign only, i.e. it encodes the same rotations."""
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(64, 4, generator=g)
+    R = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    t = torch.randn(64, 3, generator=g)
+    a = O.to_tensor_7(R, t)
+    b = O.to_tensor_7(R, t, quat_sign="w_nonneg")
+    assert (b[:, 0] >= 0).all()
+    s = torch.sign((a[:, :4] * b[:, :4]).sum(-1, keepdim=True))
+    assert torch.allclose(a[:, :4] * s, b[:, :4], atol=1e-6)
+    assert torch.equal(a[:, 4:], b[:, 4:])
+    assert torch.allclose(O.quat_to_rot(b[:, :4]), R, atol=1e-5)
