@@ -37,6 +37,8 @@ WORKLOADS = {
     "tetrapeptide_fwdsim_crop4_T1000_B16": (16, 1000, 4, True, 0),
     "atlas_crop256_T250_B1": (1, 250, 256, False, 16),
     "tetrapeptide_fwdsim_crop4_T100_B1": (1, 100, 4, True, 0),
+    "tetrapeptide_fwdsim_crop4_T1000_B8": (8, 1000, 4, True, 0),    # working-set experiments (not bench lines)
+    "tetrapeptide_fwdsim_crop4_T1000_B4": (4, 1000, 4, True, 0),
 }
 
 

@@ -133,6 +133,10 @@ int32_t mdgen_sample_euler(mdgen_ctx* ctx, const mdgen_shape* shape, int32_t n_s
  * `mdgen_profile_report` synchronises `stream`, writes a JSON object
  *   {"<class>": {"count": n, "ms": total_ms}, ...}   into buf (NUL-terminated) and resets the log. */
 int32_t mdgen_profile_enable(mdgen_ctx* ctx, int32_t on);
+/* Measurement only: the NEXT trunk MLP launch (the dominant kernel) writes per-wave s_memtime phase stamps into
+ * dev_buf ([workgroup*4 + wave][32] uint64; slot meaning: csrc/k_gemm.hip `stamp`).  One-shot; pass NULL to cancel.
+ * Only meaningful with profiling enabled or use_graph == 0 (a captured graph would replay the pointer). */
+int32_t mdgen_profile_phase_trace(mdgen_ctx* ctx, uint64_t* dev_buf, int64_t capacity_words);
 int32_t mdgen_profile_report(mdgen_ctx* ctx, void* stream, char* buf, size_t buflen);
 
 /* Host-only (no GPU): the weight-row / bias permutations behind the attention fragment layout

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MDGEN_AMD_LIB", os.path.join(_HERE, "libmdgen_amd.so"
 EXPORTS = [
     "mdgen_last_error", "mdgen_abi_version", "mdgen_ctx_create", "mdgen_ctx_destroy", "mdgen_ctx_set_weight",
     "mdgen_ctx_finalize", "mdgen_ctx_num_weights", "mdgen_ctx_weight_name", "mdgen_workspace_layout",
-    "mdgen_denoiser_forward", "mdgen_sample_euler", "mdgen_profile_enable", "mdgen_profile_report", "mdgen_debug_layout_maps",
+    "mdgen_denoiser_forward", "mdgen_sample_euler", "mdgen_profile_enable", "mdgen_profile_report", "mdgen_profile_phase_trace", "mdgen_debug_layout_maps",
     "mdgen_rigid_compose", "mdgen_rigid_invert",
     "mdgen_rigid_apply", "mdgen_quat_to_rot", "mdgen_rot_to_quat", "mdgen_prep_latents",
     "mdgen_samples_to_atom14", "mdgen_atom14_to_cond",
@@ -56,6 +56,7 @@ def _load():
     lib.mdgen_denoiser_forward.argtypes = [vp, C.POINTER(Shape)] + [vp] * 14 + [sz, vp]
     lib.mdgen_sample_euler.argtypes = [vp, C.POINTER(Shape), i32] + [vp] * 10 + [sz, i32, vp]
     lib.mdgen_profile_enable.argtypes = [vp, i32]
+    lib.mdgen_profile_phase_trace.argtypes = [vp, vp, i64]
     lib.mdgen_profile_report.argtypes = [vp, vp, C.c_char_p, sz]
     lib.mdgen_debug_layout_maps.argtypes = [vp] * 5
     lib.mdgen_rigid_compose.argtypes = [i64] + [vp] * 7

@@ -106,6 +106,8 @@ struct mdgen_ctx {
     std::vector<GraphEntry> graphs;
     bool inv_freq_set = false;
     bool prof_on = false;
+    unsigned long long* phase_trace = nullptr;   // mdgen_profile_phase_trace target (device), consumed by one launch
+    long phase_trace_cap = 0;
     std::vector<ProfRec> prof;
     static constexpr int kMaxSide = 7;
     hipStream_t side[kMaxSide] = {};
@@ -621,7 +623,6 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
     p.gated = 1;
     p.w = m.wo;
     p.bias = m.bo;
-    { const char* e = getenv("MDGEN_DEBUG_KPROJ"); p.dbg = e ? atoi(e) : 0; }
     const bool small = residue_axis && ax.len <= 8;
     if (small) {
         q.wv = m.wv_small;
@@ -674,8 +675,11 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
     p.w2 = f.w2;
     p.b1 = f.b1;
     p.b2 = f.b2;
-    { const char* e = getenv("MDGEN_DEBUG_KMLP"); p.dbg = e ? atoi(e) : 0; }
-    { const char* e = getenv("MDGEN_STAGGER_MLP"); p.stagger = e ? atoi(e) : 0; }
+    if (trunk && r.c->phase_trace) {   // one-shot: the next trunk MLP launch records its phase stamps
+        p.trace = r.c->phase_trace;
+        p.trace_cap = r.c->phase_trace_cap;
+        r.c->phase_trace = nullptr;
+    }
     { ProfScope ps(r.c, trunk ? "mlp" : "ipa.mlp", r.s); launch_mlp(p, r.s); }
     LAUNCHCHK();
     return 0;
@@ -1006,6 +1010,13 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
 extern "C" int32_t mdgen_profile_enable(mdgen_ctx* c, int32_t on) {
     if (!c) return fail(-1, "null context");
     c->prof_on = on != 0;
+    return 0;
+}
+
+extern "C" int32_t mdgen_profile_phase_trace(mdgen_ctx* c, uint64_t* dev_buf, int64_t capacity_words) {
+    if (!c) return fail(-1, "null context");
+    c->phase_trace = (unsigned long long*)dev_buf;
+    c->phase_trace_cap = dev_buf ? capacity_words : 0;
     return 0;
 }
 

@@ -107,6 +107,9 @@ __global__ void k_pack_rows(const float* __restrict__ w, int ld, const int* __re
 // cond_to_emb product is skipped for tokens whose x_cond row is all zero (every non-conditioning frame);
 // each store is a fully coalesced 1.5 KB row.
 constexpr int kEmbTok = 64;
+// POS / IPA: pos_embed / ipa_out present (compile-time so that their loads are unconditional and can be
+// issued 8 tokens ahead; a load inside `if (ptr)` in a rolled loop paid one L2 round trip per token).
+template <bool POS, bool IPA>
 __global__ __launch_bounds__(384) void k_embed(const EmbedParams p) {
     __shared__ __attribute__((aligned(16))) float xs[kEmbTok][28];
     __shared__ __attribute__((aligned(16))) float cs[kEmbTok][28];
@@ -115,17 +118,30 @@ __global__ __launch_bounds__(384) void k_embed(const EmbedParams p) {
     const long tok0 = (long)blockIdx.x * kEmbTok;
     if (threadIdx.x < kEmbTok) ms[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < kEmbTok * 28; i += 384) {
-        const int tk = i / 28, d = i % 28;
-        const long t = tok0 + tk;
-        float a = 0.f, b = 0.f;
-        if (t < p.N && d < p.D) {
-            a = p.x[t * p.D + d];
-            b = p.x_cond[t * p.D + d];
+    {   // stage x / x_cond rows: unconditional clamped loads, all in flight together
+        constexpr int NIT = (kEmbTok * 28 + 383) / 384;
+        float a[NIT], b[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = threadIdx.x + 384 * it;
+            const int tk = (i / 28) & (kEmbTok - 1), d = i % 28;
+            long t = tok0 + tk;
+            t = t < p.N ? t : p.N - 1;
+            const int dc = d < p.D ? d : 0;
+            a[it] = p.x[t * p.D + dc];
+            b[it] = p.x_cond[t * p.D + dc];
         }
-        xs[tk][d] = a;
-        cs[tk][d] = b;
-        if (b != 0.f) atomicOr(&ms[tk], 2);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = threadIdx.x + 384 * it;
+            if (i < kEmbTok * 28) {
+                const int tk = i / 28, d = i % 28;
+                const bool ok = tok0 + tk < p.N && d < p.D;
+                xs[tk][d] = ok ? a[it] : 0.f;
+                cs[tk][d] = ok ? b[it] : 0.f;
+                if (ok && b[it] != 0.f) atomicOr(&ms[tk], 2);
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x < kEmbTok) {
@@ -135,40 +151,65 @@ __global__ __launch_bounds__(384) void k_embed(const EmbedParams p) {
     float wl[28], wc[28];
 #pragma unroll
     for (int d = 0; d < 28; ++d) {
-        wl[d] = d < p.D ? p.wl[(long)c * p.D + d] : 0.f;
-        wc[d] = d < p.D ? p.wc[(long)c * p.D + d] : 0.f;
+        wl[d] = p.wl[(long)c * p.D + (d < p.D ? d : 0)];
+        wc[d] = p.wc[(long)c * p.D + (d < p.D ? d : 0)];
+        if (d >= p.D) wl[d] = wc[d] = 0.f;
     }
     const float b0 = p.bl[c] + p.bc[c];
     const float me0 = p.mask_emb[c], me1 = p.mask_emb[kC + c];
     __syncthreads();
-    const long TL = (long)p.T * p.L;
+    const int TL = p.T * p.L;
     const int ntok = (p.N - tok0 < kEmbTok) ? (int)(p.N - tok0) : kEmbTok;
-    for (int tk = 0; tk < ntok; ++tk) {
-        const long t = tok0 + tk;
-        float a = b0;
-        const f32x4* xr = reinterpret_cast<const f32x4*>(&xs[tk][0]);
+    // (b, l) of the block's first token; consecutive tokens advance l, then the frame, then b (wave-uniform)
+    int l = (int)(tok0 % p.L);
+    int fl = (int)(tok0 % TL);          // position inside sample b: frame*L + l
+    int bidx = (int)(tok0 / TL);
+    for (int tk0 = 0; tk0 < ntok; tk0 += 8) {
+        float add[8];
 #pragma unroll
-        for (int d4 = 0; d4 < 7; ++d4) {
-            const f32x4 v = xr[d4];
-            a += wl[4 * d4] * v[0] + wl[4 * d4 + 1] * v[1] + wl[4 * d4 + 2] * v[2] + wl[4 * d4 + 3] * v[3];
-        }
-        const int m = ms[tk];
-        if (m & 2) {
-            const f32x4* cr = reinterpret_cast<const f32x4*>(&cs[tk][0]);
-            float a2 = 0.f;
-#pragma unroll
-            for (int d4 = 0; d4 < 7; ++d4) {
-                const f32x4 v = cr[d4];
-                a2 += wc[4 * d4] * v[0] + wc[4 * d4 + 1] * v[1] + wc[4 * d4 + 2] * v[2] + wc[4 * d4 + 3] * v[3];
+        for (int u = 0; u < 8; ++u) {
+            float v = 0.f;
+            if (POS) v += p.pos_embed[(long)l * kC + c];
+            if (IPA) v += p.ipa_out[((long)bidx * p.L + l) * kC + c];
+            add[u] = v;
+            if (++l == p.L) l = 0;
+            if (++fl == TL) {
+                fl = 0;
+                ++bidx;
             }
-            a += a2;
+            // past the last sample the indices would run out of ipa_out: clamp (those tokens are not stored)
+            if ((long)bidx * TL + fl >= p.N) {
+                bidx = 0;
+                fl = 0;
+                l = 0;
+            }
         }
-        a += (m & 1) ? me1 : me0;
-        const int l = (int)(t % p.L);
-        const int b = (int)(t / TL);
-        if (p.pos_embed) a += p.pos_embed[(long)l * kC + c];
-        if (p.ipa_out) a += p.ipa_out[((long)b * p.L + l) * kC + c];
-        p.h[t * kC + c] = a;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int tk = tk0 + u;
+            if (tk < ntok) {
+                float a = b0;
+                const f32x4* xr = reinterpret_cast<const f32x4*>(&xs[tk][0]);
+#pragma unroll
+                for (int d4 = 0; d4 < 7; ++d4) {
+                    const f32x4 v = xr[d4];
+                    a += wl[4 * d4] * v[0] + wl[4 * d4 + 1] * v[1] + wl[4 * d4 + 2] * v[2] + wl[4 * d4 + 3] * v[3];
+                }
+                const int m = ms[tk];
+                if (m & 2) {
+                    const f32x4* cr = reinterpret_cast<const f32x4*>(&cs[tk][0]);
+                    float a2 = 0.f;
+#pragma unroll
+                    for (int d4 = 0; d4 < 7; ++d4) {
+                        const f32x4 v = cr[d4];
+                        a2 += wc[4 * d4] * v[0] + wc[4 * d4 + 1] * v[1] + wc[4 * d4 + 2] * v[2] + wc[4 * d4 + 3] * v[3];
+                    }
+                    a += a2;
+                }
+                a += (m & 1) ? me1 : me0;
+                p.h[(tok0 + tk) * kC + c] = a + add[u];
+            }
+        }
     }
 }
 
@@ -325,7 +366,11 @@ void launch_pack_rows(const float* w, int ld, const int* rowmap, int nft, int ks
                        scale, dst);
 }
 void launch_embed(const EmbedParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(k_embed, dim3((unsigned)((p.N + kEmbTok - 1) / kEmbTok)), dim3(384), 0, s, p);
+    const dim3 g((unsigned)((p.N + kEmbTok - 1) / kEmbTok)), b(384);
+    if (p.pos_embed && p.ipa_out) hipLaunchKernelGGL((k_embed<true, true>), g, b, 0, s, p);
+    else if (p.pos_embed) hipLaunchKernelGGL((k_embed<true, false>), g, b, 0, s, p);
+    else if (p.ipa_out) hipLaunchKernelGGL((k_embed<false, true>), g, b, 0, s, p);
+    else hipLaunchKernelGGL((k_embed<false, false>), g, b, 0, s, p);
 }
 void launch_ipa_init(const float* aa_emb, const int64_t* aatype, const float* rel7, const float* w7, const float* b7,
                      float* h, int ngroups, int B, int L, hipStream_t s) {

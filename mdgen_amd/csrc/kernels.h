@@ -33,7 +33,6 @@ struct ProjParams {
     MaskMap mk;
     const float *bias_k, *bias_v;
     const float* rope;
-    int dbg;               // ablation switches (scripts/kbench.py): 1 skip prologue, 2 skip GEMM, 4 skip epilogue
 };
 
 struct MlpParams {
@@ -43,8 +42,8 @@ struct MlpParams {
     int shift_chunk, scale_chunk, gate_chunk;
     const bf16x8 *w1, *w2;  // w1 [48 ftile][24][64][8]; w2 [12 ftile][96][64][8]
     const float *b1, *b2;
-    int dbg;                // ablation switches: 1 skip LN prologue, 2 skip fc1, 4 skip GELU, 8 skip fc2, 16 skip epilogue
-    int stagger;            // start delay (units of ~3.4 us) for odd dispatch rounds
+    unsigned long long* trace;   // measurement only (mdgen_profile_phase_trace): [wave][32] s_memtime stamps, or null
+    long trace_cap;              // capacity of `trace` in 64-bit words
 };
 
 struct LnLinearParams {

@@ -10,6 +10,12 @@
 
 namespace mdg {
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a workgroup-scope fence over
+// GLOBAL memory, i.e. s_waitcnt vmcnt(0): a wave that has read-modify-write stores or prefetches in flight would
+// sit at the barrier until HBM has acknowledged them, and every other wave with it.  Use where the waves
+// exchange data through LDS only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- LDS panel addressing -----------------------------------------------------------------
 // Row r holds K bf16 (ROWB = 2K bytes, a multiple of 256).  Byte offset b within the row is
 // stored at b ^ ((r & 15) << 4): the 16 rows a ds_read_b128 lane-group touches land on 16
@@ -87,16 +93,6 @@ __device__ __forceinline__ void zero_acc(f32x16* acc) {
         for (int r = 0; r < 16; ++r) acc[i][r] = opaque_zero();
 }
 
-// Phase de-synchronisation: workgroups that share a CU start together and run identical phase sequences, so
-// their HBM-bound prologue/epilogue phases and their MFMA phases coincide instead of overlapping.  Delaying
-// every second "dispatch round" (blocks b and b+256 land on the same CU) by a fraction of a workgroup's
-// lifetime keeps one workgroup's memory phase under the other's MFMA phase for the rest of the launch.
-__device__ __forceinline__ void stagger_start(int units) {
-    if (units > 0 && ((blockIdx.x >> 8) & 1)) {
-        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);   // 127 x 64 cycles ~ 3.4 us
-    }
-}
-
 // ---- panel row table (LDS) ----------------------------------------------------------------------
 // tok[r]  = global token row of panel row r, or -1 for padding rows
 // moff[r] = offset (floats) of that token's adaLN table row inside ModMap::mod
@@ -120,56 +116,69 @@ __device__ __forceinline__ void setup_rows_axis(PanelRows* pr, const AxisMap ax,
 }
 
 // rows = natural token order row0 .. row0+63 (clipped at nrows)
-__device__ __forceinline__ void setup_rows_linear(PanelRows* pr, long row0, long nrows, const ModMap mm) {
-    if (threadIdx.x < kPanel) {
-        long t = row0 + threadIdx.x, mo = 0;
+// `tid`: index of the calling thread within the group of threads that fills the table (default: the workgroup)
+__device__ __forceinline__ void setup_rows_linear(PanelRows* pr, long row0, long nrows, const ModMap mm,
+                                                  int tid = threadIdx.x) {
+    if (tid >= 0 && tid < kPanel) {
+        long t = row0 + tid, mo = 0;
         if (t < nrows) mo = mm.row_off(t); else t = -1;
-        pr->tok[threadIdx.x] = (int)t;
-        pr->moff[threadIdx.x] = (int)mo;
+        pr->tok[tid] = (int)t;
+        pr->moff[tid] = (int)mo;
     }
 }
 
 // ---- panel prologues --------------------------------------------------------------------------
 // LayerNorm (no affine, eps) + adaLN modulate  y = LN(x)*(1+scale)+shift   (layers.py:14-15), or
 // affine LayerNorm y = LN(x)*gamma+beta (AFFINE; nn.LayerNorm of IPALayer.ipa_norm, eps 1e-5).
-// 256 threads; wave w normalises rows w, w+4, ...; a row is 384 fp32 = 6 per lane as 3 float2.
+// 256 threads; wave w normalises rows 16 b + 4 w + j (b, j < 4); a row is 384 fp32 = 6 per lane as 3 float2.
 // `tok[r]` (in LDS) = global token row of panel row r, or -1 for padding rows (written as zeros).
 // Memory-level parallelism: each wave normalises FOUR rows per iteration and every global load is
 // UNCONDITIONAL (padding rows read token 0 and are written as zeros).  A load under `if (t >= 0)` makes hipcc
 // merge old and new register values right behind it, i.e. wait for the data it has just requested -- with one
 // row per iteration that exposed a full HBM round trip per row, 16 times per wave.
-template <bool AFFINE>
+// B0..B1: the batches (of 4 rows per wave) handled by this call, so a caller can split the prologue in parts;
+// w: index (0..3) of the calling wave among the four that share the panel.
+template <bool AFFINE, int B0 = 0, int B1 = 4>
 __device__ __forceinline__ void prologue_ln(unsigned char* panel, const PanelRows* pr, const float* __restrict__ x,
-                                            const ModMap mm, int shift_chunk, int scale_chunk, float eps) {
-    const int lane = lane_id(), w = wave_id();
+                                            const ModMap mm, int shift_chunk, int scale_chunk, float eps,
+                                            const int w = wave_id(), const int lane = lane_id()) {
     constexpr int ROWB = kC * 2;
-    constexpr int RB = 4;
-    for (int r0 = w * RB; r0 < kPanel; r0 += 4 * RB) {
-        int t[RB];
-        f32x2 v[RB][3], sc[RB][3], sh[RB][3];
+    constexpr int RB = 4, NB = kPanel / (4 * RB);   // a wave owns NB batches of RB rows: rows 16 b + 4 w + j
+    static_assert(0 <= B0 && B0 < B1 && B1 <= NB, "batch range");
+    // One batch of RB rows in flight at a time.  (Requesting all 16 rows of a wave up front was measured SLOWER
+    // -- prologue 28k -> 34k cycles: every workgroup of the launch is in its prologue at the same time and the
+    // bigger burst only deepens the HBM queue.)
+    int t[NB][RB];
+    f32x2 v[NB][RB][3];
 #pragma unroll
-        for (int j = 0; j < RB; ++j) t[j] = pr->tok[r0 + j];
+    for (int b = B0; b < B1; ++b) {
+        const int r0 = 4 * RB * b + RB * w;
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            const f32x2* xr = reinterpret_cast<const f32x2*>(x + (long)(t[j] < 0 ? 0 : t[j]) * kC);
+            t[b][j] = pr->tok[r0 + j];
+            // uniform base (SGPR pair) + 32-bit byte offset: no 64-bit address VGPRs to keep alive or spill
+            const unsigned off = (unsigned)(t[b][j] < 0 ? 0 : t[b][j]) * (unsigned)(kC * 4) + (unsigned)lane * 8u;
+            const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) v[j][i] = xr[lane + 64 * i];
+            for (int i = 0; i < 3; ++i) v[b][j][i] = *reinterpret_cast<const f32x2*>(xb + off + 512u * i);
         }
+        f32x2 sc[RB][3], sh[RB][3];
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            const float* mrow = AFFINE ? mm.mod : mm.mod + pr->moff[r0 + j];   // moff == 0 for padding rows
-            const f32x2* shp = reinterpret_cast<const f32x2*>(mrow + shift_chunk * kC);
-            const f32x2* scp = reinterpret_cast<const f32x2*>(mrow + scale_chunk * kC);
+            const unsigned mo = AFFINE ? 0u : (unsigned)pr->moff[r0 + j];   // moff == 0 for padding rows
+            const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
+            const unsigned osh = (mo + (unsigned)(shift_chunk * kC)) * 4u + (unsigned)lane * 8u;
+            const unsigned osc = (mo + (unsigned)(scale_chunk * kC)) * 4u + (unsigned)lane * 8u;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                sc[j][i] = scp[lane + 64 * i];
-                sh[j][i] = shp[lane + 64 * i];
+                sc[j][i] = *reinterpret_cast<const f32x2*>(mb + osc + 512u * i);
+                sh[j][i] = *reinterpret_cast<const f32x2*>(mb + osh + 512u * i);
             }
         }
         float mean[RB], rstd[RB];
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            const float s = (v[j][0][0] + v[j][0][1]) + (v[j][1][0] + v[j][1][1]) + (v[j][2][0] + v[j][2][1]);
+            const float s = (v[b][j][0][0] + v[b][j][0][1]) + (v[b][j][1][0] + v[b][j][1][1]) + (v[b][j][2][0] + v[b][j][2][1]);
             mean[j] = wave_sum(s) * (1.0f / kC);
         }
 #pragma unroll
@@ -177,9 +186,9 @@ __device__ __forceinline__ void prologue_ln(unsigned char* panel, const PanelRow
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                v[j][i][0] -= mean[j];
-                v[j][i][1] -= mean[j];
-                q += v[j][i][0] * v[j][i][0] + v[j][i][1] * v[j][i][1];
+                v[b][j][i][0] -= mean[j];
+                v[b][j][i][1] -= mean[j];
+                q += v[b][j][i][0] * v[b][j][i][0] + v[b][j][i][1] * v[b][j][i][1];
             }
             rstd[j] = 1.0f / sqrtf(wave_sum(q) * (1.0f / kC) + eps);
         }
@@ -189,10 +198,10 @@ __device__ __forceinline__ void prologue_ln(unsigned char* panel, const PanelRow
             for (int i = 0; i < 3; ++i) {
                 const float m0 = AFFINE ? sc[j][i][0] : 1.0f + sc[j][i][0];
                 const float m1 = AFFINE ? sc[j][i][1] : 1.0f + sc[j][i][1];
-                const float y0 = v[j][i][0] * rstd[j] * m0 + sh[j][i][0];
-                const float y1 = v[j][i][1] * rstd[j] * m1 + sh[j][i][1];
+                const float y0 = v[b][j][i][0] * rstd[j] * m0 + sh[j][i][0];
+                const float y1 = v[b][j][i][1] * rstd[j] * m1 + sh[j][i][1];
                 *reinterpret_cast<uint32_t*>(panel + panel_off(r0 + j, 4 * lane + 256 * i, ROWB)) =
-                    t[j] >= 0 ? pack_bf16(y0, y1) : 0u;
+                    t[b][j] >= 0 ? pack_bf16(y0, y1) : 0u;
             }
         }
     }
@@ -254,55 +263,127 @@ __device__ __forceinline__ void epilogue_gate_residual(const f32x16* acc, const 
     }
 }
 
+// Same update straight from the accumulator layout, but with every load UNCONDITIONAL and issued up front:
+// one instruction covers two rows x 128 contiguous bytes (lanes 0-31 / 32-63), i.e. whole cache lines, and a
+// wave issues 96 h loads, 96 gate loads and 96 stores per panel -- a few hundred cycles of address processing.
+// (The form above is slow only because its loads sit under `if (tk >= 0)`: one HBM round trip per row.)
+// No LDS staging: used where no free LDS slab exists (k_mlp_ws).  TT = 2, FT = 3.
+__device__ __forceinline__ void epilogue_gate_residual_direct(f32x16* acc, const PanelRows* pr, int col0,
+                                                              const float* __restrict__ bias, const ModMap mm,
+                                                              int gate_chunk, float* __restrict__ h,
+                                                              const int lane = lane_id()) {
+    const int hh = lane >> 5, n = lane & 31;
+    float b[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) b[f] = bias[col0 + f * 32 + n];
+    unsigned char* hb = reinterpret_cast<unsigned char*>(h);
+    const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
+    const unsigned colb = (unsigned)(col0 + n) * 4u;
+    // One 32-row half at a time.  The 48 h values (HBM) are requested first; while they fly, the gate values
+    // (L2-resident table) arrive in groups of 4 rows and the accumulators are turned IN PLACE into the update
+    // gate * (acc + bias) -- so the registers in flight next to the 96 accumulators stay at 48 + 12.  (Both
+    // halves' h values at once would save one HBM round trip but needs 96 + 96 + 12 registers: it spills.)
+    // Addresses are a uniform base + 32-bit byte offsets (no 64-bit address VGPRs to keep alive or spill).
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float hv[16][3];
+        int tk[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            tk[r] = pr->tok[t * 32 + mfma_row(r, hh)];
+            const unsigned ho = (unsigned)(tk[r] < 0 ? 0 : tk[r]) * (unsigned)(kC * 4) + colb;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) hv[r][f] = *reinterpret_cast<const float*>(hb + ho + 128u * f);
+        }
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 4) {
+            float gv[4][3];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned go = ((unsigned)pr->moff[t * 32 + mfma_row(r0 + r, hh)] + (unsigned)(gate_chunk * kC)) * 4u + colb;
+#pragma unroll
+                for (int f = 0; f < 3; ++f) gv[r][f] = *reinterpret_cast<const float*>(mb + go + 128u * f);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int f = 0; f < 3; ++f) acc[t * 3 + f][r0 + r] = gv[r][f] * (acc[t * 3 + f][r0 + r] + b[f]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (tk[r] >= 0) {
+                const unsigned ho = (unsigned)tk[r] * (unsigned)(kC * 4) + colb;
+#pragma unroll
+                for (int f = 0; f < 3; ++f) *reinterpret_cast<float*>(hb + ho + 128u * f) = hv[r][f] + acc[t * 3 + f][r];
+            }
+    }
+}
+
 // Same update, staged through a wave-private 12 KiB LDS slab so that the read-modify-write of h uses 16-byte
 // accesses on whole 384-byte row segments: the direct form above issues 288 dword memory instructions per
 // lane and measured 100 of the 128 us of the out-projection kernel; this one issues 32 loads + 32 stores.
-// `stage` = this wave's slab ([32 rows][96 cols] fp32); the caller guarantees the panel is no longer read.
+// `stage` = this wave's slab ([32 rows][96 cols] fp32); the caller guarantees nothing else uses it meanwhile.
+// Two steps per 32-row half t of the panel:
+//   epi_stage: accumulator tiles acc[t*3 .. t*3+2] (MFMA layout) -> slab (row-major)
+//   epi_rmw  : slab -> h[token][col0 .. col0+95] += gate * (slab + bias), 48 lanes x float4 = two rows per step
+__device__ __forceinline__ void epi_stage(const f32x16* acc3, float* stage) {
+    const int lane = lane_id();
+    const int hh = lane >> 5, n = lane & 31;
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[mfma_row(r, hh) * 96 + f * 32 + n] = acc3[f][r];
+}
+
+// The loads of BR row pairs at a time are UNCONDITIONAL (padding rows and idle lanes read token 0) and issued
+// back to back; only the stores are predicated.  With a load under `if (tk >= 0)` every row paid its own HBM
+// round trip, 32 in sequence per wave.
+template <int BR>
+__device__ __forceinline__ void epi_rmw(const int t, const PanelRows* pr, const float* stage, int col0,
+                                        const float* __restrict__ bias, const ModMap mm, int gate_chunk, bool gated,
+                                        float* __restrict__ h) {
+    static_assert(16 % BR == 0, "batches of row pairs");
+    const int lane = lane_id();
+    const int q = lane % 24, r2 = lane / 24;
+    const bool active = lane < 48;
+    const int slot = active ? lane : 0;   // lanes 48..63 idle along: keep their LDS/global addresses in range
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + col0 + 4 * q);
+    const f32x4* stage4 = reinterpret_cast<const f32x4*>(stage);
+#pragma unroll
+    for (int b = 0; b < 16 / BR; ++b) {
+        f32x4 hv[BR], g[BR];
+        int tk[BR];
+#pragma unroll
+        for (int k = 0; k < BR; ++k) {
+            const int row = active ? t * 32 + 2 * (BR * b + k) + r2 : 0;
+            tk[k] = active ? pr->tok[row] : -1;
+            const long tc = tk[k] < 0 ? 0 : tk[k];
+            hv[k] = *reinterpret_cast<const f32x4*>(h + tc * kC + col0 + 4 * q);
+            g[k] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (gated) g[k] = *reinterpret_cast<const f32x4*>(mm.mod + pr->moff[row] + gate_chunk * kC + col0 + 4 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < BR; ++k) {
+            const f32x4 v = stage4[(BR * b + k) * 48 + slot];
+            f32x4 o = hv[k];
+            o[0] += g[k][0] * (v[0] + b4[0]);
+            o[1] += g[k][1] * (v[1] + b4[1]);
+            o[2] += g[k][2] * (v[2] + b4[2]);
+            o[3] += g[k][3] * (v[3] + b4[3]);
+            if (tk[k] >= 0) *reinterpret_cast<f32x4*>(h + (long)tk[k] * kC + col0 + 4 * q) = o;
+        }
+    }
+}
+
 template <int FT>
 __device__ __forceinline__ void epilogue_gate_residual_lds(const f32x16* acc, const PanelRows* pr, float* stage, int col0,
                                                            const float* __restrict__ bias, const ModMap mm,
                                                            int gate_chunk, bool gated, float* __restrict__ h) {
     static_assert(FT == 3, "slab is [32][96]");
-    const int lane = lane_id();
-    const int hh = lane >> 5, n = lane & 31;
-    const int q = lane % 24, r2 = lane / 24;
-    const bool active = lane < 48;
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + col0 + 4 * q);
-    const f32x4* stage4 = reinterpret_cast<const f32x4*>(stage);
-    const int slot = active ? lane : 0;   // lanes 48..63 idle along: keep their LDS/global addresses in range
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int f = 0; f < FT; ++f)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) stage[mfma_row(r, hh) * 96 + f * 32 + n] = acc[t * FT + f][r];
-        // The read-modify-write of h runs in two batches of 8 rows whose loads are all UNCONDITIONAL (padding
-        // rows and idle lanes read token 0) and issued back to back; only the stores are predicated.  With a
-        // load under `if (tk >= 0)` every row paid its own HBM round trip, 32 in sequence per wave.
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x4 hv[8], g[8];
-            int tk[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int row = active ? t * 32 + 2 * (8 * b + k) + r2 : 0;
-                tk[k] = active ? pr->tok[row] : -1;
-                const long tc = tk[k] < 0 ? 0 : tk[k];
-                hv[k] = *reinterpret_cast<const f32x4*>(h + tc * kC + col0 + 4 * q);
-                g[k] = f32x4{1.f, 1.f, 1.f, 1.f};
-                if (gated) g[k] = *reinterpret_cast<const f32x4*>(mm.mod + pr->moff[row] + gate_chunk * kC + col0 + 4 * q);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const f32x4 v = stage4[(8 * b + k) * 48 + slot];
-                f32x4 o = hv[k];
-                o[0] += g[k][0] * (v[0] + b4[0]);
-                o[1] += g[k][1] * (v[1] + b4[1]);
-                o[2] += g[k][2] * (v[2] + b4[2]);
-                o[3] += g[k][3] * (v[3] + b4[3]);
-                if (tk[k] >= 0) *reinterpret_cast<f32x4*>(h + (long)tk[k] * kC + col0 + 4 * q) = o;
-            }
-        }
+        epi_stage(acc + t * FT, stage);
+        epi_rmw<8>(t, pr, stage, col0, bias, mm, gate_chunk, gated, h);
     }
 }
 

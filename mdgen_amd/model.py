@@ -98,6 +98,15 @@ class LatentMDGenModel:
     def profile(self, on: bool):
         check(lib.mdgen_profile_enable(self._ctx, int(on)))
 
+    def phase_trace(self, buf):
+        """Arm the one-shot phase trace: the next trunk MLP launch writes [wave][32] s_memtime stamps into the
+        int64 CUDA tensor `buf` (None cancels).  Measurement only; use with use_graph=False."""
+        if buf is None:
+            check(lib.mdgen_profile_phase_trace(self._ctx, None, 0))
+        else:
+            assert buf.is_cuda and buf.dtype == torch.int64 and buf.is_contiguous()
+            check(lib.mdgen_profile_phase_trace(self._ctx, buf.data_ptr(), buf.numel()))
+
     def profile_report(self) -> dict:
         """{"kernel class": {"count": n, "ms": total}} measured with hipEvents on the launch stream."""
         import json
