@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void k_proj(const ProjParams p) {
 // Phi is evaluated as a logistic function of an odd polynomial, Phi(x) = 1 / (1 + exp(-x * P(x^2))), with the
 // degree-4 P fitted to the exact CDF on |x| <= 8 (beyond that Phi is 0 or 1 to fp32 precision, hence the clamp
 // of the polynomial's argument).  Maximum absolute error of gelu over all x, evaluated in fp32: 6.2e-6
-// (scripts/fit_gelu.py), two orders of magnitude below the bf16 rounding applied to the result right after.
+// (checked by scripts/fit_gelu.py), two orders of magnitude below the bf16 rounding applied to the result right after.
 // 11 VALU ops per element (the MLP kernel's GELU phase is VALU-bound): libm erff ~40, A&S 7.1.26 rational ~17.
 // Coefficients carry the factor -log2(e) so that the exponential is a bare v_exp_f32.
 __device__ __forceinline__ float gelu_erf(float x) {
