@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
     prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
     __syncthreads();
     stamp(p, 1);
-    const int w = wave_id(), lane = lane_id(), hh = lane >> 5, tk = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform, and the compiler knows it
+    const int lane = lane_id();
     f32x16 y[6];
     zero_acc<6>(y);
     for (int c = 0; c < kF / HC; ++c) {
@@ -376,18 +377,32 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
         zero_acc<4>(a1);
         wave_gemm<2, 2, 24, true, PF1>(panel, kRowB, 0, 0, p.w1 + (size_t)(8 * c + 2 * w) * 24 * 64 + lane, 24 * 64, a1);
         stamp(p, 2 + 4 * c);
+        // Everything the GELU section derives from the lane id (bias offsets, swizzled hbuf addresses) is
+        // recomputed here from an opaque copy: computed from the plain lane id it is loop-invariant, gets hoisted
+        // out of the chunk loop, spilled, and every reload sits behind an s_waitcnt vmcnt(0) -- which also
+        // serialised the eight bias loads (one L2 round trip each, 6k cycles per chunk).
+        int gl = lane;
+        asm volatile("" : "+v"(gl));
+        const int hh = gl >> 5, tk = gl & 31;
+        f32x4 b[2][4];   // all eight bias vectors requested together (uniform base + 32-bit offset)
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const unsigned bo = (unsigned)(c * HC + 64 * w + 32 * ft + 8 * a + 4 * hh) * 4u;
+                b[ft][a] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.b1) + bo);
+            }
         if (c > 0) __syncthreads();  // previous chunk's fc2 reads of hbuf are complete
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const int hid_local = 64 * w + 32 * ft + 8 * a + 4 * hh;
-                const f32x4 b = *reinterpret_cast<const f32x4*>(p.b1 + c * HC + hid_local);
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     float g[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) g[i] = gelu_erf(a1[ft * 2 + tt][4 * a + i] + b[i]);
+                    for (int i = 0; i < 4; ++i) g[i] = gelu_erf(a1[ft * 2 + tt][4 * a + i] + b[ft][a][i]);
                     *reinterpret_cast<u32x2*>(hbuf + panel_off(tt * 32 + tk, hid_local * 2, HROWB)) =
                         u32x2{pack_bf16(g[0], g[1]), pack_bf16(g[2], g[3])};
                 }
