@@ -25,32 +25,52 @@ __device__ __forceinline__ void epilogue_heads_T(const f32x16* acc /*[3 ft][2 tt
                                                  unsigned char* __restrict__ frag, __bf16* __restrict__ small_dst,
                                                  int which) {
     const int lane = lane_id(), hh = lane >> 5, tk = lane & 31;
+    // All table reads of this epilogue (4 heads x 12 permuted biases, 2 rows x 12 rotary factors) are requested up
+    // front as 16-byte loads: left inside the head loop each head paid its own L2 round trip (16 in sequence).
+    f32x4 bq[4][3];
+    {
+        const f32x4* bp = reinterpret_cast<const f32x4*>(bias_perm + (w * 2 + hh) * 48);
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bq[hd][c] = bp[hd * 3 + c];
+    }
+    int tokv[2], posv[2];
+    f32x4 rq[2][4];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
         const int row = tt * 32 + tk;
-        const int token = pr->tok[row];
-        const bool valid = token >= 0;
-        int pos = small ? (valid ? token % len : 0) : pos0 + row;
+        tokv[tt] = pr->tok[row];
+        int pos = small ? (tokv[tt] >= 0 ? tokv[tt] % len : 0) : pos0 + row;
         if (pos > len) pos = len;  // padding rows: any in-table position (values are never used)
+        posv[tt] = pos;
+        if (ROPE) {
+            const f32x4* rc = reinterpret_cast<const f32x4*>(rope + (long)pos * kRopeRow + 16 * hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rq[tt][i] = rc[i];
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int token = tokv[tt];
+        const bool valid = token >= 0;
         float cs[6], sn[6];
         if (ROPE) {
-            const float* rc = rope + (long)pos * kRopeRow + 16 * hh;
 #pragma unroll
             for (int p = 0; p < 6; ++p) {
-                cs[p] = rc[p];
-                sn[p] = rc[8 + p];
+                cs[p] = rq[tt][p >> 2][p & 3];
+                sn[p] = rq[tt][2 + (p >> 2)][p & 3];
             }
         }
         const int tile = tile0 + tt;
 #pragma unroll
         for (int hd = 0; hd < 4; ++hd) {
             float e[12];
-            const float* bp = bias_perm + ((w * 2 + hh) * 4 + hd) * 12;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) e[4 * c + b] = acc[ft * 2 + tt][4 * a + b] + bp[4 * c + b];
+                for (int b = 0; b < 4; ++b) e[4 * c + b] = acc[ft * 2 + tt][4 * a + b] + bq[hd][c][b];
             }
             if (ROPE) {
 #pragma unroll
@@ -126,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
     __syncthreads();
     prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
     __syncthreads();
-    const int w = wave_id(), lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id();
     const int ntile = p.ax.ntile();
     const int len = p.ax.len;
     f32x16 acc[6];
@@ -289,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_proj(const ProjParams p) {
         prologue_bf16<K>(panel, pr, p.a_bf16);
     }
     __syncthreads();
-    const int w = wave_id(), lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id();
     f32x16 acc[6];
     zero_acc<6>(acc);
     wave_gemm<2, 3, KS, false>(panel, ROWB, 0, 0, p.w + (size_t)(3 * w) * KS * 64 + lane, KS * 64, acc);
@@ -587,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_linear(const LnLinearParams p) {
     __syncthreads();
     prologue_ln<true>(panel, pr, p.h, p.mm, 1, 0, 1e-5f);   // mm.mod = [gamma(C) | beta(C)]: scale chunk 0, shift chunk 1
     __syncthreads();
-    const int w = wave_id(), lane = lane_id(), hh = lane >> 5, n = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id(), hh = lane >> 5, n = lane & 31;
     const int ngroups = p.nout / 96;
     for (int g = w; g < ngroups; g += 4) {
         f32x16 acc[6];
@@ -623,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void k_final(const FinalParams p) {
     __syncthreads();
     prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
     __syncthreads();
-    const int w = wave_id(), lane = lane_id(), hh = lane >> 5, n = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id(), hh = lane >> 5, n = lane & 31;
     if (w < 2) {
         f32x16 acc[1];
         zero_acc<1>(acc);
