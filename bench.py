@@ -128,6 +128,31 @@ def cpu_baseline(cfg, sd, B, T, L, S, n_pad, budget_s=20.0):
                       f"scaled to S={S} Euler steps + pre/post"}
 
 
+# kernel class (hipEvent profile name) -> substring of the rocprof kernel name
+_KERNEL_OF_CLASS = {"mlp": "k_mlp", "flash_T": "k_flash", "flash_L": "k_flash", "ln_qkv_T": "k_ln_qkv<false>",
+                    "ln_qkv_L": "k_ln_qkv<true>", "proj_T": "k_proj<0>", "proj_L": "k_proj<2>"}
+
+
+def pmc_traffic(kernel_class, workload):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the benchmark
+    process, so this is the figure measured with scripts/pmc_traffic.sh (rocprofv3 --pmc, separate FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 correction) and committed as profiles/pmc_traffic.json -- or None when that file
+    does not cover this kernel and workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            m = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    sub = _KERNEL_OF_CLASS.get(kernel_class)
+    if m.get("workload") != workload or not sub:
+        return None, None
+    for name, v in m.get("kernels", {}).items():
+        if sub in name:
+            return v["hbm_bytes_per_launch"], "profiles/pmc_traffic.json (" + m.get("method", "") + ")"
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,8 +257,10 @@ def main():
         avg_ms = rep[dom]["ms"] / rep[dom]["count"]
         fl = algorithmic_flops(dom, B, T, L)
         ach = fl / (avg_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(dom, a.workload)
         roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_ms, 4), "launches": rep[dom]["count"],
                 "share_of_event_time": round(rep[dom]["ms"] / tot, 3),
                 "by_kernel_ms_per_call": {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}}
