@@ -3,9 +3,11 @@
 `--num_steps` (Euler steps; reference hard-codes 49) and `--synthetic` (seeded weights, no checkpoint).
 
 The rollout (sim_inference.py:61-98) stays on the device: each block's last frame is turned into the
-next block's conditioning frame by `mdgen_atom14_to_cond` (no D->H->D round trip).  Output: a float32
-`.npy` array [num_rollouts*num_frames, L, 14, 3] per peptide (PDB/XTC writers need mdtraj/Bio, which are
-IO and out of scope for this build; `--no_frames`, `--tps`, `--xtc` are accepted and rejected loudly).
+next block's conditioning frame by `mdgen_atom14_to_cond` (no D->H->D round trip).  Output, as the reference
+(sim_inference.py:117-119): `{out_dir}/{name}.pdb`, a multi-model PDB of all sampled frames written by
+`mdgen_amd.pdb.atom14_to_pdb` (byte-compatible with `mdgen.utils.atom14_to_pdb`; no mdtraj / Biopython);
+`--npy` additionally saves the float32 array [num_rollouts*num_frames, L, 14, 3].  `--xtc` needs mdtraj and
+`--no_frames` / `--tps` select other models: accepted and rejected loudly.
 """
 from __future__ import annotations
 
@@ -57,6 +59,7 @@ def main(argv=None):
     p.add_argument("--split", type=str, default="splits/4AA_test.csv")
     p.add_argument("--num_steps", type=int, default=49)
     p.add_argument("--synthetic", action="store_true", help="seeded synthetic weights instead of --sim_ckpt")
+    p.add_argument("--npy", action="store_true", help="also save the sampled atom14 array as .npy")
     args = p.parse_args(argv)
     if args.no_frames or args.tps or args.xtc:
         raise SystemExit("--no_frames / --tps / --xtc are outside this build's scope (see DESIGN.md)")
@@ -88,7 +91,11 @@ def main(argv=None):
         torch.cuda.synchronize()
         dur = time.time() - start
         print(f"{name}: {args.num_rollouts * args.num_frames / dur:.1f} frames/s ({dur:.3f} s)")
-        np.save(os.path.join(args.out_dir, f"{name}.npy"), torch.cat(out, 1)[0].cpu().numpy())
+        all_atom14 = torch.cat(out, 1)[0].cpu().numpy()
+        from .pdb import atom14_to_pdb
+        atom14_to_pdb(all_atom14, batch["seqres"][0].cpu().numpy(), os.path.join(args.out_dir, f"{name}.pdb"))
+        if args.npy:
+            np.save(os.path.join(args.out_dir, f"{name}.npy"), all_atom14)
 
 
 if __name__ == "__main__":

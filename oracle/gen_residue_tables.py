@@ -29,5 +29,6 @@ np.savez_compressed(
     chi_angles_mask=np.asarray(chi_mask).astype(np.float32),                       # [21,4]
     restypes=np.asarray(list(rc.restypes)),                                        # 20 one-letter codes
     atom_types=np.asarray(list(rc.atom_types)),                                    # 37 atom names
+    restype_3=np.asarray([rc.restype_1to3[r] for r in rc.restypes] + ["UNK"]),      # 21 three-letter codes
 )
 print("wrote", os.path.abspath(out), os.path.getsize(out), "bytes")

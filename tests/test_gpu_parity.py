@@ -244,6 +244,67 @@ def test_inference_end_to_end_vs_reference():
         assert torch.allclose(nxt["torsions"].cpu(), g[f"S{S}_b0_next_torsions"][:, 0], atol=2e-4)
 
 
+def test_tps_inference_end_to_end_vs_oracle():
+    """Two-sided (transition-path) sampling end to end: `tps_inference.get_sample` batch layout (start frame
+    expanded over T, frame -1 = end frame; tps_inference.py:43-80) -> prep_batch (D = 28 latents, both offsets,
+    cond frames 0 and -1) -> S Euler steps of the TPS model -> atom14, vs the CPU oracle with the kernel's
+    w >= 0 quaternion convention for the relative frames (see test_forward_tps_vs_oracle_with_reference_inputs)."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    from mdgen_amd.tps_inference import get_sample, collate
+    from mdgen_amd.geometry import restype_order
+    dev = _cuda()
+    T, S, seqs = 12, 3, ["FLRH", "IMRY"]
+    cfg = ModelConfig.tps(num_frames=T, crop=4)
+    sd = synth_state_dict(cfg, 9)
+    w = NewMDGenWrapper(cfg)
+    w.model.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(77)
+    samples, obatches = [], []
+    for sq in seqs:
+        seqres = torch.tensor([restype_order[c] for c in sq])
+        ends = []
+        for _ in range(2):   # two self-consistent conformations: random frames + torsions -> atom14 (oracle geometry)
+            q = torch.randn(1, 1, 4, 4, generator=gen)
+            R = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+            tr = torch.cumsum(2.2 * torch.randn(1, 1, 4, 3, generator=gen), 2)
+            ang = torch.randn(1, 1, 4, 7, 2, generator=gen)
+            ang = ang / ang.norm(dim=-1, keepdim=True)
+            ends.append(O.frames_torsions_to_atom14(R, tr, ang, seqres[None, None])[0])   # [1,L,14,3]
+        samples.append(get_sample(ends[0].numpy(), ends[1].numpy(), sq, T, dev))
+        ob = O.get_batch_from_atom14(torch.cat([ends[0]] * (T - 1) + [ends[1]], 0), seqres)
+        obatches.append({k: (v[None] if torch.is_tensor(v) else v) for k, v in ob.items()})
+    batch = collate(samples)
+    obatch = {k: torch.cat([b[k] for b in obatches], 0) for k in obatches[0]}
+    # the device glue and the oracle geometry agree on the conditioning batch.  Torsions are compared where
+    # torsion_mask is set: a masked torsion (e.g. pre-omega of residue 0, whose "previous residue" is all zeros)
+    # is a normalised rounding residue of a degenerate frame in the reference -- any unit vector or (0, 0).
+    tm = obatch["torsion_mask"].float()
+    assert torch.equal(batch["torsion_mask"].cpu().float(), tm)
+    for k in ("trans", "rots", "torsions"):
+        dk = (batch[k].cpu() - obatch[k].float()).abs()
+        if k == "torsions":
+            dk = dk * tm[:, None, :, :, None]
+        print(f"conditioning batch {k}: max abs diff {dk.max():.3e}")
+        assert dk.max() < 2e-4, (k, float(dk.max()))
+    # ... and so that both sides consume IDENTICAL conditioning (masked torsions included, they do reach the
+    # network through x_cond), the sampler below is fed the oracle's batch
+    batch = {k: v.to(dev) for k, v in obatch.items()}
+    zs = torch.randn(len(seqs), T, 4, cfg.latent_dim, generator=gen)
+    atom14, aa = w.inference(batch, zs=zs.to(dev), num_steps=S, use_graph=False)
+    torch.cuda.synchronize()
+    c = dict(O.cfg_dict(cfg), quat_sign="w_nonneg")
+    ref14, _, ref_samples = O.inference(sd, c, obatch, zs, S)
+    e_s = rel_l2(w.last_samples.cpu(), ref_samples)
+    d = (atom14.cpu() - ref14).abs()
+    print(f"TPS end-to-end S={S}: samples rel-L2 {e_s:.2e}  atom14 rms {d.pow(2).mean().sqrt():.4f} A max {d.max():.4f} A")
+    assert torch.isfinite(atom14).all()
+    assert e_s < 2e-2
+    assert d.pow(2).mean().sqrt() < 0.05 and d.max() < 0.5
+
+
 def test_graph_replay_matches_eager_bitwise():
     from mdgen_amd.config import ModelConfig
     from mdgen_amd.synthetic import synth_state_dict

@@ -93,3 +93,23 @@ def test_sampler_surface():
     # generic drift: dx/dt = 1 from x0 = 0 over [0,1] -> 1 (host loop, any callable)
     out = fn(torch.zeros(2, 3), lambda x, t: torch.ones_like(x))
     assert out.shape == (1, 2, 3) and torch.allclose(out[-1], torch.ones(2, 3), atol=1e-6)
+
+
+def test_pdb_writer_matches_reference_text():
+    """mdgen_amd.pdb.frames_to_pdb_string reproduces the reference's `atom14_to_pdb` output byte for byte
+    (fixture tests/golden/pdb_small.npz made by oracle/gen_golden_pdb.py from the reference itself: 3 frames,
+    residues FLRHGW, one atom exactly at the origin -> dropped)."""
+    import numpy as np
+    from mdgen_amd.pdb import frames_to_pdb_string, atom14_to_pdb
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pdb_small.npz"))
+    ref = bytes(g["text"]).decode()
+    assert frames_to_pdb_string(g["atom14"], g["aatype"]) == ref
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        pth = os.path.join(td, "x.pdb")
+        atom14_to_pdb(g["atom14"], g["aatype"], pth)
+        assert open(pth).read() == ref
+    with pytest.raises(ValueError):
+        frames_to_pdb_string(g["atom14"], np.full(6, 25))
+    with pytest.raises(ValueError):
+        frames_to_pdb_string(g["atom14"][0], g["aatype"])
