@@ -624,7 +624,21 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
     p.w = m.wo;
     p.bias = m.bo;
     const bool small = residue_axis && ax.len <= 8;
-    if (small) {
+    static const bool fused4 = !(getenv("MDGEN_FUSED_ATTN4") && atoi(getenv("MDGEN_FUSED_ATTN4")) == 0);
+    if (small && ax.len == 4 && fused4) {
+        // L == 4: the 5-key attention runs inside the QKV kernel (quad-local), which writes the attention output
+        q.wv = m.wv_small;
+        q.bv = m.bv_small;
+        q.bias_k = m.bias_k;
+        q.bias_v = m.bias_v;
+        q.mk = mk;
+        q.obuf = r.obufp;
+        { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv_attn4(q, r.s); }
+        LAUNCHCHK();
+        p.a_bf16 = r.obufp;
+        { ProfScope ps(r.c, c_prj, r.s); launch_proj(p, 0, r.s); }
+        LAUNCHCHK();
+    } else if (small) {
         q.wv = m.wv_small;
         q.bv = m.bv_small;
         { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv(q, true, r.s); }

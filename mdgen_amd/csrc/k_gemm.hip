@@ -171,6 +171,211 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Residue axis with L == 4 (tetrapeptides): LN -> QKV -> RoPE -> 5-key attention, all in one kernel.
+//
+// A panel is 64 consecutive tokens = 16 whole sequences of 4 residues, and in the transposed GEMM layout a lane
+// IS a token: the four keys / values a query needs sit in the other three lanes of its DPP quad.  So q, k, v
+// never leave the registers: scores are 12 quad-broadcast FMAs per (key, head) plus one half-wave swap (a lane
+// holds 12 of a head's 24 features), softmax over 4 keys + the learned bias key is lane-local, and the output
+// is written as the bf16 A-operand rows of the out-projection -- 49 MB per launch instead of the 147 MB SMALL
+// layout, which the out-projection kernel then no longer has to read back (k_proj<0> instead of k_proj<2>).
+// Same math as prologue_micro_attn (mha.py:258-268, 356-396); q and the bias key/value are rounded to bf16 as
+// there, k and v stay fp32.
+// -------------------------------------------------------------------------------------------------
+template <int J>
+__device__ __forceinline__ float quad_bcast(float v) {   // value of lane (quad base + J) in every lane of the quad
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), J * 0x55, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// the 12 values a lane holds for head hd of its token (tile tt) in the transposed QKV accumulators, + bias
+__device__ __forceinline__ void head_values(const f32x16* acc, int tt, int hd, const f32x4 (&bq)[3], float (&e)[12]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) e[4 * c + b] = acc[ft * 2 + tt][4 * a + b] + bq[c][b];
+    }
+}
+__device__ __forceinline__ void load_head_bias(const float* bias_perm, int w, int hh, f32x4 (&bq)[4][3]) {
+    const f32x4* bp = reinterpret_cast<const f32x4*>(bias_perm + (w * 2 + hh) * 48);
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bq[hd][c] = bp[hd * 3 + c];
+}
+
+__global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
+    PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
+    unsigned char* panel = smem + sizeof(PanelRows);
+    setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
+    __syncthreads();
+    prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
+    __syncthreads();
+    const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id(), hh = lane >> 5, tk = lane & 31;
+    constexpr int L = 4;
+    // per-token constants: token id, key validity of the own token; the rotary factors (position = token % 4)
+    // are re-read from the (L2-resident) table after each GEMM rather than held across it
+    int tok[2];
+    float mval[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        tok[tt] = pr->tok[tt * 32 + tk];
+        mval[tt] = p.mk.at(tok[tt] < 0 ? 0 : tok[tt]);
+    }
+    auto load_rope = [&](f32x4 (&rq)[2][4]) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int tc = tok[tt] < 0 ? 0 : tok[tt];
+            const f32x4* rc = reinterpret_cast<const f32x4*>(p.rope + (long)(tc & (L - 1)) * kRopeRow + 16 * hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rq[tt][i] = rc[i];
+        }
+    };
+    f32x16 acc[6];
+    f32x4 bb[4][3];
+    f32x4 rq[2][4];
+    // ---- Q (heads 4w..4w+3): RoPE, keep as bf16 pairs (48 registers)
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    load_head_bias(p.bq, w, hh, bb);
+    load_rope(rq);
+    uint32_t qp[2][4][6];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) {
+            float e[12];
+            head_values(acc, tt, hd, bb[hd], e);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const float c = rq[tt][q >> 2][q & 3], sn = rq[tt][2 + (q >> 2)][q & 3];
+                const float x1 = e[2 * q], x2 = e[2 * q + 1];
+                qp[tt][hd][q] = pack_bf16(x1 * c - x2 * sn, x2 * c + x1 * sn);
+            }
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- K: RoPE in place, then the scores of the 4 keys of the quad + the bias key; softmax -> P (40 registers)
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, 24, true, 2>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);   // shallow ring: q is live
+    load_head_bias(p.bk, w, hh, bb);
+    load_rope(rq);
+    // pass 1: bias + RoPE IN PLACE in the accumulators (frees the bias / rotary registers before the scores)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) {
+            float k[12];
+            head_values(acc, tt, hd, bb[hd], k);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {   // values 4c + 2 b2, 4c + 2 b2 + 1 = rotary pair q = 2c + b2
+                    const int q = 2 * c + b2;
+                    const float cs = rq[tt][q >> 2][q & 3], sn = rq[tt][2 + (q >> 2)][q & 3];
+                    const float x1 = k[2 * q], x2 = k[2 * q + 1];
+                    acc[ft * 2 + tt][4 * a + 2 * b2] = x1 * cs - x2 * sn;
+                    acc[ft * 2 + tt][4 * a + 2 * b2 + 1] = x2 * cs + x1 * sn;
+                }
+            }
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    // pass 2: scores against the 4 keys of the quad + the bias key, softmax -> P (40 registers)
+    float P[2][4][5];
+    {
+        // learned bias key (mha.py:265-268), rotated at position L like every key (:356-357), rounded to bf16
+        const float* rcL = p.rope + (long)L * kRopeRow + 16 * hh;
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) {
+            const float* bk = p.bias_k + (4 * w + hd) * kDH;
+            float kb[12];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int i = 6 * hh + q;
+                const float x1 = bk[i], x2 = bk[i + 12], c = rcL[q], sn = rcL[8 + q];
+                kb[2 * q] = bf16_lo(pack_bf16(x1 * c - x2 * sn, 0.f));
+                kb[2 * q + 1] = bf16_lo(pack_bf16(x2 * c + x1 * sn, 0.f));
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                float k[12], qf[12];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; ++b2) k[4 * c + b2] = acc[ft * 2 + tt][4 * a + b2];
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    qf[2 * q] = bf16_lo(qp[tt][hd][q]);
+                    qf[2 * q + 1] = bf16_hi(qp[tt][hd][q]);
+                }
+                float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    s[0] += qf[i] * quad_bcast<0>(k[i]);
+                    s[1] += qf[i] * quad_bcast<1>(k[i]);
+                    s[2] += qf[i] * quad_bcast<2>(k[i]);
+                    s[3] += qf[i] * quad_bcast<3>(k[i]);
+                    s[4] += qf[i] * kb[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j) s[j] = half_sum(s[j]);
+                const float m0 = quad_bcast<0>(mval[tt]), m1 = quad_bcast<1>(mval[tt]), m2 = quad_bcast<2>(mval[tt]),
+                            m3 = quad_bcast<3>(mval[tt]);
+                s[0] = m0 != 0.f ? s[0] : -1e30f;
+                s[1] = m1 != 0.f ? s[1] : -1e30f;
+                s[2] = m2 != 0.f ? s[2] : -1e30f;
+                s[3] = m3 != 0.f ? s[3] : -1e30f;
+                const float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), s[4]);   // the bias key is never masked
+                float den = 0.f;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    s[j] = s[j] > -1e29f ? __builtin_amdgcn_exp2f(s[j] - mx) : 0.f;
+                    den += s[j];
+                }
+                const float inv = 1.0f / den;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) P[tt][hd][j] = s[j] * inv;
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one head at a time: keeps the scheduler from overlapping all four
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- V (transposed as well: a lane holds features 12 hh .. 12 hh + 11 of each head of its token)
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, 24, true, 3>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    load_head_bias(p.bv, w, hh, bb);
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+        const int head = 4 * w + hd;
+        float bvv[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) bvv[i] = bf16_lo(pack_bf16(p.bias_v[head * kDH + 12 * hh + i], 0.f));
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float v[12], o[12];
+            head_values(acc, tt, hd, bb[hd], v);
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                o[i] = P[tt][hd][0] * quad_bcast<0>(v[i]) + P[tt][hd][1] * quad_bcast<1>(v[i]) +
+                       P[tt][hd][2] * quad_bcast<2>(v[i]) + P[tt][hd][3] * quad_bcast<3>(v[i]) + P[tt][hd][4] * bvv[i];
+            if (tok[tt] >= 0) {
+                u32x2* d = reinterpret_cast<u32x2*>(p.obuf + (long)tok[tt] * kC + head * kDH + hh * 12);
+                d[0] = u32x2{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+                d[1] = u32x2{pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+                d[2] = u32x2{pack_bf16(o[8], o[9]), pack_bf16(o[10], o[11])};
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // =================================================================================================
 // Attention output projection + gate + residual:  h += gate * (Wo o + bo)
 // (mha.py:397 out_proj; latent_model.py:462,476 gated residual).  A-operand sources:
@@ -681,6 +886,10 @@ void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s) {
     } else {
         hipLaunchKernelGGL(k_ln_qkv<false>, dim3(p.ax.nseq * p.panels_per_seq), dim3(256), dyn, s, p);
     }
+}
+void launch_ln_qkv_attn4(const QkvParams& p, hipStream_t s) {
+    const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
+    hipLaunchKernelGGL(k_ln_qkv_attn4, dim3(grid), dim3(256), 0, s, p);
 }
 void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);

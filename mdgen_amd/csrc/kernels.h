@@ -16,6 +16,10 @@ struct QkvParams {
     unsigned char *qf, *kf, *vf;  // FLASH layout fragment buffers
     __bf16* qkv_small;     // SMALL layout [token][3][16 head][2 half][12]
     int panels_per_seq;
+    // k_ln_qkv_attn4 only (residue axis, L == 4: attention inside the QKV kernel)
+    const float *bias_k, *bias_v;   // learned bias key / value [384]
+    MaskMap mk;                     // key-padding mask
+    __bf16* obuf;                   // attention output [token][384] bf16
 };
 
 struct ProjParams {
@@ -107,6 +111,7 @@ struct FloatChunk {
 };
 
 void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s);
+void launch_ln_qkv_attn4(const QkvParams& p, hipStream_t s);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
 void launch_mlp(const MlpParams& p, hipStream_t s);
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s);
