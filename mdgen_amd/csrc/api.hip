@@ -284,7 +284,8 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     if (d->ipa_heads != 4 || d->ipa_head_dim != 32 || d->ipa_qk != 8 || d->ipa_v != 8)
         return fail(-2, "this build supports ipa_heads=4, ipa_head_dim=32, ipa_qk=ipa_v=8 only");
     if (d->num_layers < 1 || d->num_layers > 8) return fail(-2, "num_layers must be in 1..8");
-    if (d->latent_dim < 1 || d->latent_dim > 28) return fail(-2, "latent_dim must be in 1..28");
+    if (d->latent_dim != 21 && d->latent_dim != 28)   // wrapper.py:57-60: 21, or 28 with two-sided conditioning
+        return fail(-2, "latent_dim must be 21 (forward simulation) or 28 (two-sided conditioning)");
     if (d->tps_condition && d->latent_dim != 28) return fail(-2, "tps_condition requires latent_dim 28");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
