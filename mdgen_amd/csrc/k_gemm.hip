@@ -210,6 +210,10 @@ __device__ __forceinline__ void load_head_bias(const float* bias_perm, int w, in
 
 __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
+    // q of the second 32-token tile waits in LDS while the K GEMM runs ([wave][value][lane]: conflict-free): with
+    // all 48 packed q registers live across that GEMM hipcc spilled ~90 registers per lane -- 180 MB of scratch
+    // traffic per launch, more than the q/k/v stores this kernel exists to avoid.
+    __shared__ uint32_t qstash[4][24][64];
     PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
     unsigned char* panel = smem + sizeof(PanelRows);
     setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
@@ -258,6 +262,10 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
                 qp[tt][hd][q] = pack_bf16(x1 * c - x2 * sn, x2 * c + x1 * sn);
             }
         }
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) qstash[w][hd * 6 + q][lane] = qp[1][hd][q];
     __builtin_amdgcn_sched_barrier(0);
     // ---- K: RoPE in place, then the scores of the 4 keys of the quad + the bias key; softmax -> P (40 registers)
     zero_acc<6>(acc);
@@ -312,8 +320,9 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
                 }
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
-                    qf[2 * q] = bf16_lo(qp[tt][hd][q]);
-                    qf[2 * q + 1] = bf16_hi(qp[tt][hd][q]);
+                    const uint32_t u = tt == 0 ? qp[0][hd][q] : qstash[w][hd * 6 + q][lane];
+                    qf[2 * q] = bf16_lo(u);
+                    qf[2 * q + 1] = bf16_hi(u);
                 }
                 float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -346,11 +355,27 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
             __builtin_amdgcn_sched_barrier(0);   // one head at a time: keeps the scheduler from overlapping all four
         }
     }
+    // the 40 attention weights of this lane wait in the (now free) q stash as 20 bf16 pairs while the V GEMM runs
+    // (bf16 weights: what the streaming kernel feeds its PV MFMA as well)
+    {
+        const float* Pf = &P[0][0][0];
+#pragma unroll
+        for (int i = 0; i < 20; ++i) qstash[w][i][lane] = pack_bf16(Pf[2 * i], Pf[2 * i + 1]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- V (transposed as well: a lane holds features 12 hh .. 12 hh + 11 of each head of its token)
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, true, 3>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     load_head_bias(p.bv, w, hh, bb);
+    {
+        float* Pf = &P[0][0][0];
+#pragma unroll
+        for (int i = 0; i < 20; ++i) {
+            const uint32_t u = qstash[w][i][lane];
+            Pf[2 * i] = bf16_lo(u);
+            Pf[2 * i + 1] = bf16_hi(u);
+        }
+    }
 #pragma unroll
     for (int hd = 0; hd < 4; ++hd) {
         const int head = 4 * w + hd;
