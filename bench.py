@@ -79,6 +79,8 @@ def algorithmic_flops(cls, B, T, L):
         return 2.0 * N * C * C
     if cls == "proj_L":
         return 2.0 * N * C * C + (4.0 * N * C * (L + 1) if L <= 8 else 0.0)   # + fused micro-attention
+    if cls == "attn_L_fused":   # L == 4: LN -> QKV -> 5-key attention -> out-projection -> residual, one kernel
+        return 2.0 * N * C * 3 * C + 4.0 * N * C * (L + 1) + 2.0 * N * C * C
     if cls == "flash_T":
         return 4.0 * N * C * (T + 1)
     if cls == "flash_L":
@@ -130,7 +132,8 @@ def cpu_baseline(cfg, sd, B, T, L, S, n_pad, budget_s=20.0):
 
 # kernel class (hipEvent profile name) -> substring of the rocprof kernel name
 _KERNEL_OF_CLASS = {"mlp": "k_mlp", "flash_T": "k_flash", "flash_L": "k_flash", "ln_qkv_T": "k_ln_qkv<false>",
-                    "ln_qkv_L": "k_ln_qkv<true>", "proj_T": "k_proj<0>", "proj_L": "k_proj<2>"}
+                    "ln_qkv_L": "k_ln_qkv<true>", "proj_T": "k_proj<0>", "proj_L": "k_proj<2>",
+                    "attn_L_fused": "k_ln_qkv_attn4<true>"}
 
 
 def pmc_traffic(kernel_class, workload):

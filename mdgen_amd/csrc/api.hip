@@ -634,11 +634,21 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         q.bias_v = m.bias_v;
         q.mk = mk;
         q.obuf = r.obufp;
-        { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv_attn4(q, r.s); }
-        LAUNCHCHK();
-        p.a_bf16 = r.obufp;
-        { ProfScope ps(r.c, c_prj, r.s); launch_proj(p, 0, r.s); }
-        LAUNCHCHK();
+        static const bool fuse_proj = !(getenv("MDGEN_FUSED_ATTN4") && atoi(getenv("MDGEN_FUSED_ATTN4")) == 1);
+        if (fuse_proj) {   // whole residue-axis sub-layer in one kernel (MDGEN_FUSED_ATTN4=1: attention only)
+            q.h_rw = h;
+            q.wo = m.wo;
+            q.bo = m.bo;
+            q.gate_chunk = gate;
+            { ProfScope ps(r.c, residue_axis && trunk ? "attn_L_fused" : c_qkv, r.s); launch_ln_qkv_attn4(q, true, r.s); }
+            LAUNCHCHK();
+        } else {
+            { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv_attn4(q, false, r.s); }
+            LAUNCHCHK();
+            p.a_bf16 = r.obufp;
+            { ProfScope ps(r.c, c_prj, r.s); launch_proj(p, 0, r.s); }
+            LAUNCHCHK();
+        }
     } else if (small) {
         q.wv = m.wv_small;
         q.bv = m.bv_small;

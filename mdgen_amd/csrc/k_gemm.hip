@@ -208,6 +208,9 @@ __device__ __forceinline__ void load_head_bias(const float* bias_perm, int w, in
         for (int c = 0; c < 3; ++c) bq[hd][c] = bp[hd * 3 + c];
 }
 
+// PROJ: also run the sub-layer's out-projection and gated residual update here (mha.py:397, latent_model.py:462):
+// the attention output goes straight into the LDS panel as the A operand instead of through HBM.
+template <bool PROJ>
 __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
     // q of the second 32-token tile waits in LDS while the K GEMM runs ([wave][value][lane]: conflict-free): with
@@ -376,6 +379,9 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
             Pf[2 * i + 1] = bf16_hi(u);
         }
     }
+    // PROJ: once every wave has finished its V GEMM the LN panel is dead, and the attention output is written
+    // straight into it (bf16 [64][384], swizzled: the A operand of the out-projection, as k_proj<0> builds it)
+    if (PROJ) __syncthreads();
 #pragma unroll
     for (int hd = 0; hd < 4; ++hd) {
         const int head = 4 * w + hd;
@@ -390,7 +396,13 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
             for (int i = 0; i < 12; ++i)
                 o[i] = P[tt][hd][0] * quad_bcast<0>(v[i]) + P[tt][hd][1] * quad_bcast<1>(v[i]) +
                        P[tt][hd][2] * quad_bcast<2>(v[i]) + P[tt][hd][3] * quad_bcast<3>(v[i]) + P[tt][hd][4] * bvv[i];
-            if (tok[tt] >= 0) {
+            if (PROJ) {
+                const bool ok = tok[tt] >= 0;   // padding rows enter the GEMM as zeros
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    *reinterpret_cast<u32x2*>(panel + panel_off(tt * 32 + tk, head * 48 + hh * 24 + 8 * i, kRowB)) =
+                        u32x2{ok ? pack_bf16(o[4 * i], o[4 * i + 1]) : 0u, ok ? pack_bf16(o[4 * i + 2], o[4 * i + 3]) : 0u};
+            } else if (tok[tt] >= 0) {
                 u32x2* d = reinterpret_cast<u32x2*>(p.obuf + (long)tok[tt] * kC + head * kDH + hh * 12);
                 d[0] = u32x2{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
                 d[1] = u32x2{pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
@@ -399,6 +411,14 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (!PROJ) return;
+    // ---- out-projection + gated residual, as k_proj<0>
+    __syncthreads();   // the whole attention output is in the panel
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
+    epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk,
+                                  true, p.h_rw);
 }
 
 // =================================================================================================
@@ -912,9 +932,10 @@ void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s) {
         hipLaunchKernelGGL(k_ln_qkv<false>, dim3(p.ax.nseq * p.panels_per_seq), dim3(256), dyn, s, p);
     }
 }
-void launch_ln_qkv_attn4(const QkvParams& p, hipStream_t s) {
+void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-    hipLaunchKernelGGL(k_ln_qkv_attn4, dim3(grid), dim3(256), 0, s, p);
+    if (fuse_proj) hipLaunchKernelGGL(k_ln_qkv_attn4<true>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_ln_qkv_attn4<false>, dim3(grid), dim3(256), 0, s, p);
 }
 void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);

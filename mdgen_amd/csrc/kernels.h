@@ -19,7 +19,12 @@ struct QkvParams {
     // k_ln_qkv_attn4 only (residue axis, L == 4: attention inside the QKV kernel)
     const float *bias_k, *bias_v;   // learned bias key / value [384]
     MaskMap mk;                     // key-padding mask
-    __bf16* obuf;                   // attention output [token][384] bf16
+    __bf16* obuf;                   // attention output [token][384] bf16 (PROJ == false)
+    // k_ln_qkv_attn4<true>: the out-projection + gated residual of the same sub-layer, in the same kernel
+    float* h_rw;                    // == h (the rows a workgroup normalised are the rows it updates)
+    const bf16x8* wo;               // packed out-projection weights
+    const float* bo;
+    int gate_chunk;
 };
 
 struct ProjParams {
@@ -111,7 +116,7 @@ struct FloatChunk {
 };
 
 void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s);
-void launch_ln_qkv_attn4(const QkvParams& p, hipStream_t s);
+void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
 void launch_mlp(const MlpParams& p, hipStream_t s);
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s);
