@@ -6,6 +6,7 @@ rel-L2 <= 1e-2 per network evaluation (the reference's own bf16-autocast deviate
 SE(3)/geometry kernels are fp32: max-abs <= 1e-4 (Angstrom / unit quaternions).
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -303,6 +304,45 @@ def test_tps_inference_end_to_end_vs_oracle():
     assert torch.isfinite(atom14).all()
     assert e_s < 2e-2
     assert d.pow(2).mean().sqrt() < 0.05 and d.max() < 0.5
+
+
+def test_residue_axis_paths_agree():
+    """L = 4 has three implementations of the residue-axis sub-layer: the one-kernel default
+    (k_ln_qkv_attn4<true>), attention fused but projection separate (MDGEN_FUSED_ATTN4=1), and the general
+    L <= 8 path (k_ln_qkv<SMALL> -> k_proj<2>, MDGEN_FUSED_ATTN4=0).  The switches are read once per process, so
+    the alternatives run in child processes on the fwd_full_pep golden; all three must meet the same gate against
+    the reference output and agree with each other to bf16-operand noise."""
+    import subprocess, tempfile
+    _cuda()
+    g = load_golden("fwd_full_pep")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = (
+        "import sys, os, numpy as np, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "from conftest import load_golden, weights_for\n"
+        "from mdgen_amd.model import LatentMDGenModel\n"
+        "g = load_golden('fwd_full_pep'); cfg, sd = weights_for(g)\n"
+        "m = LatentMDGenModel(cfg); m.load_state_dict(sd); d = 'cuda'\n"
+        "out = m.forward(x=g['x'].to(d), t=g['t'].to(d), mask=g['mask'].to(d), start_frames=(g['start_rot'].to(d), g['start_trans'].to(d)),\n"
+        "                x_cond=g['x_cond'].to(d), x_cond_mask=g['x_cond_mask'].to(d), aatype=g['aatype'].to(d))\n"
+        "np.save(sys.argv[1], out.cpu().numpy())\n" % (root, root))
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ("", "1", "0"):
+            env = dict(os.environ)
+            env.pop("MDGEN_FUSED_ATTN4", None)
+            if mode:
+                env["MDGEN_FUSED_ATTN4"] = mode
+            pth = os.path.join(td, f"out{mode or 'd'}.npy")
+            r = subprocess.run([sys.executable, "-c", child, pth], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            import numpy as np
+            outs[mode] = torch.from_numpy(np.load(pth))
+    for mode, o in outs.items():
+        e = rel_l2(o, g["out"])
+        print(f"MDGEN_FUSED_ATTN4={mode or '(default)'}: rel-L2 vs reference {e:.3e}")
+        assert e < TOL_FWD
+    assert rel_l2(outs["1"], outs[""]) < 5e-3 and rel_l2(outs["0"], outs[""]) < 5e-3
 
 
 def test_graph_replay_matches_eager_bitwise():
