@@ -923,13 +923,11 @@ __global__ __launch_bounds__(256, 2) void k_final(const FinalParams p) {
 
 // ---- launchers ----------------------------------------------------------------------------------
 void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s) {
-    const char* e = getenv("MDGEN_DEBUG_DYNLDS");   // debugging only: extra dynamic LDS limits WGs per CU
-    const unsigned dyn = e ? (unsigned)atoi(e) : 0u;
     if (small) {
         const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-        hipLaunchKernelGGL(k_ln_qkv<true>, dim3(grid), dim3(256), dyn, s, p);
+        hipLaunchKernelGGL(k_ln_qkv<true>, dim3(grid), dim3(256), 0, s, p);
     } else {
-        hipLaunchKernelGGL(k_ln_qkv<false>, dim3(p.ax.nseq * p.panels_per_seq), dim3(256), dyn, s, p);
+        hipLaunchKernelGGL(k_ln_qkv<false>, dim3(p.ax.nseq * p.panels_per_seq), dim3(256), 0, s, p);
     }
 }
 void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s) {
