@@ -189,6 +189,18 @@ int32_t mdgen_atom14_to_cond(int32_t B, int32_t L, const float* atom14, const in
                              float* rots, float* trans, float* torsions, float* torsion_mask,
                              void* stream);
 
+/* Flow-matching training target (transport.py:138-189 `training_losses`, velocity model; path.py:113-135 `plan`
+ * with GVPCPlan :177-187 or the linear ICPlan): per sample b with time t[b],
+ *   xt = alpha x1 + sigma x0,  ut = alpha' x1 + sigma' x0;   GVP: alpha = sin(pi t/2), sigma = cos(pi t/2);
+ *   Linear: alpha = t, sigma = 1 - t.   x0/x1/xt/ut: (B, per_sample) fp32; path_type 0 = Linear, 1 = GVP. */
+int32_t mdgen_path_plan(int64_t B, int64_t per_sample, int32_t path_type, const float* t, const float* x0,
+                        const float* x1, float* xt, float* ut, void* stream);
+
+/* Masked mean squared error per sample (transport.py:13-17 `mean_flat`, :184):
+ *   loss[b] = sum((pred - target)^2 * mask) / sum(mask)  over the per_sample elements of sample b. */
+int32_t mdgen_masked_mse(int64_t B, int64_t per_sample, const float* pred, const float* target, const float* mask,
+                         float* loss, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

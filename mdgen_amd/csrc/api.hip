@@ -1159,3 +1159,25 @@ extern "C" int32_t mdgen_atom14_to_cond(int32_t B, int32_t L, const float* atom1
     LAUNCHCHK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// flow-matching training target and loss (forward only)
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t mdgen_path_plan(int64_t B, int64_t per_sample, int32_t path_type, const float* t, const float* x0,
+                                   const float* x1, float* xt, float* ut, void* stream) {
+    NONNULL(t, x0, x1, xt, ut);
+    if (B < 1 || per_sample < 1) return fail(-2, "B, per_sample must be >= 1");
+    if (path_type != 0 && path_type != 1) return fail(-2, "path_type: 0 = Linear, 1 = GVP");
+    launch_path_plan(t, x0, x1, xt, ut, per_sample, B, path_type, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}
+
+extern "C" int32_t mdgen_masked_mse(int64_t B, int64_t per_sample, const float* pred, const float* target,
+                                    const float* mask, float* loss, void* stream) {
+    NONNULL(pred, target, mask, loss);
+    if (B < 1 || per_sample < 1) return fail(-2, "B, per_sample must be >= 1");
+    launch_masked_mse(pred, target, mask, loss, per_sample, B, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}

@@ -346,6 +346,53 @@ __global__ __launch_bounds__(256) void k_ipa_attn(const IpaAttnParams p) {
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
+// =================================================================================================
+// Flow-matching training target, forward only.
+//   plan   (path.py:113-135 with GVPCPlan :177-187 / ICPlan linear):  xt = a x1 + s x0,  ut = a' x1 + s' x0
+//          GVP: a = sin(pi t / 2), s = cos(pi t / 2);  linear: a = t, s = 1 - t.   t is per sample.
+//   loss   (transport.py:13-17 mean_flat, :184):  loss[b] = sum((pred - ut)^2 * mask) / sum(mask)
+// =================================================================================================
+__global__ void k_path_plan(const float* __restrict__ t, const float* __restrict__ x0, const float* __restrict__ x1,
+                            float* __restrict__ xt, float* __restrict__ ut, long per_sample, long total, int gvp) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float tb = t[i / per_sample];
+    float a, sg, da, ds;
+    if (gvp) {
+        const float hp = 1.57079632679489662f;   // pi / 2
+        const float sn = sinf(tb * hp), cs = cosf(tb * hp);
+        a = sn; sg = cs; da = hp * cs; ds = -hp * sn;
+    } else {
+        a = tb; sg = 1.0f - tb; da = 1.0f; ds = -1.0f;
+    }
+    const float v1 = x1[i], v0 = x0[i];
+    xt[i] = a * v1 + sg * v0;
+    ut[i] = da * v1 + ds * v0;
+}
+
+// one workgroup per sample; fp32 partial sums per lane, wave reduce, 4-wave combine through LDS
+__global__ __launch_bounds__(256) void k_masked_mse(const float* __restrict__ pred, const float* __restrict__ target,
+                                                    const float* __restrict__ mask, float* __restrict__ loss,
+                                                    long per_sample) {
+    __shared__ float red[2][4];
+    const long base = (long)blockIdx.x * per_sample;
+    float num = 0.f, den = 0.f;
+    for (long i = threadIdx.x; i < per_sample; i += 256) {
+        const float d = pred[base + i] - target[base + i], m = mask[base + i];
+        num += d * d * m;
+        den += m;
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if (lane_id() == 0) {
+        red[0][wave_id()] = num;
+        red[1][wave_id()] = den;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        loss[blockIdx.x] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+}
+
 void launch_temb(const float* t_rows, int nrows, float tmul, const float* w0, const float* b0, const float* w2,
                  const float* b2, float* silu_out, hipStream_t s) {
     hipLaunchKernelGGL(k_temb, dim3(nrows), dim3(384), 0, s, t_rows, tmul, w0, b0, w2, b2, silu_out);
@@ -364,6 +411,16 @@ void launch_pack_rows(const float* w, int ld, const int* rowmap, int nft, int ks
     const long total = (long)nft * ksteps * 64;
     hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, ld, rowmap, nft, ksteps,
                        scale, dst);
+}
+void launch_path_plan(const float* t, const float* x0, const float* x1, float* xt, float* ut, long per_sample, long B,
+                      int gvp, hipStream_t s) {
+    const long total = per_sample * B;
+    hipLaunchKernelGGL(k_path_plan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t, x0, x1, xt, ut, per_sample,
+                       total, gvp);
+}
+void launch_masked_mse(const float* pred, const float* target, const float* mask, float* loss, long per_sample, long B,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_masked_mse, dim3((unsigned)B), dim3(256), 0, s, pred, target, mask, loss, per_sample);
 }
 void launch_embed(const EmbedParams& p, hipStream_t s) {
     const dim3 g((unsigned)((p.N + kEmbTok - 1) / kEmbTok)), b(384);

@@ -123,6 +123,10 @@ void launch_ln_linear(const LnLinearParams& p, hipStream_t s);
 void launch_final(const FinalParams& p, hipStream_t s);
 void launch_flash(const FlashParams& p, hipStream_t s);
 void launch_embed(const EmbedParams& p, hipStream_t s);
+void launch_path_plan(const float* t, const float* x0, const float* x1, float* xt, float* ut, long per_sample, long B,
+                      int gvp, hipStream_t s);
+void launch_masked_mse(const float* pred, const float* target, const float* mask, float* loss, long per_sample, long B,
+                       hipStream_t s);
 void launch_ipa_attn(const IpaAttnParams& p, hipStream_t s);
 
 // small kernels (k_small.hip)

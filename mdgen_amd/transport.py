@@ -25,6 +25,51 @@ class Transport:
     def check_interval(self, *a, **k):
         return 0, 1
 
+    # ---- training target and loss, forward only (transport.py:126-189) ----------------------
+    def sample(self, x1):
+        """transport.py:126-136: x0 ~ N(0, I), t ~ U(0, 1) (velocity + GVP/Linear: t0, t1 = 0, 1), on x1's device."""
+        x0 = torch.randn_like(x1)
+        t = torch.rand((x1.shape[0],)).to(x1)
+        return t, x0, x1
+
+    def plan(self, t, x0, x1):
+        """path.py:131-135 `plan`: (t, xt, ut) with xt = alpha x1 + sigma x0, ut = alpha' x1 + sigma' x0, computed by
+        `mdgen_path_plan` (GVP: alpha = sin(pi t / 2), sigma = cos(pi t / 2); Linear: alpha = t, sigma = 1 - t)."""
+        from ._lib import lib, check, ptr, require_cuda, stream_ptr
+        x0 = x0.to(torch.float32).contiguous()
+        x1 = x1.to(torch.float32).contiguous()
+        t = t.to(torch.float32).contiguous()
+        require_cuda(t, x0, x1)
+        xt, ut = torch.empty_like(x1), torch.empty_like(x1)
+        B = x1.shape[0]
+        with torch.cuda.device(x1.device):
+            check(lib.mdgen_path_plan(B, x1.numel() // B, 1 if self.path_type == "GVP" else 0, ptr(t), ptr(x0), ptr(x1),
+                                      ptr(xt), ptr(ut), stream_ptr()))
+        return t, xt, ut
+
+    def training_losses(self, model, x1, aatype1=None, mask=None, model_kwargs=None, t=None, x0=None):
+        """transport.py:138-189 for the velocity model (non-design path): returns {'t', 'pred', 'loss'} with
+        loss = mean_flat((model(xt, t) - ut)^2, mask).  `t` / `x0` may be given to reproduce a reference run
+        (the reference draws them inside, :126-136).  Forward only: no backward kernels exist in this build."""
+        from ._lib import lib, check, ptr, require_cuda, stream_ptr
+        model_kwargs = model_kwargs or {}
+        if t is None or x0 is None:
+            t_, x0_, _ = self.sample(x1)
+            t = t_ if t is None else t
+            x0 = x0_ if x0 is None else x0
+        t, xt, ut = self.plan(t, x0, x1)
+        pred = model(xt, t, **model_kwargs)
+        if pred.shape != xt.shape:
+            raise ValueError(f"model output {tuple(pred.shape)} != input {tuple(xt.shape)}")
+        m = mask.to(torch.float32).expand_as(xt).contiguous()
+        pred = pred.to(torch.float32).contiguous()
+        require_cuda(pred, m)
+        B = xt.shape[0]
+        loss = torch.empty(B, device=xt.device, dtype=torch.float32)
+        with torch.cuda.device(xt.device):
+            check(lib.mdgen_masked_mse(B, xt.numel() // B, ptr(pred), ptr(ut), ptr(m), ptr(loss), stream_ptr()))
+        return {"t": t, "pred": pred, "loss": loss}
+
 
 def create_transport(args=None, path_type="GVP", prediction="velocity", loss_weight=None, train_eps=None,
                      sample_eps=None):

@@ -111,6 +111,16 @@ class NewMDGenWrapper:
             },
         }
 
+    def general_step(self, batch, stage="val", t=None, x0=None):
+        """The forward half of wrapper.py:367-384 `general_step`: `prep_batch` -> `transport.training_losses`
+        (flow-matching target, model forward, masked MSE).  Returns the loss per sample (B,) and the term dict.
+        No backward / optimiser step exists in this build, so `stage` is informational; `t` and
+        `x0` may be fixed for reproducibility (the reference draws them inside the transport)."""
+        prep = self.prep_batch(batch)
+        out = self.transport.training_losses(model=self.model.forward, x1=prep["latents"], aatype1=None,
+                                             mask=prep["loss_mask"], model_kwargs=prep["model_kwargs"], t=t, x0=x0)
+        return out["loss"], out
+
     def inference(self, batch, zs=None, num_steps=None, use_graph=True):
         """wrapper.py:405-484.  Extra keywords (defaults reproduce the reference): `zs` explicit noise
         (reference: device randn, wrapper.py:439), `num_steps` Euler steps S (reference: 50 grid points = 49

@@ -511,6 +511,33 @@ def rollout_glue(atom14_last, seqres):
     return {"trans": t[:, None], "rots": R[:, None], "torsions": tors[:, None]}
 
 
+def path_plan(t, x0, x1, path_type="GVP"):
+    """path.py:113-135 `ICPlan.plan` with GVPCPlan coefficients (:177-187) or the linear ICPlan (:28-40):
+    xt = alpha_t x1 + sigma_t x0,  ut = alpha_t' x1 + sigma_t' x0,  t expanded over the non-batch dims."""
+    te = t.reshape(-1, *([1] * (x1.dim() - 1)))
+    if path_type == "GVP":
+        a, da = torch.sin(te * math.pi / 2), math.pi / 2 * torch.cos(te * math.pi / 2)
+        sg, ds = torch.cos(te * math.pi / 2), -math.pi / 2 * torch.sin(te * math.pi / 2)
+    else:
+        a, da = te, torch.ones_like(te)
+        sg, ds = 1 - te, -torch.ones_like(te)
+    return a * x1 + sg * x0, da * x1 + ds * x0
+
+
+def mean_flat(x, mask):
+    """transport.py:13-17: masked mean over all non-batch dimensions."""
+    dims = list(range(1, x.dim()))
+    return torch.sum(x * mask, dim=dims) / torch.sum(mask, dim=dims)
+
+
+def training_losses(P, cfg, x1, mask, model_kwargs, t, x0, path_type="GVP"):
+    """Transport.training_losses (transport.py:138-189), velocity model, non-design path, with the noise x0 and
+    the times t given explicitly (the reference draws them at :126-136)."""
+    xt, ut = path_plan(t, x0, x1, path_type)
+    pred = forward(P, cfg, xt, t, **model_kwargs)
+    return {"t": t, "pred": pred, "loss": mean_flat((pred - ut) ** 2, mask), "xt": xt, "ut": ut}
+
+
 def cfg_dict(model_config):
     """ModelConfig dataclass -> plain dict used by this module."""
     return dict(model_config.to_dict(), latent_dim=model_config.latent_dim)

@@ -345,6 +345,42 @@ def test_residue_axis_paths_agree():
     assert rel_l2(outs["1"], outs[""]) < 5e-3 and rel_l2(outs["0"], outs[""]) < 5e-3
 
 
+def test_training_losses_vs_reference():
+    """Flow-matching target + masked loss (forward only): `Transport.training_losses` with the
+    reference's draws of x0 and t on the full-width model, vs the REFERENCE's own output (train_full_sim golden);
+    plus the two kernels on their own: `mdgen_path_plan` vs the oracle (fp32), `mdgen_masked_mse` vs torch."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.transport import create_transport
+    dev = _cuda()
+    g = load_golden("train_full_sim")
+    cfg, sd = weights_for(g)
+    m = get_model(cfg, sd, ("train_full_sim", "w"))
+    tr = create_transport()
+    kw = dict(mask=g["mask"].to(dev), start_frames=(g["start_rot"].to(dev), g["start_trans"].to(dev)),
+              x_cond=g["x_cond"].to(dev), x_cond_mask=g["x_cond_mask"].to(dev), aatype=g["aatype"].to(dev))
+    terms = tr.training_losses(m.forward, g["x1"].to(dev), mask=g["loss_mask"].to(dev), model_kwargs=kw,
+                               t=g["t"].to(dev), x0=g["x0"].to(dev))
+    torch.cuda.synchronize()
+    e_pred = rel_l2(terms["pred"].cpu(), g["pred"])
+    e_loss = ((terms["loss"].cpu() - g["loss"]).abs() / g["loss"].abs()).max().item()
+    print(f"training_losses: pred rel-L2 {e_pred:.2e}, loss rel err {e_loss:.2e}, loss {terms['loss'].tolist()}")
+    assert e_pred < TOL_FWD and e_loss < 1e-2
+    # kernels on their own
+    for path_type in ("GVP", "Linear"):
+        tr2 = create_transport(path_type=path_type)
+        _, xt, ut = tr2.plan(g["t"].to(dev), g["x0"].to(dev), g["x1"].to(dev))
+        rxt, rut = O.path_plan(g["t"], g["x0"], g["x1"], path_type)
+        assert torch.allclose(xt.cpu(), rxt, atol=2e-6) and torch.allclose(ut.cpu(), rut, atol=5e-6), path_type
+    from mdgen_amd._lib import lib, check, ptr, stream_ptr
+    a, b = torch.randn(3, 1000, device=dev), torch.randn(3, 1000, device=dev)
+    mk = (torch.rand(3, 1000, device=dev) > 0.3).float()
+    out = torch.empty(3, device=dev)
+    check(lib.mdgen_masked_mse(3, 1000, ptr(a), ptr(b), ptr(mk), ptr(out), stream_ptr()))
+    torch.cuda.synchronize()
+    ref = O.mean_flat(((a - b) ** 2).cpu(), mk.cpu())
+    assert torch.allclose(out.cpu(), ref, rtol=1e-5)
+
+
 def test_graph_replay_matches_eager_bitwise():
     from mdgen_amd.config import ModelConfig
     from mdgen_amd.synthetic import synth_state_dict

@@ -171,3 +171,22 @@ def test_quat_sign_option_is_only_a_sign():
     assert torch.allclose(a[:, :4] * s, b[:, :4], atol=1e-6)
     assert torch.equal(a[:, 4:], b[:, 4:])
     assert torch.allclose(O.quat_to_rot(b[:, :4]), R, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["train_tiny_sim", "train_full_sim"])
+def test_training_losses_vs_reference(name):
+    """Flow-matching target + masked loss: the oracle's restatement of
+    `Transport.training_losses` (transport.py:138-189, path.py:113-135, 177-187) vs the reference's own run with
+    the same draws of x0 and t (oracle/gen_golden_train.py)."""
+    g = load_golden(name)
+    cfg, sd = weights_for(g)
+    kw = dict(mask=g["mask"], start_frames=(g["start_rot"], g["start_trans"]), end_frames=(g["start_rot"], g["start_trans"]),
+              x_cond=g["x_cond"], x_cond_mask=g["x_cond_mask"], aatype=g["aatype"])
+    out = O.training_losses(sd, O.cfg_dict(cfg), g["x1"], g["loss_mask"], kw, g["t"], g["x0"])
+    assert rel_l2(out["pred"], g["pred"]) < 2e-5
+    assert torch.allclose(out["loss"], g["loss"], rtol=2e-5)
+    # the plan itself: endpoints and derivative identities of the GVP path
+    xt0, ut0 = O.path_plan(torch.zeros(2), g["x0"], g["x1"])
+    xt1, _ = O.path_plan(torch.ones(2), g["x0"], g["x1"])
+    assert torch.allclose(xt0, g["x0"], atol=1e-6) and torch.allclose(xt1, g["x1"], atol=1e-6)
+    assert torch.allclose(ut0, (math.pi / 2) * g["x1"], atol=1e-5)
