@@ -156,6 +156,10 @@ int32_t mdgen_rigid_apply(int64_t n, int64_t pts_per_frame, const float* r, cons
                           const float* pts, float* out, int32_t inverse, void* stream); /* :1047-1073 */
 int32_t mdgen_quat_to_rot(int64_t n, const float* quat, int32_t normalize, float* rot, void* stream); /* :168-188, :324 */
 int32_t mdgen_rot_to_quat(int64_t n, const float* rot, float* quat, void* stream); /* :191-210 (sign: w >= 0) */
+/* Rigid.from_3_points(p_neg_x, origin, p_xy, eps = 1e-8) (:1175-1218): Gram-Schmidt frame, R columns e0, e1, e2,
+ * t = origin.  Points (n, 3); rot (n, 3, 3); trans (n, 3). */
+int32_t mdgen_from_3_points(int64_t n, const float* p_neg_x, const float* origin, const float* p_xy, float* rot,
+                            float* trans, void* stream);
 
 /* ---- sampler pre/post-processing (mdgen/wrapper.py) ----------------------------------------
  * `NewMDGenWrapper.prep_batch` latents (wrapper.py:298-327, 339-342, 362) incl. `utils.get_offsets`

@@ -16,7 +16,7 @@ EXPORTS = [
     "mdgen_denoiser_forward", "mdgen_sample_euler", "mdgen_profile_enable", "mdgen_profile_report", "mdgen_profile_phase_trace", "mdgen_debug_layout_maps",
     "mdgen_rigid_compose", "mdgen_rigid_invert",
     "mdgen_rigid_apply", "mdgen_quat_to_rot", "mdgen_rot_to_quat", "mdgen_prep_latents",
-    "mdgen_samples_to_atom14", "mdgen_atom14_to_cond", "mdgen_path_plan", "mdgen_masked_mse",
+    "mdgen_samples_to_atom14", "mdgen_atom14_to_cond", "mdgen_path_plan", "mdgen_masked_mse", "mdgen_from_3_points",
 ]
 
 
@@ -67,6 +67,7 @@ def _load():
     lib.mdgen_prep_latents.argtypes = [C.POINTER(Shape), i32] + [vp] * 7
     lib.mdgen_samples_to_atom14.argtypes = [C.POINTER(Shape), i32, i32] + [vp] * 10
     lib.mdgen_atom14_to_cond.argtypes = [i32, i32] + [vp] * 11
+    lib.mdgen_from_3_points.argtypes = [i64] + [vp] * 6
     lib.mdgen_path_plan.argtypes = [i64, i64, i32] + [vp] * 6
     lib.mdgen_masked_mse.argtypes = [i64, i64] + [vp] * 5
     for n in EXPORTS:

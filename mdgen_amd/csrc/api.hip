@@ -1181,3 +1181,12 @@ extern "C" int32_t mdgen_masked_mse(int64_t B, int64_t per_sample, const float* 
     LAUNCHCHK();
     return 0;
 }
+
+extern "C" int32_t mdgen_from_3_points(int64_t n, const float* p_neg_x, const float* origin, const float* p_xy,
+                                       float* rot, float* trans, void* stream) {
+    NONNULL(p_neg_x, origin, p_xy, rot, trans);
+    if (n < 1) return fail(-2, "n must be >= 1");
+    launch_from_3_points(n, p_neg_x, origin, p_xy, rot, trans, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}

@@ -208,6 +208,18 @@ __global__ void k_quat_to_rot(long n, const float* q, int normalize, float* rot)
     for (int k = 0; k < 9; ++k) rot[i * 9 + k] = R[k];
 }
 
+// Rigid.from_3_points (rigid_utils.py:1175-1218, eps = 1e-8): one thread per frame
+__global__ void k_from_3_points(long n, const float* __restrict__ pnx, const float* __restrict__ org,
+                                const float* __restrict__ pxy, float* __restrict__ rot, float* __restrict__ trans) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Rig f = from3(pnx + i * 3, org + i * 3, pxy + i * 3);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rot[i * 9 + k] = f.r[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) trans[i * 3 + k] = f.t[k];
+}
+
 __global__ void k_rot_to_quat(long n, const float* rot, float* q) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -461,6 +473,10 @@ void launch_rigid_apply(long n, long ppf, const float* r, const float* t, const 
 }
 void launch_quat_to_rot(long n, const float* q, int normalize, float* rot, hipStream_t s) {
     hipLaunchKernelGGL(k_quat_to_rot, GRID1D(n), n, q, normalize, rot);
+}
+void launch_from_3_points(long n, const float* pnx, const float* org, const float* pxy, float* rot, float* trans,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(k_from_3_points, GRID1D(n), n, pnx, org, pxy, rot, trans);
 }
 void launch_rot_to_quat(long n, const float* rot, float* q, hipStream_t s) {
     hipLaunchKernelGGL(k_rot_to_quat, GRID1D(n), n, rot, q);

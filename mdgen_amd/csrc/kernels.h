@@ -150,6 +150,8 @@ void launch_rigid_invert(long n, const float* r, const float* t, float* ro, floa
 void launch_rigid_apply(long n, long ppf, const float* r, const float* t, const float* pts, float* out, int inverse,
                         hipStream_t s);
 void launch_quat_to_rot(long n, const float* q, int normalize, float* rot, hipStream_t s);
+void launch_from_3_points(long n, const float* pnx, const float* org, const float* pxy, float* rot, float* trans,
+                          hipStream_t s);
 void launch_rot_to_quat(long n, const float* rot, float* q, hipStream_t s);
 void launch_prep_latents(int B, int T, int L, int tps, const float* rots, const float* trans, const float* tors,
                          float* latents, float* x_cond, int64_t* x_cond_mask, hipStream_t s);

@@ -232,6 +232,29 @@ class Rigid:
         return Rigid(Rotation(quats=t[..., :4], normalize_quats=normalize_quats), t[..., 4:])
 
     @staticmethod
+    def from_3_points(p_neg_x: torch.Tensor, origin: torch.Tensor, p_xy: torch.Tensor, eps: float = 1e-8) -> "Rigid":
+        """rigid_utils.py:1175-1218: Gram-Schmidt frame from three points (`mdgen_from_3_points`)."""
+        if eps != 1e-8:
+            raise NotImplementedError("from_3_points is built for the reference's eps = 1e-8")
+        a, o, b = torch.broadcast_tensors(p_neg_x, origin, p_xy)
+        a, o, b = _f32c(a), _f32c(o), _f32c(b)
+        require_cuda(a, o, b)
+        rot = torch.empty(o.shape[:-1] + (3, 3), dtype=torch.float32, device=o.device)
+        trans = torch.empty_like(o)
+        check(lib.mdgen_from_3_points(o.numel() // 3, ptr(a), ptr(o), ptr(b), ptr(rot), ptr(trans), stream_ptr()))
+        return Rigid(Rotation(rot_mats=rot), trans)
+
+    def map_tensor_fn(self, fn) -> "Rigid":
+        """rigid_utils.py:1087-1107: apply a tensor -> tensor function to every rotation entry and translation
+        coordinate (the leading "virtual" dims are what `fn` sees), e.g. `lambda x: torch.sum(x, dim=-1)` over a
+        one-hot-masked group axis.  View-level glue: the function itself runs as the torch ops it is made of."""
+        r = self._rots.get_rot_mats()
+        new_r = torch.stack([fn(x) for x in torch.unbind(r.reshape(r.shape[:-2] + (9,)), dim=-1)], dim=-1)
+        new_r = new_r.reshape(new_r.shape[:-1] + (3, 3))
+        new_t = torch.stack([fn(x) for x in torch.unbind(self._trans, dim=-1)], dim=-1)
+        return Rigid(Rotation(rot_mats=new_r), new_t)
+
+    @staticmethod
     def from_tensor_4x4(t: torch.Tensor) -> "Rigid":
         """rigid_utils.py:1122-1141."""
         if t.shape[-2:] != (4, 4):

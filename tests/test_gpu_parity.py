@@ -167,6 +167,16 @@ def test_rigid_ops_fp32():
     assert (t7[:, 0] >= 0).all()
     f7 = Rigid.from_tensor_7(g["q7"].to(dev), normalize_quats=True)
     assert torch.allclose(f7.get_rots().get_rot_mats().cpu(), g["from7_R"], atol=1e-5)
+    f3 = Rigid.from_3_points(g["p3a"].to(dev), g["p3b"].to(dev), g["p3c"].to(dev))
+    assert torch.allclose(f3.get_rots().get_rot_mats().cpu(), g["f3_R"], atol=1e-5)
+    assert torch.allclose(f3.get_trans().cpu(), g["f3_t"], atol=1e-6)
+    # map_tensor_fn(sum) over a one-hot-masked axis selects a frame (geometry.py:257-260 usage)
+    grp = Rigid(Rotation(rot_mats=g["R1"][:60].reshape(12, 5, 3, 3).to(dev)), g["t1"][:60].reshape(12, 5, 3).to(dev))
+    onehot = torch.nn.functional.one_hot(torch.arange(12) % 5, 5).float().to(dev)
+    sel = (grp * onehot).map_tensor_fn(lambda x: torch.sum(x, dim=-1))
+    pick = torch.arange(12) % 5
+    assert torch.allclose(sel.get_rots().get_rot_mats().cpu(), g["R1"][:60].reshape(12, 5, 3, 3)[torch.arange(12), pick], atol=1e-6)
+    assert torch.allclose(sel.get_trans().cpu(), g["t1"][:60].reshape(12, 5, 3)[torch.arange(12), pick], atol=1e-6)
     # identities
     ident = A.compose(A.invert())
     assert torch.allclose(ident.get_rots().get_rot_mats().cpu(), torch.eye(3).expand(64, 3, 3), atol=1e-5)
