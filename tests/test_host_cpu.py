@@ -113,3 +113,15 @@ def test_pdb_writer_matches_reference_text():
         frames_to_pdb_string(g["atom14"], np.full(6, 25))
     with pytest.raises(ValueError):
         frames_to_pdb_string(g["atom14"][0], g["aatype"])
+
+
+def test_sincos_pos_embed_matches_reference():
+    """`synthetic.sincos_pos_embed` (used when a state dict has no `pos_embed`) equals the
+    reference's `get_1d_sincos_pos_embed_from_grid` table (tests/golden/pos_embed.npz, oracle/gen_golden_posembed.py)."""
+    import numpy as np
+    from mdgen_amd.synthetic import sincos_pos_embed
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pos_embed.npz"))
+    for C, key in ((384, "c384"), (48, "c48")):
+        ours = sincos_pos_embed(C, 9)[0].numpy()
+        assert ours.shape == g[key].shape
+        assert np.abs(ours - g[key]).max() < 1e-6
