@@ -10,9 +10,16 @@
 // (DESIGN.md "fragment layout"), so this kernel issues only fully-coalesced 16/8-byte loads:
 //   S^T[key][q] = K-frag (A) x Q-frag (B)      2 x mfma_32x32x16 (d = 24 padded to 32)
 //   O^T[d][q]  += V^T-frag (A) x P^T (B)       2 x mfma_32x32x16, P^T = exp2(S^T - m) packed in place
-// A lane owns one query column (q = lane&31) and half of the tile's keys, so the row max / sum are
-// lane-local plus one exchange with lane^32.
-// One wave = one head x 64 queries (2 q-tiles); workgroup = 4 heads of the same queries.
+// A lane owns one query column (q = lane&31) and half of the tile's keys, so the row max is lane-local plus
+// one exchange with lane^32.  One wave = one head x 64 queries (2 q-tiles); workgroup = 4 heads of the same
+// queries.  The kernel is VALU-bound at dh = 24 (one v_exp per score), so the softmax is reduced to
+// max3 + exp + cvt per score:
+//   * the running shift -m rides in a spare K-dim slot of Q (bf16-exact), so the score MFMA returns s - m;
+//   * an all-ones V^T row (d = 24) makes the PV MFMA accumulate the softmax denominator;
+//   * the shift is re-anchored only when a tile's max exceeds it by 2^kDefer (wave-uniform ballot);
+//   * the NEXT tile's score MFMAs are issued inside the current tile's exp block;
+//   * K/V are prefetched with unconditional, wrapped tile indices (a load under `if` is a serialised load);
+//   * the learned bias key is a register-built virtual tile after the real ones.
 #include "kernels.h"
 
 namespace mdg {
