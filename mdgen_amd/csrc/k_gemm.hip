@@ -819,9 +819,9 @@ __global__ __launch_bounds__(512, 1) void k_mlp_ws(const MlpParams p) {
             } else if (c == 1 && has_next) {   // next panel: row table
                 setup_rows_linear(orow, pnext * kPanel, p.nrows, p.mm, btid);
             } else if (c == 2 && has_next) {   // next panel: LN prologue into the other panel buffer
-                prologue_ln<false, 0, 2>(obuf, orow, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, sw, sl);
+                prologue_ln_impl<false, 0, 2, false>(obuf, orow, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, sw, sl, 0);
             } else if (c == 3 && has_next) {
-                prologue_ln<false, 2, 4>(obuf, orow, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, sw, sl);
+                prologue_ln_impl<false, 2, 4, false>(obuf, orow, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, sw, sl, 0);
             }
             stamp8(p, tr, 1 + 4 * c);
             lds_barrier();   // X(c)

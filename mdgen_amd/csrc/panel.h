@@ -96,10 +96,23 @@ __device__ __forceinline__ void zero_acc(f32x16* acc) {
 // ---- panel row table (LDS) ----------------------------------------------------------------------
 // tok[r]  = global token row of panel row r, or -1 for padding rows
 // moff[r] = offset (floats) of that token's adaLN table row inside ModMap::mod
+// uniform = that offset when every valid row of the panel shares it (the usual case: a panel rarely straddles two
+//           samples), else -1: prologues / epilogues then read the modulation vectors once instead of per row
 struct PanelRows {
     int tok[kPanel];
     int moff[kPanel];
+    int uniform;
+    int pad_[3];   // keeps the panel that follows 16-byte aligned
 };
+
+// called by the ONE full wave that fills the table (tid 0..63), with its (token, offset) pair
+__device__ __forceinline__ void set_uniform(PanelRows* pr, int tid, long t, long mo) {
+    const int mo0 = __builtin_amdgcn_readfirstlane((int)mo);
+    const int t0 = __builtin_amdgcn_readfirstlane((int)t);
+    const bool same = t < 0 || (int)mo == mo0;
+    const bool all = __builtin_amdgcn_ballot_w64(same) == ~0ull;
+    if (tid == 0) pr->uniform = (t0 >= 0 && all) ? mo0 : -1;
+}
 
 // rows = positions pos0 .. pos0+63 of sequence `seq` along an attention axis
 __device__ __forceinline__ void setup_rows_axis(PanelRows* pr, const AxisMap ax, int seq, int pos0, const ModMap mm) {
@@ -112,6 +125,7 @@ __device__ __forceinline__ void setup_rows_axis(PanelRows* pr, const AxisMap ax,
         }
         pr->tok[threadIdx.x] = (int)t;
         pr->moff[threadIdx.x] = (int)mo;
+        set_uniform(pr, threadIdx.x, t, mo);
     }
 }
 
@@ -124,6 +138,7 @@ __device__ __forceinline__ void setup_rows_linear(PanelRows* pr, long row0, long
         if (t < nrows) mo = mm.row_off(t); else t = -1;
         pr->tok[tid] = (int)t;
         pr->moff[tid] = (int)mo;
+        set_uniform(pr, tid, t, mo);
     }
 }
 
@@ -138,10 +153,10 @@ __device__ __forceinline__ void setup_rows_linear(PanelRows* pr, long row0, long
 // row per iteration that exposed a full HBM round trip per row, 16 times per wave.
 // B0..B1: the batches (of 4 rows per wave) handled by this call, so a caller can split the prologue in parts;
 // w: index (0..3) of the calling wave among the four that share the panel.
-template <bool AFFINE, int B0 = 0, int B1 = 4>
-__device__ __forceinline__ void prologue_ln(unsigned char* panel, const PanelRows* pr, const float* __restrict__ x,
+template <bool AFFINE, int B0, int B1, bool UNI>
+__device__ __forceinline__ void prologue_ln_impl(unsigned char* panel, const PanelRows* pr, const float* __restrict__ x,
                                             const ModMap mm, int shift_chunk, int scale_chunk, float eps,
-                                            const int w = wave_id(), const int lane = lane_id()) {
+                                            const int w, const int lane, const int um) {
     constexpr int ROWB = kC * 2;
     constexpr int RB = 4, NB = kPanel / (4 * RB);   // a wave owns NB batches of RB rows: rows 16 b + 4 w + j
     static_assert(0 <= B0 && B0 < B1 && B1 <= NB, "batch range");
@@ -150,6 +165,17 @@ __device__ __forceinline__ void prologue_ln(unsigned char* panel, const PanelRow
     // bigger burst only deepens the HBM queue.)
     int t[NB][RB];
     f32x2 v[NB][RB][3];
+    f32x2 scu[3], shu[3];   // UNI: the one modulation row all rows of the panel share
+    if (UNI) {
+        const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
+        const unsigned osh = ((unsigned)um + (unsigned)(shift_chunk * kC)) * 4u + (unsigned)lane * 8u;
+        const unsigned osc = ((unsigned)um + (unsigned)(scale_chunk * kC)) * 4u + (unsigned)lane * 8u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            scu[i] = *reinterpret_cast<const f32x2*>(mb + osc + 512u * i);
+            shu[i] = *reinterpret_cast<const f32x2*>(mb + osh + 512u * i);
+        }
+    }
 #pragma unroll
     for (int b = B0; b < B1; ++b) {
         const int r0 = 4 * RB * b + RB * w;
@@ -165,14 +191,22 @@ __device__ __forceinline__ void prologue_ln(unsigned char* panel, const PanelRow
         f32x2 sc[RB][3], sh[RB][3];
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            const unsigned mo = AFFINE ? 0u : (unsigned)pr->moff[r0 + j];   // moff == 0 for padding rows
-            const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
-            const unsigned osh = (mo + (unsigned)(shift_chunk * kC)) * 4u + (unsigned)lane * 8u;
-            const unsigned osc = (mo + (unsigned)(scale_chunk * kC)) * 4u + (unsigned)lane * 8u;
+            if (UNI) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                sc[j][i] = *reinterpret_cast<const f32x2*>(mb + osc + 512u * i);
-                sh[j][i] = *reinterpret_cast<const f32x2*>(mb + osh + 512u * i);
+                for (int i = 0; i < 3; ++i) {
+                    sc[j][i] = scu[i];
+                    sh[j][i] = shu[i];
+                }
+            } else {
+                const unsigned mo = AFFINE ? 0u : (unsigned)pr->moff[r0 + j];   // moff == 0 for padding rows
+                const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
+                const unsigned osh = (mo + (unsigned)(shift_chunk * kC)) * 4u + (unsigned)lane * 8u;
+                const unsigned osc = (mo + (unsigned)(scale_chunk * kC)) * 4u + (unsigned)lane * 8u;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    sc[j][i] = *reinterpret_cast<const f32x2*>(mb + osc + 512u * i);
+                    sh[j][i] = *reinterpret_cast<const f32x2*>(mb + osh + 512u * i);
+                }
             }
         }
         float mean[RB], rstd[RB];
@@ -205,6 +239,15 @@ __device__ __forceinline__ void prologue_ln(unsigned char* panel, const PanelRow
             }
         }
     }
+}
+
+template <bool AFFINE, int B0 = 0, int B1 = 4>
+__device__ __forceinline__ void prologue_ln(unsigned char* panel, const PanelRows* pr, const float* __restrict__ x,
+                                            const ModMap mm, int shift_chunk, int scale_chunk, float eps,
+                                            const int w = wave_id(), const int lane = lane_id()) {
+    const int um = AFFINE ? 0 : pr->uniform;   // wave-uniform (LDS broadcast); AFFINE: gamma/beta are one row
+    if (um >= 0) prologue_ln_impl<AFFINE, B0, B1, true>(panel, pr, x, mm, shift_chunk, scale_chunk, eps, w, lane, um);
+    else prologue_ln_impl<AFFINE, B0, B1, false>(panel, pr, x, mm, shift_chunk, scale_chunk, eps, w, lane, 0);
 }
 
 // Plain bf16 rows [token][K] -> panel (K = 384 or 256).  16-byte chunks, 256 threads.
@@ -349,6 +392,11 @@ __device__ __forceinline__ void epi_rmw(const int t, const PanelRows* pr, const 
     const int slot = active ? lane : 0;   // lanes 48..63 idle along: keep their LDS/global addresses in range
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + col0 + 4 * q);
     const f32x4* stage4 = reinterpret_cast<const f32x4*>(stage);
+    // gate vector: one read when every row of the panel shares its modulation row (PanelRows::uniform), else per row
+    const int um = gated ? pr->uniform : -1;
+    const bool per_row = gated && um < 0;
+    f32x4 gu = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (gated && um >= 0) gu = *reinterpret_cast<const f32x4*>(mm.mod + um + gate_chunk * kC + col0 + 4 * q);
 #pragma unroll
     for (int b = 0; b < 16 / BR; ++b) {
         f32x4 hv[BR], g[BR];
@@ -359,8 +407,8 @@ __device__ __forceinline__ void epi_rmw(const int t, const PanelRows* pr, const 
             tk[k] = active ? pr->tok[row] : -1;
             const long tc = tk[k] < 0 ? 0 : tk[k];
             hv[k] = *reinterpret_cast<const f32x4*>(h + tc * kC + col0 + 4 * q);
-            g[k] = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (gated) g[k] = *reinterpret_cast<const f32x4*>(mm.mod + pr->moff[row] + gate_chunk * kC + col0 + 4 * q);
+            g[k] = gu;
+            if (per_row) g[k] = *reinterpret_cast<const f32x4*>(mm.mod + pr->moff[row] + gate_chunk * kC + col0 + 4 * q);
         }
 #pragma unroll
         for (int k = 0; k < BR; ++k) {
