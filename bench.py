@@ -33,16 +33,18 @@ if ROOT not in sys.path:
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md chip table)
 
 WORKLOADS = {
-    # name: (B, T, L, abs_pos_emb, n_pad)
-    "tetrapeptide_fwdsim_crop4_T1000_B16": (16, 1000, 4, True, 0),
-    "atlas_crop256_T250_B1": (1, 250, 256, False, 16),
-    "tetrapeptide_fwdsim_crop4_T100_B1": (1, 100, 4, True, 0),
+    # name: (B, T, L, abs_pos_emb, n_pad)                 BASELINE.json configs[...]
+    "tetrapeptide_fwdsim_crop4_T1000_B16": (16, 1000, 4, True, 0),      # [1] the headline (default)
+    "atlas_crop256_T250_B1": (1, 250, 256, False, 16),                  # [3]
+    "tetrapeptide_tps_crop4_T100_B32": (32, 100, 4, True, 0),           # [2]: batch 256 sharded over 8 GPUs = 32 / GPU
+    "tetrapeptide_fwdsim_crop4_T100_B1": (1, 100, 4, True, 0),          # [0]'s shape
+    "tetrapeptide_fwdsim_crop4_T1000_B1": (1, 1000, 4, True, 0),        # what the reference's CLI runs (B = 1)
     "tetrapeptide_fwdsim_crop4_T1000_B8": (8, 1000, 4, True, 0),    # working-set experiments (not bench lines)
     "tetrapeptide_fwdsim_crop4_T1000_B4": (4, 1000, 4, True, 0),
 }
 
 
-def synth_batch(B, T, L, n_pad, dev, seed):
+def synth_batch(B, T, L, n_pad, dev, seed, tps=False):
     """Self-consistent synthetic conditioning batch: random frames + torsions ->
     atom14 (sampler post-processing kernel) -> conditioning frame (rollout-glue kernel), first frame
     expanded over T (sim_inference.py:72-79); trailing `n_pad` residues padded (dataset.py:80-89)."""
@@ -64,9 +66,14 @@ def synth_batch(B, T, L, n_pad, dev, seed):
     if n_pad:
         mask[:, L - n_pad:] = 0
         seqres[:, L - n_pad:] = 0
-    return {"torsions": c["torsions"][:, None].expand(B, T, L, 7, 2).contiguous(),
-            "torsion_mask": c["torsion_mask"], "trans": c["trans"][:, None].expand(B, T, L, 3).contiguous(),
-            "rots": c["rots"][:, None].expand(B, T, L, 3, 3).contiguous(), "seqres": seqres, "mask": mask}
+    out = {"torsions": c["torsions"][:, None].expand(B, T, L, 7, 2).contiguous(),
+           "torsion_mask": c["torsion_mask"], "trans": c["trans"][:, None].expand(B, T, L, 3).contiguous(),
+           "rots": c["rots"][:, None].expand(B, T, L, 3, 3).contiguous(), "seqres": seqres, "mask": mask}
+    if tps:   # two-sided conditioning: frame -1 is a second, different conformation (tps_inference.py:58-66)
+        e = synth_batch(B, 1, L, n_pad, dev, seed + 7919)
+        for k in ("torsions", "trans", "rots"):
+            out[k][:, -1] = e[k][:, 0]
+    return out
 
 
 def algorithmic_flops(cls, B, T, L):
@@ -164,6 +171,7 @@ def main():
     ap.add_argument("--workload", default="tetrapeptide_fwdsim_crop4_T1000_B16", choices=list(WORKLOADS))
     ap.add_argument("--euler-steps", type=int, default=49, help="Euler steps S per inference() call (reference: 49)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--streams", type=int, default=None, help="library option 'streams' (default 2; 1 = single stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -189,11 +197,14 @@ def main():
 
     B, T, L, abs_pos, n_pad = WORKLOADS[a.workload]
     S = a.euler_steps
-    cfg = ModelConfig(crop=L, num_frames=T, abs_pos_emb=abs_pos, sim_condition=True)
+    tps = "_tps_" in a.workload
+    cfg = ModelConfig(crop=L, num_frames=T, abs_pos_emb=abs_pos, sim_condition=not tps, tps_condition=tps)
     sd = synth_state_dict(cfg, 0)
     w = NewMDGenWrapper(cfg, device=dev)
     w.model.load_state_dict(sd)
-    batch = synth_batch(B, T, L, n_pad, dev, seed=100 + rank)      # every rank: its own peptides (weak scaling)
+    if a.streams is not None:
+        w.model.set_option("streams", a.streams)
+    batch = synth_batch(B, T, L, n_pad, dev, seed=100 + rank, tps=tps)   # every rank: its own peptides (weak scaling)
     zs = torch.randn(B, T, L, cfg.latent_dim, generator=torch.Generator().manual_seed(137 + rank)).to(dev)
     use_graph = not a.no_graph
 

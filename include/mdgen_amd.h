@@ -14,7 +14,7 @@
  *   - every launch goes on the caller's `stream` (a hipStream_t passed as void*) and nothing inside a
  *     call synchronises the device (graph-capturable).  One exception, documented: `mdgen_sample_euler`
  *     forks the second half of the batch onto one context-owned stream and joins it back onto `stream`
- *     before returning (event fork/join, no host wait; MDGEN_DUAL_STREAM=0 disables it).
+ *     before returning (event fork/join, no host wait; option "streams" = 1 disables it).
  *   - return 0 on success, negative = invalid argument / state, positive = hipError_t.
  *     `mdgen_last_error()` returns a thread-local message.  No exceptions cross the ABI.
  *   - a context is not thread-safe; use one per device per process.
@@ -86,6 +86,14 @@ int32_t mdgen_ctx_destroy(mdgen_ctx* ctx);
 int32_t mdgen_ctx_set_weight(mdgen_ctx* ctx, const char* key, const float* data,
                              const int64_t* shape, int32_t ndim, void* stream);
 int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
+/* Run-time options (no environment variables are read by the library):
+ *   "streams"          1..8, default 2: contiguous sub-batches of an Euler rollout run on this many concurrent
+ *                      streams (the caller's + context-owned ones, fork/join by events inside the call);
+ *   "residue_l4_path"  residue-axis attention sub-layer when L == 4: 2 (default) one kernel for the whole
+ *                      sub-layer, 1 attention inside the QKV kernel + separate out-projection, 0 the general
+ *                      L <= 8 path.  All three compute mha.py:258-397 + latent_model.py:457-462.
+ * Returns -4 for an unknown name, -2 for a value out of range. */
+int32_t mdgen_ctx_set_option(mdgen_ctx* ctx, const char* name, int32_t value);
 /* number of state_dict keys the model needs; name of the i-th (for loaders / tests) */
 int32_t mdgen_ctx_num_weights(const mdgen_ctx* ctx);
 const char* mdgen_ctx_weight_name(const mdgen_ctx* ctx, int32_t i);
@@ -127,6 +135,41 @@ int32_t mdgen_sample_euler(mdgen_ctx* ctx, const mdgen_shape* shape, int32_t n_s
                            const float* x_cond, const int64_t* x_cond_mask, const int64_t* aatype,
                            void* workspace, size_t workspace_bytes, int32_t use_graph, void* stream);
 
+/* Residue constant tables (device pointers; data of mdgen/residue_constants.py:1124-1216, 1367-1480), as the two
+ * geometry entry points below take them one by one. */
+typedef struct mdgen_residue_tables {
+    const float*   default_frames;     /* [21][8][4][4] */
+    const float*   lit_positions;      /* [21][14][3]   */
+    const int64_t* atom14_group;       /* [21][14]      */
+    const float*   atom14_mask;        /* [21][14]      */
+    const int64_t* atom37_to_atom14;   /* [21][37]      */
+    const float*   atom37_mask;        /* [21][37]      */
+    const int64_t* chi_atom_indices;   /* [21][4][4]    */
+    const float*   chi_angles_mask;    /* [21][4]       */
+} mdgen_residue_tables;
+
+/* The driver loop of `sim_inference.py:100-113` (`do`: num_rollouts x `rollout`, :61-98) in ONE call and -- with
+ * use_graph -- one hipGraph: for block r < n_blocks
+ *     ex      = conditioning frame expanded over T                      (sim_inference.py:72-79)
+ *     prep    = prep_batch(ex)  -> x_cond, x_cond_mask                  (wrapper.py:298-342)
+ *     samples = Euler(zs[r], model(., start_frames = cond frame))       (wrapper.py:439-447; as mdgen_sample_euler)
+ *     atom14[:, r*T:(r+1)*T] = frames_torsions_to_atom14(cond o offsets, torsions)   (wrapper.py:456-478)
+ *     cond frame <- atom14_to_frames / atom37_to_torsions of the block's last frame   (sim_inference.py:91-96)
+ * with nothing returning to the host between blocks.  Forward-simulation models only (sim_condition).
+ *   zs            (n_blocks, B, T, L, D) fp32: noise on entry, each block's samples[-1] on exit
+ *   mask          (B, T, L) fp32;  seqres (B, L) int64 (residue types: the model's aatype AND the geometry's)
+ *   cond_*        the conditioning frame: rots (B,L,3,3), trans (B,L,3), torsions (B,L,7,2); UPDATED in place to
+ *                 the frame that would condition block n_blocks (so a further call continues the trajectory)
+ *   x_cond, x_cond_mask   caller-owned scratch (B,T,L,D) fp32 / (B,T,L) int64
+ *   atom14        (B, n_blocks*T, L, 14, 3) fp32 out
+ * workspace: as mdgen_sample_euler (mdgen_workspace_layout with n_steps, t_shared = 1). */
+int32_t mdgen_rollout_euler(mdgen_ctx* ctx, const mdgen_shape* shape, int32_t n_steps, int32_t n_blocks,
+                            float* zs, const float* mask,
+                            float* cond_rots, float* cond_trans, float* cond_torsions,
+                            const int64_t* seqres, float* x_cond, int64_t* x_cond_mask,
+                            const mdgen_residue_tables* tables, float* atom14,
+                            void* workspace, size_t workspace_bytes, int32_t use_graph, void* stream);
+
 /* ---- measurement ----------------------------------------------------------------------------
  * Per-kernel-class timing with hipEvents recorded on the launch stream (bench.py's roofline leg).
  * While enabled, launches are bracketed by event pairs and hipGraph capture/replay is bypassed.
@@ -138,6 +181,13 @@ int32_t mdgen_profile_enable(mdgen_ctx* ctx, int32_t on);
  * Only meaningful with profiling enabled or use_graph == 0 (a captured graph would replay the pointer). */
 int32_t mdgen_profile_phase_trace(mdgen_ctx* ctx, uint64_t* dev_buf, int64_t capacity_words);
 int32_t mdgen_profile_report(mdgen_ctx* ctx, void* stream, char* buf, size_t buflen);
+
+/* Host-only (no GPU): how a call of `shape` is cut into contiguous sub-batch launch views.  One launch addresses
+ * the residual stream with 32-bit byte offsets (token * 1536), i.e. at most 2 796 202 token rows; larger batches
+ * run as several views (at least `streams` of them).  Fails with -2 if a single sample (T*L tokens) exceeds the
+ * limit -- `mdgen_workspace_layout`, `mdgen_denoiser_forward` and `mdgen_sample_euler` reject such shapes too. */
+int32_t mdgen_debug_view_plan(const mdgen_shape* shape, int32_t streams, int32_t* n_views,
+                              int32_t* max_batch_per_view);
 
 /* Host-only (no GPU): the weight-row / bias permutations behind the attention fragment layout
  * (DESIGN.md "fragment layout"), each int32[384], for layout tests:

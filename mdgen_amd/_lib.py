@@ -12,8 +12,8 @@ LIB_PATH = os.environ.get("MDGEN_AMD_LIB", os.path.join(_HERE, "libmdgen_amd.so"
 
 EXPORTS = [
     "mdgen_last_error", "mdgen_abi_version", "mdgen_ctx_create", "mdgen_ctx_destroy", "mdgen_ctx_set_weight",
-    "mdgen_ctx_finalize", "mdgen_ctx_num_weights", "mdgen_ctx_weight_name", "mdgen_workspace_layout",
-    "mdgen_denoiser_forward", "mdgen_sample_euler", "mdgen_profile_enable", "mdgen_profile_report", "mdgen_profile_phase_trace", "mdgen_debug_layout_maps",
+    "mdgen_ctx_finalize", "mdgen_ctx_set_option", "mdgen_debug_view_plan", "mdgen_ctx_num_weights", "mdgen_ctx_weight_name", "mdgen_workspace_layout",
+    "mdgen_denoiser_forward", "mdgen_sample_euler", "mdgen_rollout_euler", "mdgen_profile_enable", "mdgen_profile_report", "mdgen_profile_phase_trace", "mdgen_debug_layout_maps",
     "mdgen_rigid_compose", "mdgen_rigid_invert",
     "mdgen_rigid_apply", "mdgen_quat_to_rot", "mdgen_rot_to_quat", "mdgen_prep_latents",
     "mdgen_samples_to_atom14", "mdgen_atom14_to_cond", "mdgen_path_plan", "mdgen_masked_mse", "mdgen_from_3_points",
@@ -36,6 +36,12 @@ class WsLayout(C.Structure):
         "ipa_feat", "mask_bl", "rel7", "tgrid")]
 
 
+class ResidueTables(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "default_frames", "lit_positions", "atom14_group", "atom14_mask", "atom37_to_atom14", "atom37_mask",
+        "chi_atom_indices", "chi_angles_mask")]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -49,12 +55,15 @@ def _load():
     lib.mdgen_ctx_destroy.argtypes = [vp]
     lib.mdgen_ctx_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(i64), i32, vp]
     lib.mdgen_ctx_finalize.argtypes = [vp, vp]
+    lib.mdgen_ctx_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.mdgen_debug_view_plan.argtypes = [C.POINTER(Shape), i32, C.POINTER(i32), C.POINTER(i32)]
     lib.mdgen_ctx_num_weights.argtypes = [vp]
     lib.mdgen_ctx_weight_name.argtypes = [vp, i32]
     lib.mdgen_ctx_weight_name.restype = C.c_char_p
     lib.mdgen_workspace_layout.argtypes = [vp, C.POINTER(Shape), i32, i32, C.POINTER(WsLayout)]
     lib.mdgen_denoiser_forward.argtypes = [vp, C.POINTER(Shape)] + [vp] * 14 + [sz, vp]
     lib.mdgen_sample_euler.argtypes = [vp, C.POINTER(Shape), i32] + [vp] * 10 + [sz, i32, vp]
+    lib.mdgen_rollout_euler.argtypes = [vp, C.POINTER(Shape), i32, i32] + [vp] * 9 + [C.POINTER(ResidueTables), vp, vp, sz, i32, vp]
     lib.mdgen_profile_enable.argtypes = [vp, i32]
     lib.mdgen_profile_phase_trace.argtypes = [vp, vp, i64]
     lib.mdgen_profile_report.argtypes = [vp, vp, C.c_char_p, sz]
@@ -106,5 +115,19 @@ def ptr(t, dtype=None):
     return C.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on `device` (default: the current device)."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_device_of(t):
+    """Context manager making `t`'s device current: kernels are enqueued on THAT device's current stream
+    (a launch on device 0's stream with device-1 pointers faults or loses its stream dependency)."""
+    return torch.cuda.device(t.device)
+
+
+def launch(fn, like, *args):
+    """Call a stream-taking entry point `fn(*args, stream)` on `like`'s device: that device is made current for
+    the call and the launch goes on ITS current stream (centralised device guard)."""
+    with torch.cuda.device(like.device):
+        check(fn(*args, stream_ptr()))

@@ -106,6 +106,9 @@ struct mdgen_ctx {
     std::vector<GraphEntry> graphs;
     bool inv_freq_set = false;
     bool prof_on = false;
+    // run-time options (mdgen_ctx_set_option)
+    int opt_streams = 2;        // concurrent sub-batch streams of the Euler rollout (1 = caller's stream only)
+    int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
     unsigned long long* phase_trace = nullptr;   // mdgen_profile_phase_trace target (device), consumed by one launch
     long phase_trace_cap = 0;
     std::vector<ProfRec> prof;
@@ -323,20 +326,30 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     TRY(c->dalloc(&c->ada_b, (size_t)c->modrow));
     TRY(c->dalloc(&c->inv_freq, (size_t)12));
     TRY(c->dalloc(&c->rope, (size_t)(kMaxPos + 1) * kRopeRow));
+    // a failing HIP call must not leak the half-built context
+#define TRYHIP(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            mdgen_ctx_destroy(c);                                                                       \
+            return fail((int)e_, "%s failed: %s", #expr, hipGetErrorString(e_));                        \
+        }                                                                                               \
+    } while (0)
     for (int i = 0; i < mdgen_ctx::kMaxSide; ++i) {
-        HIPCHK(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+        TRYHIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        TRYHIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
-    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    TRYHIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     TRY(c->dalloc(&c->zero_page, (size_t)64));
-    HIPCHK(hipMemset(c->zero_page, 0, 256));
+    TRYHIP(hipMemset(c->zero_page, 0, 256));
     {   // bytes 128..143: eight bf16 1.0 (the all-ones V^T row that accumulates the softmax denominator)
         const uint16_t ones[8] = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
-        HIPCHK(hipMemcpy((unsigned char*)c->zero_page + 128, ones, sizeof(ones), hipMemcpyHostToDevice));
+        TRYHIP(hipMemcpy((unsigned char*)c->zero_page + 128, ones, sizeof(ones), hipMemcpyHostToDevice));
     }
     TRY(c->dalloc(&c->wfin, (size_t)kKS * 64));
     TRY(c->dalloc(&c->bfin, (size_t)32));
-    HIPCHK(hipMemset(c->bfin, 0, 32 * sizeof(float)));
+    TRYHIP(hipMemset(c->bfin, 0, 32 * sizeof(float)));
+#undef TRYHIP
     SETTER("latent_to_emb.weight", { WANT(kC, c->D); if (int r = copy_f32(c->wl, data, (size_t)kC * c->D, s)) return r; });
     SETTER("latent_to_emb.bias", { WANT(kC); if (int r = copy_f32(c->bl, data, kC, s)) return r; });
     SETTER("cond_to_emb.weight", { WANT(kC, c->D); if (int r = copy_f32(c->wc, data, (size_t)kC * c->D, s)) return r; });
@@ -480,6 +493,21 @@ extern "C" int32_t mdgen_ctx_finalize(mdgen_ctx* c, void* stream) {
     return 0;
 }
 
+extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t value) {
+    if (!c || !name) return fail(-1, "null argument");
+    const std::string n(name);
+    if (n == "streams") {
+        if (value < 1 || value > mdgen_ctx::kMaxSide + 1) return fail(-2, "streams must be in 1..%d", mdgen_ctx::kMaxSide + 1);
+        c->opt_streams = value;
+    } else if (n == "residue_l4_path") {
+        if (value < 0 || value > 2) return fail(-2, "residue_l4_path must be 0, 1 or 2");
+        c->opt_residue_l4 = value;
+    } else {
+        return fail(-4, "unknown option '%s'", name);
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // workspace
 // ---------------------------------------------------------------------------------------------
@@ -487,12 +515,47 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static size_t frag_bytes(long nseq, int len) { return (size_t)nseq * kH * (len / 32 + 1) * kFragBytes; }
 
+// The panel prologues / epilogues (csrc/panel.h) address the residual stream as a uniform base + a 32-bit byte
+// offset token * 1536, so ONE launch may cover at most kMaxViewTokens token rows.  Larger batches are run as
+// several contiguous sub-batch views (plan_views); one sample (T * L tokens) must fit a view by itself.
+constexpr long kMaxViewTokens = 0xFFFFFFFFL / (kC * 4);   // 2 796 202
+
+// Contiguous sub-batch views of a call: at least `streams` of them (capped by B), and as many as the per-launch
+// token limit requires.  Returns the number of views, 0 if a single sample already exceeds the limit.
+static int plan_views(long B, long T, long L, int streams) {
+    const long tl = T * L;
+    if (tl > kMaxViewTokens) return 0;
+    const long per = kMaxViewTokens / tl;              // samples per view at most
+    long nv = (B + per - 1) / per;
+    if (nv < streams) nv = streams;
+    if (nv > B) nv = B;
+    while ((B + nv - 1) / nv > per) ++nv;              // the largest view (ceil(B / nv) samples) must fit
+    return (int)nv;
+}
+
+extern "C" int32_t mdgen_debug_view_plan(const mdgen_shape* sh, int32_t streams, int32_t* n_views,
+                                         int32_t* max_batch_per_view) {
+    if (!sh || !n_views || !max_batch_per_view) return fail(-1, "null argument");
+    if (sh->B < 1 || sh->T < 1 || sh->L < 1 || streams < 1) return fail(-2, "B, T, L, streams must be >= 1");
+    const int nv = plan_views(sh->B, sh->T, sh->L, streams);
+    if (nv == 0) return fail(-2, "one sample (T*L = %ld tokens) exceeds the per-launch limit of %ld tokens",
+                             (long)sh->T * sh->L, kMaxViewTokens);
+    *n_views = nv;
+    *max_batch_per_view = (sh->B + nv - 1) / nv;
+    return 0;
+}
+
 static int check_shape(const mdgen_ctx* c, const mdgen_shape* sh, int S) {
     if (!c || !sh) return fail(-1, "null argument");
     if (sh->B < 1 || sh->T < 1 || sh->L < 1 || S < 1) return fail(-2, "B, T, L, n_steps must be >= 1");
     if (sh->T > kMaxPos - 1 || sh->L > kMaxPos - 1) return fail(-2, "T and L must be < %d", kMaxPos - 1);
-    if ((long)sh->B * sh->T * sh->L > 1500000000L || (long)S * sh->B * sh->L > 1500000000L)
-        return fail(-2, "token count too large");
+    if ((long)sh->B * sh->T * sh->L > 1500000000L) return fail(-2, "token count too large");
+    if ((long)sh->T * sh->L > kMaxViewTokens)
+        return fail(-2, "one sample (T*L = %ld tokens) exceeds the per-launch limit of %ld tokens", (long)sh->T * sh->L,
+                    kMaxViewTokens);
+    if ((long)S * sh->B * sh->L > kMaxViewTokens)
+        return fail(-2, "n_steps*B*L = %ld rows of the IPA table exceed the per-launch limit of %ld", (long)S * sh->B * sh->L,
+                    kMaxViewTokens);
     if (c->d.abs_pos_emb && sh->L > c->d.crop) return fail(-2, "L=%d exceeds pos_embed crop=%d", sh->L, c->d.crop);
     return 0;
 }
@@ -536,13 +599,6 @@ extern "C" int32_t mdgen_workspace_layout(const mdgen_ctx* c, const mdgen_shape*
 // ---------------------------------------------------------------------------------------------
 // orchestration
 // ---------------------------------------------------------------------------------------------
-// MDGEN_DEBUG_SKIP (tests only): bit0/1/2 skip the trunk's residue-attention / temporal-attention / MLP
-// sub-layers, bit3/4/5 skip the IPA layer's point-attention / residue-attention / MLP sub-layers.
-static int debug_skip() {
-    const char* e = getenv("MDGEN_DEBUG_SKIP");
-    return e ? atoi(e) : 0;
-}
-
 struct Run {
     mdgen_ctx* c;
     int B, T, L, D, S;
@@ -625,8 +681,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
     p.w = m.wo;
     p.bias = m.bo;
     const bool small = residue_axis && ax.len <= 8;
-    static const bool fused4 = !(getenv("MDGEN_FUSED_ATTN4") && atoi(getenv("MDGEN_FUSED_ATTN4")) == 0);
-    if (small && ax.len == 4 && fused4) {
+    if (small && ax.len == 4 && r.c->opt_residue_l4 != 0) {
         // L == 4: the 5-key attention runs inside the QKV kernel (quad-local), which writes the attention output
         q.wv = m.wv_small;
         q.bv = m.bv_small;
@@ -634,8 +689,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         q.bias_v = m.bias_v;
         q.mk = mk;
         q.obuf = r.obufp;
-        static const bool fuse_proj = !(getenv("MDGEN_FUSED_ATTN4") && atoi(getenv("MDGEN_FUSED_ATTN4")) == 1);
-        if (fuse_proj) {   // whole residue-axis sub-layer in one kernel (MDGEN_FUSED_ATTN4=1: attention only)
+        if (r.c->opt_residue_l4 == 2) {   // whole residue-axis sub-layer in one kernel (option 1: attention only)
             q.h_rw = h;
             q.wo = m.wo;
             q.bo = m.bo;
@@ -719,11 +773,9 @@ static int ipa_stack(const Run& r, float* hbuf, const float* rel7, const float* 
     LAUNCHCHK();
     AxisMap ax{G, r.L, G, 0, r.L, 1};
     MaskMap mk{(const float*)(r.ws + r.lay.mask_bl), (long)r.B * r.L};
-    const int skip = debug_skip();
     for (int i = 0; i < c->nl; ++i) {
         const IpaW& w = c->ipa[i];
         ModMap mm{r.mod() + c->ipa_off(i), r.L, r.B, r.mod_step_stride, r.mod_group_stride};
-        if (!(skip & 8)) {
         LnLinearParams lp{};
         lp.h = hbuf;
         lp.nrows = r.Mp;
@@ -756,11 +808,8 @@ static int ipa_stack(const Run& r, float* hbuf, const float* rel7, const float* 
         pp.a_bf16 = ap.feat;
         { ProfScope ps(c, "ipa.linear_out", r.s); launch_proj(pp, 1, r.s); }
         LAUNCHCHK();
-        }
-        if (!(skip & 16))
-            if (int e = attn_sublayer(r, w.mha_l, hbuf, r.Mp, ax, mm, 0, 1, 2, mk, true, false)) return e;
-        if (!(skip & 32))
-            if (int e = mlp_sublayer(r, w.ffn, hbuf, r.Mp, mm, 3, 4, 5, false)) return e;
+        if (int e = attn_sublayer(r, w.mha_l, hbuf, r.Mp, ax, mm, 0, 1, 2, mk, true, false)) return e;
+        if (int e = mlp_sublayer(r, w.ffn, hbuf, r.Mp, mm, 3, 4, 5, false)) return e;
     }
     return 0;
 }
@@ -840,16 +889,12 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
     AxisMap axL{r.B * r.T, r.L, r.B * r.T, 0, r.L, 1};
     AxisMap axT{r.B * r.L, r.T, r.L, r.T * r.L, 1, r.L};
     MaskMap mk{r.mask, 0};
-    const int skip = debug_skip();
     for (int i = 0; i < c->nl; ++i) {
         const TrunkW& w = c->trunk[i];
         ModMap mm{modstep + c->trunk_off(i), r.T * r.L, r.B, 0, r.mod_group_stride};
-        if (!(skip & 1))
-            if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true)) return er;
-        if (!(skip & 2))
-            if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true)) return er;
-        if (!(skip & 4))
-            if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true)) return er;
+        if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true)) return er;
+        if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true)) return er;
+        if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true)) return er;
         if (trace_h) HIPCHK(hipMemcpyAsync(trace_h + (size_t)(i + 1) * r.N * kC, h, hbytes, hipMemcpyDeviceToDevice, r.s));
     }
     FinalParams f{};
@@ -924,7 +969,18 @@ extern "C" int32_t mdgen_denoiser_forward(mdgen_ctx* c, const mdgen_shape* sh, c
     if (int e = prepare(r, t, nullptr)) return e;
     if (trace_ipa)
         HIPCHK(hipMemcpyAsync(trace_ipa, r.ws + r.lay.ipa_out, (size_t)r.B * r.L * kC * 4, hipMemcpyDeviceToDevice, r.s));
-    return denoise_step(r, 0, const_cast<float*>(x), out, 0, 0.f, trace_h);
+    const int nv = plan_views(r.B, r.T, r.L, 1);
+    if (nv <= 1) return denoise_step(r, 0, const_cast<float*>(x), out, 0, 0.f, trace_h);
+    if (trace_h) return fail(-2, "trace_h is not available when the batch needs more than one launch view");
+    int b0 = 0;
+    for (int i = 0; i < nv; ++i) {   // sequential sub-batch views on the caller's stream
+        const int Bs = r.B / nv + (i < r.B % nv ? 1 : 0);
+        const Run v = sub_run(r, b0, Bs, r.s);
+        const long o = (long)b0 * r.T * r.L * r.D;
+        if (int e = denoise_step(v, 0, const_cast<float*>(x) + o, out + o, 0, 0.f, nullptr)) return e;
+        b0 += Bs;
+    }
+    return 0;
 }
 
 // torch.linspace(0, 1, n) in fp32 (ATen RangeFactories: symmetric evaluation around the midpoint)
@@ -935,13 +991,9 @@ static void linspace01(int n, std::vector<float>* out) {
     for (int i = 0; i < n; ++i) (*out)[i] = i < half ? 0.0f + step * (float)i : 1.0f - step * (float)(n - 1 - i);
 }
 
-// Number of concurrent sub-batch streams for the Euler rollout (MDGEN_STREAMS, default 2; 1 disables).
+// Number of concurrent sub-batch streams for the Euler rollout (option "streams", default 2; 1 disables).
 static int n_streams(const Run& r) {
-    const char* e = getenv("MDGEN_DUAL_STREAM");
-    if (e && atoi(e) == 0) return 1;
-    int n = 2;
-    if (const char* e2 = getenv("MDGEN_STREAMS")) n = atoi(e2);
-    if (n > mdgen_ctx::kMaxSide + 1) n = mdgen_ctx::kMaxSide + 1;
+    int n = r.c->opt_streams;
     if (n > r.B) n = r.B;
     if (n < 2 || r.c->prof_on || r.N < 4096) return 1;
     return n;
@@ -958,24 +1010,70 @@ static int euler_steps(const Run& v, const std::vector<float>& tg, float* x) {
 static int euler_body(const Run& r, const std::vector<float>& tg, float* x) {
     if (int e = prepare(r, nullptr, tg.data())) return e;
     const int ns = n_streams(r);
-    if (ns == 1) return euler_steps(r, tg, x);
-    // contiguous sub-batches on `ns` streams (fork after the shared preparation, join at the end)
+    const int nv = plan_views(r.B, r.T, r.L, ns);   // >= ns views; more when a view would exceed kMaxViewTokens
+    if (nv == 0) return fail(-2, "sample too large for one launch");
+    if (nv == 1) return euler_steps(r, tg, x);
+    // contiguous sub-batch views, view i on stream i % ns (fork after the shared preparation, join at the end)
     mdgen_ctx* c = r.c;
-    HIPCHK(hipEventRecord(c->ev_fork, r.s));
-    int e = 0, b0 = 0;
-    for (int i = 0; i < ns; ++i) {
-        const int Bs = r.B / ns + (i < r.B % ns ? 1 : 0);
-        hipStream_t st = i == 0 ? r.s : c->side[i - 1];
-        if (i > 0) HIPCHK(hipStreamWaitEvent(st, c->ev_fork, 0));
+    if (ns > 1) HIPCHK(hipEventRecord(c->ev_fork, r.s));
+    for (int i = 1; i < ns; ++i) HIPCHK(hipStreamWaitEvent(c->side[i - 1], c->ev_fork, 0));
+    int b0 = 0;
+    for (int i = 0; i < nv; ++i) {
+        const int Bs = r.B / nv + (i < r.B % nv ? 1 : 0);
+        hipStream_t st = (i % ns) == 0 ? r.s : c->side[i % ns - 1];
         const Run v = sub_run(r, b0, Bs, st);
-        if (!e) e = euler_steps(v, tg, x + (long)b0 * r.T * r.L * r.D);
-        if (i > 0) {
-            HIPCHK(hipEventRecord(c->ev_join[i - 1], st));
-            HIPCHK(hipStreamWaitEvent(r.s, c->ev_join[i - 1], 0));
-        }
+        if (int e = euler_steps(v, tg, x + (long)b0 * r.T * r.L * r.D)) return e;
         b0 += Bs;
     }
-    return e;
+    for (int i = 1; i < ns; ++i) {
+        HIPCHK(hipEventRecord(c->ev_join[i - 1], c->side[i - 1]));
+        HIPCHK(hipStreamWaitEvent(r.s, c->ev_join[i - 1], 0));
+    }
+    return 0;
+}
+
+// Replay the cached hipGraph for `key`, or capture `body` (which enqueues work on `s`, possibly forking onto the
+// context's side streams and joining back) into a new one, cache it (LRU, 8 entries) and launch it.
+static int replay_or_capture(mdgen_ctx* c, const std::vector<uint64_t>& key, hipStream_t s, const std::function<int()>& body) {
+    if (!s) return fail(-8, "use_graph requires a non-default stream");
+    for (size_t gi = 0; gi < c->graphs.size(); ++gi)
+        if (c->graphs[gi].key == key) {
+            if (gi + 1 != c->graphs.size()) {   // most recently used goes to the back (eviction takes the front)
+                GraphEntry hit = c->graphs[gi];
+                c->graphs.erase(c->graphs.begin() + gi);
+                c->graphs.push_back(hit);
+            }
+            HIPCHK(hipGraphLaunch(c->graphs.back().exec, s));
+            return 0;
+        }
+    GraphEntry ge;
+    ge.key = key;
+    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int e = body();
+    hipError_t ce = hipStreamEndCapture(s, &ge.graph);
+    if (e) {
+        if (ge.graph) (void)hipGraphDestroy(ge.graph);
+        return e;
+    }
+    if (ce != hipSuccess) {
+        if (ge.graph) (void)hipGraphDestroy(ge.graph);
+        return fail((int)ce, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    }
+    {
+        hipError_t ie = hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) {
+            (void)hipGraphDestroy(ge.graph);
+            return fail((int)ie, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+        }
+    }
+    if (c->graphs.size() >= 8) {
+        (void)hipGraphExecDestroy(c->graphs.front().exec);
+        (void)hipGraphDestroy(c->graphs.front().graph);
+        c->graphs.erase(c->graphs.begin());
+    }
+    c->graphs.push_back(ge);
+    HIPCHK(hipGraphLaunch(ge.exec, s));
+    return 0;
 }
 
 extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32_t S, float* x, const float* mask,
@@ -998,35 +1096,71 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<float> tg;
     linspace01(S + 1, &tg);   // integrators.py:88  th.linspace(t0, t1, num_steps)
     if (!use_graph || c->prof_on) return euler_body(r, tg, x);
-    if (!stream) return fail(-8, "use_graph requires a non-default stream");
-    std::vector<uint64_t> key = {(uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
+    std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r)};
-    for (auto& g : c->graphs)
-        if (g.key == key) {
-            HIPCHK(hipGraphLaunch(g.exec, r.s));
-            return 0;
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)c->opt_residue_l4};
+    return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
+}
+
+// Multi-block rollout (sim_inference.py:61-98, 110-113) as ONE call / ONE hipGraph: per block
+//   conditioning frame (B, L) expanded over T -> prep_batch latents (wrapper.py:298-342)
+//   -> S Euler steps from the block's noise (wrapper.py:439-447) -> atom14 (wrapper.py:456-478)
+//   -> last frame -> next block's conditioning frame (sim_inference.py:91-96),
+// nothing returning to the host in between.
+extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int32_t S, int32_t n_blocks, float* zs,
+                                       const float* mask, float* cond_rots, float* cond_trans, float* cond_torsions,
+                                       const int64_t* seqres, float* x_cond, int64_t* x_cond_mask,
+                                       const mdgen_residue_tables* tb, float* atom14, void* ws, size_t ws_bytes,
+                                       int32_t use_graph, void* stream) {
+    if (!zs || !mask || !cond_rots || !cond_trans || !cond_torsions || !seqres || !x_cond || !x_cond_mask || !tb || !atom14)
+        return fail(-1, "null tensor argument");
+    if (!tb->default_frames || !tb->lit_positions || !tb->atom14_group || !tb->atom14_mask || !tb->atom37_to_atom14 ||
+        !tb->atom37_mask || !tb->chi_atom_indices || !tb->chi_angles_mask)
+        return fail(-1, "null residue table");
+    if (n_blocks < 1) return fail(-2, "n_blocks must be >= 1");
+    if (c && c->d.tps_condition) return fail(-2, "the block rollout is defined for forward-simulation models (sim_condition)");
+    Run r{};
+    if (int e = make_run(&r, c, sh, S, 1, ws, ws_bytes, stream)) return e;
+    if ((long)n_blocks * sh->T > 2000000000L / ((long)sh->L * 42)) return fail(-2, "trajectory too long for one call");
+    r.mask = mask;
+    r.start_rot = cond_rots;
+    r.start_trans = cond_trans;
+    r.end_rot = nullptr;
+    r.end_trans = nullptr;
+    r.x_cond = x_cond;
+    r.x_cond_mask = x_cond_mask;
+    r.aatype = seqres;
+    std::vector<float> tg;
+    linspace01(S + 1, &tg);
+    const mdgen_residue_tables t = *tb;
+    const long blk = (long)sh->B * sh->T * sh->L * r.D;
+    float* tmask_scratch = (float*)(r.ws + r.lay.rel7);   // (B, L, 7) fp32: fits the (unused, non-TPS) 2 x (B, L, 7) slot
+    auto body = [&]() -> int {
+        for (int b = 0; b < n_blocks; ++b) {
+            float* x = zs + (long)b * blk;
+            launch_prep_latents(r.B, r.T, r.L, 0, 1, cond_rots, cond_trans, cond_torsions, nullptr, x_cond, x_cond_mask, r.s);
+            LAUNCHCHK();
+            if (int e = euler_body(r, tg, x)) return e;
+            launch_samples_to_atom14(r.B, r.T, r.L, r.D, 0, x, cond_rots, cond_trans, seqres, t.default_frames,
+                                     t.lit_positions, t.atom14_group, t.atom14_mask, atom14, n_blocks * r.T, b * r.T, r.s);
+            LAUNCHCHK();
+            // last frame of this block (frame b*T + T-1 of every trajectory) -> conditioning frame of the next
+            const float* last = atom14 + ((long)(b + 1) * r.T - 1) * r.L * 42;
+            launch_atom14_to_cond(r.B, r.L, last, (long)n_blocks * r.T * r.L * 42, seqres, t.atom37_to_atom14, t.atom37_mask,
+                                  t.chi_atom_indices, t.chi_angles_mask, cond_rots, cond_trans, cond_torsions,
+                                  tmask_scratch, r.s);
+            LAUNCHCHK();
         }
-    GraphEntry ge;
-    ge.key = key;
-    HIPCHK(hipStreamBeginCapture(r.s, hipStreamCaptureModeThreadLocal));
-    const int e = euler_body(r, tg, x);
-    hipError_t ce = hipStreamEndCapture(r.s, &ge.graph);
-    if (e) {
-        if (ge.graph) (void)hipGraphDestroy(ge.graph);
-        return e;
-    }
-    if (ce != hipSuccess) return fail((int)ce, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-    HIPCHK(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
-    if (c->graphs.size() >= 8) {
-        (void)hipGraphExecDestroy(c->graphs.front().exec);
-        (void)hipGraphDestroy(c->graphs.front().graph);
-        c->graphs.erase(c->graphs.begin());
-    }
-    c->graphs.push_back(ge);
-    HIPCHK(hipGraphLaunch(ge.exec, r.s));
-    return 0;
+        return 0;
+    };
+    if (!use_graph || c->prof_on) return body();
+    std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
+                                 (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
+                                 (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)c->opt_residue_l4,
+                                 (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14};
+    return replay_or_capture(c, key, r.s, body);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1129,7 +1263,7 @@ extern "C" int32_t mdgen_prep_latents(const mdgen_shape* sh, int32_t tps, const 
     if (!sh) return fail(-1, "null shape");
     NONNULL(rots, trans, torsions, latents, x_cond, x_cond_mask);
     if (sh->B < 1 || sh->T < 1 || sh->L < 1) return fail(-2, "B, T, L must be >= 1");
-    launch_prep_latents(sh->B, sh->T, sh->L, tps, rots, trans, torsions, latents, x_cond, x_cond_mask,
+    launch_prep_latents(sh->B, sh->T, sh->L, tps, 0, rots, trans, torsions, latents, x_cond, x_cond_mask,
                         (hipStream_t)stream);
     LAUNCHCHK();
     return 0;
@@ -1144,7 +1278,7 @@ extern "C" int32_t mdgen_samples_to_atom14(const mdgen_shape* sh, int32_t D, int
     if (sh->B < 1 || sh->T < 1 || sh->L < 1) return fail(-2, "B, T, L must be >= 1");
     if (D < (tps ? 28 : 21)) return fail(-2, "latent_dim too small");
     launch_samples_to_atom14(sh->B, sh->T, sh->L, D, tps, samples, rot0, trans0, seqres, default_frames, lit_positions,
-                             atom14_group, atom14_mask, atom14, (hipStream_t)stream);
+                             atom14_group, atom14_mask, atom14, sh->T, 0, (hipStream_t)stream);
     LAUNCHCHK();
     return 0;
 }
@@ -1154,7 +1288,7 @@ extern "C" int32_t mdgen_atom14_to_cond(int32_t B, int32_t L, const float* atom1
                                         void* stream) {
     NONNULL(atom14, seqres, a37to14, a37mask, chi_idx, chi_mask, rots, trans, tors, tmask);
     if (B < 1 || L < 1) return fail(-2, "B, L must be >= 1");
-    launch_atom14_to_cond(B, L, atom14, seqres, a37to14, a37mask, chi_idx, chi_mask, rots, trans, tors, tmask,
+    launch_atom14_to_cond(B, L, atom14, (long)L * 42, seqres, a37to14, a37mask, chi_idx, chi_mask, rots, trans, tors, tmask,
                           (hipStream_t)stream);
     LAUNCHCHK();
     return 0;

@@ -2,7 +2,6 @@
 // fused MLP, IPA projections, final layer.  gfx950 only (MFMA 32x32x16 bf16, wave64).
 #include "kernels.h"
 #include "panel.h"
-#include <cstdlib>
 
 namespace mdg {
 
@@ -609,16 +608,6 @@ __device__ __forceinline__ void stamp(const MlpParams& p, int slot, unsigned lon
 __device__ __forceinline__ void stamp(const MlpParams& p, int slot) {
     if (p.trace) stamp(p, slot, __builtin_amdgcn_s_memtime());
 }
-// k_mlp_ws: [workgroup][8 waves][32]; the SECOND panel of each workgroup is recorded (steady state):
-// slot 0 panel start; per chunk c: 1+4c, 2+4c, 3+4c, 4+4c = A: after fc1, after GELU, after X, after Y(+hbuf write);
-// B: after slot work, after X, after Y, after fc2; slot 25 = panel end.
-__device__ __forceinline__ void stamp8(const MlpParams& p, bool on, int slot) {
-    if (p.trace && on && lane_id() == 0) {
-        const long i = ((long)blockIdx.x * 8 + wave_id()) * 32 + slot;
-        if (i < p.trace_cap) p.trace[i] = __builtin_amdgcn_s_memtime();
-    }
-}
-
 // PF1 / PF2: weight prefetch depth (k-steps) of the fc1 / fc2 streams.  fc1 runs with y (96) + a1 (64)
 // accumulator registers live, fc2 with y only, so fc2 can afford the deeper ring.
 template <int PF1, int PF2>
@@ -691,157 +680,6 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
     epilogue_gate_residual_lds<3>(y, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.b2, p.mm, p.gate_chunk,
                                   true, p.h);
     stamp(p, 27);
-}
-
-// -------------------------------------------------------------------------------------------------
-// Warp-specialised, persistent form of the same block (the one the trunk uses).
-//
-// Why: in k_mlp above every wave runs LN prologue -> [fc1 -> GELU -> fc2] x 6 -> residual epilogue, and the
-// two workgroups that share a CU run those phases in lockstep (they are dispatched together), so the MFMA pipe
-// idles through every prologue (HBM burst), GELU (VALU) and epilogue (HBM burst): phase stamps
-// (mdgen_profile_phase_trace) showed the two GEMM phases at ~90 % of what two waves sharing a SIMD can get, yet
-// only 37 % of a workgroup's lifetime.
-//
-// Here one 8-wave workgroup per CU walks over panels.  Waves 0-3 ("A", one per SIMD) do fc1 + GELU of chunk c+1
-// while waves 4-7 ("B", the other wave of each SIMD) do fc2 of chunk c -- B's MFMAs run under A's GELU VALU --
-// and B's idle slots carry all the HBM work: the residual epilogue of the PREVIOUS panel and the LN prologue of
-// the NEXT one (double-buffered panel), so no phase of one panel ever has the matrix pipe to itself.
-//   per chunk c:   A: fc1(c), GELU -> regs | barrier X | A: regs -> hbuf | barrier Y | B: fc2(c) from hbuf
-//   X(c) also tells A that B has finished reading hbuf for chunk c-1 (B arrives at X only after its fc2(c-1)).
-// B's slot work (executed before it arrives at X(c)):  c=0,1: epilogue halves of the previous panel;
-// c=1: row table of the next panel; c=2,3: LN prologue halves of the next panel (into the other panel buffer).
-// -------------------------------------------------------------------------------------------------
-template <int PF1, int PF2, int STAG>
-__global__ __launch_bounds__(512, 1) void k_mlp_ws(const MlpParams p) {
-    constexpr int HC = 256, HROWB = HC * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kPanelBytes + kPanel * HROWB + 2 * sizeof(PanelRows)];
-    unsigned char* hbuf = smem + 2 * kPanelBytes;
-    PanelRows* rows = reinterpret_cast<PanelRows*>(hbuf + kPanel * HROWB);
-    const int w = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform, and the compiler knows it
-    const int lane = lane_id(), hh = lane >> 5, tk = lane & 31;
-    const bool roleA = w < 4;
-    const int rw = w & 3;                       // index of this wave within its role
-    const int btid = (int)threadIdx.x - 256;    // thread index among the B threads (negative for A)
-    const long npanels = (p.nrows + kPanel - 1) / kPanel;
-    auto panel_buf = [&](int k) { return smem + (k & 1) * kPanelBytes; };
-
-    // ---- preamble: first panel's row table and LN prologue (B); everyone waits
-    long pcur = blockIdx.x;
-    if (!roleA) setup_rows_linear(&rows[0], pcur * kPanel, p.nrows, p.mm, btid);
-    __syncthreads();
-    if (!roleA) prologue_ln<false>(panel_buf(0), &rows[0], p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, rw);
-    __syncthreads();
-
-    // The two roles are two separate loops with the SAME barrier sequence (two per chunk): kept in one loop the
-    // compiler has to keep A's and B's long-lived registers (a1 + GELU results, y) allocated together.
-    const long stride = gridDim.x;
-    if (roleA) {
-        int k = 0;
-        for (; pcur < npanels; pcur += stride, ++k) {
-            const unsigned char* panel = panel_buf(k);
-            const bool tr = k == 1;
-            stamp8(p, tr, 0);
-#pragma unroll 1
-            for (int c = 0; c < kF / HC; ++c) {
-                u32x2 g[2][4][2];
-                f32x16 a1[4];
-                zero_acc<4>(a1);
-                if (STAG == 2) __builtin_amdgcn_s_setprio(2);   // A's fc1 MFMAs first, so that A reaches its GELU early
-                wave_gemm<2, 2, 24, true, PF1>(panel, kRowB, 0, 0, p.w1 + (size_t)(8 * c + 2 * rw) * 24 * 64 + lane, 24 * 64, a1);
-                if (STAG == 2) __builtin_amdgcn_s_setprio(0);
-                stamp8(p, tr, 1 + 4 * c);
-#pragma unroll
-                for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const int hid_local = 64 * rw + 32 * ft + 8 * a + 4 * hh;
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b1 + c * HC + hid_local);
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) {
-                            float v[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = gelu_erf(a1[ft * 2 + tt][4 * a + i] + b[i]);
-                            g[ft][a][tt] = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                        }
-                    }
-                // pin the GELU results BEFORE the barrier: left alone, hipcc sinks the whole GELU computation below
-                // it (into the window where B is waiting for hbuf) instead of overlapping it with B's fc2
-#pragma unroll
-                for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) asm volatile("" : "+v"(g[ft][a][tt][0]), "+v"(g[ft][a][tt][1]));
-                stamp8(p, tr, 2 + 4 * c);
-                lds_barrier();   // X(c): B has left hbuf (its fc2(c-1) is done)
-                stamp8(p, tr, 3 + 4 * c);
-#pragma unroll
-                for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) {
-                            const int hid_local = 64 * rw + 32 * ft + 8 * a + 4 * hh;
-                            *reinterpret_cast<u32x2*>(hbuf + panel_off(tt * 32 + tk, hid_local * 2, HROWB)) = g[ft][a][tt];
-                        }
-                lds_barrier();   // Y(c): hbuf holds chunk c
-                stamp8(p, tr, 4 + 4 * c);
-            }
-            stamp8(p, tr, 25);
-        }
-        return;
-    }
-    // ---- role B.  The chunk loop is unrolled so that each slot's work is straight-line code.
-    f32x16 y[6];   // fc2 accumulators of the current panel
-    zero_acc<6>(y);
-    int k = 0;
-    for (; pcur < npanels; pcur += stride, ++k) {
-        const long pnext = pcur + stride;
-        const bool has_next = pnext < npanels, has_prev = k > 0;
-        // previous panel (k-1): row table rows[(k-1)&1] == rows[(k+1)&1], replaced by the next panel's at c = 1;
-        // its panel buffer is the next panel's
-        PanelRows* orow = &rows[(k + 1) & 1];
-        unsigned char* obuf = panel_buf(k + 1);
-        const bool tr = k == 1;
-        stamp8(p, tr, 0);
-#pragma unroll
-        for (int c = 0; c < kF / HC; ++c) {
-            // ---- slot work for this chunk (runs while A computes fc1 + GELU of chunk c).
-            // `sl` = the lane id behind an opaque asm: everything a slot derives from it (swizzled LDS
-            // addresses, column offsets ...) is recomputed in the slot.  Derived from the plain lane id it is
-            // loop-invariant, gets hoisted out of the panel loop, spilled, and every reload sits behind an
-            // s_waitcnt vmcnt(0) that drains the loads in flight.
-            int sl = lane, sw = rw;
-            asm volatile("" : "+v"(sl), "+s"(sw));
-            if (c == 0 && has_prev) {          // previous panel's residual update, then y restarts from zero
-                epilogue_gate_residual_direct(y, orow, 96 * sw, p.b2, p.mm, p.gate_chunk, p.h, sl);
-                zero_acc<6>(y);
-            } else if (c == 1 && has_next) {   // next panel: row table
-                setup_rows_linear(orow, pnext * kPanel, p.nrows, p.mm, btid);
-            } else if (c == 2 && has_next) {   // next panel: LN prologue into the other panel buffer
-                prologue_ln_impl<false, 0, 2, false>(obuf, orow, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, sw, sl, 0);
-            } else if (c == 3 && has_next) {
-                prologue_ln_impl<false, 2, 4, false>(obuf, orow, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, sw, sl, 0);
-            }
-            stamp8(p, tr, 1 + 4 * c);
-            lds_barrier();   // X(c)
-            stamp8(p, tr, 2 + 4 * c);
-            lds_barrier();   // Y(c)
-            stamp8(p, tr, 3 + 4 * c);
-            // uniform base + 32-bit byte offset, laundered so that the six chunks' address arithmetic stays inside
-            // its chunk (else it is hoisted out of the panel loop and spilled)
-            unsigned w2off = (unsigned)((((3 * rw) * 96 + 16 * c) * 64 + lane) * 16);
-            asm volatile("" : "+v"(w2off));
-            const bf16x8* w2c = reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(p.w2) + w2off);
-            if (STAG == 1) __builtin_amdgcn_s_setprio(2);   // B's MFMAs first; A's GELU VALU fills the gaps
-            wave_gemm<2, 3, 16, false, PF2>(hbuf, HROWB, 0, 0, w2c, 96 * 64, y);
-            if (STAG == 1) __builtin_amdgcn_s_setprio(0);
-            stamp8(p, tr, 4 + 4 * c);
-        }
-        stamp8(p, tr, 25);
-    }
-    // ---- the last panel's residual update (row table rows[(k-1)&1])
-    if (k > 0) epilogue_gate_residual_direct(y, &rows[(k - 1) & 1], 96 * rw, p.b2, p.mm, p.gate_chunk, p.h);
 }
 
 // =================================================================================================
@@ -943,20 +781,7 @@ void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
 }
 void launch_mlp(const MlpParams& p, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-    static const int variant = getenv("MDGEN_MLP_VARIANT") ? atoi(getenv("MDGEN_MLP_VARIANT")) : 0;   // tuning knob
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-            ncu = 256;
-    }
-    const int pgrid = grid < ncu ? grid : ncu;   // persistent: one 8-wave workgroup per CU walks over panels
-    // default: the classic two-workgroups-per-CU kernel.  MDGEN_MLP_VARIANT=2 selects the warp-specialised
-    // persistent kernel (faster in isolation, 215 vs 230 us at cfg-2, but it owns whole CUs and loses more than
-    // that when two sub-batches run on concurrent streams -- DESIGN.md section 5).
-    if (variant == 2) hipLaunchKernelGGL((k_mlp_ws<3, 5, 0>), dim3(pgrid), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((k_mlp<2, 2>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((k_mlp<2, 2>), dim3(grid), dim3(256), 0, s, p);
 }
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);

@@ -263,8 +263,10 @@ __global__ void k_rel7(const float* r1, const float* t1, const float* r2, const 
 }
 
 // NewMDGenWrapper.prep_batch latents (wrapper.py:298-327,339-342,362) + get_offsets (utils.py:7-14)
-__global__ void k_prep_latents(int B, int T, int L, int tps, const float* rots, const float* trans, const float* tors,
-                               float* latents, float* x_cond, int64_t* x_cond_mask) {
+// BCAST: rots / trans / tors hold ONE frame per (b, l) that stands for every t (the rollout's conditioning frame
+// expanded over T, sim_inference.py:72-79) -- same arithmetic on the same values, without materialising the copies.
+__global__ void k_prep_latents(int B, int T, int L, int tps, int bcast, const float* rots, const float* trans,
+                               const float* tors, float* latents, float* x_cond, int64_t* x_cond_mask) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long N = (long)B * T * L;
     if (i >= N) return;
@@ -272,14 +274,15 @@ __global__ void k_prep_latents(int B, int T, int L, int tps, const float* rots, 
     const int t = (int)((i / L) % T);
     const int b = (int)(i / ((long)L * T));
     const int D = tps ? 28 : 21;
+    const long src = bcast ? (long)b * L + l : i;
     float R[9], tt[3];
-    load_rot(rots + i * 9, R);
+    load_rot(rots + src * 9, R);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) tt[k] = trans[i * 3 + k];
+    for (int k = 0; k < 3; ++k) tt[k] = trans[src * 3 + k];
     float lat[28];
     const int nref = tps ? 2 : 1;
     for (int ref = 0; ref < nref; ++ref) {
-        const long j = ((long)b * T + (ref == 0 ? 0 : T - 1)) * L + l;
+        const long j = bcast ? src : ((long)b * T + (ref == 0 ? 0 : T - 1)) * L + l;
         float R0[9], t0[3];
         load_rot(rots + j * 9, R0);
 #pragma unroll
@@ -301,10 +304,10 @@ __global__ void k_prep_latents(int B, int T, int L, int tps, const float* rots, 
     }
     const int toff = tps ? 14 : 7;
 #pragma unroll
-    for (int k = 0; k < 14; ++k) lat[toff + k] = tors[i * 14 + k];
+    for (int k = 0; k < 14; ++k) lat[toff + k] = tors[src * 14 + k];
     const bool cond = (t == 0) || (tps && t == T - 1);
     for (int k = 0; k < D; ++k) {
-        latents[i * D + k] = lat[k];
+        if (latents) latents[i * D + k] = lat[k];
         x_cond[i * D + k] = cond ? lat[k] : 0.f;
     }
     x_cond_mask[i] = cond ? 1 : 0;
@@ -314,12 +317,14 @@ __global__ void k_prep_latents(int B, int T, int L, int tps, const float* rots, 
 __global__ void k_samples_to_atom14(int B, int T, int L, int D, int tps, const float* samples, const float* rot0,
                                     const float* trans0, const int64_t* seqres, const float* default_frames,
                                     const float* lit_positions, const int64_t* atom14_group, const float* atom14_mask,
-                                    float* atom14) {
+                                    float* atom14, int out_T, int out_t0) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long N = (long)B * T * L;
     if (i >= N) return;
     const int l = (int)(i % L);
     const int b = (int)(i / ((long)L * T));
+    // output row: frame out_t0 + t of a trajectory of out_T frames (out_T == T, out_t0 == 0: the block itself)
+    const long io = ((long)b * out_T + out_t0 + (int)((i / L) % T)) * L + l;
     const float* s = samples + i * D;
     // frames = rigids[:,0:1] o from_tensor_7(offsets, normalize_quats=True)
     Rig off, f0;
@@ -377,7 +382,7 @@ __global__ void k_samples_to_atom14(int B, int T, int L, int D, int tps, const f
         float o[3];
         matvec3(fr.r, lp, o);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) atom14[(i * 14 + a) * 3 + k] = (o[k] + fr.t[k]) * m;
+        for (int k = 0; k < 3; ++k) atom14[(io * 14 + a) * 3 + k] = (o[k] + fr.t[k]) * m;
     }
 }
 
@@ -391,13 +396,15 @@ __device__ __forceinline__ void atom37_pos(const float* a14, const int64_t* a37t
     for (int k = 0; k < 3; ++k) o[k] = a14[s * 3 + k] * m;
 }
 
-__global__ void k_atom14_to_cond(int B, int L, const float* atom14, const int64_t* seqres, const int64_t* a37to14,
-                                 const float* a37mask, const int64_t* chi_idx, const float* chi_mask, float* rots,
-                                 float* trans, float* tors, float* tmask) {
+// in_bstride: floats between consecutive batch elements of `atom14` (L * 42 when it is a plain (B, L, 14, 3) array;
+// larger when the frame is picked out of a (B, frames, L, 14, 3) trajectory)
+__global__ void k_atom14_to_cond(int B, int L, const float* atom14, long in_bstride, const int64_t* seqres,
+                                 const int64_t* a37to14, const float* a37mask, const int64_t* chi_idx,
+                                 const float* chi_mask, float* rots, float* trans, float* tors, float* tmask) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * L) return;
     const int l = (int)(i % L);
-    const float* a14 = atom14 + i * 42;
+    const float* a14 = atom14 + (i / L) * in_bstride + (long)l * 42;
     const int aa = (int)seqres[i];
     {   // backbone frame: from_3_points(C, CA, N) right-composed with diag(-1, 1, -1)
         const Rig f = from3(a14 + 6, a14 + 3, a14 + 0);
@@ -484,25 +491,25 @@ void launch_rot_to_quat(long n, const float* rot, float* q, hipStream_t s) {
 void launch_rel7(const float* r1, const float* t1, const float* r2, const float* t2, float* out7, long n, hipStream_t s) {
     hipLaunchKernelGGL(k_rel7, GRID1D(n), r1, t1, r2, t2, out7, n);
 }
-void launch_prep_latents(int B, int T, int L, int tps, const float* rots, const float* trans, const float* tors,
-                         float* latents, float* x_cond, int64_t* x_cond_mask, hipStream_t s) {
+void launch_prep_latents(int B, int T, int L, int tps, int bcast, const float* rots, const float* trans,
+                         const float* tors, float* latents, float* x_cond, int64_t* x_cond_mask, hipStream_t s) {
     const long n = (long)B * T * L;
-    hipLaunchKernelGGL(k_prep_latents, GRID1D(n), B, T, L, tps, rots, trans, tors, latents, x_cond, x_cond_mask);
+    hipLaunchKernelGGL(k_prep_latents, GRID1D(n), B, T, L, tps, bcast, rots, trans, tors, latents, x_cond, x_cond_mask);
 }
 void launch_samples_to_atom14(int B, int T, int L, int D, int tps, const float* samples, const float* rot0,
                               const float* trans0, const int64_t* seqres, const float* default_frames,
                               const float* lit_positions, const int64_t* atom14_group, const float* atom14_mask,
-                              float* atom14, hipStream_t s) {
+                              float* atom14, int out_T, int out_t0, hipStream_t s) {
     const long n = (long)B * T * L;
     hipLaunchKernelGGL(k_samples_to_atom14, GRID1D(n), B, T, L, D, tps, samples, rot0, trans0, seqres, default_frames,
-                       lit_positions, atom14_group, atom14_mask, atom14);
+                       lit_positions, atom14_group, atom14_mask, atom14, out_T, out_t0);
 }
-void launch_atom14_to_cond(int B, int L, const float* atom14, const int64_t* seqres, const int64_t* a37to14,
-                           const float* a37mask, const int64_t* chi_idx, const float* chi_mask, float* rots,
-                           float* trans, float* tors, float* tmask, hipStream_t s) {
+void launch_atom14_to_cond(int B, int L, const float* atom14, long in_bstride, const int64_t* seqres,
+                           const int64_t* a37to14, const float* a37mask, const int64_t* chi_idx, const float* chi_mask,
+                           float* rots, float* trans, float* tors, float* tmask, hipStream_t s) {
     const long n = (long)B * L;
-    hipLaunchKernelGGL(k_atom14_to_cond, GRID1D(n), B, L, atom14, seqres, a37to14, a37mask, chi_idx, chi_mask, rots,
-                       trans, tors, tmask);
+    hipLaunchKernelGGL(k_atom14_to_cond, GRID1D(n), B, L, atom14, in_bstride, seqres, a37to14, a37mask, chi_idx,
+                       chi_mask, rots, trans, tors, tmask);
 }
 
 }  // namespace mdg

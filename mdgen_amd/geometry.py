@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from ._lib import lib, check, ptr, require_cuda
+from ._lib import lib, launch, ptr, require_cuda
 
 _TABLES = {}
 _NPZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "residue_tables.npz")
@@ -41,9 +41,8 @@ def samples_to_atom14(samples, rot0, trans0, seqres, tps: bool):
     sq = seqres.to(torch.int64).contiguous()
     out = torch.empty(B, T, L_, 14, 3, dtype=torch.float32, device=s.device)
     sh = L.Shape(B, T, L_)
-    check(lib.mdgen_samples_to_atom14(C.byref(sh), D, int(tps), ptr(s), ptr(r0), ptr(t0), ptr(sq),
-                                      ptr(tb["default_frames"]), ptr(tb["lit_positions"]), ptr(tb["atom14_group"]),
-                                      ptr(tb["atom14_mask"]), ptr(out), L.stream_ptr()))
+    launch(lib.mdgen_samples_to_atom14, s, C.byref(sh), D, int(tps), ptr(s), ptr(r0), ptr(t0), ptr(sq),
+           ptr(tb["default_frames"]), ptr(tb["lit_positions"]), ptr(tb["atom14_group"]), ptr(tb["atom14_mask"]), ptr(out))
     return out
 
 
@@ -61,9 +60,8 @@ def atom14_to_cond(atom14, seqres):
     trans = torch.empty(B, L_, 3, device=dev)
     tors = torch.empty(B, L_, 7, 2, device=dev)
     tmask = torch.empty(B, L_, 7, device=dev)
-    check(lib.mdgen_atom14_to_cond(B, L_, ptr(a), ptr(sq), ptr(tb["atom37_to_atom14"]), ptr(tb["atom37_mask"]),
-                                   ptr(tb["chi_atom_indices"]), ptr(tb["chi_angles_mask"]), ptr(rots), ptr(trans),
-                                   ptr(tors), ptr(tmask), L.stream_ptr()))
+    launch(lib.mdgen_atom14_to_cond, a, B, L_, ptr(a), ptr(sq), ptr(tb["atom37_to_atom14"]), ptr(tb["atom37_mask"]),
+           ptr(tb["chi_atom_indices"]), ptr(tb["chi_angles_mask"]), ptr(rots), ptr(trans), ptr(tors), ptr(tmask))
     return {"rots": rots, "trans": trans, "torsions": tors, "torsion_mask": tmask}
 
 

@@ -9,7 +9,6 @@ are what make hipGraph replay possible).
 from __future__ import annotations
 
 import ctypes as C
-import os
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -46,8 +45,14 @@ class LatentMDGenModel:
         self._ctx = C.c_void_p()
         with torch.cuda.device(self.device):
             check(lib.mdgen_ctx_create(C.byref(self._ctx), C.byref(d)))
-        self._ws: Dict[tuple, torch.Tensor] = {}
-        self._stage: Dict[tuple, dict] = {}
+        # small LRU caches, keyed independently: a workspace per (B, T, L, S, t_shared) and the persistent staging
+        # buffers of the Euler rollout per (B, T, L) -- stable device pointers are what lets a captured hipGraph be
+        # replayed, so alternating shapes (ATLAS inference runs on full sequences, L = 39..724) or alternating
+        # forward() / sample_euler() calls must not evict each other's buffers on every call.
+        self._ws: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()
+        self._stage: "OrderedDict[tuple, dict]" = OrderedDict()
+        self.max_cached_shapes = 4
+        self.poison_workspace = False     # tests: fill new workspaces with 0xFF (NaN in fp32 and bf16)
         self._side = None
         self._loaded = False
 
@@ -94,6 +99,11 @@ class LatentMDGenModel:
             raise L.MdgenError("mdgen_amd has no CPU path")
         return self
 
+    def set_option(self, name: str, value: int):
+        """Library run-time options (include/mdgen_amd.h `mdgen_ctx_set_option`): "streams", "residue_l4_path"."""
+        check(lib.mdgen_ctx_set_option(self._ctx, name.encode(), int(value)))
+        return self
+
     # ---- measurement ------------------------------------------------------------------------
     def profile(self, on: bool):
         check(lib.mdgen_profile_enable(self._ctx, int(on)))
@@ -127,12 +137,14 @@ class LatentMDGenModel:
         ws = self._ws.get(key)
         if ws is None:
             lay = self.workspace_layout(B, T, L_, S, t_shared)
+            while len(self._ws) >= self.max_cached_shapes:
+                self._ws.popitem(last=False)                  # least recently used
             ws = torch.empty(lay.total_bytes, dtype=torch.uint8, device=self.device)
-            if os.environ.get("MDGEN_POISON_WORKSPACE"):      # tests: every byte 0xFF = NaN in fp32 and bf16
+            if self.poison_workspace:
                 ws.fill_(255)
-            self._ws.clear()           # one live workspace (they are large)
-            self._stage.clear()
             self._ws[key] = ws
+        else:
+            self._ws.move_to_end(key)
         return ws
 
     # ---- forward ----------------------------------------------------------------------------
@@ -195,9 +207,13 @@ class LatentMDGenModel:
         if sr is None:
             raise L.MdgenError("start_frames is required")
         ws = self._workspace(B, T, L_, S, True)
-        key = (B, T, L_, S)
+        key = (B, T, L_)
         stg = self._stage.get(key)
-        if stg is None:   # persistent staging buffers: stable device pointers => hipGraph replay
+        if stg is not None:
+            self._stage.move_to_end(key)
+        else:   # persistent staging buffers: stable device pointers => hipGraph replay
+            while len(self._stage) >= self.max_cached_shapes:
+                self._stage.popitem(last=False)
             dev = self.device
             stg = dict(
                 x=torch.empty(B, T, L_, self.cfg.latent_dim, device=dev), mask=torch.empty(B, T, L_, device=dev),
@@ -236,3 +252,59 @@ class LatentMDGenModel:
             if use_graph:
                 cur.wait_stream(self._side)
         return stg["x"].clone()
+
+    # ---- multi-block rollout -----------------------------------------------------------------
+    def rollout_euler(self, zs, num_steps: int, mask, cond_rots, cond_trans, cond_torsions, seqres, tables,
+                      use_graph: bool = True):
+        """`mdgen_rollout_euler`: R = zs.shape[0] chained T-frame blocks in one call (one hipGraph), the driver loop
+        of sim_inference.py:100-113.  zs (R,B,T,L,D) noise; mask (B,T,L); cond_* the first conditioning frame
+        (B,L,...); seqres (B,L) int64; tables: dict of residue tables on the device (geometry.residue_tables).
+        Returns (atom14 (B, R*T, L, 14, 3), samples (R,B,T,L,D), next conditioning frame dict)."""
+        if zs.dim() != 5 or zs.shape[-1] != self.cfg.latent_dim:
+            raise L.MdgenError(f"zs must be (R,B,T,L,{self.cfg.latent_dim}), got {tuple(zs.shape)}")
+        R, B, T, L_, D = zs.shape
+        require_cuda(zs, mask, cond_rots, cond_trans, cond_torsions, seqres)
+        S = int(num_steps)
+        ws = self._workspace(B, T, L_, S, True)
+        key = ("rollout", R, B, T, L_)
+        stg = self._stage.get(key)
+        if stg is not None:
+            self._stage.move_to_end(key)
+        else:
+            while len(self._stage) >= self.max_cached_shapes:
+                self._stage.popitem(last=False)
+            dev = self.device
+            stg = dict(zs=torch.empty(R, B, T, L_, D, device=dev), mask=torch.empty(B, T, L_, device=dev),
+                       rots=torch.empty(B, L_, 3, 3, device=dev), trans=torch.empty(B, L_, 3, device=dev),
+                       tors=torch.empty(B, L_, 7, 2, device=dev), seqres=torch.empty(B, L_, dtype=torch.int64, device=dev),
+                       x_cond=torch.empty(B, T, L_, D, device=dev),
+                       x_cond_mask=torch.empty(B, T, L_, dtype=torch.int64, device=dev),
+                       atom14=torch.empty(B, R * T, L_, 14, 3, device=dev))
+            self._stage[key] = stg
+        stg["zs"].copy_(zs)
+        stg["mask"].copy_(mask)
+        stg["rots"].copy_(cond_rots)
+        stg["trans"].copy_(cond_trans)
+        stg["tors"].copy_(cond_torsions)
+        stg["seqres"].copy_(seqres)
+        tb = L.ResidueTables(*[tables[n].data_ptr() for n in (
+            "default_frames", "lit_positions", "atom14_group", "atom14_mask", "atom37_to_atom14", "atom37_mask",
+            "chi_atom_indices", "chi_angles_mask")])
+        sh = L.Shape(B, T, L_)
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream()
+            if use_graph:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                self._side.wait_stream(cur)
+                stream = self._side
+            else:
+                stream = cur
+            check(lib.mdgen_rollout_euler(
+                self._ctx, C.byref(sh), S, R, ptr(stg["zs"]), ptr(stg["mask"]), ptr(stg["rots"]), ptr(stg["trans"]),
+                ptr(stg["tors"]), ptr(stg["seqres"]), ptr(stg["x_cond"]), ptr(stg["x_cond_mask"]), C.byref(tb),
+                ptr(stg["atom14"]), ptr(ws), ws.numel(), int(use_graph), C.c_void_p(stream.cuda_stream)))
+            if use_graph:
+                cur.wait_stream(self._side)
+        nxt = {"rots": stg["rots"].clone(), "trans": stg["trans"].clone(), "torsions": stg["tors"].clone()}
+        return stg["atom14"].clone(), stg["zs"].clone(), nxt

@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from ._lib import lib, check, ptr, stream_ptr, require_cuda
+from ._lib import lib, launch, ptr, require_cuda
 
 
 def _bcast(shape_a, shape_b):
@@ -86,7 +86,7 @@ class Rotation:
         q = _f32c(self._quats)
         require_cuda(q)
         out = torch.empty(q.shape[:-1] + (3, 3), dtype=torch.float32, device=q.device)
-        check(lib.mdgen_quat_to_rot(q.numel() // 4, ptr(q), int(self._normalize), ptr(out), stream_ptr()))
+        launch(lib.mdgen_quat_to_rot, q, q.numel() // 4, ptr(q), int(self._normalize), ptr(out))
         return out
 
     def get_quats(self) -> torch.Tensor:
@@ -98,7 +98,7 @@ class Rotation:
         r = _f32c(self._rot_mats)
         require_cuda(r)
         out = torch.empty(r.shape[:-2] + (4,), dtype=torch.float32, device=r.device)
-        check(lib.mdgen_rot_to_quat(r.numel() // 9, ptr(r), ptr(out), stream_ptr()))
+        launch(lib.mdgen_rot_to_quat, r, r.numel() // 9, ptr(r), ptr(out))
         return out
 
     def invert(self) -> "Rotation":
@@ -193,14 +193,14 @@ class Rigid:
         r1, t1 = self._flat(shp)
         r2, t2 = r._flat(shp)
         ro, to = torch.empty_like(r1), torch.empty_like(t1)
-        check(lib.mdgen_rigid_compose(t1.numel() // 3, ptr(r1), ptr(t1), ptr(r2), ptr(t2), ptr(ro), ptr(to), stream_ptr()))
+        launch(lib.mdgen_rigid_compose, t1, t1.numel() // 3, ptr(r1), ptr(t1), ptr(r2), ptr(t2), ptr(ro), ptr(to))
         return Rigid(Rotation(rot_mats=ro), to)
 
     def invert(self) -> "Rigid":
         """rigid_utils.py:1075-1085."""
         r1, t1 = self._flat(self.shape)
         ro, to = torch.empty_like(r1), torch.empty_like(t1)
-        check(lib.mdgen_rigid_invert(t1.numel() // 3, ptr(r1), ptr(t1), ptr(ro), ptr(to), stream_ptr()))
+        launch(lib.mdgen_rigid_invert, t1, t1.numel() // 3, ptr(r1), ptr(t1), ptr(ro), ptr(to))
         return Rigid(Rotation(rot_mats=ro), to)
 
     def _apply(self, pts, inverse):
@@ -209,7 +209,7 @@ class Rigid:
         p = _f32c(pts.expand(tuple(shp) + (3,)))
         require_cuda(p)
         out = torch.empty_like(p)
-        check(lib.mdgen_rigid_apply(p.numel() // 3, 1, ptr(r1), ptr(t1), ptr(p), ptr(out), int(inverse), stream_ptr()))
+        launch(lib.mdgen_rigid_apply, p, p.numel() // 3, 1, ptr(r1), ptr(t1), ptr(p), ptr(out), int(inverse))
         return out
 
     def apply(self, pts: torch.Tensor) -> torch.Tensor:
@@ -241,7 +241,7 @@ class Rigid:
         require_cuda(a, o, b)
         rot = torch.empty(o.shape[:-1] + (3, 3), dtype=torch.float32, device=o.device)
         trans = torch.empty_like(o)
-        check(lib.mdgen_from_3_points(o.numel() // 3, ptr(a), ptr(o), ptr(b), ptr(rot), ptr(trans), stream_ptr()))
+        launch(lib.mdgen_from_3_points, o, o.numel() // 3, ptr(a), ptr(o), ptr(b), ptr(rot), ptr(trans))
         return Rigid(Rotation(rot_mats=rot), trans)
 
     def map_tensor_fn(self, fn) -> "Rigid":

@@ -26,6 +26,8 @@ def max_over_ranks(seconds: float, dist=None, device=None) -> float:
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return float(seconds)
     import torch
+    if device is None and dist.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -35,6 +37,8 @@ def sum_over_ranks(value: float, dist=None, device=None) -> float:
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
     import torch
+    if device is None and dist.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())

@@ -135,3 +135,53 @@ def synth_state_dict(cfg: ModelConfig, seed: int = 0) -> "OrderedDict[str, torch
         assert tuple(t.shape) == tuple(shp), (name, t.shape, shp)
         out[name] = t.contiguous()
     return out
+
+
+def _quat_to_rot_cpu(q: torch.Tensor) -> torch.Tensor:
+    """Hamilton (w, x, y, z) unit quaternion -> rotation matrix (plain torch; input data only)."""
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(*q.shape[:-1], 3, 3)
+
+
+def synth_forward_inputs(cfg: ModelConfig, B: int, T: int, L: int, n_pad: int, data_seed: int) -> dict:
+    """Seeded CPU inputs of one `LatentMDGenModel.forward` call at any size (fixtures of full-size
+    configurations store only the seed, an input checksum and sub-sampled outputs): x, per-sample t, mask with
+    the last `n_pad` residues of every sample padded (dataset.py:80-89: aatype 0, identity frames), start/end
+    frames, conditioning latents on frame 0 (and -1 for two-sided models), aatype."""
+    g = torch.Generator().manual_seed(data_seed)
+    D = cfg.latent_dim
+    x = torch.randn(B, T, L, D, generator=g)
+    t = torch.rand(B, generator=g)
+    mask = torch.ones(B, L)
+    aatype = torch.randint(0, 20, (B, L), generator=g)
+
+    def rot():
+        q = torch.randn(B, L, 4, generator=g)
+        return _quat_to_rot_cpu(q / q.norm(dim=-1, keepdim=True))
+
+    sR, eR = rot(), rot()
+    st = torch.cumsum(2.2 * torch.randn(B, L, 3, generator=g), 1)
+    et = st + torch.randn(B, L, 3, generator=g)
+    if n_pad:
+        mask[:, L - n_pad:] = 0
+        aatype[:, L - n_pad:] = 0
+        for R_, t_ in ((sR, st), (eR, et)):
+            R_[:, L - n_pad:] = torch.eye(3)
+            t_[:, L - n_pad:] = 0
+    cm = torch.zeros(B, T, L, dtype=torch.long)
+    cm[:, 0] = 1
+    if cfg.tps_condition:
+        cm[:, -1] = 1
+    lat = torch.randn(B, T, L, D, generator=g)
+    x_cond = torch.where(cm.unsqueeze(-1).bool(), lat, torch.zeros(()))
+    return dict(x=x, t=t, mask=mask[:, None].expand(B, T, L).contiguous(), start_rot=sR, start_trans=st,
+                end_rot=eR, end_trans=et, x_cond=x_cond, x_cond_mask=cm, aatype=aatype)
+
+
+def tensor_checksum(d: dict) -> np.ndarray:
+    """[sum, sum of |.|] over all tensors of a dict in float64: detects drift of a seeded generator."""
+    return np.array([sum(float(v.double().sum()) for v in d.values()),
+                     sum(float(v.double().abs().sum()) for v in d.values())])

@@ -44,3 +44,79 @@ def get_sample(start_arr, end_arr, seqres_str: str, num_frames: int, device="cud
 def collate(samples):
     """Stack `get_sample` dicts along the batch dimension (the reference uses a DataLoader for this, :127)."""
     return {k: torch.cat([s[k] for s in samples], 0) for k in samples[0]}
+
+
+def build_parser():
+    """Arguments of the reference's driver (tps_inference.py:6-18) minus the MSM analysis inputs (`--mddir`), plus
+    the two MD frame indices the MSM would have chosen, `--num_steps` and `--synthetic`."""
+    import argparse
+    p = argparse.ArgumentParser()
+    p.add_argument("--sim_ckpt", type=str, default=None)
+    p.add_argument("--data_dir", type=str, default="share/4AA_data")
+    p.add_argument("--suffix", type=str, default="")
+    p.add_argument("--pdb_id", nargs="*", default=[])
+    p.add_argument("--num_frames", type=int, default=1000)
+    p.add_argument("--num_batches", type=int, default=100)
+    p.add_argument("--batch_size", type=int, default=10)
+    p.add_argument("--out_dir", type=str, default=".")
+    p.add_argument("--split", type=str, default="splits/4AA_test.csv")
+    p.add_argument("--chunk_idx", type=int, default=0)
+    p.add_argument("--n_chunks", type=int, default=1)
+    p.add_argument("--start_frame", type=int, default=0, help="MD frame of {name}.npy used as the start state")
+    p.add_argument("--end_frame", type=int, default=-1, help="MD frame of {name}.npy used as the end state")
+    p.add_argument("--num_steps", type=int, default=None)
+    p.add_argument("--synthetic", action="store_true")
+    return p
+
+
+def run(args, model, device, names_seqres, rank=0, world=1):
+    """tps_inference.py:118-168 (`do` + `main`): for every peptide of this process's chunk / rank shard,
+    `num_batches` batches of `batch_size` transition paths between the two end states -> `{name}_{idx}.pdb`."""
+    import os
+    from .geometry import restype_order
+    from .pdb import atom14_to_pdb
+    from .sim_inference import select_names
+    names = select_names(list(names_seqres), args.pdb_id, args.chunk_idx, args.n_chunks, rank, world)
+    os.makedirs(args.out_dir, exist_ok=True)
+    done = []
+    for name in names:
+        arr = np.lib.format.open_memmap(f"{args.data_dir}/{name}{args.suffix}.npy", "r")
+        seq = names_seqres[name]
+        one = get_sample(arr[args.start_frame], arr[args.end_frame], seq, args.num_frames, device)
+        batch = collate([one] * args.batch_size)
+        aat = np.array([restype_order[c] for c in seq])
+        for i in range(args.num_batches):
+            atom14s, _ = model.inference(batch, num_steps=args.num_steps)
+            host = atom14s.cpu().numpy()
+            for j in range(args.batch_size):
+                idx = i * args.batch_size + j
+                atom14_to_pdb(host[j], aat, os.path.join(args.out_dir, f"{name}_{idx}.pdb"))
+        done.append(name)
+    return {"names": done, "paths": len(done) * args.num_batches * args.batch_size}
+
+
+def main(argv=None):
+    import pandas as pd
+    from .config import ModelConfig
+    from .sim_inference import dist_env
+    from .synthetic import synth_state_dict
+    from .wrapper import NewMDGenWrapper
+    args = build_parser().parse_args(argv)
+    rank, world, local_rank = dist_env()
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if args.synthetic:
+        cfg = ModelConfig.tps(num_frames=args.num_frames)
+        model = NewMDGenWrapper(cfg, device=device)
+        model.model.load_state_dict(synth_state_dict(cfg, 0))
+    else:
+        if not args.sim_ckpt:
+            raise SystemExit("--sim_ckpt is required (or --synthetic)")
+        model = NewMDGenWrapper.load_from_checkpoint(args.sim_ckpt, device=device)
+    df = pd.read_csv(args.split, index_col="name")
+    return run(args, model, device, {str(n): df.seqres[n] for n in df.index}, rank, world)
+
+
+if __name__ == "__main__":
+    with torch.no_grad():
+        main()

@@ -35,23 +35,22 @@ class Transport:
     def plan(self, t, x0, x1):
         """path.py:131-135 `plan`: (t, xt, ut) with xt = alpha x1 + sigma x0, ut = alpha' x1 + sigma' x0, computed by
         `mdgen_path_plan` (GVP: alpha = sin(pi t / 2), sigma = cos(pi t / 2); Linear: alpha = t, sigma = 1 - t)."""
-        from ._lib import lib, check, ptr, require_cuda, stream_ptr
+        from ._lib import lib, launch, ptr, require_cuda
         x0 = x0.to(torch.float32).contiguous()
         x1 = x1.to(torch.float32).contiguous()
         t = t.to(torch.float32).contiguous()
         require_cuda(t, x0, x1)
         xt, ut = torch.empty_like(x1), torch.empty_like(x1)
         B = x1.shape[0]
-        with torch.cuda.device(x1.device):
-            check(lib.mdgen_path_plan(B, x1.numel() // B, 1 if self.path_type == "GVP" else 0, ptr(t), ptr(x0), ptr(x1),
-                                      ptr(xt), ptr(ut), stream_ptr()))
+        launch(lib.mdgen_path_plan, x1, B, x1.numel() // B, 1 if self.path_type == "GVP" else 0, ptr(t), ptr(x0), ptr(x1),
+               ptr(xt), ptr(ut))
         return t, xt, ut
 
     def training_losses(self, model, x1, aatype1=None, mask=None, model_kwargs=None, t=None, x0=None):
         """transport.py:138-189 for the velocity model (non-design path): returns {'t', 'pred', 'loss'} with
         loss = mean_flat((model(xt, t) - ut)^2, mask).  `t` / `x0` may be given to reproduce a reference run
         (the reference draws them inside, :126-136).  Forward only: no backward kernels exist in this build."""
-        from ._lib import lib, check, ptr, require_cuda, stream_ptr
+        from ._lib import lib, launch, ptr, require_cuda
         model_kwargs = model_kwargs or {}
         if t is None or x0 is None:
             t_, x0_, _ = self.sample(x1)
@@ -66,8 +65,7 @@ class Transport:
         require_cuda(pred, m)
         B = xt.shape[0]
         loss = torch.empty(B, device=xt.device, dtype=torch.float32)
-        with torch.cuda.device(xt.device):
-            check(lib.mdgen_masked_mse(B, xt.numel() // B, ptr(pred), ptr(ut), ptr(m), ptr(loss), stream_ptr()))
+        launch(lib.mdgen_masked_mse, xt, B, xt.numel() // B, ptr(pred), ptr(ut), ptr(m), ptr(loss))
         return {"t": t, "pred": pred, "loss": loss}
 
 
@@ -95,12 +93,14 @@ class Sampler:
         def _sample(x0, model_fn, **model_kwargs):
             from .model import LatentMDGenModel
             fn, kw = model_fn, dict(model_kwargs)
+            use_graph = kw.pop("use_graph", True)   # build-specific keyword: capture / replay the rollout as a hipGraph
+            model_kwargs = dict(kw)
             if isinstance(fn, partial):
                 kw = {**fn.keywords, **kw}
                 fn = fn.func
             owner = getattr(fn, "__self__", None)
             if isinstance(owner, LatentMDGenModel) and getattr(fn, "__name__", "") in ("forward", "forward_inference"):
-                return owner.sample_euler(x0, S, **kw)[None]
+                return owner.sample_euler(x0, S, use_graph=use_graph, **kw)[None]
             # generic drift (any callable): explicit Euler on the host side, x stays on the device
             tg = torch.linspace(0, 1, S + 1)
             x = x0

@@ -11,7 +11,7 @@ from functools import partial
 import torch
 
 from . import _lib as L
-from ._lib import lib, check, ptr, require_cuda
+from ._lib import lib, launch, ptr, require_cuda
 from .config import ModelConfig
 from .geometry import samples_to_atom14
 from .model import LatentMDGenModel
@@ -44,6 +44,12 @@ class NewMDGenWrapper:
             raise L.MdgenError(f"flags outside the accelerated sampler path: {bad}")
         if not getattr(args, "prepend_ipa", False):
             raise L.MdgenError("the accelerated path implements the prepend_ipa models (README.md:48,60)")
+        # latent_model.py:183-207 tests sim_condition first and tps_condition second, and only these two branches
+        # set up the IPA inputs; wrapper.py:339-342 marks the conditioning frames for exactly one of them.  A
+        # checkpoint with both flags or neither would silently run something else here: reject it.
+        if bool(args.sim_condition) == bool(args.tps_condition):
+            raise L.MdgenError("exactly one of sim_condition / tps_condition must be set "
+                               f"(got sim_condition={args.sim_condition}, tps_condition={args.tps_condition})")
         self.args = args
         self.cfg = ModelConfig.from_args(args)
         self.latent_dim = self.cfg.latent_dim
@@ -84,8 +90,8 @@ class NewMDGenWrapper:
         x_cond = torch.empty(B, T, L_, D, device=dev)
         cond_mask = torch.empty(B, T, L_, dtype=torch.int64, device=dev)
         sh = L.Shape(B, T, L_)
-        check(lib.mdgen_prep_latents(C.byref(sh), int(tps), ptr(rots), ptr(trans), ptr(tors), ptr(latents), ptr(x_cond),
-                                     ptr(cond_mask), L.stream_ptr()))
+        launch(lib.mdgen_prep_latents, trans, C.byref(sh), int(tps), ptr(rots), ptr(trans), ptr(tors), ptr(latents),
+               ptr(x_cond), ptr(cond_mask))
         rigids = Rigid(Rotation(rot_mats=rots), trans)
         mask = batch["mask"].to(torch.float32)
         frame_lm = mask.unsqueeze(-1).expand(-1, -1, 7)
@@ -131,16 +137,57 @@ class NewMDGenWrapper:
         dev = prep["latents"].device
         if zs is None:
             zs = torch.randn(B, T, L_, self.latent_dim, device=dev)
+        # wrapper.py:441 samples with args.sampling_method (argparse default 'dopri5', parsing.py:102) on the
+        # solver's own 50-point grid.  Only fixed-grid Euler exists here: without an explicit `num_steps` a
+        # non-Euler checkpoint is rejected instead of being silently sampled with a different solver.
+        method = getattr(self.args, "sampling_method", "euler")
+        if num_steps is None and method != "euler":
+            raise L.MdgenError(f"checkpoint args say sampling_method={method!r}; this build implements fixed-grid "
+                               "Euler only -- pass num_steps=... (CLI: --num_steps) to sample with Euler explicitly")
         S = 49 if num_steps is None else int(num_steps)
         kw = dict(prep["model_kwargs"])
         kw["mask"] = kw["mask"].contiguous()
         if not self.args.tps_condition:
             kw["end_frames"] = None
         sample_fn = self.transport_sampler.sample_ode(sampling_method="euler", num_steps=S + 1)
-        samples = sample_fn(zs, partial(self.model.forward_inference, **kw))[-1]
+        samples = sample_fn(zs, partial(self.model.forward_inference, **kw), use_graph=use_graph)[-1]
         r0 = rigids[:, 0]
         atom14 = samples_to_atom14(samples, r0.get_rots().get_rot_mats(), r0.get_trans(), batch["seqres"],
                                    bool(self.args.tps_condition))
         aa_out = batch["seqres"][:, None].expand(B, T, L_)
         self.last_samples = samples
         return atom14, aa_out
+
+    def rollout(self, batch, num_frames: int, num_rollouts: int, num_steps=None, zs=None, use_graph=True,
+                return_next: bool = False):
+        """`num_rollouts` chained blocks of `num_frames` frames from the B = 1-frame conditioning batch of
+        `sim_inference.get_batch` (torsions (B,1,L,7,2), trans (B,1,L,3), rots (B,1,L,3,3), seqres, mask (B,L)):
+        the loop of sim_inference.py:100-113 (`rollout` :61-98 per block) as ONE library call
+        (`mdgen_rollout_euler`), captured as one hipGraph.  `zs`: optional noise (num_rollouts, B, T, L, D)
+        (reference: a fresh device randn per block, wrapper.py:439).  Returns atom14 (B, num_rollouts*T, L, 14, 3)
+        [, the batch that would condition the next block]."""
+        from .geometry import residue_tables
+        if self.args.tps_condition:
+            raise L.MdgenError("rollout() is the forward-simulation driver (sim_condition models)")
+        method = getattr(self.args, "sampling_method", "euler")
+        if num_steps is None and method != "euler":
+            raise L.MdgenError(f"checkpoint args say sampling_method={method!r}; pass num_steps=... to sample with Euler")
+        S = 49 if num_steps is None else int(num_steps)
+        tors = batch["torsions"][:, 0].to(torch.float32)
+        trans = batch["trans"][:, 0].to(torch.float32)
+        rots = batch["rots"][:, 0].to(torch.float32)
+        require_cuda(tors, trans, rots)
+        B, L_ = trans.shape[:2]
+        T, R = int(num_frames), int(num_rollouts)
+        dev = trans.device
+        if zs is None:
+            zs = torch.randn(R, B, T, L_, self.latent_dim, device=dev)
+        mask = batch["mask"].to(torch.float32).unsqueeze(1).expand(-1, T, -1)
+        atom14, samples, nxt = self.model.rollout_euler(zs, S, mask, rots, trans, tors, batch["seqres"],
+                                                        residue_tables(dev), use_graph=use_graph)
+        self.last_samples = samples
+        if not return_next:
+            return atom14
+        new = dict(batch)
+        new["trans"], new["rots"], new["torsions"] = nxt["trans"][:, None], nxt["rots"][:, None], nxt["torsions"][:, None]
+        return atom14, new

@@ -22,7 +22,7 @@ from mdgen import geometry as G
 from mdgen.utils import get_offsets
 
 from mdgen_amd.config import ModelConfig
-from mdgen_amd.synthetic import synth_state_dict
+from mdgen_amd.synthetic import synth_state_dict, synth_forward_inputs, tensor_checksum
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -168,6 +168,29 @@ def gen_forward(name, cfg, seed, B, T, L, n_pad, data_seed, keep=("ipa_out", "h0
          aatype=aatype, out=out, **extra)
 
 
+def gen_forward_big(name, cfg, seed, B, T, L, n_pad, data_seed, sub):
+    """Full-size configuration (e.g. cfg-4: B1 T250 L256): inputs are NOT stored (they are regenerated from
+    `data_seed` by mdgen_amd.synthetic.synth_forward_inputs on both sides, with a checksum); outputs and traces
+    of the reference are stored SUB-SAMPLED: `out` at frames [::sub[0]], residues [::sub[1]]; the 384-wide traces
+    (h0, h_last) at a 5x / 4x coarser stride, ipa_out at residues [::sub[1]]."""
+    m, chk = build(cfg, seed)
+    inp = synth_forward_inputs(cfg, B, T, L, n_pad, data_seed)
+    out, tr = trace_forward(
+        m, x=inp["x"], t=inp["t"], mask=inp["mask"],
+        start_frames=Rigid(trans=inp["start_trans"], rots=Rotation(rot_mats=inp["start_rot"])),
+        end_frames=Rigid(trans=inp["end_trans"], rots=Rotation(rot_mats=inp["end_rot"])),
+        x_cond=inp["x_cond"], x_cond_mask=inp["x_cond_mask"], aatype=inp["aatype"])
+    nl = cfg.num_layers
+    st, sl = sub
+    ht, hl = 5 * st, 4 * sl
+    save(name, cfg=str(cfg.to_dict()), seed=seed, weight_checksum=chk, shape=np.array([B, T, L, n_pad]),
+         data_seed=data_seed, input_checksum=tensor_checksum(inp), sub=np.array(sub), sub_h=np.array([ht, hl]),
+         out=out[:, ::st, ::sl], ipa_out=tr["ipa_out"][:, ::sl], h0=tr["h0"][:, ::ht, ::hl],
+         **{f"h{nl}": tr[f"h{nl}"][:, ::ht, ::hl]},
+         norms=np.array([float(out.double().norm()), float(tr["ipa_out"].double().norm()),
+                         float(tr["h0"].double().norm()), float(tr[f"h{nl}"].double().norm())]))
+
+
 def gen_prep(name, cfg, B, T, L, data_seed):
     g = torch.Generator().manual_seed(data_seed)
     m, _ = build(ModelConfig(embed_dim=48, mha_heads=2, num_layers=1, crop=L, num_frames=T,
@@ -278,23 +301,32 @@ def gen_geometry(name, data_seed):
 
 if __name__ == "__main__":
     tiny = dict(embed_dim=48, mha_heads=2, num_layers=2)
-    gen_rigid("rigid_ops", 11)
-    gen_geometry("geometry", 12)
-    gen_forward("fwd_tiny_sim", ModelConfig(crop=5, num_frames=6, **tiny), 3, B=2, T=6, L=5, n_pad=2,
-                data_seed=21, keep=("ipa_out", "h0", "h1"))
-    gen_forward("fwd_tiny_tps", ModelConfig(crop=5, num_frames=6, sim_condition=False, tps_condition=True, **tiny),
-                4, B=2, T=6, L=5, n_pad=1, data_seed=22, keep=("ipa_out", "h0", "h1"))
-    gen_forward("fwd_full_sim", ModelConfig.forward_sim(num_frames=6, crop=5), 5, B=2, T=6, L=5, n_pad=2,
-                data_seed=23)
-    gen_forward("fwd_full_pep", ModelConfig.forward_sim(num_frames=40, crop=4), 5, B=1, T=40, L=4, n_pad=0,
-                data_seed=26)
-    gen_forward("fwd_full_atlas", ModelConfig.atlas(num_frames=8, crop=40), 6, B=1, T=8, L=40, n_pad=6,
-                data_seed=24)
-    gen_forward("fwd_full_tps", ModelConfig.tps(num_frames=6, crop=4), 7, B=2, T=6, L=4, n_pad=0,
-                data_seed=25)
-    gen_prep("prep_sim", ModelConfig.forward_sim(num_frames=6, crop=5), B=2, T=6, L=5, data_seed=31)
-    gen_prep("prep_tps", ModelConfig.tps(num_frames=6, crop=5), B=2, T=6, L=5, data_seed=32)
-    gen_inference("inference_sim", ModelConfig.forward_sim(num_frames=12, crop=4), 8, B=2, T=12, L=4,
-                  steps=[1, 10], data_seed=41, n_blocks=2)
-    gen_inference("inference_tiny", ModelConfig(crop=4, num_frames=10, **tiny), 9, B=1, T=10, L=4,
-                  steps=[10, 49], data_seed=42, n_blocks=1)
+    JOBS = {
+        "rigid_ops": lambda: gen_rigid("rigid_ops", 11),
+        "geometry": lambda: gen_geometry("geometry", 12),
+        "fwd_tiny_sim": lambda: gen_forward("fwd_tiny_sim", ModelConfig(crop=5, num_frames=6, **tiny), 3, B=2, T=6, L=5,
+                                            n_pad=2, data_seed=21, keep=("ipa_out", "h0", "h1")),
+        "fwd_tiny_tps": lambda: gen_forward("fwd_tiny_tps", ModelConfig(crop=5, num_frames=6, sim_condition=False,
+                                                                        tps_condition=True, **tiny),
+                                            4, B=2, T=6, L=5, n_pad=1, data_seed=22, keep=("ipa_out", "h0", "h1")),
+        "fwd_full_sim": lambda: gen_forward("fwd_full_sim", ModelConfig.forward_sim(num_frames=6, crop=5), 5, B=2, T=6,
+                                            L=5, n_pad=2, data_seed=23),
+        "fwd_full_pep": lambda: gen_forward("fwd_full_pep", ModelConfig.forward_sim(num_frames=40, crop=4), 5, B=1, T=40,
+                                            L=4, n_pad=0, data_seed=26),
+        "fwd_full_atlas": lambda: gen_forward("fwd_full_atlas", ModelConfig.atlas(num_frames=8, crop=40), 6, B=1, T=8,
+                                              L=40, n_pad=6, data_seed=24),
+        "fwd_full_tps": lambda: gen_forward("fwd_full_tps", ModelConfig.tps(num_frames=6, crop=4), 7, B=2, T=6, L=4,
+                                            n_pad=0, data_seed=25),
+        # BASELINE.json configs[3] at its full size: ATLAS crop 256 x 250 frames, B 1, 16 padded residues
+        "fwd_cfg4_atlas_full": lambda: gen_forward_big("fwd_cfg4_atlas_full", ModelConfig.atlas(num_frames=250, crop=256),
+                                                       6, B=1, T=250, L=256, n_pad=16, data_seed=27, sub=(10, 8)),
+        "prep_sim": lambda: gen_prep("prep_sim", ModelConfig.forward_sim(num_frames=6, crop=5), B=2, T=6, L=5, data_seed=31),
+        "prep_tps": lambda: gen_prep("prep_tps", ModelConfig.tps(num_frames=6, crop=5), B=2, T=6, L=5, data_seed=32),
+        # S = 49 is the reference's hard-coded step count (wrapper.py:441-442) and the product default
+        "inference_sim": lambda: gen_inference("inference_sim", ModelConfig.forward_sim(num_frames=12, crop=4), 8, B=2,
+                                               T=12, L=4, steps=[1, 10, 49], data_seed=41, n_blocks=2),
+        "inference_tiny": lambda: gen_inference("inference_tiny", ModelConfig(crop=4, num_frames=10, **tiny), 9, B=1,
+                                                T=10, L=4, steps=[10, 49], data_seed=42, n_blocks=1),
+    }
+    for n in (sys.argv[1:] or list(JOBS)):
+        JOBS[n]()

@@ -10,6 +10,6 @@ R=$PWD
 # (a) product mode: two sub-batches on two streams -> half-batch launches, overlapping
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o ktrace -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $R/gpurun_out/rocprof.log 2>&1)
 # (b) single stream: full-batch launches, the mode bench.py's hipEvent roofline leg measures
-(cd /tmp && MDGEN_DUAL_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof1 -o ktrace -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $R/gpurun_out/rocprof1.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof1 -o ktrace -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-graph --streams 1 > $R/gpurun_out/rocprof1.log 2>&1)
 tail -3 gpurun_out/pytest_gpu.log; cat gpurun_out/smoke.log | tail -2; tail -2 gpurun_out/bench.log
 head -4 gpurun_out/prof1/ktrace_kernel_stats.csv

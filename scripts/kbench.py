@@ -26,6 +26,7 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 B, T, L, abs_pos, n_pad = bench.WORKLOADS[wl]
 cfg = ModelConfig(crop=L, num_frames=T, abs_pos_emb=abs_pos, sim_condition=True)
 w = NewMDGenWrapper(cfg, device=dev); w.model.load_state_dict(synth_state_dict(cfg, 0))
+w.model.set_option("streams", 1)   # full-batch launches on one stream (what the profiling leg measures)
 batch = bench.synth_batch(B, T, L, n_pad, dev, seed=100)
 zs = torch.randn(B, T, L, 21, generator=torch.Generator().manual_seed(137)).to(dev)
 w.inference(batch, zs=zs, num_steps=S, use_graph=False)

@@ -4,7 +4,7 @@
 # FETCH_SIZE is reported in KiB and, on gfx950, counts 64 B per 128-B request of a wide coalesced read -> doubled.
 # Output: gpurun_out/pmc_traffic.json (copy to profiles/).
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
-R=$PWD; mkdir -p gpurun_out; export TMPDIR=/tmp PYTHONUNBUFFERED=1 MDGEN_DUAL_STREAM=0
+R=$PWD; mkdir -p gpurun_out; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 RE="k_mlp|k_ln_qkv|k_proj|k_flash|k_final|k_embed"
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-include-regex "$RE" --output-format csv -d $R/gpurun_out/pmc_$c -o pmc -- python $R/scripts/kbench.py tetrapeptide_fwdsim_crop4_T1000_B16 1 > $R/gpurun_out/pmc_$c.log 2>&1)
@@ -30,7 +30,7 @@ for (k, g), d in acc.items():
               "FETCH_SIZE_KiB_raw": round(f, 1), "WRITE_SIZE_KiB_raw": round(w, 1),
               "hbm_read_bytes": round(2 * f * 1024), "hbm_write_bytes": round(w * 1024),
               "hbm_bytes_per_launch": round((2 * f + w) * 1024)}
-meta = {"workload": "tetrapeptide_fwdsim_crop4_T1000_B16", "mode": "single stream, eager launches (MDGEN_DUAL_STREAM=0)",
+meta = {"workload": "tetrapeptide_fwdsim_crop4_T1000_B16", "mode": "single stream, eager launches (library option streams = 1)",
         "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 wide-read correction); KiB -> bytes",
         "kernels": out}
 json.dump(meta, open(f"{R}/gpurun_out/pmc_traffic.json", "w"), indent=1)

@@ -18,7 +18,7 @@ cfg = ModelConfig(crop=L, num_frames=T, abs_pos_emb=abs_pos, sim_condition=True)
 w = NewMDGenWrapper(cfg, device=dev); w.model.load_state_dict(synth_state_dict(cfg, 0))
 batch = bench.synth_batch(B, T, L, n_pad, dev, seed=100)
 zs = torch.randn(B, T, L, 21, generator=torch.Generator().manual_seed(137)).to(dev)
-os.environ["MDGEN_DUAL_STREAM"] = "0"
+w.model.set_option("streams", 1)
 w.inference(batch, zs=zs, num_steps=2, use_graph=False)
 nwg = (B * T * L + 63) // 64
 buf = torch.zeros(nwg * 4 * 32, dtype=torch.int64, device=dev)

@@ -317,42 +317,32 @@ def test_tps_inference_end_to_end_vs_oracle():
 
 
 def test_residue_axis_paths_agree():
-    """L = 4 has three implementations of the residue-axis sub-layer: the one-kernel default
-    (k_ln_qkv_attn4<true>), attention fused but projection separate (MDGEN_FUSED_ATTN4=1), and the general
-    L <= 8 path (k_ln_qkv<SMALL> -> k_proj<2>, MDGEN_FUSED_ATTN4=0).  The switches are read once per process, so
-    the alternatives run in child processes on the fwd_full_pep golden; all three must meet the same gate against
-    the reference output and agree with each other to bf16-operand noise."""
-    import subprocess, tempfile
-    _cuda()
+    """L = 4 has three implementations of the residue-axis sub-layer, selected by the library option
+    "residue_l4_path": 2 = the one-kernel default (k_ln_qkv_attn4<true>), 1 = attention fused but projection
+    separate, 0 = the general L <= 8 path (k_ln_qkv<SMALL> -> k_proj<2>).  All three must meet the same gate
+    against the reference output (fwd_full_pep golden) and agree with each other to bf16-operand noise."""
+    dev = _cuda()
     g = load_golden("fwd_full_pep")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    child = (
-        "import sys, os, numpy as np, torch\n"
-        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
-        "from conftest import load_golden, weights_for\n"
-        "from mdgen_amd.model import LatentMDGenModel\n"
-        "g = load_golden('fwd_full_pep'); cfg, sd = weights_for(g)\n"
-        "m = LatentMDGenModel(cfg); m.load_state_dict(sd); d = 'cuda'\n"
-        "out = m.forward(x=g['x'].to(d), t=g['t'].to(d), mask=g['mask'].to(d), start_frames=(g['start_rot'].to(d), g['start_trans'].to(d)),\n"
-        "                x_cond=g['x_cond'].to(d), x_cond_mask=g['x_cond_mask'].to(d), aatype=g['aatype'].to(d))\n"
-        "np.save(sys.argv[1], out.cpu().numpy())\n" % (root, root))
+    cfg, sd = weights_for(g)
+    m = get_model(cfg, sd, ("fwd_full_pep", "paths"))
     outs = {}
-    with tempfile.TemporaryDirectory() as td:
-        for mode in ("", "1", "0"):
-            env = dict(os.environ)
-            env.pop("MDGEN_FUSED_ATTN4", None)
-            if mode:
-                env["MDGEN_FUSED_ATTN4"] = mode
-            pth = os.path.join(td, f"out{mode or 'd'}.npy")
-            r = subprocess.run([sys.executable, "-c", child, pth], env=env, capture_output=True, text=True, timeout=300)
-            assert r.returncode == 0, r.stderr[-2000:]
-            import numpy as np
-            outs[mode] = torch.from_numpy(np.load(pth))
+    try:
+        for mode in (2, 1, 0):
+            m.set_option("residue_l4_path", mode)
+            outs[mode] = m.forward(**_kw(g, dev)).cpu()
+    finally:
+        m.set_option("residue_l4_path", 2)
     for mode, o in outs.items():
         e = rel_l2(o, g["out"])
-        print(f"MDGEN_FUSED_ATTN4={mode or '(default)'}: rel-L2 vs reference {e:.3e}")
+        print(f"residue_l4_path={mode}: rel-L2 vs reference {e:.3e}")
         assert e < TOL_FWD
-    assert rel_l2(outs["1"], outs[""]) < 5e-3 and rel_l2(outs["0"], outs[""]) < 5e-3
+    assert not torch.equal(outs[0], outs[2])          # the option really switches the code path
+    assert rel_l2(outs[1], outs[2]) < 5e-3 and rel_l2(outs[0], outs[2]) < 5e-3
+    from mdgen_amd._lib import MdgenError
+    with pytest.raises(MdgenError):
+        m.set_option("residue_l4_path", 7)
+    with pytest.raises(MdgenError):
+        m.set_option("no_such_option", 1)
 
 
 def test_training_losses_vs_reference():
@@ -418,8 +408,9 @@ def test_graph_replay_matches_eager_bitwise():
 
 
 def test_dual_stream_split_matches_single_stream():
-    """The Euler rollout runs the two halves of the batch on two streams; the result
-    must match the single-stream run to rounding level (panel boundaries move, arithmetic does not)."""
+    """The Euler rollout runs contiguous sub-batch views on concurrent streams (option "streams", default 2;
+    DESIGN.md section 3); the result must match the single-stream run to rounding level (panel boundaries move,
+    arithmetic does not), eager and graph-replayed alike."""
     from mdgen_amd.config import ModelConfig
     from mdgen_amd.synthetic import synth_state_dict
     dev = _cuda()
@@ -438,16 +429,20 @@ def test_dual_stream_split_matches_single_stream():
     aat = torch.randint(0, 20, (B, L), generator=gen).to(dev)
     kw = dict(mask=mask, start_frames=(R, tr_), x_cond=xc, x_cond_mask=cm, aatype=aat)
     outs = {}
-    for dual in ("0", "1"):
-        os.environ["MDGEN_DUAL_STREAM"] = dual
-        for g in (False, True):
-            outs[dual, g] = m.sample_euler(zs, 4, use_graph=g, **kw)
-    os.environ.pop("MDGEN_DUAL_STREAM")
+    try:
+        for ns in (1, 2, 3):        # 3 streams: views of 2, 2 and 1 samples
+            m.set_option("streams", ns)
+            for g in (False, True):
+                outs[ns, g] = m.sample_euler(zs, 4, use_graph=g, **kw)
+    finally:
+        m.set_option("streams", 2)
     torch.cuda.synchronize()
-    ref = outs["0", False]
+    ref = outs[1, False]
     assert torch.isfinite(ref).all()
-    assert torch.equal(outs["0", True], ref) and torch.equal(outs["1", True], outs["1", False])
-    assert rel_l2(outs["1", False], ref) < 1e-3
+    assert torch.equal(outs[1, True], ref)
+    for ns in (2, 3):
+        assert torch.equal(outs[ns, True], outs[ns, False])
+        assert rel_l2(outs[ns, False], ref) < 1e-3
 
 
 def test_full_size_properties_cfg2():
@@ -486,3 +481,325 @@ def test_full_size_properties_cfg2():
                x_cond=xc[perm].contiguous(), x_cond_mask=cm[perm].contiguous(), aatype=aat[perm].contiguous())
     yp = m.forward(x[perm].contiguous(), **kwp)
     assert rel_l2(yp, y1[perm]) < 1e-3 and (yp - y1[perm]).abs().max() < 2e-2
+
+
+def test_forward_cfg4_full_size_vs_reference_and_oracle():
+    """BASELINE.json configs[3] at FULL size: ATLAS crop 256 x 250 frames, B 1, 16 padded residues.  Exercises what
+    no small fixture reaches: residue-axis k_flash with 4 q-chunks x 9 key tiles and key padding, k_ipa_attn over
+    4 x 256 x 256 logits (ipa.py:161-203), 1000 panels per launch.  (a) vs the REFERENCE's own run, stored
+    sub-sampled (fwd_cfg4_atlas_full; inputs regenerated from the seed and checksummed); (b) vs the CPU oracle run
+    here on the host cores (every element, every trace)."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.synthetic import synth_forward_inputs, tensor_checksum
+    dev = _cuda()
+    g = load_golden("fwd_cfg4_atlas_full")
+    cfg, sd = weights_for(g)
+    B, T, L, n_pad = (int(v) for v in g["shape"])
+    assert (B, T, L, n_pad) == (1, 250, 256, 16)
+    inp = synth_forward_inputs(cfg, B, T, L, n_pad, int(g["data_seed"]))
+    np.testing.assert_allclose(tensor_checksum(inp), g["input_checksum"].numpy(), rtol=1e-12)
+    m = get_model(cfg, sd, ("cfg4", "w"))
+    kw = dict(x=inp["x"], t=inp["t"], mask=inp["mask"], start_frames=(inp["start_rot"], inp["start_trans"]),
+              end_frames=(inp["end_rot"], inp["end_trans"]), x_cond=inp["x_cond"], x_cond_mask=inp["x_cond_mask"],
+              aatype=inp["aatype"])
+    out, tr = m.forward(**{k: (tuple(u.to(dev) for u in v) if isinstance(v, tuple) else v.to(dev)) for k, v in kw.items()},
+                        return_trace=True)
+    torch.cuda.synchronize()
+    out = out.cpu()
+    tr = {k: v.cpu() for k, v in tr.items()}
+    assert torch.isfinite(out).all()
+    st, sl = (int(v) for v in g["sub"])
+    ht, hl = (int(v) for v in g["sub_h"])
+    nl = cfg.num_layers
+    rep = {"out": rel_l2(out[:, ::st, ::sl], g["out"]), "ipa_out": rel_l2(tr["ipa_out"][:, ::sl], g["ipa_out"]),
+           "h0": rel_l2(tr["h0"][:, ::ht, ::hl], g["h0"]), f"h{nl}": rel_l2(tr[f"h{nl}"][:, ::ht, ::hl], g[f"h{nl}"])}
+    print("cfg-4 full vs reference (sub-sampled):", {k: f"{v:.2e}" for k, v in rep.items()})
+    for k, v in rep.items():
+        assert v < TOL_FWD, (k, v)
+    ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
+    rep2 = {k: rel_l2(tr[k], rtr[k]) for k in ["ipa_out"] + [f"h{i}" for i in range(nl + 1)]}
+    rep2["out"] = rel_l2(out, ref)
+    print("cfg-4 full vs oracle (all elements):", {k: f"{v:.2e}" for k, v in rep2.items()})
+    for k in ("ipa_out", "h0", f"h{nl}", "out"):
+        assert rep2[k] < TOL_FWD, (k, rep2[k])
+    # padded residues never influence the valid ones: same call with garbage in the padded inputs
+    x2 = inp["x"].clone()
+    x2[:, :, L - n_pad:] = 1e3
+    kw2 = dict(kw, x=x2)
+    out2 = m.forward(**{k: (tuple(u.to(dev) for u in v) if isinstance(v, tuple) else v.to(dev)) for k, v in kw2.items()}).cpu()
+    assert torch.equal(out2[:, :, :L - n_pad], out[:, :, :L - n_pad])
+
+
+def test_tps_cfg3_size_properties():
+    """BASELINE.json configs[2] at its per-GPU size: TPS model (D = 28, two-sided conditioning, dual-stream IPA),
+    crop 4, 100 frames, batch 256 / 8 GPUs = 32.  Size-independent properties of the Euler rollout through
+    `NewMDGenWrapper.inference`: finite; bit-reproducible run to run (graph replay); a batch of 32 equals the
+    concatenation of its two halves sampled separately (samples are independent; rounding level, since panel
+    boundaries move); frame 0 / frame -1 conditioning is honoured by prep_batch."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    from mdgen_amd.tps_inference import get_sample, collate
+    from mdgen_amd.geometry import samples_to_atom14
+    from mdgen_amd.rigid_utils import Rotation
+    dev = _cuda()
+    B, T, L, S = 32, 100, 4, 10
+    cfg = ModelConfig.tps(num_frames=T, crop=L)
+    w = NewMDGenWrapper(cfg)
+    w.model.load_state_dict(synth_state_dict(cfg, 11))
+    gen = torch.Generator().manual_seed(303)
+    seqs = ["FLRH", "IMRY", "AWKD", "GSTV"]
+    samples = []
+    for b in range(B):
+        ends = []
+        for _ in range(2):
+            q = torch.randn(1, L, 4, generator=gen)
+            R = Rotation(quats=(q / q.norm(dim=-1, keepdim=True)).to(dev)).get_rot_mats()
+            tr_ = torch.cumsum(2.2 * torch.randn(1, L, 3, generator=gen), 1).to(dev)
+            ang = 6.2831853 * torch.rand(1, L, 7, generator=gen)
+            lat = torch.zeros(1, 1, L, 21, device=dev)
+            lat[..., 0] = 1.0
+            lat[..., 7:21] = torch.stack([ang.sin(), ang.cos()], -1).reshape(1, 1, L, 14).to(dev)
+            from mdgen_amd.geometry import restype_order
+            sq = torch.tensor([[restype_order[c] for c in seqs[b % 4]]], device=dev)
+            ends.append(samples_to_atom14(lat, R, tr_, sq, tps=False)[0].cpu().numpy())   # [1,L,14,3]
+        samples.append(get_sample(ends[0], ends[1], seqs[b % 4], T, dev))
+    batch = collate(samples)
+    prep = w.prep_batch(batch)
+    cm = prep["model_kwargs"]["x_cond_mask"]
+    assert cm[:, 0].all() and cm[:, -1].all() and not cm[:, 1:-1].any()
+    assert prep["latents"].shape == (B, T, L, 28)
+    zs = torch.randn(B, T, L, 28, generator=gen).to(dev)
+    a1, _ = w.inference(batch, zs=zs, num_steps=S)
+    s1 = w.last_samples.clone()
+    a2, _ = w.inference(batch, zs=zs, num_steps=S)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a1).all() and torch.equal(a1, a2)
+    halves = []
+    for lo in (0, 16):
+        hb = {k: v[lo:lo + 16].contiguous() for k, v in batch.items()}
+        w.inference(hb, zs=zs[lo:lo + 16].contiguous(), num_steps=S)
+        halves.append(w.last_samples.clone())
+    e = rel_l2(torch.cat(halves, 0), s1)
+    print(f"cfg-3 size TPS: batch 32 vs 2 x 16: samples rel-L2 {e:.2e}")
+    assert e < 2e-3
+
+
+def test_inference_S49_error_growth():
+    """The product default and the bench use S = 49 Euler steps (the reference's hard-coded 50-point grid,
+    wrapper.py:441-442).  Report the error against the reference's own S = 1 / 10 / 49 runs (inference_sim golden)
+    and gate S = 49 at the bf16-operand bounds of BASELINE.md section 3."""
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    dev = _cuda()
+    g = load_golden("inference_sim")
+    assert 49 in [int(s) for s in g["steps"]]
+    cfg, sd = weights_for(g)
+    w = NewMDGenWrapper(cfg)
+    w.model.load_state_dict(sd)
+    batch0 = {k[3:]: v.to(dev) for k, v in g.items() if k.startswith("in_")}
+    T = g["S49_b0_zs"].shape[1]
+    ex = dict(batch0)
+    ex["torsions"] = batch0["torsions"].expand(-1, T, -1, -1, -1)
+    ex["trans"] = batch0["trans"].expand(-1, T, -1, -1)
+    ex["rots"] = batch0["rots"].expand(-1, T, -1, -1, -1)
+    rows = {}
+    for S in (1, 10, 49):
+        atom14, _ = w.inference(ex, zs=g[f"S{S}_b0_zs"].to(dev), num_steps=S)
+        d = (atom14.cpu() - g[f"S{S}_b0_atom14"]).abs()
+        rows[S] = (rel_l2(w.last_samples.cpu(), g[f"S{S}_b0_samples"]), float(d.pow(2).mean().sqrt()), float(d.max()))
+        print(f"S={S:2d}: samples rel-L2 {rows[S][0]:.2e}  atom14 rms {rows[S][1]:.4f} A  max {rows[S][2]:.4f} A")
+    assert rows[49][0] < 2e-2 and rows[49][1] < 0.05 and rows[49][2] < 0.5
+
+
+def test_multi_block_rollout_one_graph():
+    """`NewMDGenWrapper.rollout` = `mdgen_rollout_euler`: R chained blocks (prep -> S Euler steps -> atom14 -> next
+    conditioning frame) in one library call / one hipGraph (sim_inference.py:100-113).  (a) identical, bit for bit,
+    to chaining `inference()` + `atom14_to_cond` from Python block by block (same kernels, same order); (b) graph
+    replay == eager; (c) vs the reference's own two chained blocks (inference_sim golden, S = 10): block 0 at the
+    single-block gate, block 1 (conditioned on OUR block-0 end frame, i.e. error carried over) reported and gated
+    at twice that."""
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    from mdgen_amd.sim_inference import rollout as py_rollout
+    dev = _cuda()
+    g = load_golden("inference_sim")
+    cfg, sd = weights_for(g)
+    w = NewMDGenWrapper(cfg)
+    w.model.load_state_dict(sd)
+    batch0 = {k[3:]: v.to(dev) for k, v in g.items() if k.startswith("in_")}
+    S, R = 10, 2
+    T = g[f"S{S}_b0_zs"].shape[1]
+    zs = torch.stack([g[f"S{S}_b{r}_zs"] for r in range(R)]).to(dev)
+    chained, cur = [], dict(batch0)
+    for r in range(R):
+        a, cur = py_rollout(w, cur, T, S, zs=zs[r])
+        chained.append(a)
+    chained = torch.cat(chained, 1)
+    one_e, nxt_e = w.rollout(batch0, T, R, num_steps=S, zs=zs, use_graph=False, return_next=True)
+    one_g = w.rollout(batch0, T, R, num_steps=S, zs=zs, use_graph=True)
+    one_g2 = w.rollout(batch0, T, R, num_steps=S, zs=zs, use_graph=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(one_e).all()
+    assert torch.equal(one_e, chained)
+    assert torch.equal(one_g, one_e) and torch.equal(one_g2, one_e)
+    for k in ("trans", "rots", "torsions"):
+        assert torch.equal(nxt_e[k], cur[k]), k
+    for r in range(R):
+        d = (one_g[:, r * T:(r + 1) * T].cpu() - g[f"S{S}_b{r}_atom14"]).abs()
+        rms, mx = float(d.pow(2).mean().sqrt()), float(d.max())
+        print(f"rollout block {r} vs reference: atom14 rms {rms:.4f} A max {mx:.4f} A")
+        assert rms < 0.05 * (r + 1) and mx < 0.5 * (r + 1)
+
+
+def test_many_views_beyond_the_32bit_offset_limit():
+    """One launch addresses the residual stream with 32-bit byte offsets (token * 1536): at most 2 796 202 token rows.
+    A batch of 45 ATLAS-size samples (2.88 M tokens) must therefore run as two sub-batch launch views
+    (`mdgen_debug_view_plan`) and give, for every sample, what that sample gives alone (rounding level)."""
+    import ctypes as C
+    import mdgen_amd._lib as L
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict, synth_forward_inputs
+    dev = _cuda()
+    B, T, L_, n_pad = 45, 250, 256, 16
+    nv, per = C.c_int32(), C.c_int32()
+    L.check(L.lib.mdgen_debug_view_plan(C.byref(L.Shape(B, T, L_)), 1, C.byref(nv), C.byref(per)))
+    assert nv.value == 2 and per.value == 23
+    cfg = ModelConfig.atlas(num_frames=T, crop=L_)
+    sd = synth_state_dict(cfg, 6)
+    m = get_model(cfg, sd, ("cfg4", "w"))
+    one = synth_forward_inputs(cfg, 3, T, L_, n_pad, 91)          # three distinct samples, tiled over the batch
+    idx = torch.arange(B) % 3
+
+    def kw_for(sel):
+        k = {n: one[n][sel].contiguous() for n in ("x", "t", "mask", "x_cond", "x_cond_mask", "aatype")}
+        k["start_frames"] = (one["start_rot"][sel].contiguous().to(dev), one["start_trans"][sel].contiguous().to(dev))
+        return {n: (v if isinstance(v, tuple) else v.to(dev)) for n, v in k.items()}
+    big = m.forward(**kw_for(idx))
+    torch.cuda.synchronize()
+    assert torch.isfinite(big).all()
+    small = m.forward(**kw_for(torch.arange(3)))
+    for b in (0, 1, 22, 23, 44):          # both views, both ends of each
+        assert rel_l2(big[b], small[b % 3]) < 1e-3, b
+    del big
+    m._ws.clear()
+    torch.cuda.empty_cache()
+
+
+def test_checkpoint_and_cli_end_to_end(tmp_path):
+    """The boundary's file half: a Lightning-layout checkpoint ({'state_dict': {'model.*'}, 'hyper_parameters':
+    {'args': Namespace}}, wrapper.py:50,120-130) -> `NewMDGenWrapper.load_from_checkpoint` -> the
+    `sim_inference`-compatible CLI on a synthetic fp16 `.npy` trajectory + split CSV -> `{name}.pdb`, equal to what
+    the Python API gives for the same seed; a checkpoint whose args say `sampling_method='dopri5'` (the reference's
+    argparse default) is REFUSED unless `--num_steps` is given."""
+    import argparse
+    import pandas as pd
+    from mdgen_amd._lib import MdgenError
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.geometry import restype_order, samples_to_atom14
+    from mdgen_amd.rigid_utils import Rotation
+    from mdgen_amd.synthetic import synth_state_dict
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    from mdgen_amd import sim_inference as cli
+    from mdgen_amd.pdb import frames_to_pdb_string
+    dev = _cuda()
+    T, R, S = 24, 2, 3
+    cfg = ModelConfig.forward_sim(num_frames=T, crop=4)
+    sd = synth_state_dict(cfg, 21)
+
+    def write_ckpt(path, sampling_method):
+        a = argparse.Namespace(**cfg.to_dict(), path_type="GVP", prediction="velocity", sampling_method=sampling_method,
+                               lr=1e-4, batch_size=8, ema=False)
+        torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}, "hyper_parameters": {"args": a},
+                    "epoch": 3, "global_step": 1234}, path)
+    ck_euler, ck_dopri = str(tmp_path / "euler.ckpt"), str(tmp_path / "dopri5.ckpt")
+    write_ckpt(ck_euler, "euler")
+    write_ckpt(ck_dopri, "dopri5")
+    # synthetic MD data: {data_dir}/{name}.npy fp16 [frames, L, 14, 3] (scripts/prep_sims.py:54-77), split CSV name,seqres
+    names = {"FLRH": "FLRH", "IMRY": "IMRY", "AWKD": "AWKD"}
+    gen = torch.Generator().manual_seed(5)
+    data = tmp_path / "data"
+    data.mkdir()
+    for n, sq in names.items():
+        q = torch.randn(1, 4, 4, generator=gen)
+        Rm = Rotation(quats=(q / q.norm(dim=-1, keepdim=True)).to(dev)).get_rot_mats()
+        tr_ = torch.cumsum(2.2 * torch.randn(1, 4, 3, generator=gen), 1).to(dev)
+        ang = 6.2831853 * torch.rand(1, 4, 7, generator=gen)
+        lat = torch.zeros(1, 1, 4, 21, device=dev)
+        lat[..., 0] = 1.0
+        lat[..., 7:21] = torch.stack([ang.sin(), ang.cos()], -1).reshape(1, 1, 4, 14).to(dev)
+        a14 = samples_to_atom14(lat, Rm, tr_, torch.tensor([[restype_order[c] for c in sq]], device=dev), tps=False)[0]
+        np.save(data / f"{n}.npy", a14.cpu().numpy().repeat(3, 0).astype(np.float16))
+    split = tmp_path / "split.csv"
+    pd.DataFrame({"name": list(names), "seqres": list(names.values())}).to_csv(split, index=False)
+    out = tmp_path / "out"
+    base = ["--data_dir", str(data), "--split", str(split), "--out_dir", str(out), "--num_frames", str(T),
+            "--num_rollouts", str(R), "--npy"]
+    # (1) dopri5 checkpoint without --num_steps: refused, loudly
+    with pytest.raises(MdgenError, match="dopri5"):
+        cli.main(["--sim_ckpt", ck_dopri] + base)
+    # (2) the same checkpoint with explicit Euler steps runs; (3) Euler checkpoint, batched, one device rollout
+    torch.manual_seed(1234)
+    res = cli.main(["--sim_ckpt", ck_dopri, "--num_steps", str(S), "--batch", "3"] + base)
+    assert res["names"] == list(names) and res["frames"] == 3 * R * T
+    got = {n: np.load(out / f"{n}.npy") for n in names}
+    for n in names:
+        assert got[n].shape == (R * T, 4, 14, 3) and np.isfinite(got[n]).all()
+        text = open(out / f"{n}.pdb").read()
+        assert text.count("MODEL") == R * T
+        assert text == frames_to_pdb_string(got[n], np.array([restype_order[c] for c in names[n]]))
+    # the same through the Python API (same seed -> same device noise)
+    w = NewMDGenWrapper.load_from_checkpoint(ck_euler)
+    assert w.cfg == cfg and w.args.sampling_method == "euler"
+    batch = cli.collate([cli.get_batch(np.load(data / f"{n}.npy"), names[n], dev) for n in names])
+    torch.manual_seed(1234)
+    api = w.rollout(batch, T, R, num_steps=S).cpu().numpy()
+    for i, n in enumerate(names):
+        assert np.array_equal(api[i], got[n]), n
+    # (4) --chunk_idx / --n_chunks (tps_inference.py:160-161) and --pdb_id select the work; B = 1 per call
+    res = cli.main(["--sim_ckpt", ck_euler, "--chunk_idx", "1", "--n_chunks", "2", "--per_block"] + base)
+    assert res["names"] == ["AWKD"]
+    res = cli.main(["--sim_ckpt", ck_euler, "--pdb_id", "IMRY"] + base)
+    assert res["names"] == ["IMRY"]
+    # flags of models outside the path are refused at load time
+    bad = argparse.Namespace(**cfg.to_dict(), sampling_method="euler", design=True)
+    torch.save({"state_dict": {}, "hyper_parameters": {"args": bad}}, tmp_path / "bad.ckpt")
+    with pytest.raises(MdgenError, match="design"):
+        NewMDGenWrapper.load_from_checkpoint(str(tmp_path / "bad.ckpt"))
+    both = argparse.Namespace(**dict(cfg.to_dict(), tps_condition=True), sampling_method="euler")
+    torch.save({"state_dict": {}, "hyper_parameters": {"args": both}}, tmp_path / "both.ckpt")
+    with pytest.raises(MdgenError, match="exactly one"):
+        NewMDGenWrapper.load_from_checkpoint(str(tmp_path / "both.ckpt"))
+
+
+def test_use_graph_flag_reaches_the_library():
+    """`inference(use_graph=False)` must launch eagerly (the flag used to be dropped): with profiling
+    off, an eager call leaves the context's graph cache untouched, a graph call adds exactly one entry -- observed
+    through the launch counts of the profiling report, which only eager launches feed."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    dev = _cuda()
+    cfg = ModelConfig.forward_sim(num_frames=40, crop=4)
+    w = NewMDGenWrapper(cfg)
+    w.model.load_state_dict(synth_state_dict(cfg, 2))
+    seen = []
+    orig = w.model.sample_euler
+
+    def spy(*a, **k):
+        seen.append(k.get("use_graph"))
+        return orig(*a, **k)
+    w.model.sample_euler = spy
+    gen = torch.Generator().manual_seed(0)
+    B, T, L_ = 2, 40, 4
+    from mdgen_amd.rigid_utils import Rotation
+    q = torch.randn(B, 1, L_, 4, generator=gen)
+    Rm = Rotation(quats=(q / q.norm(dim=-1, keepdim=True)).to(dev)).get_rot_mats()
+    ang = 6.2831853 * torch.rand(B, 1, L_, 7, generator=gen)
+    batch = {"torsions": torch.stack([ang.sin(), ang.cos()], -1).expand(B, T, L_, 7, 2).contiguous().to(dev),
+             "torsion_mask": torch.ones(B, L_, 7, device=dev), "trans": torch.randn(B, 1, L_, 3, generator=gen).expand(B, T, L_, 3).contiguous().to(dev),
+             "rots": Rm.expand(B, T, L_, 3, 3).contiguous(), "seqres": torch.randint(0, 20, (B, L_), generator=gen).to(dev),
+             "mask": torch.ones(B, L_, device=dev)}
+    zs = torch.randn(B, T, L_, 21, generator=gen).to(dev)
+    a, _ = w.inference(batch, zs=zs, num_steps=2, use_graph=False)
+    b, _ = w.inference(batch, zs=zs, num_steps=2, use_graph=True)
+    assert seen == [False, True]
+    assert torch.equal(a, b)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     import mdgen_amd._lib as L
     lib = ctypes.CDLL(so)
     names = _declared_symbols()
-    assert len(names) >= 19
+    assert len(names) >= 23
     for n in names:
         assert hasattr(lib, n), n
     assert set(L.EXPORTS) == set(names)
@@ -125,3 +125,113 @@ def test_sincos_pos_embed_matches_reference():
         ours = sincos_pos_embed(C, 9)[0].numpy()
         assert ours.shape == g[key].shape
         assert np.abs(ours - g[key]).max() < 1e-6
+
+
+def test_view_plan_respects_the_32bit_offset_limit():
+    """panel prologues/epilogues address h as base + 32-bit byte offset token*1536 -> at most 2 796 202
+    token rows per launch.  `mdgen_debug_view_plan` (the function `mdgen_sample_euler` / `mdgen_denoiser_forward`
+    cut batches with) must keep every view under the limit, cover the batch, and reject a single over-size sample."""
+    import ctypes as C
+    import mdgen_amd._lib as L
+    LIMIT = 0xFFFFFFFF // 1536
+    nv, per = C.c_int32(), C.c_int32()
+    for (B, T, Lr, streams) in [(16, 1000, 4, 2), (1, 250, 256, 2), (44, 250, 256, 1), (45, 250, 256, 1), (45, 250, 256, 2),
+                                (1000, 250, 256, 2), (5, 300, 4, 3), (3, 8000, 300, 8), (7, 1, 1, 8)]:
+        assert L.lib.mdgen_debug_view_plan(C.byref(L.Shape(B, T, Lr)), streams, C.byref(nv), C.byref(per)) == 0
+        assert per.value * T * Lr <= LIMIT, (B, T, Lr)
+        assert nv.value >= min(streams, B) and nv.value <= B
+        assert per.value == -(-B // nv.value)                    # views differ by at most one sample
+        assert (nv.value - 1) * per.value < B <= nv.value * per.value
+    assert nv.value == 7
+    L.lib.mdgen_debug_view_plan(C.byref(L.Shape(43, 250, 256)), 1, C.byref(nv), C.byref(per))
+    assert nv.value == 1                                          # 43 * 64 000 = 2 752 000 tokens fit one launch
+    L.lib.mdgen_debug_view_plan(C.byref(L.Shape(44, 250, 256)), 1, C.byref(nv), C.byref(per))
+    assert nv.value == 2 and per.value == 22                      # 44 * 64 000 = 2 816 000 do not
+    assert L.lib.mdgen_debug_view_plan(C.byref(L.Shape(1, 8000, 400)), 1, C.byref(nv), C.byref(per)) == -2
+    assert b"per-launch limit" in L.lib.mdgen_last_error()
+
+
+def test_cli_work_selection():
+    """`sim_inference.select_names` / `group_batches`: the reference's --chunk_idx/--n_chunks split
+    (tps_inference.py:160-161, np.array_split), rank sharding under torch.distributed.run, --pdb_id filter; batches
+    group peptides of equal length."""
+    from mdgen_amd.sim_inference import select_names, group_batches
+    names = [f"p{i}" for i in range(11)]
+    assert select_names(names) == names
+    chunks = [select_names(names, chunk_idx=i, n_chunks=3) for i in range(3)]
+    assert [len(c) for c in chunks] == [4, 4, 3] and sum(chunks, []) == names          # np.array_split sizes
+    per_rank = [select_names(names, chunk_idx=1, n_chunks=3, rank=r, world=2) for r in range(2)]
+    assert sum(per_rank, []) == chunks[1] and abs(len(per_rank[0]) - len(per_rank[1])) <= 1
+    assert select_names(names, pdb_id=["p2", "p9"], chunk_idx=0, n_chunks=3) == ["p2"]
+    with pytest.raises(ValueError):
+        select_names(names, chunk_idx=3, n_chunks=3)
+    seq = {"a": "FLRH", "b": "IMRY", "c": "AAAAAAAA", "d": "GSTV", "e": "WWWWWWWW", "f": "KKKK"}
+    g = group_batches(list(seq), seq, 3)
+    assert g == [["a", "b", "d"], ["f"], ["c", "e"]]
+    assert group_batches(list(seq), seq, 1) == [["a"], ["b"], ["d"], ["f"], ["c"], ["e"]]
+
+
+def test_rigid_view_level_ops_cpu():
+    """`Rigid.__init__` identity fill, `Rigid.identity`, `__getitem__`, `unsqueeze`,
+    `cat`, `Rotation.cat`, `from_tensor_4x4`, `from_tensor_7` field handling -- view-level glue that runs no kernel,
+    checked on CPU tensors against the semantics of rigid_utils.py:820-862, 892-921, 1122-1141, 1220-1261."""
+    from mdgen_amd.rigid_utils import Rigid, Rotation
+    g = torch.Generator().manual_seed(0)
+    R = torch.linalg.qr(torch.randn(2, 5, 3, 3, generator=g))[0]
+    t = torch.randn(2, 5, 3, generator=g)
+    # r-7: missing half filled with identity (rigid_utils.py:838-853); shape / device checks
+    a = Rigid(Rotation(rot_mats=R), None)
+    assert a.shape == (2, 5) and torch.equal(a.get_trans(), torch.zeros(2, 5, 3)) and a.get_trans().dtype == torch.float32
+    b = Rigid(None, t)
+    assert torch.equal(b.get_rots().get_rot_mats(), torch.eye(3).expand(2, 5, 3, 3))
+    with pytest.raises(ValueError):
+        Rigid(None, None)
+    with pytest.raises(ValueError):
+        Rigid(Rotation(rot_mats=R), t[:1])
+    with pytest.raises(ValueError):
+        Rotation(rot_mats=R, quats=torch.zeros(2, 5, 4))
+    with pytest.raises(ValueError):
+        Rotation(rot_mats=R[..., :2])
+    i = Rigid.identity((4, 3), fmt="rot_mat")       # dataset.py:82-85 padding frames
+    assert i.shape == (4, 3) and torch.equal(i.get_rots().get_rot_mats(), torch.eye(3).expand(4, 3, 3, 3))
+    assert torch.equal(i.get_trans(), torch.zeros(4, 3, 3))
+    # fp32 is forced (rigid_utils.py:318-322, 859)
+    assert Rigid(Rotation(rot_mats=R.double()), t.double()).get_trans().dtype == torch.float32
+    assert Rotation(rot_mats=R.double()).get_rot_mats().dtype == torch.float32
+    # r-8: indexing / unsqueeze / cat act on the virtual batch shape
+    r = Rigid(Rotation(rot_mats=R), t)
+    assert r[:, 0:1].shape == (2, 1) and torch.equal(r[:, 0:1].get_trans(), t[:, 0:1])
+    assert torch.equal(r[1].get_rots().get_rot_mats(), R[1]) and r[1, 2].shape == ()
+    assert torch.equal(r[..., 3].get_trans(), t[:, 3])
+    assert r[..., None].shape == (2, 5, 1) and r.unsqueeze(-1).shape == (2, 5, 1) and r.unsqueeze(0).shape == (1, 2, 5)
+    assert torch.equal(r.unsqueeze(-1).get_rots().get_rot_mats(), R[:, :, None])
+    with pytest.raises(ValueError):
+        r.unsqueeze(2)
+    c = Rigid.cat([r, r[:, :2]], dim=1)
+    assert c.shape == (2, 7) and torch.equal(c.get_trans(), torch.cat([t, t[:, :2]], 1))
+    assert torch.equal(c.get_rots().get_rot_mats(), torch.cat([R, R[:, :2]], 1))
+    c2 = Rigid.cat([r, r], dim=-1)
+    assert c2.shape == (2, 10) and torch.equal(c2.get_rots().get_rot_mats()[:, 5:], R)
+    assert Rotation.cat([Rotation(rot_mats=R), Rotation(rot_mats=R)], dim=0).shape == (4, 5)
+    # quaternion-backed rotations keep their format and normalisation flag through views
+    q = torch.randn(2, 5, 4, generator=g)
+    rq = Rotation(quats=q, normalize_quats=True)
+    assert rq[0].shape == (5,) and rq[0]._quats is not None and rq[0]._normalize and rq.unsqueeze(1).shape == (2, 1, 5)
+    assert torch.allclose(rq.get_quats().norm(dim=-1), torch.ones(2, 5), atol=1e-6)
+    assert torch.equal(Rotation(quats=q, normalize_quats=False).get_quats(), q)
+    # `* mask` multiplies all 9 + 3 entries (rigid_utils.py:923-942)
+    mk = torch.tensor([[1., 0, 1, 0, 1], [0, 1, 0, 1, 0]])
+    m = r * mk
+    assert torch.equal(m.get_trans(), t * mk[..., None]) and torch.equal(m.get_rots().get_rot_mats(), R * mk[..., None, None])
+    # r-9: from_tensor_4x4 / from_tensor_7 split the fields; wrong shapes raise
+    T4 = torch.zeros(2, 5, 4, 4)
+    T4[..., :3, :3], T4[..., :3, 3], T4[..., 3, 3] = R, t, 1.0
+    f = Rigid.from_tensor_4x4(T4)
+    assert torch.equal(f.get_rots().get_rot_mats(), R) and torch.equal(f.get_trans(), t)
+    with pytest.raises(ValueError):
+        Rigid.from_tensor_4x4(T4[..., :3, :])
+    x7 = torch.cat([q, t], -1)
+    f7 = Rigid.from_tensor_7(x7, normalize_quats=True)
+    assert torch.equal(f7.get_trans(), t) and f7.get_rots()._normalize and torch.equal(f7.get_rots()._quats, q)
+    with pytest.raises(ValueError):
+        Rigid.from_tensor_7(x7[..., :6])

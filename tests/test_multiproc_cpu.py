@@ -51,6 +51,68 @@ def test_two_rank_batch_sharding():
     assert all(r[3] == 1000 * n_items for r in res)                                   # whole-job frames
 
 
+class _FakeSampler:
+    """Stands in for NewMDGenWrapper on CPU: `rollout` returns a deterministic trajectory that encodes which
+    peptide it belongs to (so the test can see who sampled what)."""
+
+    def rollout(self, batch, num_frames, num_rollouts, num_steps=None):
+        B, L = batch["seqres"].shape
+        base = batch["tag"].view(B, 1, 1, 1, 1).float()
+        return base + torch.zeros(B, num_rollouts * num_frames, L, 14, 3) + torch.arange(14).view(1, 1, 1, 14, 1) * 0.1
+
+
+def _cli_worker(rank, world, port, data_dir, out_dir, q):
+    """The REAL driver (`mdgen_amd.sim_inference.run`: chunking, rank sharding, batching by length, PDB writing,
+    barrier + max-over-ranks timing) on a fake sampler, gloo backend."""
+    import argparse
+    from mdgen_amd import sim_inference as cli
+    from mdgen_amd.geometry import restype_order
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seqs = {"pA": "FLRH", "pB": "IMRY", "pC": "AWKDGG", "pD": "GSTV", "pE": "KKKK", "pF": "WWWWWW", "pG": "AAAA"}
+    args = cli.build_parser().parse_args(["--data_dir", data_dir, "--out_dir", out_dir, "--num_frames", "3",
+                                          "--num_rollouts", "2", "--batch", "2", "--npy"])
+
+    def batch_fn(names, arrs, seqres, device):      # CPU stand-in for get_batch + collate (those need the GPU glue)
+        for n in names:
+            assert arrs[n].shape[1] == len(seqres[n])
+        return {"seqres": torch.tensor([[restype_order[c] for c in seqres[n]] for n in names]),
+                "tag": torch.tensor([float(ord(n[1])) for n in names])}
+    res = cli.run(args, _FakeSampler(), "cpu", seqs, rank, world, batch_fn=batch_fn, dist=dist)
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_two_rank_cli_driver_on_fake_sampler(tmp_path):
+    import numpy as np
+    seqs = {"pA": 4, "pB": 4, "pC": 6, "pD": 4, "pE": 4, "pF": 6, "pG": 4}
+    data = tmp_path / "data"
+    data.mkdir()
+    for n, L in seqs.items():
+        np.save(data / f"{n}.npy", np.zeros((2, L, 14, 3), np.float16))
+    out = tmp_path / "out"
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cli_worker, args=(r, world, port, str(data), str(out), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]["names"] == ["pA", "pB", "pC", "pD"] and res[1]["names"] == ["pE", "pF", "pG"]      # contiguous shards
+    assert res[0]["frames"] == 4 * 6 and res[1]["frames"] == 3 * 6
+    assert res[0]["job_frames"] == res[1]["job_frames"] == 7 * 6                                    # whole job, both ranks
+    assert res[0]["job_seconds"] == res[1]["job_seconds"] == max(res[0]["seconds"], res[1]["seconds"])
+    for n, L in seqs.items():                                                                        # every peptide once
+        a = np.load(out / f"{n}.npy")
+        assert a.shape == (6, L, 14, 3) and abs(a[0, 0, 0, 0] - ord(n[1])) < 1e-6
+        assert open(out / f"{n}.pdb").read().count("MODEL") == 6
+
+
 def test_shard_range_properties():
     from mdgen_amd.sharding import shard_range
     for n in (0, 1, 5, 16, 255, 256):

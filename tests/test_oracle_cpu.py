@@ -190,3 +190,28 @@ def test_training_losses_vs_reference(name):
     xt1, _ = O.path_plan(torch.ones(2), g["x0"], g["x1"])
     assert torch.allclose(xt0, g["x0"], atol=1e-6) and torch.allclose(xt1, g["x1"], atol=1e-6)
     assert torch.allclose(ut0, (math.pi / 2) * g["x1"], atol=1e-5)
+
+
+def test_forward_cfg4_full_size_matches_reference():
+    """BASELINE.json configs[3] at its FULL size (ATLAS crop 256 x 250 frames, B 1, 16 padded residues): the oracle
+    vs the reference's own run (fixture fwd_cfg4_atlas_full: seeded inputs regenerated here, checked by checksum;
+    reference outputs stored sub-sampled)."""
+    from mdgen_amd.synthetic import synth_forward_inputs, tensor_checksum
+    g = load_golden("fwd_cfg4_atlas_full")
+    cfg, sd = weights_for(g)
+    B, T, L, n_pad = (int(v) for v in g["shape"])
+    inp = synth_forward_inputs(cfg, B, T, L, n_pad, int(g["data_seed"]))
+    np.testing.assert_allclose(tensor_checksum(inp), g["input_checksum"].numpy(), rtol=1e-12)
+    out, tr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, x=inp["x"], t=inp["t"], mask=inp["mask"],
+                        start_frames=(inp["start_rot"], inp["start_trans"]), end_frames=(inp["end_rot"], inp["end_trans"]),
+                        x_cond=inp["x_cond"], x_cond_mask=inp["x_cond_mask"], aatype=inp["aatype"])
+    st, sl = (int(v) for v in g["sub"])
+    ht, hl = (int(v) for v in g["sub_h"])
+    nl = cfg.num_layers
+    assert rel_l2(out[:, ::st, ::sl], g["out"]) < 2e-5
+    assert rel_l2(tr["ipa_out"][:, ::sl], g["ipa_out"]) < 2e-5
+    assert rel_l2(tr["h0"][:, ::ht, ::hl], g["h0"]) < 2e-5
+    assert rel_l2(tr[f"h{nl}"][:, ::ht, ::hl], g[f"h{nl}"]) < 2e-5
+    norms = [float(out.double().norm()), float(tr["ipa_out"].double().norm()), float(tr["h0"].double().norm()),
+             float(tr[f"h{nl}"].double().norm())]
+    np.testing.assert_allclose(norms, g["norms"].numpy(), rtol=1e-5)
