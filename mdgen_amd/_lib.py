@@ -63,7 +63,7 @@ def _load():
     lib.mdgen_workspace_layout.argtypes = [vp, C.POINTER(Shape), i32, i32, C.POINTER(WsLayout)]
     lib.mdgen_denoiser_forward.argtypes = [vp, C.POINTER(Shape)] + [vp] * 14 + [sz, vp]
     lib.mdgen_sample_euler.argtypes = [vp, C.POINTER(Shape), i32] + [vp] * 10 + [sz, i32, vp]
-    lib.mdgen_rollout_euler.argtypes = [vp, C.POINTER(Shape), i32, i32] + [vp] * 9 + [C.POINTER(ResidueTables), vp, vp, sz, i32, vp]
+    lib.mdgen_rollout_euler.argtypes = [vp, C.POINTER(Shape), i32, i32] + [vp] * 8 + [C.POINTER(ResidueTables), vp, vp, sz, i32, vp]
     lib.mdgen_profile_enable.argtypes = [vp, i32]
     lib.mdgen_profile_phase_trace.argtypes = [vp, vp, i64]
     lib.mdgen_profile_report.argtypes = [vp, vp, C.c_char_p, sz]

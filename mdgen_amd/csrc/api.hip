@@ -340,11 +340,13 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
         TRYHIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
     TRYHIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    TRY(c->dalloc(&c->zero_page, (size_t)64));
-    TRYHIP(hipMemset(c->zero_page, 0, 256));
-    {   // bytes 128..143: eight bf16 1.0 (the all-ones V^T row that accumulates the softmax denominator)
+    TRY(c->dalloc(&c->zero_page, (size_t)512));
+    TRYHIP(hipMemset(c->zero_page, 0, 2048));
+    {   // bytes 128..143 and 896..911 (= +768, the k-step-1 offset of a V^T fragment): eight bf16 1.0 -- the all-ones
+        // V^T row that accumulates the softmax denominator
         const uint16_t ones[8] = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
         TRYHIP(hipMemcpy((unsigned char*)c->zero_page + 128, ones, sizeof(ones), hipMemcpyHostToDevice));
+        TRYHIP(hipMemcpy((unsigned char*)c->zero_page + 128 + 768, ones, sizeof(ones), hipMemcpyHostToDevice));
     }
     TRY(c->dalloc(&c->wfin, (size_t)kKS * 64));
     TRY(c->dalloc(&c->bfin, (size_t)32));
@@ -719,6 +721,8 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
     } else {
         q.wv = m.wv_flash;
         q.bv = m.bv_flash;
+        q.bias_k = m.bias_k;   // written into key slot `len` of the K / V^T fragments by the sequence's last panel
+        q.bias_v = m.bias_v;
         { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv(q, false, r.s); }
         LAUNCHCHK();
         FlashParams f{};

@@ -11,15 +11,18 @@
 //   S^T[key][q] = K-frag (A) x Q-frag (B)      2 x mfma_32x32x16 (d = 24 padded to 32)
 //   O^T[d][q]  += V^T-frag (A) x P^T (B)       2 x mfma_32x32x16, P^T = exp2(S^T - m) packed in place
 // A lane owns one query column (q = lane&31) and half of the tile's keys, so the row max is lane-local plus
-// one exchange with lane^32.  One wave = one head x 64 queries (2 q-tiles); workgroup = 4 heads of the same
-// queries.  The kernel is VALU-bound at dh = 24 (one v_exp per score), so the softmax is reduced to
-// max3 + exp + cvt per score:
+// one exchange with lane^32.  One wave = one head x 64 queries (two 32-query tiles A, B); workgroup = 4 heads of
+// the same queries; three workgroups per CU (<= 168 VGPRs): per-wave issue (one instruction per ~4-5 cycles,
+// profiles/r02_issue_rate.txt) is what bounds a softmax loop, so waves per SIMD matter more than anything else.
+// Per score: max3 + exp + cvt, nothing more:
 //   * the running shift -m rides in a spare K-dim slot of Q (bf16-exact), so the score MFMA returns s - m;
 //   * an all-ones V^T row (d = 24) makes the PV MFMA accumulate the softmax denominator;
-//   * the shift is re-anchored only when a tile's max exceeds it by 2^kDefer (wave-uniform ballot);
-//   * the NEXT tile's score MFMAs are issued inside the current tile's exp block;
-//   * K/V are prefetched with unconditional, wrapped tile indices (a load under `if` is a serialised load);
-//   * the learned bias key is a register-built virtual tile after the real ones.
+//   * the shift is re-anchored only when a tile's max exceeds it by 2^kDefer (one scalar test per pair);
+//   * software pipeline over (key tile, query tile) pairs A0 B0 A1 B1 ...: the block of a pair issues the score
+//     MFMAs of the NEXT pair and the PV MFMAs of the PREVIOUS pair beside its own 16 exps -- every MFMA of a block
+//     has its operands ready when the block starts, and the two neighbours belong to the other query tile;
+//   * K/V are prefetched one to two tiles ahead with unconditional loads, tiles in linear order (K: SGPR base);
+//   * the learned bias key is an ordinary entry of the fragments (key slot len, written by k_ln_qkv).
 #include "kernels.h"
 
 namespace mdg {
@@ -44,15 +47,21 @@ struct VTile {
     u32x4 v0;   // V^T k-step 0
     u32x4 v1;   // V^T k-step 1
 };
+struct QTile {
+    bf16x8 q0, q1;   // k-steps 0 / 1 of one 32-query tile; k-step-1 slot 4 of the lanes hh == 0 carries -m
+};
+struct PTile {
+    bf16x8 p0, p1;   // P^T = exp2(S^T - m) of one (32-key, 32-query) tile, k-steps 0 / 1 of the PV MFMAs
+};
 
-// Running softmax state of the wave's two 32-query tiles.  The row sum is NOT kept here: V^T row 24 (a padding
-// row, d >= 24) is all ones, so the PV MFMA accumulates l = sum_k P[k][q] into O^T[24][q] (register 12 of the
-// lanes with hh == 0) and every rescale of O rescales l with it.
-struct FlashState {
-    f32x16 o0, o1;
-    float m0, m1;        // applied shift (exactly representable in bf16; rides in a spare K-dim slot of Q)
-    bool anch0, anch1;   // the shift has been anchored to a finite score at least once
-    bool settled;        // wave-uniform: every lane is anchored -> only "max moved up" needs checking
+// Running softmax state of ONE 32-query tile.  The row sum is NOT kept here: V^T row 24 (a padding row, d >= 24)
+// is all ones, so the PV MFMA accumulates l = sum_k P[k][q] into O^T[24][q] (register 12 of the lanes with
+// hh == 0) and every rescale of O rescales l with it.
+struct Half {
+    f32x16 o;
+    float m;                     // applied shift (exactly representable in bf16; rides in a spare K-dim slot of Q)
+    unsigned long long unanch;   // wave-level lane mask (SGPR pair): lanes whose shift has NOT yet been anchored to a
+                                 // finite score.  All zero after the first tile or two: then only "max moved up" matters
 };
 
 __device__ __forceinline__ float half_max(float x) {   // max over the two half-waves (lane, lane^32)
@@ -65,133 +74,112 @@ __device__ __forceinline__ float round_bf16(float x) { return __uint_as_float(pa
 // How far the running shift may lag the true row max before O is rescaled (log2 units: P <= 2^kDefer).
 constexpr float kDefer = 8.f;
 
-struct QFrags {
-    bf16x8 q00, q01, q10, q11;   // [q-tile][k-step]; k-step-1 slot 4 of the lanes hh == 0 carries -m
-    f32x16 zc;                   // all-zero accumulator input of the score MFMAs (opaque to the compiler)
-};
-
-// S^T - m for one 32-key tile against both q-tiles.  C is a LIVE all-zero register tuple (QFrags::zc), never the
-// inline constant 0: with the constant hipcc lets the destination overlap A (caught by build.py check_isa).
-__device__ __forceinline__ void scores(const KTile& t, const QFrags& q, f32x16& s0, f32x16& s1) {
-    const f32x16& zc = q.zc;
-    const bf16x8 k0 = __builtin_bit_cast(bf16x8, t.k0);
-    const u32x4 k1w = u32x4{t.k1[0], t.k1[1], 0x00003f80u, 0u};   // slot 4 = 1.0: picks up -m from Q
-    const bf16x8 k1 = __builtin_bit_cast(bf16x8, k1w);
-    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q.q00, zc, 0, 0, 0);
-    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q.q10, zc, 0, 0, 0);
-    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q.q01, s0, 0, 0, 0);
-    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q.q11, s1, 0, 0, 0);
-}
-
-// Softmax bookkeeping of the current tile (everything except exp): key-padding mask, row max, and -- rarely --
-// moving the shift.  Must run BEFORE the next tile's scores are issued, because it may rewrite Q's -m slot.
-__device__ __forceinline__ void softmax_stats(FlashState& st, f32x16& s0, f32x16& s1, QFrags& q, uint32_t vm, int hh) {
-    if (vm != 0xffffffffu) {
-        const uint32_t vmh = vm >> (4 * hh);
+// Softmax bookkeeping of one (key tile, query tile) pair, everything except exp: key-padding mask, row max, and
+// -- rarely -- moving the shift (which rewrites Q's -m slot and rescales O).  `vm`: validity bits of the tile's 32
+// keys (wave-uniform, in an SGPR).
+__device__ __forceinline__ void softmax_stats(Half& st, f32x16& s, QTile& q, uint32_t vm, int hh) {
+    if (vm != 0xffffffffu) {   // rare (the last tile of a sequence, padded residues): keep ALL of it inside the branch
+        uint32_t vmh = vm >> (4 * hh);
+        asm volatile("" : "+v"(vmh));   // opaque: else the 16 bit tests are hoisted above the branch and always run
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool ok = (vmh >> ((r & 3) + 8 * (r >> 2))) & 1u;
-            s0[r] = ok ? s0[r] : -1e30f;
-            s1[r] = ok ? s1[r] : -1e30f;
+            s[r] = ok ? s[r] : -1e30f;
         }
     }
-    float t0 = fmaxf(s0[0], s0[1]), t1 = fmaxf(s1[0], s1[1]);
+    float t = fmaxf(s[0], s[1]);
 #pragma unroll
-    for (int r = 2; r < 16; r += 2) {
-        t0 = fmaxf(fmaxf(t0, s0[r]), s0[r + 1]);   // v_max3_f32
-        t1 = fmaxf(fmaxf(t1, s1[r]), s1[r + 1]);
-    }
-    t0 = half_max(t0);
-    t1 = half_max(t1);
-    const bool up = fmaxf(t0, t1) > kDefer;
-    if (!st.settled || __builtin_amdgcn_ballot_w64(up) != 0) {   // wave-uniform and rare after the first tiles
-        // Re-anchor when the shift lags the tile max by more than kDefer, or (first finite tile of a query
-        // only) leads it by more than kDefer.  Both half-waves of a query see the same t -> same decision.
-        const bool fin0 = t0 > -1e29f, fin1 = t1 > -1e29f;
-        const bool mv0 = (t0 > kDefer) | (!st.anch0 & fin0 & (t0 < -kDefer));
-        const bool mv1 = (t1 > kDefer) | (!st.anch1 & fin1 & (t1 < -kDefer));
-        st.anch0 |= fin0;
-        st.anch1 |= fin1;
-        st.settled = __builtin_amdgcn_ballot_w64(st.anch0 & st.anch1) == ~0ull;
+    for (int r = 2; r < 16; r += 2) t = fmaxf(fmaxf(t, s[r]), s[r + 1]);   // v_max3_f32
+    t = half_max(t);
+    // one scalar test per pair: some lane's max ran ahead of its shift, or some lane is still unanchored
+    if ((__builtin_amdgcn_ballot_w64(t > kDefer) | st.unanch) != 0) {   // wave-uniform and rare after the first tiles
+        // Re-anchor when the shift lags the tile max by more than kDefer, or (first finite tile of a query only)
+        // leads it by more than kDefer.  Both half-waves of a query see the same t -> same decision.
+        const bool fin = t > -1e29f;
+        const bool un = (st.unanch >> lane_id()) & 1ull;
+        const bool mv = (t > kDefer) | (un & fin & (t < -kDefer));
+        st.unanch &= ~__builtin_amdgcn_ballot_w64(fin);
         // new shift = bf16(m + tile max); e = what this tile's already-shifted scores still have to lose
-        const float r0 = mv0 ? round_bf16(st.m0 + t0) : st.m0, r1 = mv1 ? round_bf16(st.m1 + t1) : st.m1;
-        const float e0 = r0 - st.m0, e1 = r1 - st.m1;
-        st.m0 = r0;
-        st.m1 = r1;
+        const float r = mv ? round_bf16(st.m + t) : st.m;
+        const float e = r - st.m;
+        st.m = r;
         // e < 0 only while nothing has been accumulated yet (first anchoring): O is still zero, keep it so
-        const float a0 = __builtin_amdgcn_exp2f(fminf(-e0, 0.f)), a1 = __builtin_amdgcn_exp2f(fminf(-e1, 0.f));
+        const float a = __builtin_amdgcn_exp2f(fminf(-e, 0.f));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            st.o0[r] *= a0;
-            st.o1[r] *= a1;
-            s0[r] -= e0;
-            s1[r] -= e1;
+        for (int i = 0; i < 16; ++i) {
+            st.o[i] *= a;
+            s[i] -= e;
         }
-        if (hh == 0) {   // -m into Q's spare slot (k-step 1, slot 4)
-            q.q01[4] = (__bf16)(-r0);
-            q.q11[4] = (__bf16)(-r1);
-        }
+        if (hh == 0) q.q1[4] = (__bf16)(-r);   // -m into Q's spare slot (k-step 1, slot 4)
     }
 }
 
-// The MFMA-dense block of one tile: P^T = exp2(S^T - m) packed in place, O^T += V^T P^T, and the scores of the
-// FOLLOWING tile issued into the same straight-line block so its MFMAs run under this tile's exps.  It is one
-// unconditional block on purpose (after the last tile the "next" scores are computed from stale K registers
-// and dropped): with a branch hipcc hoists the exps above it and the overlap is lost.
-__device__ __forceinline__ void exp_pv(FlashState& st, const f32x16& s0, const f32x16& s1, const bf16x8 v0, const bf16x8 v1,
-                                       const KTile& kn, const QFrags& q, f32x16& n0, f32x16& n1) {
-    scores(kn, q, n0, n1);
-    bf16x8 p00, p01, p10, p11;
+// The MFMA-dense block of one (key tile, query tile) pair, one straight-line region in which every MFMA has its
+// operands ready at entry:
+//   od += V^T P^T of the PREVIOUS pair            2 MFMAs (that pair belongs to the OTHER query tile, so a shift
+//                                                 moved by this pair's softmax_stats never concerns it)
+//   n  = S^T - m of the FOLLOWING pair            K-frag (A) x Q-frag (B), 2 MFMAs
+//   pc = exp2(s) of THIS pair, packed to bf16     16 v_exp + 8 v_cvt_pk
+// i.e. 4 MFMAs (128 matrix-pipe cycles) beside 24 VALU operations, none waiting for another.  The PV MFMAs go
+// first: once they have been issued the previous pair's P registers are dead, and the packed results of this pair
+// can take their place (one P tuple live instead of two).
+// The score MFMAs take the INLINE CONSTANT 0 as C (no 16-register zero tuple to keep alive).  With that operand form
+// hipcc does not mark the destination early-clobber and may allocate it on top of a source that dies at the MFMA --
+// which corrupts results.  Both sources are therefore kept alive across the MFMAs: Q is loop
+// invariant, K gets a no-op use after the block.  (build.py check_isa still rejects any overlap in the final ISA.)
+__device__ __forceinline__ void block(const KTile& kn, const QTile& qn, f32x16& n,
+                                      const VTile& vp, const PTile& pp, f32x16& od,
+                                      const f32x16& s, PTile& pc) {
+    const bf16x8 k0 = __builtin_bit_cast(bf16x8, kn.k0);
+    const u32x4 k1w = u32x4{kn.k1[0], kn.k1[1], 0x00003f80u, 0u};   // slot 4 = 1.0: picks up -m from Q
+    const bf16x8 k1 = __builtin_bit_cast(bf16x8, k1w);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    od = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vp.v0), pp.p0, od, 0, 0, 0);
+    n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qn.q0, zero, 0, 0, 0);
+    od = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vp.v1), pp.p1, od, 0, 0, 0);
+    n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qn.q1, n, 0, 0, 0);
+    float e[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) e[j] = __builtin_amdgcn_exp2f(s[j]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        p00[j] = (__bf16)__builtin_amdgcn_exp2f(s0[j]);
-        p10[j] = (__bf16)__builtin_amdgcn_exp2f(s1[j]);
+        pc.p0[j] = (__bf16)e[j];
+        pc.p1[j] = (__bf16)e[8 + j];
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        p01[j] = (__bf16)__builtin_amdgcn_exp2f(s0[8 + j]);
-        p11[j] = (__bf16)__builtin_amdgcn_exp2f(s1[8 + j]);
+    for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);   // six VALU / transcendental
     }
-    st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p00, st.o0, 0, 0, 0);
-    st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p10, st.o1, 0, 0, 0);
-    st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p01, st.o0, 0, 0, 0);
-    st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p11, st.o1, 0, 0, 0);
-    {   // interleave: 4 score MFMAs under the first 32 exp/cvt, then the PV MFMAs as their P arrives
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x402, 8, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x402, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    }
+    // sources outlive the MFMAs (see above); the packed P is pinned HERE, inside the block: left alone hipcc sinks the
+    // exps below the block (next to their consumer, the next block's PV MFMA) and the overlap is lost
+    asm volatile("" : "+v"(pc.p0), "+v"(pc.p1) : "v"(k0), "v"(k1), "v"(qn.q0), "v"(qn.q1));
 }
 
-__global__ __launch_bounds__(256, 2) void k_flash(const FlashParams p) {
-    const int lane = lane_id(), w = wave_id(), hh = lane >> 5, ql = lane & 31;
-    const int len = p.ax.len, ntile = p.ax.ntile();   // ntile: tiles per (seq, head) in the fragment LAYOUT
-    const int nreal = (len + 31) >> 5;                // tiles that hold real keys
+__global__ __launch_bounds__(256, 3) void k_flash(const FlashParams p) {
+    const int lane = lane_id(), hh = lane >> 5, ql = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform, and the compiler knows it: the K stream
+                                                               // is then addressed as SGPR base + lane offset
+    const int len = p.ax.len, nt = p.ax.ntile();   // tiles per (seq, head): they cover the len keys + the bias key
     const int nqc = (len + 63) / 64;
-    const int hg = blockIdx.x & 3;
-    const int rest = blockIdx.x >> 2;
-    const int qc = rest % nqc, seq = rest / nqc;
+    // (sequence, head group) pairs are dealt to the 8 XCDs (block b runs on XCD b % 8) so that ALL q-chunks of a
+    // pair -- which stream the same K/V -- share one L2: K/V leave HBM once.
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int qc = rest % nqc, pair = (rest / nqc) * 8 + xcd;
+    const int seq = pair >> 2, hg = pair & 3;
+    if (seq >= p.ax.nseq) return;
     const int head = hg * 4 + w;
-    const long fbase = (long)(seq * kH + head) * ntile * kFragBytes;
+    const long fbase = (long)(seq * kH + head) * nt * kFragBytes;
     const unsigned char* qb = p.qf + fbase;
     const long seq_base = p.ax.token(seq, 0);
     const int pstride = p.ax.pos_stride;
 
-    // ---- per-tile key validity bitmasks (key-padding mask; positions >= len are invalid), shared by the
-    //      4 waves (same sequence): wave w fills tiles w, w+4, ...
-    __shared__ uint32_t vmask[256];
-    for (int kt = w; kt < nreal; kt += 4) {
+    // ---- per-tile key validity bitmasks (key-padding mask; the bias key at position len is always valid;
+    //      positions > len are invalid), shared by the 4 waves (same sequence): wave w fills tiles w, w+4, ...
+    __shared__ uint32_t vmask[260];
+    for (int kt = w; kt < nt + 1; kt += 4) {
         const int pos = kt * 32 + ql;
-        const bool ok = pos < len && p.mk.at(seq_base + (long)pos * pstride) != 0.f;
+        const bool ok = kt < nt && (pos == len || (pos < len && p.mk.at(seq_base + (long)(pos < len ? pos : 0) * pstride) != 0.f));
         const uint32_t vm = (uint32_t)__ballot(ok && hh == 0);
         if (lane == 0) vmask[kt] = vm;
     }
@@ -201,121 +189,105 @@ __global__ __launch_bounds__(256, 2) void k_flash(const FlashParams p) {
     const int qt0 = 2 * qc;
     const bool has2 = (qt0 + 1) * 32 < len;
     const int qt1 = has2 ? qt0 + 1 : qt0;
-    QFrags q;
-    q.q00 = frag16(qb + (long)qt0 * kFragBytes + lane * 16);
-    q.q01 = frag8(qb + (long)qt0 * kFragBytes + 1024 + lane * 8);
-    q.q10 = frag16(qb + (long)qt1 * kFragBytes + lane * 16);
-    q.q11 = frag8(qb + (long)qt1 * kFragBytes + 1024 + lane * 8);
+    QTile qa, qb_;
+    qa.q0 = frag16(qb + (long)qt0 * kFragBytes + lane * 16);
+    qa.q1 = frag8(qb + (long)qt0 * kFragBytes + 1024 + lane * 8);
+    qb_.q0 = frag16(qb + (long)qt1 * kFragBytes + lane * 16);
+    qb_.q1 = frag8(qb + (long)qt1 * kFragBytes + 1024 + lane * 8);
 
-    // per-lane fragment streams: K rows are lanes; V^T rows d > 24 read a zero page, row 24 a ones page (stride
-    // 0): row 24 is the all-ones row that accumulates the softmax denominator
+    // per-lane fragment streams.  K: uniform base + lane offset.  V^T: rows d < 24 are lanes of the fragment; rows
+    // d > 24 read a zero page, row 24 a ones page (stride 0): the all-ones row accumulates the softmax denominator.
     const bool vreal = ql < kDH;
-    const unsigned char* vp = vreal ? p.vf + fbase + hh * 384 + ql * 16 : p.zero_page + (ql == kDH ? 128 : 0);
-    const long vstep = vreal ? kFragBytes : 0;
-    const long v1off = vreal ? 768 : 0;
-    // K fragment: k-step 0 at +lane*16, k-step 1 at +1024+lane*8 -> two base pointers
-    const unsigned char* k0p = p.kf + fbase + lane * 16;
-    const unsigned char* k1p = p.kf + fbase + 1024 + lane * 8;
+    const unsigned char* vptr = vreal ? p.vf + fbase + hh * 384 + ql * 16 : p.zero_page + (ql == kDH ? 128 : 0);
+    const unsigned vstep = vreal ? kFragBytes : 0;
+    const unsigned char* kbase = p.kf + fbase;   // wave-uniform
+    const unsigned ko0 = lane * 16, ko1 = 1024 + lane * 8;
 
-    FlashState st;
+    Half ha, hb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        st.o0[r] = opaque_zero();
-        st.o1[r] = opaque_zero();
-        q.zc[r] = opaque_zero();
+        ha.o[r] = opaque_zero();
+        hb.o[r] = opaque_zero();
     }
-    st.m0 = st.m1 = 0.f;
-    st.anch0 = st.anch1 = false;
-    st.settled = false;
+    ha.m = hb.m = 0.f;
+    ha.unanch = hb.unanch = ~0ull;
 
-    // Loads are UNCONDITIONAL (the tile index wraps instead): a load under `if` makes hipcc merge old and new
-    // register values right behind it, i.e. wait for the data it has just requested.
+    // Loads are UNCONDITIONAL: tiles past the end of this (sequence, head) read whatever follows in the fragment
+    // buffer (finite bf16 of the next head, or the zeroed tail) and their results are dropped -- a load under `if`
+    // makes hipcc wait for the data right behind it.
     auto issue_k = [&](KTile& t, int kt) {
-        t.k0 = *reinterpret_cast<const u32x4*>(k0p + (long)kt * kFragBytes);
-        t.k1 = *reinterpret_cast<const u32x2*>(k1p + (long)kt * kFragBytes);
+        const unsigned char* b = kbase + (long)kt * kFragBytes;
+        t.k0 = *reinterpret_cast<const u32x4*>(b + ko0);
+        t.k1 = *reinterpret_cast<const u32x2*>(b + ko1);
     };
     auto issue_v = [&](VTile& t, int kt) {
-        t.v0 = *reinterpret_cast<const u32x4*>(vp + (long)kt * vstep);
-        t.v1 = *reinterpret_cast<const u32x4*>(vp + (long)kt * vstep + v1off);
-    };
-    // One tile: `s` holds its shifted scores (issued during the previous tile), `vt` its V^T, `kn` the NEXT
-    // tile's K.  Order: stats (may move the shift in Q) -> [next scores || exp || PV].
-    // The two score tuples ping-pong between "current" and "next" so nothing is copied.
-    f32x16 sa0, sa1, sb0, sb1;
-    auto step = [&](const KTile& kn, const VTile& vt, uint32_t vm, f32x16& s0, f32x16& s1, f32x16& n0, f32x16& n1) {
-        softmax_stats(st, s0, s1, q, vm, hh);
-        exp_pv(st, s0, s1, __builtin_bit_cast(bf16x8, vt.v0), __builtin_bit_cast(bf16x8, vt.v1), kn, q, n0, n1);
+        const unsigned char* b = vptr + (unsigned long)((unsigned)kt * vstep);
+        t.v0 = *reinterpret_cast<const u32x4*>(b);
+        t.v1 = *reinterpret_cast<const u32x4*>(b + 768);   // the constant page repeats itself at +768
     };
 
-    // Key tiles are visited in ROTATED order, starting at a q-chunk dependent tile (softmax does not care), so
-    // that the workgroups sharing one sequence's K/V stream are not all first-touching the same lines.
-    const int start = (qc * nreal) / nqc;
-    auto tile = [&](int i) {   // i <= nreal + 2
-        int t = start + i;
-        t = t >= nreal ? t - nreal : t;
-        t = t >= nreal ? t - nreal : t;
-        return t >= nreal ? 0 : t;
+    // One key tile = two (key tile, query tile) pairs, A then B.  Pipeline: the block of pair i issues the score
+    // MFMAs of pair i+1 and the PV MFMAs of pair i-1 beside its own exps.  Score tuples sa / sb and P tuples pa / pb
+    // belong to query tile A / B for good, so nothing is ever copied; K / V tiles alternate between two slots by
+    // tile parity (kx, vx: even tiles; ky, vy: odd tiles).
+    f32x16 sa, sb;
+    PTile pa, pb;
+    KTile kx, ky;
+    VTile vx, vy;
+    pb.p0 = pb.p1 = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});   // "previous pair" of the very first block: P = 0
+    uint32_t vm_next = __builtin_amdgcn_readfirstlane(vmask[0]);
+    auto tile = [&](int t, KTile& kc, KTile& kn, VTile& vc, VTile& vprev) {
+        const uint32_t vm = vm_next;
+        const uint32_t vmv = vmask[t + 1];   // the next tile's mask: requested now, moved to an SGPR at the end
+        // pair (t, A): scores in sa.  Block: sb <- scores (t, B);  hb.o += V(t-1) P_B(t-1);  pa <- exp(sa)
+        softmax_stats(ha, sa, qa, vm, hh);
+        __builtin_amdgcn_sched_barrier(0);
+        block(kc, qb_, sb, vprev, pb, hb.o, sa, pa);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_v(vprev, t + 1);   // V(t-1) and K(t) (for query tile B: just issued) are consumed: refill both slots
+        issue_k(kc, t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // pair (t, B): scores in sb.  Block: sa <- scores (t+1, A);  ha.o += V(t) P_A(t);  pb <- exp(sb)
+        softmax_stats(hb, sb, qb_, vm, hh);
+        __builtin_amdgcn_sched_barrier(0);
+        block(kn, qa, sa, vc, pa, ha.o, sb, pb);
+        __builtin_amdgcn_sched_barrier(0);
+        vm_next = __builtin_amdgcn_readfirstlane(vmv);
     };
 
-    KTile ka, kb;
-    VTile va, vb;
-    issue_k(ka, tile(0));
-    issue_v(va, tile(0));
-    issue_k(kb, tile(1));
+    issue_k(kx, 0);
+    issue_v(vy, 0);    // stands in for "V(-1)": any finite values (its P is zero)
+    issue_k(ky, 1);
+    issue_v(vx, 0);
     __builtin_amdgcn_sched_barrier(0);
-    scores(ka, q, sa0, sa1);
-    // Positions >= len of the last real tile hold finite leftovers (the K/V fragment regions are zeroed once per
-    // call and only ever receive finite bf16), masked to P = 0.  After the last real tile the "next" scores are
-    // computed from wrapped-around K and dropped.
-    // The loop body is a PAIR of steps with a single exit (an exit between the two steps makes hipcc keep O in
-    // different registers in the two halves and copy it mid-chain); an odd tile count gets a tail step.
-    int i = 0;
-    for (; i + 1 < nreal; i += 2) {
-        // even step: V in va, next K in kb; refill vb <- V(i+1), ka <- K(i+2)
-        issue_v(vb, tile(i + 1));
-        issue_k(ka, tile(i + 2));
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch AHEAD of the tile that is about to be computed
-        step(kb, va, vmask[tile(i)], sa0, sa1, sb0, sb1);
-        __builtin_amdgcn_sched_barrier(0);
-        // odd step: V in vb, next K in ka; refill va <- V(i+2), kb <- K(i+3)
-        issue_v(va, tile(i + 2));
-        issue_k(kb, tile(i + 3));
-        __builtin_amdgcn_sched_barrier(0);
-        step(ka, vb, vmask[tile(i + 1)], sb0, sb1, sa0, sa1);
-        __builtin_amdgcn_sched_barrier(0);
+    {   // scores of pair (0, A)
+        const bf16x8 k0 = __builtin_bit_cast(bf16x8, kx.k0);
+        const u32x4 k1w = u32x4{kx.k1[0], kx.k1[1], 0x00003f80u, 0u};
+        const bf16x8 k1 = __builtin_bit_cast(bf16x8, k1w);
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qa.q0, zero, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qa.q1, sa, 0, 0, 0);
+        asm volatile("" :: "v"(k0), "v"(k1), "v"(qa.q0), "v"(qa.q1));
     }
-    if (i < nreal) step(kb, va, vmask[tile(i)], sa0, sa1, sb0, sb1);
-
-    // ---- the learned bias key/value (mha.py:265-268): one extra key at index `len`, rotated at position `len`,
-    //      always valid.  It is processed as a virtual tile built in registers: every K row is the bias key, only
-    //      key slot 0 is unmasked, V^T column 0 is the bias value.
-    {
-        KTile kbias;
-        const float* bk = p.bias_k + head * kDH;
-        const float* rc = p.rope + (long)len * kRopeRow + 16 * hh;
-        float e[12];
-#pragma unroll
-        for (int pp = 0; pp < 6; ++pp) {
-            const int i = 6 * hh + pp;
-            const float x1 = bk[i], x2 = bk[i + 12], c = rc[pp], sn = rc[8 + pp];
-            e[2 * pp] = x1 * c - x2 * sn;
-            e[2 * pp + 1] = x2 * c + x1 * sn;
-        }
-        kbias.k0 = u32x4{pack_bf16(e[0], e[1]), pack_bf16(e[2], e[3]), pack_bf16(e[4], e[5]), pack_bf16(e[6], e[7])};
-        kbias.k1 = u32x2{pack_bf16(e[8], e[9]), pack_bf16(e[10], e[11])};
-        // V^T fragment row d = lane&31 (24 = ones row, 25.. = zero); feature of row d = psi(d)
-        const int dpsi = 12 * ((ql >> 2) & 1) + 4 * (ql >> 3) + (ql & 3);
-        const float bvf = (ql < kDH) ? p.bias_v[head * kDH + dpsi] : (ql == kDH ? 1.f : 0.f);
-        VTile vbias;
-        vbias.v0 = u32x4{hh == 0 ? pack_bf16(bvf, 0.f) : 0u, 0u, 0u, 0u};   // key slot 0 = k-step 0, hh 0, j 0
-        vbias.v1 = u32x4{0u, 0u, 0u, 0u};
-        f32x16 c0, c1, d0, d1;
-        scores(kbias, q, c0, c1);
-        step(kbias, vbias, 0x1u, c0, c1, d0, d1);
+    // The loop body is a PAIR of tiles with a single exit (an exit between the two makes hipcc keep O in
+    // different registers in the two halves and copy it mid-chain); an odd tile count gets a tail tile.
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+        tile(t, kx, ky, vx, vy);
+        tile(t + 1, ky, kx, vy, vx);
     }
-    const float l0 = __shfl(st.o0[12], ql, 64);   // O^T row 24 = softmax denominator, held by lanes hh == 0
-    const float l1 = __shfl(st.o1[12], ql, 64);
-    const f32x16 o0 = st.o0, o1 = st.o1;
+    if (t < nt) {
+        tile(t, kx, ky, vx, vy);
+        // pending: P_B of the last tile (in pb) with V(last) = vx
+        hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vx.v0), pb.p0, hb.o, 0, 0, 0);
+        hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vx.v1), pb.p1, hb.o, 0, 0, 0);
+    } else {
+        hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vy.v0), pb.p0, hb.o, 0, 0, 0);
+        hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vy.v1), pb.p1, hb.o, 0, 0, 0);
+    }
+    const float l0 = __shfl(ha.o[12], ql, 64);   // O^T row 24 = softmax denominator, held by lanes hh == 0
+    const float l1 = __shfl(hb.o[12], ql, 64);
+    const f32x16 o0 = ha.o, o1 = hb.o;
     // ---- epilogue: registers 0..11 of lane-half hh are features 12*hh .. 12*hh+11 of this head
     {
         const int pos = qt0 * 32 + ql;
@@ -341,7 +313,8 @@ __global__ __launch_bounds__(256, 2) void k_flash(const FlashParams p) {
 
 void launch_flash(const FlashParams& p, hipStream_t s) {
     const int nqc = (p.ax.len + 63) / 64;
-    hipLaunchKernelGGL(k_flash, dim3(p.ax.nseq * nqc * 4), dim3(256), 0, s, p);
+    const int npair8 = (p.ax.nseq * 4 + 7) / 8;   // (sequence, head group) pairs, in groups of 8 (one per XCD)
+    hipLaunchKernelGGL(k_flash, dim3(npair8 * nqc * 8), dim3(256), 0, s, p);
 }
 
 }  // namespace mdg

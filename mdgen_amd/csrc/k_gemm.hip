@@ -127,6 +127,46 @@ __device__ __forceinline__ void epilogue_v_flash(const f32x16* acc /*[2 tt][3 ft
     }
 }
 
+// The learned bias key / value (mha.py:265-268: one extra key at index `len`, rotated at position `len` like every
+// key, :356-357; never masked) as a REAL entry of the K / V^T fragments: key slot len % 32 of tile len / 32 (the
+// fragment layout covers len + 1 keys).  Written by the workgroup of a sequence's last panel, wave w for its heads
+// 4w..4w+3, AFTER the same wave's K / V epilogues (which may have stored padding-row values into that slot: same wave,
+// same address, program order).  The attention kernel then needs no special case for it.
+__device__ __forceinline__ void write_bias_slots(const QkvParams& p, int seq, int w) {
+    const int lane = lane_id();
+    const int len = p.ax.len, nt = p.ax.ntile();
+    const int kt = len >> 5, sl = len & 31;
+    if (lane < 8) {   // K: (half hh, head hd) -> 12 rotated values = 16 B (k-step 0) + 8 B (k-step 1) of key slot sl
+        const int hd = lane & 3, hh = lane >> 2, head = 4 * w + hd;
+        const float* bk = p.bias_k + head * kDH;
+        const float* rc = p.rope + (long)len * kRopeRow + 16 * hh;
+        float e[12];
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) {
+            const int i = 6 * hh + pp;
+            const float x1 = bk[i], x2 = bk[i + 12], c = rc[pp], sn = rc[8 + pp];
+            e[2 * pp] = x1 * c - x2 * sn;
+            e[2 * pp + 1] = x2 * c + x1 * sn;
+        }
+        unsigned char* base = p.kf + ((long)(seq * kH + head) * nt + kt) * kFragBytes;
+        *reinterpret_cast<u32x4*>(base + (hh * 32 + sl) * 16) =
+            u32x4{pack_bf16(e[0], e[1]), pack_bf16(e[2], e[3]), pack_bf16(e[4], e[5]), pack_bf16(e[6], e[7])};
+        *reinterpret_cast<u32x2*>(base + 1024 + (hh * 32 + sl) * 8) = u32x2{pack_bf16(e[8], e[9]), pack_bf16(e[10], e[11])};
+    }
+    if (lane < kDH) {   // V^T: row d = lane; key slot sl = register r of lane-half hk: r = (sl & 3) + 4 (sl >> 3)
+        const int d = lane;
+        const int dpsi = 12 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3);   // feature of V^T row d (api.hip feat_vflash)
+        const int hk = (sl >> 2) & 1, r = (sl & 3) + 4 * (sl >> 3);
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) {
+            const int head = 4 * w + hd;
+            unsigned char* base = p.vf + ((long)(seq * kH + head) * nt + kt) * kFragBytes;
+            const uint32_t v = pack_bf16(p.bias_v[head * kDH + dpsi], 0.f);
+            *reinterpret_cast<uint16_t*>(base + (r >> 3) * 768 + hk * 384 + d * 16 + (r & 7) * 2) = (uint16_t)v;
+        }
+    }
+}
+
 template <bool SMALL>
 __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
@@ -167,6 +207,10 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
     } else {
         wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
         epilogue_v_flash(acc, w, p.bv, seq, ntile, tile0, p.vf);
+        if ((int)blockIdx.x - seq * p.panels_per_seq == p.panels_per_seq - 1) {   // the sequence's last panel
+            __builtin_amdgcn_sched_barrier(0);   // after this wave's own K / V stores
+            write_bias_slots(p, seq, w);
+        }
     }
 }
 

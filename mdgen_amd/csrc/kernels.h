@@ -86,7 +86,7 @@ struct FlashParams {
     const float *bias_k, *bias_v;  // natural fp32 [384]
     const float* rope;
     __bf16* obuf;           // [N][384]
-    const unsigned char* zero_page;   // 16 zero bytes (V^T padding rows d > 24); +128: eight bf16 1.0 (row 24)
+    const unsigned char* zero_page;   // 2 KB: zeros (V^T padding rows d > 24); eight bf16 1.0 at +128 and +896 (row 24)
 };
 
 struct EmbedParams {

@@ -23,8 +23,10 @@ constexpr int ITER = 256;
 #define FMA(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(c1), "v"(c2))
 #define MFMA(acc) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(fa), "v"(fb))
 template <int MODE>
-__global__ __launch_bounds__(256) void k(unsigned long long* out, float* sink, float seed) {
+__global__ __launch_bounds__(1024) void k(unsigned long long* out, float* sink, float seed) {
+    extern __shared__ float lds_pad[];   // 100 KB requested at launch: exactly one workgroup per CU
     const int lane = threadIdx.x & 63;
+    if (seed == 123.f) lds_pad[threadIdx.x] = seed;
     float v[16], w[8];
     unsigned u[8];
 #pragma unroll
@@ -89,24 +91,25 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, float* sink, f
 template <int MODE>
 void run(const char* name, double insts_per_iter, unsigned long long* out, float* sink) {
     printf("%-44s", name);
-    // waves per SIMD = blocks per CU (256 threads = 4 waves = 1 per SIMD); grid = 256 CUs x wps (all resident)
+    // ONE workgroup of 256 * wps threads per CU (100 KB of LDS each: a second one cannot be co-resident), so every
+    // SIMD holds exactly wps waves of it (a workgroup's waves are dealt round-robin over the 4 SIMDs)
+    hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     for (int wps = 1; wps <= 4; ++wps) {
-        const int grid = 256 * wps;
-        hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 0, 0, out, sink, 1.0f);
+        const int grid = 256;
+        hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256 * wps), 100 * 1024, 0, out, sink, 1.0f);
         hipDeviceSynchronize();
-        std::vector<unsigned long long> h(grid * 4);
-        hipMemcpy(h.data(), out, grid * 4 * 8, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> h(grid * 4 * wps);
+        hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
         std::sort(h.begin(), h.end());
-        const double cyc = (double)h[h.size() / 2] / ITER;
-        printf("  %dw/SIMD: %7.1f cyc/iter (%5.2f /inst/wave, %5.2f /inst/SIMD)", wps, cyc, cyc / insts_per_iter,
-               cyc / insts_per_iter / wps);
+        const double cyc = (double)h[h.size() / 2] / ITER, mx = (double)h.back() / ITER;
+        printf("  %dw/SIMD: %6.1f (max %6.1f) cyc/iter = %5.2f /inst/SIMD |", wps, cyc, mx, cyc / insts_per_iter / wps);
     }
     printf("\n");
 }
 
 int main() {
     unsigned long long* out; float* sink;
-    hipMalloc(&out, 4096 * 8 * 8); hipMalloc(&sink, 4);
+    hipMalloc(&out, 8192 * 8 * 8); hipMalloc(&sink, 4);
     run<0>("16 x v_exp_f32", 16, out, sink);
     run<1>("16 x v_cvt_pk_bf16_f32", 16, out, sink);
     run<2>("16 x v_max3_f32", 16, out, sink);
