@@ -641,8 +641,8 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 // Phase stamps for mdgen_profile_phase_trace (measurement only; p.trace is null in normal operation):
-// slot 0 start, 1 after LN prologue, per chunk c: 2+4c after fc1, 3+4c after GELU, 4+4c after the barrier,
-// 5+4c after fc2; 26 before the epilogue, 27 end, 28 HW_ID, 29 XCC_ID.
+// slot 0 start, 1 after LN prologue + fc1(0), per chunk c (12 chunks): 2+2c after GELU(c) || fc2(c-1), 3+2c after the
+// barrier + fc1(c+1); 26 before the epilogue, 27 end, 28 HW_ID, 29 XCC_ID.
 __device__ __forceinline__ void stamp(const MlpParams& p, int slot, unsigned long long v) {
     if (p.trace && lane_id() == 0) {
         const long i = ((long)blockIdx.x * 4 + wave_id()) * 32 + slot;
@@ -652,15 +652,77 @@ __device__ __forceinline__ void stamp(const MlpParams& p, int slot, unsigned lon
 __device__ __forceinline__ void stamp(const MlpParams& p, int slot) {
     if (p.trace) stamp(p, slot, __builtin_amdgcn_s_memtime());
 }
-// PF1 / PF2: weight prefetch depth (k-steps) of the fc1 / fc2 streams.  fc1 runs with y (96) + a1 (64)
-// accumulator registers live, fc2 with y only, so fc2 can afford the deeper ring.
-template <int PF1, int PF2>
+// One chunk = 128 hidden units.  Per chunk a wave runs
+//   X(c): fc1 for its 32 hidden units of chunk c                     48 MFMAs
+//   Y(c): GELU of X(c)'s accumulators -> hbuf[c & 1]  INTERLEAVED with  fc2 of chunk c-1 from hbuf[(c-1) & 1]
+//         8 k-steps of [6 MFMAs beside 4 GELU evaluations (~50 VALU, 8 of them transcendental) + 1 ds_write]
+// and one LDS barrier (hbuf[c & 1] complete, everybody out of hbuf[(c-1) & 1]).
+// Why: the GELU phase is VALU work of the same length as a GEMM phase, and the two workgroups of a CU run their
+// phases in lockstep, so with GELU as a phase of its own the matrix pipe idled through it (PMC round 2: MFMA busy
+// 38 %, VALU busy 42 %, next to nothing overlapped).  Inside ONE wave MFMAs and independent VALU work overlap
+// almost perfectly when interleaved finely (profiles/r02_issue_rate.txt: 8 MFMAs + 48 FMAs take 292 cycles, the
+// MFMAs alone 256) -- so the GELU of chunk c rides in the shadow of the fc2 MFMAs of chunk c-1 (double-buffered hbuf).
+// PF1: weight prefetch depth (k-steps) of the fc1 stream.
+constexpr int kHC = 128, kHRowB = kHC * 2, kNChunk = kF / kHC;
+
+// GELU of one (a, tt) group: hidden units 32 w + 8 a + 4 hh .. +3 of token row tt * 32 + tk -> 8 bytes of hbuf
+__device__ __forceinline__ void gelu_group(const f32x16* a1, const f32x4 (&b)[4], unsigned char* hw, int g, int w,
+                                           int hh, int tk) {
+    const int a = g >> 1, tt = g & 1;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(a1[tt][4 * a + i] + b[a][i]);
+    *reinterpret_cast<u32x2*>(hw + panel_off(tt * 32 + tk, (32 * w + 8 * a + 4 * hh) * 2, kHRowB)) =
+        u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+}
+
+// y += hbuf_prev (64 x 128) . W2 slab^T, eight k-steps, each carrying one GELU group of the current chunk
+__device__ __forceinline__ void fc2_with_gelu(const unsigned char* hr, const bf16x8* __restrict__ wfrag, f32x16* y,
+                                              const f32x16* a1, const f32x4 (&b)[4], unsigned char* hw, int w, int hh,
+                                              int tk) {
+    constexpr int KS = 8, PF = 2, WS = 96 * 64;
+    bf16x8 wring[PF + 1][3];
+    bf16x8 aring[2][2];
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) wring[pf][f] = wfrag[(size_t)f * WS + pf * 64];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) aring[0][t] = panel_frag(hr, kHRowB, t, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + PF < KS) {
+#pragma unroll
+            for (int f = 0; f < 3; ++f) wring[(ks + PF) % (PF + 1)][f] = wfrag[(size_t)f * WS + (ks + PF) * 64];
+        }
+        if (ks + 1 < KS) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) aring[(ks + 1) & 1][t] = panel_frag(hr, kHRowB, t, ks + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+                y[t * 3 + f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[ks & 1][t], wring[ks % (PF + 1)][f], y[t * 3 + f], 0, 0, 0);
+        gelu_group(a1, b, hw, ks, w, hh, tk);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);   // nine VALU / transcendental
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int PF1>
 __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
-    constexpr int HC = 256, HROWB = HC * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kPanelBytes + kPanel * HROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kPanelBytes + 2 * kPanel * kHRowB];
     unsigned char* panel = smem;
-    unsigned char* hbuf = smem + kPanelBytes;
-    PanelRows* pr = reinterpret_cast<PanelRows*>(hbuf);  // aliases hbuf: live only outside the chunk loop
+    unsigned char* hb0 = smem + kPanelBytes;
+    unsigned char* hb1 = hb0 + kPanel * kHRowB;
+    PanelRows* pr = reinterpret_cast<PanelRows*>(hb0);  // aliases hbuf 0: live only outside the chunk loop
     stamp(p, 0);
     if (p.trace) {
         stamp(p, 28, __builtin_amdgcn_s_getreg((31 << 11) | 4));    // HW_REG_HW_ID
@@ -675,48 +737,59 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
     const int lane = lane_id();
     f32x16 y[6];
     zero_acc<6>(y);
-    for (int c = 0; c < kF / HC; ++c) {
-        f32x16 a1[4];
-        zero_acc<4>(a1);
-        wave_gemm<2, 2, 24, true, PF1>(panel, kRowB, 0, 0, p.w1 + (size_t)(8 * c + 2 * w) * 24 * 64 + lane, 24 * 64, a1);
-        stamp(p, 2 + 4 * c);
-        // Everything the GELU section derives from the lane id (bias offsets, swizzled hbuf addresses) is
-        // recomputed here from an opaque copy: computed from the plain lane id it is loop-invariant, gets hoisted
-        // out of the chunk loop, spilled, and every reload sits behind an s_waitcnt vmcnt(0) -- which also
-        // serialised the eight bias loads (one L2 round trip each, 6k cycles per chunk).
+    f32x16 a1[2];
+    zero_acc<2>(a1);
+    wave_gemm<2, 1, 24, true, PF1>(panel, kRowB, 0, 0, p.w1 + (size_t)w * 24 * 64 + lane, 24 * 64, a1);
+    // per-chunk pieces.  Everything the GELU section derives from the lane id (bias offsets, swizzled hbuf addresses)
+    // is recomputed per chunk from an opaque copy: computed from the plain lane id it is loop-invariant, gets hoisted
+    // out of the chunk loop, spilled, and every reload sits behind an s_waitcnt vmcnt(0) that drains the loads in flight.
+    auto load_bias = [&](int c, f32x4 (&b)[4], int& hh, int& tk) {
         int gl = lane;
         asm volatile("" : "+v"(gl));
-        const int hh = gl >> 5, tk = gl & 31;
-        f32x4 b[2][4];   // all eight bias vectors requested together (uniform base + 32-bit offset)
+        hh = gl >> 5;
+        tk = gl & 31;
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const unsigned bo = (unsigned)(c * HC + 64 * w + 32 * ft + 8 * a + 4 * hh) * 4u;
-                b[ft][a] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.b1) + bo);
-            }
-        if (c > 0) __syncthreads();  // previous chunk's fc2 reads of hbuf are complete
-#pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int hid_local = 64 * w + 32 * ft + 8 * a + 4 * hh;
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    float g[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) g[i] = gelu_erf(a1[ft * 2 + tt][4 * a + i] + b[ft][a][i]);
-                    *reinterpret_cast<u32x2*>(hbuf + panel_off(tt * 32 + tk, hid_local * 2, HROWB)) =
-                        u32x2{pack_bf16(g[0], g[1]), pack_bf16(g[2], g[3])};
-                }
-            }
+        for (int a = 0; a < 4; ++a) {   // the four bias vectors of this wave's 32 hidden units, requested together
+            const unsigned bo = (unsigned)(c * kHC + 32 * w + 8 * a + 4 * hh) * 4u;
+            b[a] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.b1) + bo);
         }
-        stamp(p, 3 + 4 * c);
-        __syncthreads();
-        stamp(p, 4 + 4 * c);
-        wave_gemm<2, 3, 16, false, PF2>(hbuf, HROWB, 0, 0, p.w2 + ((size_t)(3 * w) * 96 + 16 * c) * 64 + lane, 96 * 64, y);
-        stamp(p, 5 + 4 * c);
+    };
+    auto stage_y = [&](int c) {   // GELU(c) -> hbuf[c & 1]  ||  fc2(c - 1) from hbuf[(c - 1) & 1];  c >= 1
+        unsigned char* hw = (c & 1) ? hb1 : hb0;
+        const unsigned char* hr = (c & 1) ? hb0 : hb1;
+        f32x4 b[4];
+        int hh, tk;
+        load_bias(c, b, hh, tk);
+        unsigned w2off = (unsigned)((((3 * w) * 96 + 8 * (c - 1)) * 64 + lane) * 16);
+        asm volatile("" : "+v"(w2off));
+        fc2_with_gelu(hr, reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(p.w2) + w2off), y, a1, b, hw,
+                      w, hh, tk);
+    };
+    auto stage_x = [&](int c) {   // fc1 of chunk c
+        zero_acc<2>(a1);
+        wave_gemm<2, 1, 24, true, PF1>(panel, kRowB, 0, 0, p.w1 + (size_t)(4 * c + w) * 24 * 64 + lane, 24 * 64, a1);
+    };
+    {   // chunk 0: nothing to overlap the GELU with yet
+        f32x4 b[4];
+        int hh, tk;
+        load_bias(0, b, hh, tk);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) gelu_group(a1, b, hb0, g, w, hh, tk);
     }
+    stamp(p, 2);
+    lds_barrier();   // hbuf[0] is complete
+    stage_x(1);
+#pragma unroll 1
+    for (int c = 1; c + 1 < kNChunk; ++c) {
+        stage_y(c);
+        lds_barrier();   // hbuf[c & 1] is complete; every wave has left hbuf[(c - 1) & 1]
+        stage_x(c + 1);
+    }
+    stage_y(kNChunk - 1);
+    stamp(p, 3);
+    lds_barrier();
+    wave_gemm<2, 3, 8, false, 3>((kNChunk & 1) ? hb0 : hb1, kHRowB, 0, 0,
+                                 p.w2 + ((size_t)(3 * w) * 96 + 8 * (kNChunk - 1)) * 64 + lane, 96 * 64, y);
     __syncthreads();
     setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
     __syncthreads();
@@ -825,7 +898,7 @@ void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
 }
 void launch_mlp(const MlpParams& p, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-    hipLaunchKernelGGL((k_mlp<2, 2>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((k_mlp<3>), dim3(grid), dim3(256), 0, s, p);
 }
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
