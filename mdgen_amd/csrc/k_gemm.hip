@@ -641,8 +641,8 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 // Phase stamps for mdgen_profile_phase_trace (measurement only; p.trace is null in normal operation):
-// slot 0 start, 1 after LN prologue + fc1(0), per chunk c (12 chunks): 2+2c after GELU(c) || fc2(c-1), 3+2c after the
-// barrier + fc1(c+1); 26 before the epilogue, 27 end, 28 HW_ID, 29 XCC_ID.
+// slot 0 start, 1 after LN prologue, 2 after fc1(0) + GELU(0); chunk c = 1..11: 1+2c after the barrier + fc1(c), 2+2c
+// after GELU(c) || fc2(c-1); 24 after fc2(11); 26 before the epilogue, 27 end, 28 HW_ID, 29 XCC_ID.
 __device__ __forceinline__ void stamp(const MlpParams& p, int slot, unsigned long long v) {
     if (p.trace && lane_id() == 0) {
         const long i = ((long)blockIdx.x * 4 + wave_id()) * 32 + slot;
@@ -676,29 +676,90 @@ __device__ __forceinline__ void gelu_group(const f32x16* a1, const f32x4 (&b)[4]
         u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
 }
 
-// y += hbuf_prev (64 x 128) . W2 slab^T, eight k-steps, each carrying one GELU group of the current chunk
-__device__ __forceinline__ void fc2_with_gelu(const unsigned char* hr, const bf16x8* __restrict__ wfrag, f32x16* y,
-                                              const f32x16* a1, const f32x4 (&b)[4], unsigned char* hw, int w, int hh,
-                                              int tk) {
-    constexpr int KS = 8, PF = 2, WS = 96 * 64;
+// Operands a stage needs for its first k-steps, requested during the LAST k-steps of the stage before it (weights
+// are L2-resident but an L2 round trip is several hundred cycles, and both waves of a SIMD start their stages
+// together: with the first loads issued at the stage's own start every stage -- 24 per panel -- began with that
+// bubble; phase stamps showed both stage kinds at ~55 % of their MFMA / VALU bound).
+struct XPre {            // fc1 stage
+    bf16x8 w[3];         // W1 fragments of k-steps 0..2
+    bf16x8 a[2];         // panel fragments (two 32-token tiles) of k-step 0
+};
+struct YPre {            // fc2 stage
+    bf16x8 w[2][3];      // W2 fragments of k-steps 0, 1 (three feature tiles each)
+    bf16x8 a[2];         // hbuf fragments of k-step 0
+};
+constexpr int kW2S = 96 * 64;   // bf16x8 elements between two feature tiles of the packed W2
+
+// X(c): a1 = fc1 of this wave's 32 hidden units of chunk c (transposed: D[hidden][token]), 24 k-steps.  Its last
+// k-steps request what the following Y stage starts with.
+// It also requests the fc1 bias of its own 32 hidden units (b1c), consumed by the GELU of that Y stage.
+template <bool NEXT>
+__device__ __forceinline__ void stage_x(const unsigned char* panel, const bf16x8* __restrict__ w1c, const XPre& pre, f32x16* a1,
+                                        const float* b1c, f32x4 (&b)[4], const bf16x8* __restrict__ w2n,
+                                        const unsigned char* hrn, YPre& nxt) {
+    constexpr int KS = 24, PF = 3;
+    bf16x8 wring[PF + 1];
+    bf16x8 aring[2][2];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) wring[i] = pre.w[i];
+    aring[0][0] = pre.a[0];
+    aring[0][1] = pre.a[1];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + PF < KS) wring[(ks + PF) % (PF + 1)] = w1c[(ks + PF) * 64];
+        if (ks + 1 < KS) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) aring[(ks + 1) & 1][t] = panel_frag(panel, kRowB, t, ks + 1);
+        }
+        if (NEXT && (ks == KS - 3 || ks == KS - 2)) {
+#pragma unroll
+            for (int f = 0; f < 3; ++f) nxt.w[ks - (KS - 3)][f] = w2n[(size_t)f * kW2S + (ks - (KS - 3)) * 64];
+        }
+        if (NEXT && ks == KS - 1) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) nxt.a[t] = panel_frag(hrn, kHRowB, t, 0);
+        }
+        if (ks == KS - 4) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) b[a] = *reinterpret_cast<const f32x4*>(b1c + 8 * a);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            a1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[ks % (PF + 1)], aring[ks & 1][t], a1[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Y(c): y += hbuf[(c-1)&1] (64 x 128) . W2 slab^T, eight k-steps, each carrying one GELU group of chunk c (written to
+// hbuf[c&1]); its last k-steps request what the following X stage starts with.
+template <bool NEXT>
+__device__ __forceinline__ void stage_y(const unsigned char* hr, const bf16x8* __restrict__ w2c, const YPre& pre, f32x16* y,
+                                        const f32x16* a1, const f32x4 (&b)[4], unsigned char* hw, int w, int hh, int tk,
+                                        const unsigned char* panel, const bf16x8* __restrict__ w1n, XPre& nxt) {
+    constexpr int KS = 8, PF = 2;
     bf16x8 wring[PF + 1][3];
     bf16x8 aring[2][2];
 #pragma unroll
-    for (int pf = 0; pf < PF; ++pf)
+    for (int i = 0; i < PF; ++i)
 #pragma unroll
-        for (int f = 0; f < 3; ++f) wring[pf][f] = wfrag[(size_t)f * WS + pf * 64];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) aring[0][t] = panel_frag(hr, kHRowB, t, 0);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int f = 0; f < 3; ++f) wring[i][f] = pre.w[i][f];
+    aring[0][0] = pre.a[0];
+    aring[0][1] = pre.a[1];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         if (ks + PF < KS) {
 #pragma unroll
-            for (int f = 0; f < 3; ++f) wring[(ks + PF) % (PF + 1)][f] = wfrag[(size_t)f * WS + (ks + PF) * 64];
+            for (int f = 0; f < 3; ++f) wring[(ks + PF) % (PF + 1)][f] = w2c[(size_t)f * kW2S + (ks + PF) * 64];
         }
         if (ks + 1 < KS) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) aring[(ks + 1) & 1][t] = panel_frag(hr, kHRowB, t, ks + 1);
+        }
+        if (NEXT && ks >= KS - 3) nxt.w[ks - (KS - 3)] = w1n[(ks - (KS - 3)) * 64];
+        if (NEXT && ks == KS - 1) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) nxt.a[t] = panel_frag(panel, kRowB, t, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -734,62 +795,53 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
     __syncthreads();
     stamp(p, 1);
     const int w = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform, and the compiler knows it
-    const int lane = lane_id();
+    const int lane = lane_id(), hh = lane >> 5, tk = lane & 31;
+    // per-lane views of the packed weights / bias: W1 fragment stream of chunk c starts at w1l + c * (4 * 24 * 64)
+    const bf16x8* w1l = p.w1 + (size_t)w * 24 * 64 + lane;
+    const bf16x8* w2l = p.w2 + (size_t)(3 * w) * 96 * 64 + lane;      // chunk c: + 8 c * 64
+    const float* b1l = p.b1 + 32 * w + 4 * hh;                        // chunk c: + 128 c; group a: + 8 a
+    constexpr size_t W1C = (size_t)4 * 24 * 64;
     f32x16 y[6];
     zero_acc<6>(y);
     f32x16 a1[2];
-    zero_acc<2>(a1);
-    wave_gemm<2, 1, 24, true, PF1>(panel, kRowB, 0, 0, p.w1 + (size_t)w * 24 * 64 + lane, 24 * 64, a1);
-    // per-chunk pieces.  Everything the GELU section derives from the lane id (bias offsets, swizzled hbuf addresses)
-    // is recomputed per chunk from an opaque copy: computed from the plain lane id it is loop-invariant, gets hoisted
-    // out of the chunk loop, spilled, and every reload sits behind an s_waitcnt vmcnt(0) that drains the loads in flight.
-    auto load_bias = [&](int c, f32x4 (&b)[4], int& hh, int& tk) {
-        int gl = lane;
-        asm volatile("" : "+v"(gl));
-        hh = gl >> 5;
-        tk = gl & 31;
+    XPre xp;
+    YPre yp;
+    {   // what X(0) starts with: nothing ran before it that could have prefetched
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {   // the four bias vectors of this wave's 32 hidden units, requested together
-            const unsigned bo = (unsigned)(c * kHC + 32 * w + 8 * a + 4 * hh) * 4u;
-            b[a] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.b1) + bo);
-        }
-    };
-    auto stage_y = [&](int c) {   // GELU(c) -> hbuf[c & 1]  ||  fc2(c - 1) from hbuf[(c - 1) & 1];  c >= 1
-        unsigned char* hw = (c & 1) ? hb1 : hb0;
-        const unsigned char* hr = (c & 1) ? hb0 : hb1;
-        f32x4 b[4];
-        int hh, tk;
-        load_bias(c, b, hh, tk);
-        unsigned w2off = (unsigned)((((3 * w) * 96 + 8 * (c - 1)) * 64 + lane) * 16);
-        asm volatile("" : "+v"(w2off));
-        fc2_with_gelu(hr, reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(p.w2) + w2off), y, a1, b, hw,
-                      w, hh, tk);
-    };
-    auto stage_x = [&](int c) {   // fc1 of chunk c
-        zero_acc<2>(a1);
-        wave_gemm<2, 1, 24, true, PF1>(panel, kRowB, 0, 0, p.w1 + (size_t)(4 * c + w) * 24 * 64 + lane, 24 * 64, a1);
-    };
-    {   // chunk 0: nothing to overlap the GELU with yet
-        f32x4 b[4];
-        int hh, tk;
-        load_bias(0, b, hh, tk);
+        for (int i = 0; i < 3; ++i) xp.w[i] = w1l[i * 64];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) xp.a[t] = panel_frag(panel, kRowB, t, 0);
+    }
+    f32x4 b[4];
+    zero_acc<2>(a1);
+    stage_x<false>(panel, w1l, xp, a1, b1l, b, nullptr, nullptr, yp);
+    {   // chunk 0: nothing to overlap its GELU with yet; request X(1)'s first operands under it
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xp.w[i] = w1l[W1C + i * 64];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) xp.a[t] = panel_frag(panel, kRowB, t, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 8; ++g) gelu_group(a1, b, hb0, g, w, hh, tk);
     }
     stamp(p, 2);
     lds_barrier();   // hbuf[0] is complete
-    stage_x(1);
 #pragma unroll 1
-    for (int c = 1; c + 1 < kNChunk; ++c) {
-        stage_y(c);
+    for (int c = 1; c < kNChunk; ++c) {
+        unsigned char* hw = (c & 1) ? hb1 : hb0;           // GELU(c) writes it
+        const unsigned char* hr = (c & 1) ? hb0 : hb1;     // fc2(c - 1) reads it
+        // X(c): fc1 of chunk c; requests the first fc2(c - 1) operands
+        zero_acc<2>(a1);
+        stage_x<true>(panel, w1l + (size_t)c * W1C, xp, a1, b1l + c * kHC, b, w2l + (size_t)8 * (c - 1) * 64, hr, yp);
+        stamp(p, 1 + 2 * c);
+        // Y(c): GELU(c) -> hw  ||  fc2(c - 1) from hr; requests the first operands of X(c + 1) (clamped at the end)
+        const int cn = c + 1 < kNChunk ? c + 1 : c;
+        stage_y<true>(hr, w2l + (size_t)8 * (c - 1) * 64, yp, y, a1, b, hw, w, hh, tk, panel, w1l + (size_t)cn * W1C, xp);
+        stamp(p, 2 + 2 * c);
         lds_barrier();   // hbuf[c & 1] is complete; every wave has left hbuf[(c - 1) & 1]
-        stage_x(c + 1);
     }
-    stage_y(kNChunk - 1);
-    stamp(p, 3);
-    lds_barrier();
-    wave_gemm<2, 3, 8, false, 3>((kNChunk & 1) ? hb0 : hb1, kHRowB, 0, 0,
-                                 p.w2 + ((size_t)(3 * w) * 96 + 8 * (kNChunk - 1)) * 64 + lane, 96 * 64, y);
+    wave_gemm<2, 3, 8, false, 3>((kNChunk & 1) ? hb0 : hb1, kHRowB, 0, 0, w2l + (size_t)8 * (kNChunk - 1) * 64, kW2S, y);
+    stamp(p, 24);
     __syncthreads();
     setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
     __syncthreads();

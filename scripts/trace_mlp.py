@@ -28,11 +28,13 @@ torch.cuda.synchronize()
 t = buf.cpu().numpy().reshape(nwg, 4, 32).astype(np.int64)
 t0 = t[..., 0].min()
 rel = t[..., :28] - t0
-names = ["prologue"]
-for c in range(6):
-    names += [f"c{c}.fc1", f"c{c}.gelu", f"c{c}.barrier", f"c{c}.fc2"]
-names += ["tail-barriers", "epilogue"]
-slots = [1] + [s for c in range(6) for s in (2 + 4 * c, 3 + 4 * c, 4 + 4 * c, 5 + 4 * c)] + [26, 27]
+names = ["prologue", "fc1(0)+gelu(0)"]
+slots = [1, 2]
+for c in range(1, 12):
+    names += [f"c{c}.barrier+fc1", f"c{c}.gelu||fc2"]
+    slots += [1 + 2 * c, 2 + 2 * c]
+names += ["fc2(11)", "tail-barriers", "epilogue"]
+slots += [24, 26, 27]
 prev = 0
 print(f"workgroups {nwg}; kernel span {rel[..., 27].max()} ticks (s_memtime)")
 agg = {}
