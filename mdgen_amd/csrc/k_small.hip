@@ -346,6 +346,154 @@ __global__ __launch_bounds__(256) void k_ipa_attn(const IpaAttnParams p) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same attention for long sequences (ATLAS: L = 256, 4 x 256 x 256 logits per group): one workgroup per
+// (group, head, 256-query tile), one thread per query, keys staged through LDS 32 at a time.
+// What the per-thread kernel above pays per (query, key) PAIR is paid here once per KEY by the staging step: the
+// global loads (every lane of a wave wanted the same key row: a chain of L dependent L2 round trips per thread) and
+// the rotation of the 16 key / value points into the global frame (ipa.py:143-147: R_j p + t_j).  The inner loop
+// then reads the tile from LDS with wave-uniform addresses (broadcast, conflict-free) and is pure fp32 FMA work;
+// the softmax is renormalised once per 32-key tile (one max, one exp per key) instead of twice per key.
+// 4.1 ms -> ~0.1 ms per launch at cfg-4 (B 1, L 256, 49 prepared steps).
+// -------------------------------------------------------------------------------------------------
+constexpr int kIpaKT = 32;   // keys per LDS tile
+__global__ __launch_bounds__(256) void k_ipa_attn_tiled(const IpaAttnParams p) {
+    __shared__ __attribute__((aligned(16))) float sk[kIpaKT][32];    // k vectors of this head
+    __shared__ __attribute__((aligned(16))) float sv[kIpaKT][32];    // v vectors
+    __shared__ __attribute__((aligned(16))) float skp[kIpaKT][24];   // key points, global frame [pt][xyz]
+    __shared__ __attribute__((aligned(16))) float svp[kIpaKT][24];   // value points, global frame
+    __shared__ float sm[kIpaKT];                                     // key mask (0 beyond L: see below)
+    const int nqt = (p.L + 255) / 256;
+    const int qt = blockIdx.x % nqt;
+    const int hd = (blockIdx.x / nqt) & 3;
+    const long g = blockIdx.x / (nqt * 4);
+    const int b = (int)(g % p.B);
+    const int tid = threadIdx.x;
+    const int i = qt * 256 + tid;
+    const bool qok = i < p.L;
+    const int ic = qok ? i : p.L - 1;     // idle threads shadow the last query (loads stay in range), never store
+    const long gi = g * p.L + ic;
+    const float* pi = p.proj + gi * kIpaProj;
+    float Ri[9], ti[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ri[k] = p.rot[((long)b * p.L + ic) * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ti[k] = p.trans[((long)b * p.L + ic) * 3 + k];
+    const float mi = p.mask_bl[(long)b * p.L + ic];
+    const float qk_scale = 0.10206207261596575f;                    // sqrt(1/(3*32))
+    float q[32], qp[8][3];
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pi + hd * 32 + c);
+        q[c] = v[0] * qk_scale; q[c + 1] = v[1] * qk_scale; q[c + 2] = v[2] * qk_scale; q[c + 3] = v[3] * qk_scale;
+    }
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt)
+        rot_apply(Ri, ti, pi[384 + hd * 8 + pt], pi[416 + hd * 8 + pt], pi[448 + hd * 8 + pt], qp[pt][0], qp[pt][1],
+                  qp[pt][2]);
+    const float hwraw = p.head_w[hd];
+    const float sp = (hwraw > 20.f) ? hwraw : log1pf(expf(hwraw));  // torch softplus (threshold 20)
+    const float hwh = -0.5f * sp * 0.09622504486493763f;            // -1/2 softplus(w_h) sqrt(1/108)
+    float o[32], op[8][3];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) op[pt][0] = op[pt][1] = op[pt][2] = 0.f;
+    float mrun = -3.0e38f, den = 0.f;
+    // staging roles: thread -> (key of the tile, 8-float slice / point index)
+    const int skey = tid >> 3, ssub = tid & 7;
+    for (int j0 = 0; j0 < p.L; j0 += kIpaKT) {
+        __syncthreads();   // the previous tile has been consumed
+        {
+            const int j = j0 + skey;
+            const int jc = j < p.L ? j : p.L - 1;
+            const float* pj = p.proj + (g * p.L + jc) * kIpaProj;
+            const f32x4 kk = *reinterpret_cast<const f32x4*>(pj + 128 + hd * 64 + 4 * ssub);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(pj + 128 + hd * 64 + 32 + 4 * ssub);
+            float Rj[9], tj[3];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Rj[k] = p.rot[((long)b * p.L + jc) * 9 + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tj[k] = p.trans[((long)b * p.L + jc) * 3 + k];
+            float kx, ky, kz, vx, vy, vz;
+            rot_apply(Rj, tj, pj[480 + hd * 16 + ssub], pj[544 + hd * 16 + ssub], pj[608 + hd * 16 + ssub], kx, ky, kz);
+            rot_apply(Rj, tj, pj[480 + hd * 16 + 8 + ssub], pj[544 + hd * 16 + 8 + ssub], pj[608 + hd * 16 + 8 + ssub], vx,
+                      vy, vz);
+            *reinterpret_cast<f32x4*>(&sk[skey][4 * ssub]) = kk;
+            *reinterpret_cast<f32x4*>(&sv[skey][4 * ssub]) = vv;
+            skp[skey][3 * ssub] = kx; skp[skey][3 * ssub + 1] = ky; skp[skey][3 * ssub + 2] = kz;
+            svp[skey][3 * ssub] = vx; svp[skey][3 * ssub + 1] = vy; svp[skey][3 * ssub + 2] = vz;
+            // keys beyond L do not exist: mark them with a NaN-free sentinel that the consumer turns into weight 0
+            if (ssub == 0) sm[skey] = j < p.L ? p.mask_bl[(long)b * p.L + jc] : -1.0f;
+        }
+        __syncthreads();
+        float lg[kIpaKT];
+        float tmax = -3.0e38f;
+#pragma unroll
+        for (int jj = 0; jj < kIpaKT; ++jj) {
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < 32; c += 4) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(&sk[jj][c]);
+                dot += q[c] * kv[0] + q[c + 1] * kv[1] + q[c + 2] * kv[2] + q[c + 3] * kv[3];
+            }
+            float d2 = 0.f;
+#pragma unroll
+            for (int pt = 0; pt < 8; ++pt) {
+                const float dx = qp[pt][0] - skp[jj][3 * pt], dy = qp[pt][1] - skp[jj][3 * pt + 1],
+                            dz = qp[pt][2] - skp[jj][3 * pt + 2];
+                d2 += dx * dx + dy * dy + dz * dz;
+            }
+            const float mj = sm[jj];
+            const float l = dot + hwh * d2 + 1e5f * (mi * mj - 1.0f);   // ipa.py:161-203
+            lg[jj] = mj < 0.f ? -3.0e38f : l;
+            tmax = fmaxf(tmax, lg[jj]);
+        }
+        const float mnew = fmaxf(mrun, tmax);
+        const float alpha = expf(mrun - mnew);
+        mrun = mnew;
+        den *= alpha;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) o[c] *= alpha;
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt) {
+            op[pt][0] *= alpha; op[pt][1] *= alpha; op[pt][2] *= alpha;
+        }
+#pragma unroll
+        for (int jj = 0; jj < kIpaKT; ++jj) {
+            const float pw = lg[jj] > -1.0e38f ? expf(lg[jj] - mnew) : 0.f;
+            den += pw;
+#pragma unroll
+            for (int c = 0; c < 32; c += 4) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(&sv[jj][c]);
+                o[c] += pw * vv[0]; o[c + 1] += pw * vv[1]; o[c + 2] += pw * vv[2]; o[c + 3] += pw * vv[3];
+            }
+#pragma unroll
+            for (int pt = 0; pt < 8; ++pt) {
+                op[pt][0] += pw * svp[jj][3 * pt];
+                op[pt][1] += pw * svp[jj][3 * pt + 1];
+                op[pt][2] += pw * svp[jj][3 * pt + 2];
+            }
+        }
+    }
+    if (!qok) return;
+    const float inv = 1.0f / den;
+    __bf16* f = p.feat + gi * kIpaFeat;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) f[hd * 32 + c] = (__bf16)(o[c] * inv);
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {
+        const float gx = op[pt][0] * inv - ti[0], gy = op[pt][1] * inv - ti[1], gz = op[pt][2] * inv - ti[2];
+        const float lx = Ri[0] * gx + Ri[3] * gy + Ri[6] * gz;   // R^T (p - t)  (rigid_utils.py:1061-1073)
+        const float ly = Ri[1] * gx + Ri[4] * gy + Ri[7] * gz;
+        const float lz = Ri[2] * gx + Ri[5] * gy + Ri[8] * gz;
+        f[128 + hd * 8 + pt] = (__bf16)lx;
+        f[160 + hd * 8 + pt] = (__bf16)ly;
+        f[192 + hd * 8 + pt] = (__bf16)lz;
+        f[224 + hd * 8 + pt] = (__bf16)sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
+    }
+}
+
 // ---- launchers ----------------------------------------------------------------------------------
 // =================================================================================================
 // Flow-matching training target, forward only.
@@ -447,6 +595,11 @@ void launch_add_inplace(float* dst, const float* src, long n, hipStream_t s) {
     hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n);
 }
 void launch_ipa_attn(const IpaAttnParams& p, hipStream_t s) {
+    if (p.L >= 24) {   // long sequences: keys staged through LDS, one thread per query
+        const int nqt = (p.L + 255) / 256;
+        hipLaunchKernelGGL(k_ipa_attn_tiled, dim3((unsigned)((long)p.ngroups * 4 * nqt)), dim3(256), 0, s, p);
+        return;
+    }
     const long total = (long)p.ngroups * p.L * 4;
     hipLaunchKernelGGL(k_ipa_attn, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
 }
