@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--workload", default="tetrapeptide_fwdsim_crop4_T1000_B16", choices=list(WORKLOADS))
     ap.add_argument("--euler-steps", type=int, default=49, help="Euler steps S per inference() call (reference: 49)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
+                    help="operand precision of the GEMM family / attention (fp32 = tolerance mode, ~10x slower)")
     ap.add_argument("--streams", type=int, default=None, help="library option 'streams' (default 2; 1 = single stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -200,7 +202,7 @@ def main():
     tps = "_tps_" in a.workload
     cfg = ModelConfig(crop=L, num_frames=T, abs_pos_emb=abs_pos, sim_condition=not tps, tps_condition=tps)
     sd = synth_state_dict(cfg, 0)
-    w = NewMDGenWrapper(cfg, device=dev)
+    w = NewMDGenWrapper(cfg, device=dev, precision=a.precision)
     w.model.load_state_dict(sd)
     if a.streams is not None:
         w.model.set_option("streams", a.streams)
@@ -288,7 +290,8 @@ def main():
         out = {
             "metric": "sampled MD frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if a.precision == "bf16" else "f32",
             "data": "synthetic (seeded random-init weights, synthetic peptide frames/torsions, CPU-seeded noise)",
             "config": {"workload": a.workload, "batch_per_gpu": B, "num_frames": T, "crop": L,
                        "euler_steps": S, "hipgraph": use_graph, "parallelism": f"batch-sharded x{world}, no collective"},

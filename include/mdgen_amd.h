@@ -70,6 +70,8 @@ typedef struct mdgen_ws_layout {
     size_t mask_bl;    /* fp32 compact mask[:,0]      [B][L]                           */
     size_t rel7;       /* fp32 TPS relative frames    [2][B][L][7]                     */
     size_t tgrid;      /* fp32 per-step times         [S][B]                           */
+    size_t f32_scratch;/* fp32 path: LN out | q,k,v | attention out | MLP hidden | IPA features (0 bytes unless the
+                          context keeps fp32 weights)                                            */
 } mdgen_ws_layout;
 
 const char* mdgen_last_error(void);
@@ -89,6 +91,11 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
 /* Run-time options (no environment variables are read by the library):
  *   "streams"          1..8, default 2: contiguous sub-batches of an Euler rollout run on this many concurrent
  *                      streams (the caller's + context-owned ones, fork/join by events inside the call);
+ *   "keep_fp32_weights" 0/1, default 0; set to 1 BEFORE handing weights over to keep an fp32 copy of each (137 MB);
+ *   "precision"        16 (default): bf16 MFMA operands, fp32 accumulate / softmax / LayerNorm / residual stream
+ *                      (rel-L2 4-6e-3 per network evaluation against the fp32 reference);
+ *                      32: fp32 operands everywhere (v_mfma_f32_32x32x2_f32, csrc/k_fp32.hip), the reference's own
+ *                      arithmetic -- a tolerance mode ~10x slower; needs keep_fp32_weights;
  *   "residue_l4_path"  residue-axis attention sub-layer when L == 4: 2 (default) one kernel for the whole
  *                      sub-layer, 1 attention inside the QKV kernel + separate out-projection, 0 the general
  *                      L <= 8 path.  All three compute mha.py:258-397 + latent_model.py:457-462.

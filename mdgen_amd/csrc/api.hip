@@ -107,6 +107,9 @@ struct mdgen_ctx {
     bool inv_freq_set = false;
     bool prof_on = false;
     // run-time options (mdgen_ctx_set_option)
+    int opt_precision = 16;     // GEMM / attention operand precision: 16 = bf16 MFMA path, 32 = fp32 path (k_fp32.hip)
+    int opt_keep_fp32 = 0;      // keep an fp32 copy of every weight handed over (required by precision 32)
+    std::map<std::string, float*> w32;   // fp32 copies, natural layout, keyed by the reference's state_dict key
     int opt_streams = 2;        // concurrent sub-batch streams of the Euler rollout (1 = caller's stream only)
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
     unsigned long long* phase_trace = nullptr;   // mdgen_profile_phase_trace target (device), consumed by one launch
@@ -479,6 +482,14 @@ extern "C" int32_t mdgen_ctx_set_weight(mdgen_ctx* c, const char* key, const flo
         return r;
     }
     LAUNCHCHK();
+    if (c->opt_keep_fp32) {
+        size_t n = 1;
+        for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+        float*& dst = c->w32[key];
+        if (!dst)
+            if (int e = c->dalloc(&dst, n)) return e;
+        HIPCHK(hipMemcpyAsync(dst, data, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
     c->provided[key] = true;
     c->finalized = false;
     return 0;
@@ -501,6 +512,14 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     if (n == "streams") {
         if (value < 1 || value > mdgen_ctx::kMaxSide + 1) return fail(-2, "streams must be in 1..%d", mdgen_ctx::kMaxSide + 1);
         c->opt_streams = value;
+    } else if (n == "keep_fp32_weights") {
+        if (value != 0 && value != 1) return fail(-2, "keep_fp32_weights must be 0 or 1");
+        c->opt_keep_fp32 = value;
+    } else if (n == "precision") {
+        if (value != 16 && value != 32) return fail(-2, "precision must be 16 (bf16 operands) or 32 (fp32 operands)");
+        if (value == 32 && (!c->opt_keep_fp32 || c->w32.empty()))
+            return fail(-6, "precision 32 needs the fp32 weight copies: set option keep_fp32_weights = 1 before loading weights");
+        c->opt_precision = value;
     } else if (n == "residue_l4_path") {
         if (value < 0 || value > 2) return fail(-2, "residue_l4_path must be 0, 1 or 2");
         c->opt_residue_l4 = value;
@@ -594,6 +613,9 @@ extern "C" int32_t mdgen_workspace_layout(const mdgen_ctx* c, const mdgen_shape*
     o->mask_bl = take((size_t)B * L * 4);
     o->rel7 = take((size_t)2 * B * L * 7 * 4);
     o->tgrid = take((size_t)S * B * 4);
+    // fp32 path scratch: LN output [rows][384] | q,k,v [rows][1152] | attention output [rows][384] | MLP hidden
+    // [rows][1536] | IPA features [Mp][256]   (only when the context keeps fp32 weights)
+    o->f32_scratch = take(c->opt_keep_fp32 ? (size_t)maxrows * (kC + 3 * kC + kC + kF) * 4 + (size_t)Mp * kIpaFeat * 4 : 0);
     o->total_bytes = off;
     return 0;
 }
@@ -650,6 +672,64 @@ static Run sub_run(const Run& r, int b0, int Bs, hipStream_t stream) {
     v.modp = r.modp + (long)b0 * r.mod_group_stride;
     v.ipa_out_p = r.ipa_out_p + (long)b0 * r.L * kC;
     return v;
+}
+
+// ---- fp32-operand path (option "precision" = 32; kernels in k_fp32.hip) ------------------------------------------
+struct F32Bufs {
+    float *y, *qkv, *att, *hid, *feat;
+};
+static F32Bufs f32_bufs(const Run& r) {
+    const long maxrows = r.N > r.Mp ? r.N : r.Mp;
+    float* b = (float*)(r.ws + r.lay.f32_scratch);
+    F32Bufs o;
+    o.y = b;
+    o.qkv = o.y + maxrows * kC;
+    o.att = o.qkv + maxrows * 3 * kC;
+    o.hid = o.att + maxrows * kC;
+    o.feat = o.hid + maxrows * kF;
+    return o;
+}
+static const float* w32(const mdgen_ctx* c, const std::string& key) {
+    auto it = c->w32.find(key);
+    return it == c->w32.end() ? nullptr : it->second;
+}
+#define W32(var, key)                                                                      \
+    const float* var = w32(r.c, key);                                                      \
+    if (!var) return fail(-6, "fp32 copy of weight '%s' is missing (option keep_fp32_weights)", std::string(key).c_str())
+
+// one attention sub-layer, fp32: LN + modulate -> q, k, v -> RoPE -> softmax attention -> out-projection + gated residual
+static int attn_sublayer_fp32(const Run& r, const std::string& pre, float* h, long nrows, const AxisMap& ax,
+                              const ModMap& mm, int shift, int scale, int gate, const MaskMap& mk, long pos_div, int pos_mod) {
+    const F32Bufs b = f32_bufs(r);
+    W32(wq, pre + "q_proj.weight"); W32(bq, pre + "q_proj.bias");
+    W32(wk, pre + "k_proj.weight"); W32(bk, pre + "k_proj.bias");
+    W32(wv, pre + "v_proj.weight"); W32(bv, pre + "v_proj.bias");
+    W32(wo, pre + "out_proj.weight"); W32(bo, pre + "out_proj.bias");
+    W32(biask, pre + "bias_k"); W32(biasv, pre + "bias_v");
+    const ModMap none{nullptr, 1, 1, 0, 0};
+    launch32_ln_mod(h, nrows, mm, shift, scale, 0, 1e-6f, b.y, r.s);
+    const float qscale = 1.0f / std::sqrt((float)kDH);   // mha.py:263 q *= head_dim ** -0.5
+    launch32_linear(b.y, kC, wq, kC, bq, nrows, kC, kC, 4, b.qkv, 3 * kC, 0, none, 0, 0, qscale, r.s);
+    launch32_linear(b.y, kC, wk, kC, bk, nrows, kC, kC, 0, b.qkv, 3 * kC, kC, none, 0, 0, 0.f, r.s);
+    launch32_linear(b.y, kC, wv, kC, bv, nrows, kC, kC, 0, b.qkv, 3 * kC, 2 * kC, none, 0, 0, 0.f, r.s);
+    launch32_rope(b.qkv, nrows, 3 * kC, pos_div, pos_mod, r.c->inv_freq, r.s);
+    launch32_attn(b.qkv, 3 * kC, ax, mk, biask, biasv, r.c->inv_freq, b.att, r.s);
+    launch32_linear(b.att, kC, wo, kC, bo, nrows, kC, kC, 2, h, kC, 0, mm, gate, 1, 0.f, r.s);
+    LAUNCHCHK();
+    return 0;
+}
+
+static int mlp_sublayer_fp32(const Run& r, const std::string& pre, float* h, long nrows, const ModMap& mm, int shift, int scale,
+                             int gate) {
+    const F32Bufs b = f32_bufs(r);
+    W32(w1, pre + "fc1.weight"); W32(b1, pre + "fc1.bias");
+    W32(w2, pre + "fc2.weight"); W32(b2, pre + "fc2.bias");
+    const ModMap none{nullptr, 1, 1, 0, 0};
+    launch32_ln_mod(h, nrows, mm, shift, scale, 0, 1e-6f, b.y, r.s);
+    launch32_linear(b.y, kC, w1, kC, b1, nrows, kF, kC, 1, b.hid, kF, 0, none, 0, 0, 0.f, r.s);
+    launch32_linear(b.hid, kF, w2, kF, b2, nrows, kC, kF, 2, h, kC, 0, mm, gate, 1, 0.f, r.s);
+    LAUNCHCHK();
+    return 0;
 }
 
 static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, const AxisMap& ax, const ModMap& mm,
@@ -780,6 +860,39 @@ static int ipa_stack(const Run& r, float* hbuf, const float* rel7, const float* 
     for (int i = 0; i < c->nl; ++i) {
         const IpaW& w = c->ipa[i];
         ModMap mm{r.mod() + c->ipa_off(i), r.L, r.B, r.mod_step_stride, r.mod_group_stride};
+        if (c->opt_precision == 32) {   // ---- fp32 operands: ipa_norm -> four projections -> point attention -> linear_out
+            const std::string pre = "ipa_layers." + std::to_string(i) + ".";
+            const F32Bufs fb = f32_bufs(r);
+            W32(wq, pre + "ipa.linear_q.weight"); W32(bq, pre + "ipa.linear_q.bias");
+            W32(wkv, pre + "ipa.linear_kv.weight"); W32(bkv, pre + "ipa.linear_kv.bias");
+            W32(wqp, pre + "ipa.linear_q_points.weight"); W32(bqp, pre + "ipa.linear_q_points.bias");
+            W32(wkp, pre + "ipa.linear_kv_points.weight"); W32(bkp, pre + "ipa.linear_kv_points.bias");
+            W32(wout, pre + "ipa.linear_out.weight"); W32(bout, pre + "ipa.linear_out.bias");
+            const ModMap none{nullptr, 1, 1, 0, 0};
+            float* proj = (float*)(r.ws + r.lay.ipa_proj);
+            launch32_ln_mod(hbuf, r.Mp, ModMap{w.gamma_beta, 1, 1, 0, 0}, 1, 0, 1, 1e-5f, fb.y, r.s);
+            launch32_linear(fb.y, kC, wq, kC, bq, r.Mp, 128, kC, 0, proj, kIpaProj, 0, none, 0, 0, 0.f, r.s);
+            launch32_linear(fb.y, kC, wkv, kC, bkv, r.Mp, 256, kC, 0, proj, kIpaProj, 128, none, 0, 0, 0.f, r.s);
+            launch32_linear(fb.y, kC, wqp, kC, bqp, r.Mp, 96, kC, 0, proj, kIpaProj, 384, none, 0, 0, 0.f, r.s);
+            launch32_linear(fb.y, kC, wkp, kC, bkp, r.Mp, 192, kC, 0, proj, kIpaProj, 480, none, 0, 0, 0.f, r.s);
+            IpaAttnParams ap{};
+            ap.proj = proj;
+            ap.rot = rot;
+            ap.trans = trans;
+            ap.mask_bl = (const float*)(r.ws + r.lay.mask_bl);
+            ap.head_w = w.head_w;
+            ap.feat = nullptr;
+            ap.feat32 = fb.feat;
+            ap.ngroups = G;
+            ap.B = r.B;
+            ap.L = r.L;
+            launch_ipa_attn(ap, r.s);
+            launch32_linear(fb.feat, kIpaFeat, wout, kIpaFeat, bout, r.Mp, kC, kIpaFeat, 2, hbuf, kC, 0, none, 0, 0, 0.f, r.s);
+            LAUNCHCHK();
+            if (int e = attn_sublayer_fp32(r, pre + "mha_l.attn.", hbuf, r.Mp, ax, mm, 0, 1, 2, mk, 1, r.L)) return e;
+            if (int e = mlp_sublayer_fp32(r, pre, hbuf, r.Mp, mm, 3, 4, 5)) return e;
+            continue;
+        }
         LnLinearParams lp{};
         lp.h = hbuf;
         lp.nrows = r.Mp;
@@ -893,6 +1006,25 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
     AxisMap axL{r.B * r.T, r.L, r.B * r.T, 0, r.L, 1};
     AxisMap axT{r.B * r.L, r.T, r.L, r.T * r.L, 1, r.L};
     MaskMap mk{r.mask, 0};
+    if (c->opt_precision == 32) {   // ---- fp32 operands (k_fp32.hip): same dataflow, one kernel per reference op group
+        for (int i = 0; i < c->nl; ++i) {
+            const std::string pre = "layers." + std::to_string(i) + ".";
+            ModMap mm{modstep + c->trunk_off(i), r.T * r.L, r.B, 0, r.mod_group_stride};
+            if (int er = attn_sublayer_fp32(r, pre + "mha_l.attn.", h, r.N, axL, mm, 0, 1, 2, mk, 1, r.L)) return er;
+            if (int er = attn_sublayer_fp32(r, pre + "mha_t.attn.", h, r.N, axT, mm, 3, 4, 5, mk, r.L, r.T)) return er;
+            if (int er = mlp_sublayer_fp32(r, pre, h, r.N, mm, 6, 7, 8)) return er;
+            if (trace_h) HIPCHK(hipMemcpyAsync(trace_h + (size_t)(i + 1) * r.N * kC, h, hbytes, hipMemcpyDeviceToDevice, r.s));
+        }
+        W32(wfin, "emb_to_latent.linear.weight");
+        W32(bfin, "emb_to_latent.linear.bias");
+        const F32Bufs fb = f32_bufs(r);
+        const ModMap fm{modstep + c->final_off(), r.T * r.L, r.B, 0, r.mod_group_stride};
+        const ModMap none{nullptr, 1, 1, 0, 0};
+        launch32_ln_mod(h, r.N, fm, 0, 1, 0, 1e-6f, fb.y, r.s);
+        launch32_linear(fb.y, kC, wfin, kC, bfin, r.N, r.D, kC, euler ? 3 : 0, euler ? x : out, r.D, 0, none, 0, 0, dt, r.s);
+        LAUNCHCHK();
+        return 0;
+    }
     for (int i = 0; i < c->nl; ++i) {
         const TrunkW& w = c->trunk[i];
         ModMap mm{modstep + c->trunk_off(i), r.T * r.L, r.B, 0, r.mod_group_stride};
@@ -928,6 +1060,7 @@ static int make_run(Run* r, mdgen_ctx* c, const mdgen_shape* sh, int S, int t_sh
     if (ws_bytes < r->lay.total_bytes)
         return fail(-7, "workspace too small: %zu < %zu bytes", ws_bytes, r->lay.total_bytes);
     if (((uintptr_t)ws & 255) != 0) return fail(-7, "workspace must be 256-byte aligned");
+    if (c->opt_precision == 32 && !c->opt_keep_fp32) return fail(-6, "precision 32 requires option keep_fp32_weights");
     r->c = c;
     r->B = sh->B;
     r->T = sh->T;
@@ -973,7 +1106,7 @@ extern "C" int32_t mdgen_denoiser_forward(mdgen_ctx* c, const mdgen_shape* sh, c
     if (int e = prepare(r, t, nullptr)) return e;
     if (trace_ipa)
         HIPCHK(hipMemcpyAsync(trace_ipa, r.ws + r.lay.ipa_out, (size_t)r.B * r.L * kC * 4, hipMemcpyDeviceToDevice, r.s));
-    const int nv = plan_views(r.B, r.T, r.L, 1);
+    const int nv = c->opt_precision == 32 ? 1 : plan_views(r.B, r.T, r.L, 1);
     if (nv <= 1) return denoise_step(r, 0, const_cast<float*>(x), out, 0, 0.f, trace_h);
     if (trace_h) return fail(-2, "trace_h is not available when the batch needs more than one launch view");
     int b0 = 0;
@@ -999,7 +1132,7 @@ static void linspace01(int n, std::vector<float>* out) {
 static int n_streams(const Run& r) {
     int n = r.c->opt_streams;
     if (n > r.B) n = r.B;
-    if (n < 2 || r.c->prof_on || r.N < 4096) return 1;
+    if (n < 2 || r.c->prof_on || r.N < 4096 || r.c->opt_precision == 32) return 1;
     return n;
 }
 
@@ -1014,7 +1147,8 @@ static int euler_steps(const Run& v, const std::vector<float>& tg, float* x) {
 static int euler_body(const Run& r, const std::vector<float>& tg, float* x) {
     if (int e = prepare(r, nullptr, tg.data())) return e;
     const int ns = n_streams(r);
-    const int nv = plan_views(r.B, r.T, r.L, ns);   // >= ns views; more when a view would exceed kMaxViewTokens
+    // >= ns views; more when a view would exceed kMaxViewTokens (the fp32 kernels index with 64 bits: one view)
+    const int nv = r.c->opt_precision == 32 ? 1 : plan_views(r.B, r.T, r.L, ns);
     if (nv == 0) return fail(-2, "sample too large for one launch");
     if (nv == 1) return euler_steps(r, tg, x);
     // contiguous sub-batch views, view i on stream i % ns (fork after the shared preparation, join at the end)
@@ -1103,7 +1237,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)c->opt_residue_l4};
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)c->opt_residue_l4, (uint64_t)c->opt_precision};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
 
@@ -1163,7 +1297,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
                                  (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)c->opt_residue_l4,
-                                 (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14};
+                                 (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision};
     return replay_or_capture(c, key, r.s, body);
 }
 

@@ -1,0 +1,261 @@
+// k_fp32.hip -- the fp32-operand ("reference tolerance") form of the denoiser's GEMM family and attention.
+//
+// The product path feeds the matrix cores bf16 operands (rel-L2 4-6e-3 per network evaluation).  The reference
+// itself runs fp32 throughout (mha.py:19-23 softmax in fp32, rigid_utils.py:318-322), and BASELINE.md section 3 gates
+// fp32 kernels at rel-L2 <= 1e-5 / 1e-3 A.  This file is the same arithmetic with fp32 operands, selected by the
+// context option "precision" = 32: plain row-major fp32 buffers, one kernel per reference op group,
+//   k32_ln_mod      LayerNorm (no affine, eps 1e-6) + adaLN modulate, or affine LayerNorm (eps 1e-5)
+//                   (layers.py:14-15, latent_model.py:373)
+//   k32_linear      y = x W^T + b on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate: an fmaf chain),
+//                   with the epilogues the layers need: store, exact-erf GELU (layers.py:77-84), gated residual
+//                   h += gate * y (latent_model.py:462,476,481), Euler update / velocity (integrators.py:106)
+//   k32_rope        q * dh^-1/2 and rotate-half RoPE of q, k in place (mha.py:260-263, 356-357)
+//   k32_attn        softmax(q k^T [+ bias key] with key padding) v, streaming over key tiles (mha.py:265-268, 359-396)
+// It is a tolerance mode, not a fast path: ~10x slower than the bf16 kernels (157 TFLOP/s fp32 MFMA peak vs 2.5
+// PFLOP/s bf16, and an unfused structure).  It shares everything that is fp32 already: time embedding, adaLN table,
+// token embedding, IPA point attention, SE(3) kernels.
+#include "kernels.h"
+
+namespace mdg {
+
+// one wave per row; rows in natural token order
+__global__ __launch_bounds__(256) void k32_ln_mod(const float* __restrict__ x, long nrows, ModMap mm, int shift_chunk,
+                                                  int scale_chunk, int affine, float eps, float* __restrict__ y) {
+    const long row = (long)blockIdx.x * 4 + wave_id();
+    if (row >= nrows) return;
+    const int lane = lane_id();
+    const float* xr = x + row * kC;
+    float v[6];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v[i] = xr[lane + 64 * i];
+        s += v[i];
+    }
+    const float mean = wave_sum(s) * (1.0f / kC);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v[i] -= mean;
+        q += v[i] * v[i];
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kC) + eps);
+    const float* mod = mm.mod + (affine ? 0 : mm.row_off(row));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = lane + 64 * i;
+        const float sc = mod[scale_chunk * kC + c], sh = mod[shift_chunk * kC + c];
+        y[row * kC + c] = v[i] * rstd * (affine ? sc : 1.0f + sc) + sh;
+    }
+}
+
+// C[n][col0 + m] (ldc) = sum_k A[n][k] (lda) W[m][k] (ldw) + bias[m], 64 x 64 tile per workgroup, 32 x 32 per wave.
+struct LinearParams {
+    const float* a; int lda;
+    const float* w; int ldw;
+    const float* bias;
+    long n; int m, k;
+    int mode;             // 0 store, 1 GELU store, 2 gated residual into c, 3 Euler: c += dt * val, 4 store * scale
+    float* c; int ldc; int col0;
+    ModMap mm; int gate_chunk; int gated;   // mode 2
+    float scalar;                           // mode 3: dt; mode 4: scale
+};
+
+__global__ __launch_bounds__(256) void k32_linear(const LinearParams p) {
+    constexpr int BK = 16, LD = BK + 1;
+    __shared__ float As[64 * LD];
+    __shared__ float Ws[64 * LD];
+    const int lane = lane_id(), w = wave_id();
+    const long row0 = (long)blockIdx.x * 64;
+    const int colt = blockIdx.y * 64;
+    const int wr = w >> 1, wc = w & 1;   // wave -> 32 x 32 sub-tile
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = opaque_zero();   // a real zero tuple, not the inline constant (common.h)
+    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 4;   // staging: 64 rows x 4 float4 per tile
+    for (int k0 = 0; k0 < p.k; k0 += BK) {
+        {
+            const long ar = row0 + lr < p.n ? row0 + lr : p.n - 1;
+            const int wrow = colt + lr < p.m ? colt + lr : p.m - 1;
+            float av[4], wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = k0 + lk + j;
+                av[j] = kk < p.k ? p.a[ar * p.lda + kk] : 0.f;
+                wv[j] = kk < p.k ? p.w[(long)wrow * p.ldw + kk] : 0.f;
+            }
+            __syncthreads();   // previous tile consumed
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                As[lr * LD + lk + j] = av[j];
+                Ws[lr * LD + lk + j] = wv[j];
+            }
+        }
+        __syncthreads();
+        const int i = lane & 31, kh = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = As[(wr * 32 + i) * LD + kk + kh];
+            const float b = Ws[(wc * 32 + i) * LD + kk + kh];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    const int col = colt + wc * 32 + (lane & 31);
+    if (col >= p.m) return;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long row = row0 + wr * 32 + mfma_row(r, hh);
+        if (row >= p.n) continue;
+        float v = acc[r] + bias;
+        float* dst = p.c + row * p.ldc + p.col0 + col;
+        if (p.mode == 0) {
+            *dst = v;
+        } else if (p.mode == 1) {
+            *dst = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        } else if (p.mode == 2) {
+            const float g = p.gated ? p.mm.mod[p.mm.row_off(row) + p.gate_chunk * kC + col] : 1.0f;
+            *dst = *dst + g * v;
+        } else if (p.mode == 3) {
+            *dst = *dst + p.scalar * v;
+        } else {
+            *dst = v * p.scalar;
+        }
+    }
+}
+
+// q (pre-scaled by the caller's linear, mode 4) and k: rotate-half RoPE in place.  buf[token][ld]: q at col 0, k at col
+// 384 (v at 768 untouched).  pos = (token / pos_div) % pos_mod.  One thread per (token, head, pair i < 12).
+__global__ void k32_rope(float* __restrict__ buf, long ntok, int ld, long pos_div, int pos_mod,
+                         const float* __restrict__ inv_freq) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = ntok * kH * 12 * 2;
+    if (idx >= total) return;
+    const int i = (int)(idx % 12);
+    const int hd = (int)((idx / 12) % kH);
+    const int which = (int)((idx / (12 * kH)) & 1);
+    const long token = idx / (12 * kH * 2);
+    const int pos = (int)((token / pos_div) % pos_mod);
+    const float ang = (float)pos * inv_freq[i];
+    const float c = cosf(ang), s = sinf(ang);
+    float* v = buf + token * ld + which * kC + hd * kDH;
+    const float x1 = v[i], x2 = v[i + 12];
+    v[i] = x1 * c - x2 * s;          // x * cos + rotate_half(x) * sin, rotate_half(x) = [-x2, x1]
+    v[i + 12] = x2 * c + x1 * s;
+}
+
+// Attention of one axis, fp32: one workgroup per (sequence, head, 256-query block), one thread per query, keys
+// staged through LDS 64 at a time (broadcast reads), online softmax renormalised once per tile.  The learned bias
+// key / value (rotated at position len) is the last key; padded keys are excluded (mha.py:367-373 -inf fill).
+__global__ __launch_bounds__(256) void k32_attn(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
+                                                const float* __restrict__ bias_k, const float* __restrict__ bias_v,
+                                                const float* __restrict__ inv_freq, float* __restrict__ out) {
+    constexpr int KT = 64;
+    __shared__ __attribute__((aligned(16))) float sk[KT][kDH];
+    __shared__ __attribute__((aligned(16))) float sv[KT][kDH];
+    __shared__ float sm[KT];
+    const int len = ax.len;
+    const int nqb = (len + 255) / 256;
+    const int qb = blockIdx.x % nqb;
+    const int hd = (blockIdx.x / nqb) % kH;
+    const int seq = blockIdx.x / (nqb * kH);
+    const int tid = threadIdx.x;
+    const int qi = qb * 256 + tid;
+    const bool qok = qi < len;
+    const long qtok = ax.token(seq, qok ? qi : len - 1);
+    float q[kDH], o[kDH];
+#pragma unroll
+    for (int d = 0; d < kDH; ++d) {
+        q[d] = qkv[qtok * ld + hd * kDH + d];
+        o[d] = 0.f;
+    }
+    float mrun = -3.0e38f, den = 0.f;
+    for (int j0 = 0; j0 < len + 1; j0 += KT) {
+        __syncthreads();
+        for (int e = tid; e < KT * kDH; e += 256) {   // stage: key row j0 + e / 24, feature e % 24
+            const int jj = e / kDH, d = e % kDH;
+            const int j = j0 + jj;
+            float kvv = 0.f, vvv = 0.f;
+            if (j < len) {
+                const long t = ax.token(seq, j);
+                kvv = qkv[t * ld + kC + hd * kDH + d];
+                vvv = qkv[t * ld + 2 * kC + hd * kDH + d];
+            } else if (j == len) {   // bias key: rotate-half RoPE at position len
+                const int i = d % 12;
+                const float ang = (float)len * inv_freq[i];
+                const float c = cosf(ang), s = sinf(ang);
+                const float x1 = bias_k[hd * kDH + i], x2 = bias_k[hd * kDH + i + 12];
+                kvv = d < 12 ? x1 * c - x2 * s : x2 * c + x1 * s;
+                vvv = bias_v[hd * kDH + d];
+            }
+            sk[jj][d] = kvv;
+            sv[jj][d] = vvv;
+        }
+        if (tid < KT) {
+            const int j = j0 + tid;
+            sm[tid] = j < len ? (mk.at(ax.token(seq, j)) != 0.f ? 1.f : 0.f) : (j == len ? 1.f : 0.f);
+        }
+        __syncthreads();
+        float lg[KT];
+        float tmax = -3.0e38f;
+#pragma unroll
+        for (int jj = 0; jj < KT; ++jj) {
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < kDH; d += 4) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(&sk[jj][d]);
+                dot += q[d] * kv[0] + q[d + 1] * kv[1] + q[d + 2] * kv[2] + q[d + 3] * kv[3];
+            }
+            lg[jj] = sm[jj] != 0.f ? dot : -3.0e38f;
+            tmax = fmaxf(tmax, lg[jj]);
+        }
+        const float mnew = fmaxf(mrun, tmax);
+        const float alpha = expf(mrun - mnew);
+        mrun = mnew;
+        den *= alpha;
+#pragma unroll
+        for (int d = 0; d < kDH; ++d) o[d] *= alpha;
+#pragma unroll
+        for (int jj = 0; jj < KT; ++jj) {
+            const float pw = lg[jj] > -1.0e38f ? expf(lg[jj] - mnew) : 0.f;
+            den += pw;
+#pragma unroll
+            for (int d = 0; d < kDH; d += 4) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(&sv[jj][d]);
+                o[d] += pw * vv[0]; o[d + 1] += pw * vv[1]; o[d + 2] += pw * vv[2]; o[d + 3] += pw * vv[3];
+            }
+        }
+    }
+    if (!qok) return;
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int d = 0; d < kDH; ++d) out[qtok * kC + hd * kDH + d] = o[d] * inv;
+}
+
+// x += dt * v (Euler) is mode 3 of k32_linear; bf16 IPA features -> fp32 is avoided by the fp32 feature output of the
+// IPA attention kernels (IpaAttnParams::feat32).
+
+void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chunk, int scale_chunk, int affine, float eps,
+                     float* y, hipStream_t s) {
+    hipLaunchKernelGGL(k32_ln_mod, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, x, nrows, mm, shift_chunk, scale_chunk,
+                       affine, eps, y);
+}
+void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
+                     float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s) {
+    LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, c, ldc, col0, mm, gate_chunk, gated, scalar};
+    hipLaunchKernelGGL(k32_linear, dim3((unsigned)((n + 63) / 64), (unsigned)((m + 63) / 64)), dim3(256), 0, s, p);
+}
+void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, hipStream_t s) {
+    const long total = ntok * kH * 12 * 2;
+    hipLaunchKernelGGL(k32_rope, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, buf, ntok, ld, pos_div, pos_mod,
+                       inv_freq);
+}
+void launch32_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
+                   const float* inv_freq, float* out, hipStream_t s) {
+    const int nqb = (ax.len + 255) / 256;
+    hipLaunchKernelGGL(k32_attn, dim3((unsigned)((long)ax.nseq * kH * nqb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
+                       inv_freq, out);
+}
+
+}  // namespace mdg

@@ -258,6 +258,30 @@ __device__ __forceinline__ void rot_apply(const float* R, const float* t, float 
     oz = R[6] * x + R[7] * y + R[8] * z + t[2];
 }
 
+// concat features of one (token, head): [ o(32) | o_pt.x(8) | o_pt.y(8) | o_pt.z(8) | |o_pt|(8) ] at their places in the
+// 256-wide row (ipa.py:226-254), bf16 for the MFMA path or fp32 for the fp32 path
+__device__ __forceinline__ void ipa_store_features(const IpaAttnParams& p, long gi, int hd, const float (&o)[32],
+                                                   const float (&op)[8][3], float inv, const float (&Ri)[9],
+                                                   const float (&ti)[3]) {
+    auto put = [&](int col, float v) {
+        if (p.feat32) p.feat32[gi * kIpaFeat + col] = v;
+        else p.feat[gi * kIpaFeat + col] = (__bf16)v;
+    };
+#pragma unroll
+    for (int c = 0; c < 32; ++c) put(hd * 32 + c, o[c] * inv);
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {
+        const float gx = op[pt][0] * inv - ti[0], gy = op[pt][1] * inv - ti[1], gz = op[pt][2] * inv - ti[2];
+        const float lx = Ri[0] * gx + Ri[3] * gy + Ri[6] * gz;   // R^T (p - t)  (rigid_utils.py:1061-1073)
+        const float ly = Ri[1] * gx + Ri[4] * gy + Ri[7] * gz;
+        const float lz = Ri[2] * gx + Ri[5] * gy + Ri[8] * gz;
+        put(128 + hd * 8 + pt, lx);
+        put(160 + hd * 8 + pt, ly);
+        put(192 + hd * 8 + pt, lz);
+        put(224 + hd * 8 + pt, sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ipa_attn(const IpaAttnParams p) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)p.ngroups * p.L * 4;
@@ -330,20 +354,7 @@ __global__ __launch_bounds__(256) void k_ipa_attn(const IpaAttnParams p) {
         }
     }
     const float inv = 1.0f / den;
-    __bf16* f = p.feat + gi * kIpaFeat;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) f[hd * 32 + c] = (__bf16)(o[c] * inv);
-#pragma unroll
-    for (int pt = 0; pt < 8; ++pt) {
-        const float gx = op[pt][0] * inv - ti[0], gy = op[pt][1] * inv - ti[1], gz = op[pt][2] * inv - ti[2];
-        const float lx = Ri[0] * gx + Ri[3] * gy + Ri[6] * gz;   // R^T (p - t)  (rigid_utils.py:1061-1073)
-        const float ly = Ri[1] * gx + Ri[4] * gy + Ri[7] * gz;
-        const float lz = Ri[2] * gx + Ri[5] * gy + Ri[8] * gz;
-        f[128 + hd * 8 + pt] = (__bf16)lx;
-        f[160 + hd * 8 + pt] = (__bf16)ly;
-        f[192 + hd * 8 + pt] = (__bf16)lz;
-        f[224 + hd * 8 + pt] = (__bf16)sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
-    }
+    ipa_store_features(p, gi, hd, o, op, inv, Ri, ti);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -478,20 +489,7 @@ __global__ __launch_bounds__(256) void k_ipa_attn_tiled(const IpaAttnParams p) {
     }
     if (!qok) return;
     const float inv = 1.0f / den;
-    __bf16* f = p.feat + gi * kIpaFeat;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) f[hd * 32 + c] = (__bf16)(o[c] * inv);
-#pragma unroll
-    for (int pt = 0; pt < 8; ++pt) {
-        const float gx = op[pt][0] * inv - ti[0], gy = op[pt][1] * inv - ti[1], gz = op[pt][2] * inv - ti[2];
-        const float lx = Ri[0] * gx + Ri[3] * gy + Ri[6] * gz;   // R^T (p - t)  (rigid_utils.py:1061-1073)
-        const float ly = Ri[1] * gx + Ri[4] * gy + Ri[7] * gz;
-        const float lz = Ri[2] * gx + Ri[5] * gy + Ri[8] * gz;
-        f[128 + hd * 8 + pt] = (__bf16)lx;
-        f[160 + hd * 8 + pt] = (__bf16)ly;
-        f[192 + hd * 8 + pt] = (__bf16)lz;
-        f[224 + hd * 8 + pt] = (__bf16)sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
-    }
+    ipa_store_features(p, gi, hd, o, op, inv, Ri, ti);
 }
 
 // ---- launchers ----------------------------------------------------------------------------------

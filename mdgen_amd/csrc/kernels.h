@@ -107,6 +107,7 @@ struct IpaAttnParams {
     const float* mask_bl;   // [B][L]
     const float* head_w;    // [4]
     __bf16* feat;           // [M][256]
+    float* feat32;          // fp32 mode: features written here (fp32) instead of `feat`
     int ngroups, B, L;
 };
 
@@ -128,6 +129,15 @@ void launch_path_plan(const float* t, const float* x0, const float* x1, float* x
 void launch_masked_mse(const float* pred, const float* target, const float* mask, float* loss, long per_sample, long B,
                        hipStream_t s);
 void launch_ipa_attn(const IpaAttnParams& p, hipStream_t s);
+
+// fp32-operand path (k_fp32.hip)
+void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chunk, int scale_chunk, int affine, float eps,
+                     float* y, hipStream_t s);
+void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
+                     float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s);
+void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, hipStream_t s);
+void launch32_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
+                   const float* inv_freq, float* out, hipStream_t s);
 
 // small kernels (k_small.hip)
 void launch_temb(const float* t_rows, int nrows, float tmul, const float* w0, const float* b0, const float* w2,

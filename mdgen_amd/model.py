@@ -32,10 +32,16 @@ def _frames(fr):
 
 
 class LatentMDGenModel:
-    def __init__(self, cfg: ModelConfig, device: Optional[torch.device] = None):
+    def __init__(self, cfg: ModelConfig, device: Optional[torch.device] = None, precision: str = "bf16"):
+        """`precision`: "bf16" (default) -- bf16 MFMA operands, fp32 accumulate / softmax / LayerNorm / residual stream;
+        "fp32" -- the reference's own arithmetic on fp32 operands (csrc/k_fp32.hip), a tolerance mode ~10x slower.
+        A model built with "fp32" keeps fp32 weight copies and can switch at run time (`set_precision`)."""
         if isinstance(cfg, ModelConfig) is False:
             cfg = ModelConfig.from_args(cfg)
+        if precision not in ("bf16", "fp32"):
+            raise L.MdgenError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
         self.cfg = cfg
+        self.precision = precision
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise L.MdgenError("mdgen_amd.LatentMDGenModel needs a GPU (gfx950); there is no CPU path")
@@ -45,6 +51,8 @@ class LatentMDGenModel:
         self._ctx = C.c_void_p()
         with torch.cuda.device(self.device):
             check(lib.mdgen_ctx_create(C.byref(self._ctx), C.byref(d)))
+        if precision == "fp32":
+            check(lib.mdgen_ctx_set_option(self._ctx, b"keep_fp32_weights", 1))
         # small LRU caches, keyed independently: a workspace per (B, T, L, S, t_shared) and the persistent staging
         # buffers of the Euler rollout per (B, T, L) -- stable device pointers are what lets a captured hipGraph be
         # replayed, so alternating shapes (ATLAS inference runs on full sequences, L = 39..724) or alternating
@@ -89,6 +97,17 @@ class LatentMDGenModel:
             check(lib.mdgen_ctx_finalize(self._ctx, s))
             torch.cuda.current_stream().synchronize()   # packing kernels read `keep` asynchronously
         self._loaded = True
+        if self.precision == "fp32":
+            self.set_precision("fp32")
+        return self
+
+    def set_precision(self, precision: str):
+        """Switch between the bf16 MFMA path and the fp32 path (the latter only on a model constructed with
+        precision="fp32", which keeps the fp32 weight copies)."""
+        if precision not in ("bf16", "fp32"):
+            raise L.MdgenError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        check(lib.mdgen_ctx_set_option(self._ctx, b"precision", 32 if precision == "fp32" else 16))
+        self.precision = precision
         return self
 
     def eval(self):

@@ -169,6 +169,8 @@ def build_parser():
     p.add_argument("--n_chunks", type=int, default=1)
     p.add_argument("--per_block", action="store_true",
                    help="one inference() call per block from Python instead of the multi-block device rollout")
+    p.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
+                   help="bf16 MFMA operands (default) or the fp32-operand tolerance mode (~10x slower)")
     p.add_argument("--synthetic", action="store_true", help="seeded synthetic weights instead of --sim_ckpt")
     p.add_argument("--npy", action="store_true", help="also save the sampled atom14 array as .npy")
     return p
@@ -193,12 +195,12 @@ def main(argv=None):
         dist = dist_
     if args.synthetic:
         cfg = ModelConfig.forward_sim(num_frames=args.num_frames)
-        model = NewMDGenWrapper(cfg, device=device)
+        model = NewMDGenWrapper(cfg, device=device, precision=args.precision)
         model.model.load_state_dict(synth_state_dict(cfg, 0))
     else:
         if not args.sim_ckpt:
             raise SystemExit("--sim_ckpt is required (or --synthetic)")
-        model = NewMDGenWrapper.load_from_checkpoint(args.sim_ckpt, device=device)
+        model = NewMDGenWrapper.load_from_checkpoint(args.sim_ckpt, device=device, precision=args.precision)
     df = pd.read_csv(args.split, index_col="name")
     names_seqres = {str(n): df.seqres[n] for n in df.index}
     return run(args, model, device, names_seqres, rank, world, sync=torch.cuda.synchronize, dist=dist)

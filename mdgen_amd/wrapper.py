@@ -33,7 +33,7 @@ def default_args(cfg: ModelConfig) -> argparse.Namespace:
 
 
 class NewMDGenWrapper:
-    def __init__(self, args, device="cuda"):
+    def __init__(self, args, device="cuda", precision="bf16"):
         if isinstance(args, ModelConfig):
             args = default_args(args)
         for k in _BACKFILL:                       # wrapper.py:178-194: newer flags default to False
@@ -54,16 +54,16 @@ class NewMDGenWrapper:
         self.cfg = ModelConfig.from_args(args)
         self.latent_dim = self.cfg.latent_dim
         self.device = torch.device(device)
-        self.model = LatentMDGenModel(self.cfg, self.device)
+        self.model = LatentMDGenModel(self.cfg, self.device, precision=precision)
         self.transport = create_transport(args, getattr(args, "path_type", "GVP"), getattr(args, "prediction", "velocity"))
         self.transport_sampler = Sampler(self.transport)
 
     # Lightning surface used by the drivers (sim_inference.py:129-130)
     @classmethod
-    def load_from_checkpoint(cls, path, device="cuda"):
+    def load_from_checkpoint(cls, path, device="cuda", precision="bf16"):
         ckpt = torch.load(path, map_location="cpu", weights_only=False)
         args = ckpt["hyper_parameters"]["args"]
-        w = cls(args, device=device)
+        w = cls(args, device=device, precision=precision)
         sd = {k[len("model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("model.")}
         w.model.load_state_dict(sd)
         return w

@@ -803,3 +803,67 @@ def test_use_graph_flag_reaches_the_library():
     b, _ = w.inference(batch, zs=zs, num_steps=2, use_graph=True)
     assert seen == [False, True]
     assert torch.equal(a, b)
+
+
+TOL_FP32 = 1e-5
+
+
+@pytest.mark.parametrize("name", ["fwd_full_sim", "fwd_full_pep", "fwd_full_atlas", "fwd_full_tps"])
+def test_fp32_mode_forward_vs_reference_golden(name):
+    """Option "precision" = 32 (csrc/k_fp32.hip): fp32 operands on v_mfma_f32_32x32x2_f32, the reference's own
+    arithmetic, gated at BASELINE.md section 3's fp32 bound rel-L2 <= 1e-5 against the REFERENCE's outputs.  The
+    two-sided model is compared with the oracle in the kernel's w >= 0 quaternion convention (see
+    test_forward_tps_vs_oracle_with_reference_inputs)."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.model import LatentMDGenModel
+    dev = _cuda()
+    g = load_golden(name)
+    cfg, sd = weights_for(g)
+    m = LatentMDGenModel(cfg, precision="fp32")
+    m.load_state_dict(sd)
+    out, tr = m.forward(**_kw(g, dev), return_trace=True)
+    torch.cuda.synchronize()
+    nl = cfg.num_layers
+    if cfg.tps_condition:
+        kw = {k: (tuple(u.cpu() for u in v) if isinstance(v, tuple) else v.cpu()) for k, v in _kw(g, "cpu").items()}
+        ref, rtr = O.forward(sd, dict(O.cfg_dict(cfg), quat_sign="w_nonneg"), return_trace=True, **kw)
+        want = {"ipa_out": rtr["ipa_out"], "h0": rtr["h0"], f"h{nl}": rtr[f"h{nl}"], "out": ref}
+    else:
+        want = {k: g[k] for k in ("ipa_out", "h0", f"h{nl}", "out")}
+    got = {"ipa_out": tr["ipa_out"], "h0": tr["h0"], f"h{nl}": tr[f"h{nl}"], "out": out}
+    rep = {k: rel_l2(got[k].cpu(), want[k]) for k in want}
+    print(name, "fp32 mode:", {k: f"{v:.2e}" for k, v in rep.items()})
+    assert torch.isfinite(out).all()
+    for k, v in rep.items():
+        assert v < TOL_FP32, (k, v)
+    # the same context switched to bf16 operands gives the (different) bf16-gate result
+    m.set_precision("bf16")
+    out16 = m.forward(**_kw(g, dev))
+    assert not torch.equal(out16, out)
+    e16 = rel_l2(out16.cpu(), want["out"])
+    assert TOL_FP32 < e16 < TOL_FWD, e16
+
+
+def test_fp32_mode_inference_end_to_end_vs_reference():
+    """fp32 mode through `NewMDGenWrapper.inference`, S = 1 / 10 / 49 Euler steps with the reference's noise:
+    BASELINE.md section 3 gate for fp32 kernels, end-to-end atom14 max-abs <= 1e-3 A (and torsion / offset samples
+    to rel-L2 <= 1e-5 x steps), eager and graph-replayed alike."""
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    dev = _cuda()
+    g = load_golden("inference_sim")
+    cfg, sd = weights_for(g)
+    w = NewMDGenWrapper(cfg, precision="fp32")
+    w.model.load_state_dict(sd)
+    batch0 = {k[3:]: v.to(dev) for k, v in g.items() if k.startswith("in_")}
+    T = g["S1_b0_zs"].shape[1]
+    ex = dict(batch0)
+    ex["torsions"] = batch0["torsions"].expand(-1, T, -1, -1, -1)
+    ex["trans"] = batch0["trans"].expand(-1, T, -1, -1)
+    ex["rots"] = batch0["rots"].expand(-1, T, -1, -1, -1)
+    for S in (1, 10, 49):
+        for use_graph in (False, True):
+            atom14, _ = w.inference(ex, zs=g[f"S{S}_b0_zs"].to(dev), num_steps=S, use_graph=use_graph)
+            e_s = rel_l2(w.last_samples.cpu(), g[f"S{S}_b0_samples"])
+            d = (atom14.cpu() - g[f"S{S}_b0_atom14"]).abs()
+            print(f"fp32 mode S={S:2d} graph={use_graph}: samples rel-L2 {e_s:.2e}  atom14 max {float(d.max()):.2e} A")
+            assert e_s < 1e-5 * max(S, 3) and float(d.max()) < 1e-3
