@@ -262,6 +262,24 @@ int32_t mdgen_path_plan(int64_t B, int64_t per_sample, int32_t path_type, const 
 int32_t mdgen_masked_mse(int64_t B, int64_t per_sample, const float* pred, const float* target, const float* mask,
                          float* loss, void* stream);
 
+/* ---- optimiser side of the training step ----------------------------------------------
+ * Parameters, gradients and the two Adam moments each live in ONE flat fp32 device buffer of n elements.
+ *
+ * mdgen_grad_sumsq: out[0] = sum((grads[i] * scale)^2), deterministic (fixed block slices); `scratch`: >= 1024 floats.
+ *   Feeds gradient clipping (train.py:56 gradient_clip_val -> torch.nn.utils.clip_grad_norm_, 2-norm) without a
+ *   host round trip: pass `out` as `sumsq` below.
+ * mdgen_adam_step: torch.optim.Adam / AdamW (wrapper.py:167-172; betas (0.9, 0.999), eps 1e-8 are torch's defaults;
+ *   adamw != 0: decoupled weight decay).  g = grads * grad_scale * min(1, max_norm / (sqrt(sumsq) + 1e-6)) when sumsq is
+ *   non-NULL (clip_grad_norm_), else grads * grad_scale (grad_scale = 1 / world_size averages a summed all-reduce).
+ *   `step` is the 1-based update count (bias correction 1 - beta^step).
+ * mdgen_ema_update: ema -= (ema - params) * (1 - decay)   (ema.py:41-58). */
+int32_t mdgen_grad_sumsq(int64_t n, const float* grads, float scale, float* scratch, int32_t scratch_floats,
+                         float* out, void* stream);
+int32_t mdgen_adam_step(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                        int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        int32_t adamw, float grad_scale, const float* sumsq, float max_norm, void* stream);
+int32_t mdgen_ema_update(int64_t n, float* ema, const float* params, float decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@ EXPORTS = [
     "mdgen_rigid_compose", "mdgen_rigid_invert",
     "mdgen_rigid_apply", "mdgen_quat_to_rot", "mdgen_rot_to_quat", "mdgen_prep_latents",
     "mdgen_samples_to_atom14", "mdgen_atom14_to_cond", "mdgen_path_plan", "mdgen_masked_mse", "mdgen_from_3_points",
+    "mdgen_grad_sumsq", "mdgen_adam_step", "mdgen_ema_update",
 ]
 
 
@@ -79,6 +80,10 @@ def _load():
     lib.mdgen_from_3_points.argtypes = [i64] + [vp] * 6
     lib.mdgen_path_plan.argtypes = [i64, i64, i32] + [vp] * 6
     lib.mdgen_masked_mse.argtypes = [i64, i64] + [vp] * 5
+    f32 = C.c_float
+    lib.mdgen_grad_sumsq.argtypes = [i64, vp, f32, vp, i32, vp, vp]
+    lib.mdgen_adam_step.argtypes = [i64, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp, f32, vp]
+    lib.mdgen_ema_update.argtypes = [i64, vp, vp, f32, vp]
     for n in EXPORTS:
         getattr(lib, n)
         if n not in ("mdgen_last_error", "mdgen_ctx_weight_name"):

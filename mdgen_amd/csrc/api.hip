@@ -1462,3 +1462,40 @@ extern "C" int32_t mdgen_from_3_points(int64_t n, const float* p_neg_x, const fl
     LAUNCHCHK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// optimiser side of the training step (flat fp32 buffers; csrc/k_optim.hip)
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t mdgen_grad_sumsq(int64_t n, const float* grads, float scale, float* scratch, int32_t scratch_floats,
+                                    float* out, void* stream) {
+    NONNULL(grads, scratch, out);
+    if (n < 1) return fail(-2, "n must be >= 1");
+    if (scratch_floats < 1) return fail(-2, "scratch_floats must be >= 1");
+    const int nb = scratch_floats < 1024 ? scratch_floats : 1024;
+    launch_sumsq(grads, n, scale, scratch, nb, out, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}
+
+extern "C" int32_t mdgen_adam_step(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                   int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                   int32_t adamw, float grad_scale, const float* sumsq, float max_norm, void* stream) {
+    NONNULL(params, grads, exp_avg, exp_avg_sq);
+    if (n < 1 || step < 1) return fail(-2, "n and step must be >= 1");
+    if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f) || !(eps > 0.f) || !(lr >= 0.f))
+        return fail(-2, "invalid Adam hyper-parameters");
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);          // torch: 1 - beta ** step (python floats)
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, adamw, (float)bc1,
+                (float)std::sqrt(bc2), grad_scale, sumsq, max_norm, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}
+
+extern "C" int32_t mdgen_ema_update(int64_t n, float* ema, const float* params, float decay, void* stream) {
+    NONNULL(ema, params);
+    if (n < 1) return fail(-2, "n must be >= 1");
+    launch_ema(ema, params, n, 1.0f - decay, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}

@@ -139,6 +139,13 @@ void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, con
 void launch32_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
                    const float* inv_freq, float* out, hipStream_t s);
 
+// optimiser (k_optim.hip)
+void launch_sumsq(const float* g, long n, float scale, float* partial, int nblocks, float* out, hipStream_t s);
+void launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int adamw, float bc1, float bc2_sqrt, float grad_scale, const float* sumsq,
+                 float max_norm, hipStream_t s);
+void launch_ema(float* ema, const float* p, long n, float one_minus_decay, hipStream_t s);
+
 // small kernels (k_small.hip)
 void launch_temb(const float* t_rows, int nrows, float tmul, const float* w0, const float* b0, const float* w2,
                  const float* b2, float* silu_out, hipStream_t s);

@@ -867,3 +867,119 @@ def test_fp32_mode_inference_end_to_end_vs_reference():
             d = (atom14.cpu() - g[f"S{S}_b0_atom14"]).abs()
             print(f"fp32 mode S={S:2d} graph={use_graph}: samples rel-L2 {e_s:.2e}  atom14 max {float(d.max()):.2e} A")
             assert e_s < 1e-5 * max(S, 3) and float(d.max()) < 1e-3
+
+
+def test_fp32_mode_cfg4_full_size_vs_reference():
+    """fp32 mode at BASELINE.json configs[3]'s full size (ATLAS 256 x 250, 16 padded residues) against the
+    reference's sub-sampled outputs: rel-L2 <= 1e-5 on the velocity, the IPA table and the residual stream."""
+    from mdgen_amd.model import LatentMDGenModel
+    from mdgen_amd.synthetic import synth_forward_inputs
+    dev = _cuda()
+    g = load_golden("fwd_cfg4_atlas_full")
+    cfg, sd = weights_for(g)
+    B, T, L, n_pad = (int(v) for v in g["shape"])
+    inp = synth_forward_inputs(cfg, B, T, L, n_pad, int(g["data_seed"]))
+    m = LatentMDGenModel(cfg, precision="fp32")
+    m.load_state_dict(sd)
+    out, tr = m.forward(x=inp["x"].to(dev), t=inp["t"].to(dev), mask=inp["mask"].to(dev),
+                        start_frames=(inp["start_rot"].to(dev), inp["start_trans"].to(dev)),
+                        x_cond=inp["x_cond"].to(dev), x_cond_mask=inp["x_cond_mask"].to(dev), aatype=inp["aatype"].to(dev),
+                        return_trace=True)
+    torch.cuda.synchronize()
+    st, sl = (int(v) for v in g["sub"])
+    ht, hl = (int(v) for v in g["sub_h"])
+    nl = cfg.num_layers
+    rep = {"out": rel_l2(out.cpu()[:, ::st, ::sl], g["out"]), "ipa_out": rel_l2(tr["ipa_out"].cpu()[:, ::sl], g["ipa_out"]),
+           "h0": rel_l2(tr["h0"].cpu()[:, ::ht, ::hl], g["h0"]), f"h{nl}": rel_l2(tr[f"h{nl}"].cpu()[:, ::ht, ::hl], g[f"h{nl}"])}
+    print("cfg-4 full, fp32 mode vs reference:", {k: f"{v:.2e}" for k, v in rep.items()})
+    for k, v in rep.items():
+        assert v < TOL_FP32, (k, v)
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_dataset_window_crop_pad_vs_reference(tmp_path):
+    """`MDGenDataset.__getitem__` (dataset.py:19-100) against the reference's own items (tests/golden/dataset.npz,
+    oracle/gen_golden_dataset.py): same numpy seeds -> same replica / window / crop, ATLAS crop (L 14 > 8), ATLAS padding
+    (L 6 < 8: identity frames, zero torsions, mask 0) and the uncropped tetrapeptide case; geometry on the GPU."""
+    import argparse
+    import pandas as pd
+    from mdgen_amd.dataset import MDGenDataset
+    _cuda()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dataset.npz"))
+    for k in g.files:
+        if k.startswith("arr_"):
+            np.save(tmp_path / (k[4:] + ".npy"), g[k])
+    seqs = dict(zip([str(x) for x in g["seq_names"]], [str(x) for x in g["seq_strings"]]))
+    done = 0
+    for tag, names, atlas, crop in (("atlas", ["pLong", "pShort"], True, 8), ("pep", ["FLRH"], False, 4)):
+        split = tmp_path / f"{tag}.csv"
+        pd.DataFrame({"name": names, "seqres": [seqs[n] for n in names]}).to_csv(split, index=False)
+        args = argparse.Namespace(data_dir=str(tmp_path), suffix="", atlas=atlas, crop=crop, num_frames=4, overfit=False,
+                                  overfit_peptide=None, overfit_frame=False, frame_interval=None, copy_frames=False,
+                                  no_frames=False)
+        ds = MDGenDataset(args, str(split), repeat=2)
+        assert len(ds) == 2 * len(names)
+        for seed in (0, 1, 2, 3):
+            for idx in range(len(ds)):
+                np.random.seed(100 * seed + idx)
+                it = ds[idx]
+                key = f"{tag}_s{seed}_i{idx}"
+                assert it["name"] == str(g[key + "_name"]) and int(it["frame_start"]) == int(g[key + "_frame_start"]), key
+                assert np.array_equal(it["seqres"].cpu().numpy(), g[key + "_seqres"]), key
+                assert np.array_equal(it["mask"].cpu().numpy(), g[key + "_mask"]), key
+                assert np.array_equal(it["torsion_mask"].cpu().numpy(), g[key + "_torsion_mask"]), key
+                assert np.abs(it["rots"].cpu().numpy() - g[key + "_rots"]).max() < 1e-5, key
+                assert np.abs(it["trans"].cpu().numpy() - g[key + "_trans"]).max() < 1e-5, key
+                tm = g[key + "_torsion_mask"][None, :, :, None]            # masked torsions are degenerate in the reference
+                assert (np.abs(it["torsions"].cpu().numpy() - g[key + "_torsions"]) * tm).max() < 2e-4, key
+                done += 1
+    assert done == 24
+    # the items collate and feed prep_batch (the training step's first stage)
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, num_workers=0)
+    batch = next(iter(loader))
+    w = NewMDGenWrapper(ModelConfig.forward_sim(num_frames=4, crop=4))
+    prep = w.prep_batch(batch)
+    assert prep["latents"].shape == (2, 4, 4, 21) and torch.isfinite(prep["latents"]).all()
+
+
+def test_optimizer_kernels_vs_torch():
+    """csrc/k_optim.hip against torch itself on the CPU: gradient-norm clipping (clip_grad_norm_, what Lightning's
+    gradient_clip_val does, train.py:56) + torch.optim.Adam / AdamW (wrapper.py:167-172) over several steps, DDP's
+    1 / world averaging folded in, and the weight EMA (ema.py:41-58)."""
+    from collections import OrderedDict
+    from mdgen_amd.optim import FlatParams, Adam, EMA
+    dev = _cuda()
+    shapes = OrderedDict([("a.weight", (257, 129)), ("a.bias", (257,)), ("b.weight", (1000, 999)), ("c", (3, 5, 7))])
+    gen = torch.Generator().manual_seed(0)
+    sd = OrderedDict((k, torch.randn(*v, generator=gen)) for k, v in shapes.items())
+    for adamw, clip, world in ((False, 1.0, 1), (True, 0.5, 8), (False, None, 2)):
+        fp = FlatParams(shapes, device=dev).load_state_dict(sd)
+        opt = Adam(fp, lr=1e-2, adamw=adamw, grad_clip=clip)
+        ema = EMA(fp, 0.99)
+        ref_p = [torch.nn.Parameter(v.clone()) for v in sd.values()]
+        ref_opt = (torch.optim.AdamW if adamw else torch.optim.Adam)(ref_p, lr=1e-2)
+        ref_ema = [p.detach().clone() for p in ref_p]
+        for step in range(6):
+            gs = [torch.randn(*v, generator=gen) * (10.0 if step % 2 else 0.01) for v in shapes.values()]   # clipped / not
+            flat = torch.cat([x.reshape(-1) for x in gs]).to(dev)
+            n_dev = opt.grad_norm(flat, 1.0 / world).item()
+            for p, x in zip(ref_p, gs):
+                p.grad = x / world                                # DDP: mean over ranks of the summed gradient
+            if clip is not None:
+                n_ref = float(torch.nn.utils.clip_grad_norm_(ref_p, clip))
+                assert abs(n_dev - n_ref) / n_ref < 1e-5
+            ref_opt.step()
+            opt.step(flat, grad_scale=1.0 / world)
+            ema.update()
+            for e, p in zip(ref_ema, ref_p):                      # ema.py:47-51
+                diff = e - p.detach()
+                diff *= 1 - 0.99
+                e -= diff
+        got = fp.state_dict()
+        for (k, v), p, e in zip(got.items(), ref_p, ref_ema):
+            assert torch.allclose(v.cpu(), p.detach(), rtol=2e-5, atol=1e-6), (k, adamw, clip)
+            assert torch.allclose(ema.state_dict()["params"][k].cpu(), e, rtol=2e-5, atol=1e-6), k
+        assert opt.step_count == 6
