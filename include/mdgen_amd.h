@@ -265,7 +265,7 @@ int32_t mdgen_masked_mse(int64_t B, int64_t per_sample, const float* pred, const
 /* ---- optimiser side of the training step ----------------------------------------------
  * Parameters, gradients and the two Adam moments each live in ONE flat fp32 device buffer of n elements.
  *
- * mdgen_grad_sumsq: out[0] = sum((grads[i] * scale)^2), deterministic (fixed block slices); `scratch`: >= 1024 floats.
+ * mdgen_grad_sumsq: out[0] = sum((grads[i] * scale)^2), deterministic (fixed block slices, fp64 accumulation); `scratch`: 1024 floats, 8-byte aligned.
  *   Feeds gradient clipping (train.py:56 gradient_clip_val -> torch.nn.utils.clip_grad_norm_, 2-norm) without a
  *   host round trip: pass `out` as `sumsq` below.
  * mdgen_adam_step: torch.optim.Adam / AdamW (wrapper.py:167-172; betas (0.9, 0.999), eps 1e-8 are torch's defaults;

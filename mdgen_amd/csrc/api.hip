@@ -1470,8 +1470,9 @@ extern "C" int32_t mdgen_grad_sumsq(int64_t n, const float* grads, float scale, 
                                     float* out, void* stream) {
     NONNULL(grads, scratch, out);
     if (n < 1) return fail(-2, "n must be >= 1");
-    if (scratch_floats < 1) return fail(-2, "scratch_floats must be >= 1");
-    const int nb = scratch_floats < 1024 ? scratch_floats : 1024;
+    if (scratch_floats < 2) return fail(-2, "scratch_floats must be >= 2");
+    if (((uintptr_t)scratch & 7) != 0) return fail(-2, "scratch must be 8-byte aligned");
+    const int nb = scratch_floats / 2 < 512 ? scratch_floats / 2 : 512;   // fp64 partial sums
     launch_sumsq(grads, n, scale, scratch, nb, out, (hipStream_t)stream);
     LAUNCHCHK();
     return 0;

@@ -10,30 +10,37 @@
 
 namespace mdg {
 
-// partial[b] = sum over the block's slice of (g * scale)^2 ; deterministic (fixed slice per block, tree inside)
+// partial[b] = sum over the block's slice of (g * scale)^2 ; deterministic (fixed slice per block, tree inside) and
+// accumulated in fp64 (the kernel is HBM-bound; an fp32 sum of 3e7 squares would carry ~1e-5 relative error into the
+// clip coefficient)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 __global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__ g, long n, float scale,
-                                                       float* __restrict__ partial) {
-    __shared__ float red[4];
+                                                       double* __restrict__ partial) {
+    __shared__ double red[4];
     const long per = (n + gridDim.x - 1) / gridDim.x;
     const long lo = (long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-    float s = 0.f;
+    double s = 0.0;
     for (long i = lo + threadIdx.x; i < hi; i += 256) {
         const float v = g[i] * scale;
-        s += v * v;
+        s += (double)v * (double)v;
     }
-    s = wave_sum(s);
+    s = wave_sum_f64(s);
     if (lane_id() == 0) red[wave_id()] = s;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ __launch_bounds__(256) void k_sumsq_final(const float* __restrict__ partial, int nb, float* __restrict__ out) {
-    __shared__ float red[4];
-    float s = 0.f;
+__global__ __launch_bounds__(256) void k_sumsq_final(const double* __restrict__ partial, int nb, float* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
     for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
-    s = wave_sum(s);
+    s = wave_sum_f64(s);
     if (lane_id() == 0) red[wave_id()] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 struct AdamParams {
@@ -78,8 +85,9 @@ __global__ __launch_bounds__(256) void k_ema(float* __restrict__ ema, const floa
 }
 
 void launch_sumsq(const float* g, long n, float scale, float* partial, int nblocks, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_sumsq_partial, dim3(nblocks), dim3(256), 0, s, g, n, scale, partial);
-    hipLaunchKernelGGL(k_sumsq_final, dim3(1), dim3(256), 0, s, partial, nblocks, out);
+    double* pd = reinterpret_cast<double*>(partial);   // scratch is used as fp64 partials: nblocks <= floats / 2
+    hipLaunchKernelGGL(k_sumsq_partial, dim3(nblocks), dim3(256), 0, s, g, n, scale, pd);
+    hipLaunchKernelGGL(k_sumsq_final, dim3(1), dim3(256), 0, s, pd, nblocks, out);
 }
 void launch_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int adamw, float bc1, float bc2_sqrt, float grad_scale, const float* sumsq,
