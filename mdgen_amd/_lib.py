@@ -17,7 +17,8 @@ EXPORTS = [
     "mdgen_rigid_compose", "mdgen_rigid_invert",
     "mdgen_rigid_apply", "mdgen_quat_to_rot", "mdgen_rot_to_quat", "mdgen_prep_latents",
     "mdgen_samples_to_atom14", "mdgen_atom14_to_cond", "mdgen_path_plan", "mdgen_masked_mse", "mdgen_from_3_points",
-    "mdgen_grad_sumsq", "mdgen_adam_step", "mdgen_ema_update",
+    "mdgen_grad_sumsq", "mdgen_adam_step", "mdgen_ema_update", "mdgen_train_workspace_bytes",
+    "mdgen_train_forward_backward",
 ]
 
 
@@ -84,6 +85,8 @@ def _load():
     lib.mdgen_grad_sumsq.argtypes = [i64, vp, f32, vp, i32, vp, vp]
     lib.mdgen_adam_step.argtypes = [i64, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp, f32, vp]
     lib.mdgen_ema_update.argtypes = [i64, vp, vp, f32, vp]
+    lib.mdgen_train_workspace_bytes.argtypes = [vp, C.POINTER(Shape), C.POINTER(sz)]
+    lib.mdgen_train_forward_backward.argtypes = [vp, C.POINTER(Shape)] + [vp] * 14 + [vp, sz, vp, sz, vp]
     for n in EXPORTS:
         getattr(lib, n)
         if n not in ("mdgen_last_error", "mdgen_ctx_weight_name"):

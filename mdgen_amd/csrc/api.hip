@@ -1500,3 +1500,5 @@ extern "C" int32_t mdgen_ema_update(int64_t n, float* ema, const float* params, 
     LAUNCHCHK();
     return 0;
 }
+
+#include "train.inc"

@@ -55,10 +55,13 @@ struct LinearParams {
     const float* w; int ldw;
     const float* bias;
     long n; int m, k;
-    int mode;             // 0 store, 1 GELU store, 2 gated residual into c, 3 Euler: c += dt * val, 4 store * scale
+    int mode;             // 0 store, 1 GELU store, 2 gated residual into c, 3 Euler: c += dt * val, 4 store * scale,
+                          // 5 accumulate (c += val), 6 store val AND GELU(val) (second copy at c2: training tape)
+    int wtrans;           // 1: the weight operand is stored [k][m] (ldw = row stride): y = x W, used for dX = dY W
     float* c; int ldc; int col0;
     ModMap mm; int gate_chunk; int gated;   // mode 2
     float scalar;                           // mode 3: dt; mode 4: scale
+    float* c2;                              // mode 6: GELU output
 };
 
 __global__ __launch_bounds__(256) void k32_linear(const LinearParams p) {
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void k32_linear(const LinearParams p) {
             for (int j = 0; j < 4; ++j) {
                 const int kk = k0 + lk + j;
                 av[j] = kk < p.k ? p.a[ar * p.lda + kk] : 0.f;
-                wv[j] = kk < p.k ? p.w[(long)wrow * p.ldw + kk] : 0.f;
+                wv[j] = kk < p.k ? (p.wtrans ? p.w[(long)kk * p.ldw + wrow] : p.w[(long)wrow * p.ldw + kk]) : 0.f;
             }
             __syncthreads();   // previous tile consumed
 #pragma unroll
@@ -119,8 +122,13 @@ __global__ __launch_bounds__(256) void k32_linear(const LinearParams p) {
             *dst = *dst + g * v;
         } else if (p.mode == 3) {
             *dst = *dst + p.scalar * v;
-        } else {
+        } else if (p.mode == 4) {
             *dst = v * p.scalar;
+        } else if (p.mode == 5) {
+            *dst = *dst + v;
+        } else {
+            *dst = v;
+            p.c2[row * p.ldc + p.col0 + col] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
         }
     }
 }
@@ -242,8 +250,9 @@ void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chu
                        affine, eps, y);
 }
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
-                     float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s) {
-    LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, c, ldc, col0, mm, gate_chunk, gated, scalar};
+                     float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
+                     int wtrans, float* c2) {
+    LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, wtrans, c, ldc, col0, mm, gate_chunk, gated, scalar, c2};
     hipLaunchKernelGGL(k32_linear, dim3((unsigned)((n + 63) / 64), (unsigned)((m + 63) / 64)), dim3(256), 0, s, p);
 }
 void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, hipStream_t s) {

@@ -1,0 +1,632 @@
+// k_fp32_bwd.hip -- backward kernels of the training step, fp32 operands.
+//
+// The training step differentiates the fp32 form of the network (k_fp32.hip): every reference op group is one kernel
+// there, so every derivative is one kernel here, and gradients can be checked against the reference's own autograd at
+// fp32 tolerance.  All reductions over tokens are two-stage with fixed slices (bit-reproducible run to run).
+//   k32_dw / k32_reduce_add     dW[m][k] += sum_n dY[n][m] X[n][k]   (v_mfma_f32_32x32x2_f32, split over n)
+//   k32_colsum / _final         per-group column sums  sum_t a[t][c] * b[t][c]  (biases, adaLN shift / scale / gate)
+//   k32_ln_bwd                  LayerNorm (+ modulate / affine) backward
+//   k32_gate_mul, k32_gelu_*    gated residual, exact-erf GELU
+//   k32_attn_bwd_q / _kv        softmax attention backward (query pass: dq; key pass: dk, dv incl. the bias key)
+//   k32_rope_bwd                inverse rotation of dq, dk and the q scale
+//   k32_loss_grad               d(mean_b masked-MSE_b) / d pred
+//   k32_sum_frames              d ipa_out[b,l] = sum_t dh0[b,t,l]
+#include "kernels.h"
+
+namespace mdg {
+
+// ---- dW ---------------------------------------------------------------------------------------------------------------
+// part[z][m][k] = sum_{n in slice z} dY[n][m] * X[n][k];  grid (ceil(M/64), ceil(K/64), nsplit), 256 threads.
+__global__ __launch_bounds__(256) void k32_dw(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                                              long n, int m, int k, float* __restrict__ part) {
+    constexpr int BN = 16, LD = BN + 1;
+    __shared__ float As[64 * LD];   // dY^T tile: [m][n]
+    __shared__ float Bs[64 * LD];   // X^T  tile: [k][n]
+    const int lane = lane_id(), w = wave_id();
+    const int m0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const long per = ((n + gridDim.z - 1) / gridDim.z + BN - 1) / BN * BN;
+    const long nlo = (long)blockIdx.z * per, nhi = nlo + per < n ? nlo + per : n;
+    const int wr = w >> 1, wc = w & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = opaque_zero();
+    const int ln = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 4;   // staging: 16 n-rows x 64 columns (4 per thread)
+    for (long n0 = nlo; n0 < nhi; n0 += BN) {
+        float av[4], bv[4];
+        const long row = n0 + ln;
+        const bool rok = row < nhi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mc = m0 + lc + j, kc = k0 + lc + j;
+            av[j] = (rok && mc < m) ? dy[row * ldy + mc] : 0.f;
+            bv[j] = (rok && kc < k) ? x[row * ldx + kc] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            As[(lc + j) * LD + ln] = av[j];
+            Bs[(lc + j) * LD + ln] = bv[j];
+        }
+        __syncthreads();
+        const int i = lane & 31, kh = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < BN; kk += 2) {
+            const float a = As[(wr * 32 + i) * LD + kk + kh];
+            const float b = Bs[(wc * 32 + i) * LD + kk + kh];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    const int col = k0 + wc * 32 + (lane & 31);
+    if (col >= k) return;
+    const int hh = lane >> 5;
+    float* dst = part + (long)blockIdx.z * m * k;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 32 + mfma_row(r, hh);
+        if (row < m) dst[(long)row * k + col] = acc[r];
+    }
+}
+// dst[i] += sum_z part[z][i]  (fixed order)
+__global__ void k32_reduce_add(const float* __restrict__ part, int nsplit, long count, float* __restrict__ dst) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += part[(long)z * count + i];
+    dst[i] += s;
+}
+
+// ---- grouped column sums ----------------------------------------------------------------------------------------------
+// partial[slice][c] = sum over the slice's rows of a[t][c] * B(t, c), B by `mode`:
+//   0: 1     1: b[t][c]     2: xhat(t, c) = (x[t][c] - mean_t) * rstd_t with x = b (LayerNorm statistics recomputed)
+//   3: roww[t] (a per-row weight, e.g. an indicator)
+// Groups are contiguous runs of tokens_per_group rows; slice = (group, i) covers rows_per_slice rows of it.
+struct ColsumParams {
+    const float* a; int lda;
+    const float* b; int ldb;
+    const float* roww;
+    int mode;
+    long nrows; int ncols;
+    long tokens_per_group; int rows_per_slice; int slices_per_group;
+    float eps;
+    float* partial;
+};
+__global__ __launch_bounds__(384) void k32_colsum(const ColsumParams p) {
+    const int c = blockIdx.y * 384 + threadIdx.x;   // column chunks of 384 (mode 2: exactly one chunk)
+    const long g = blockIdx.x / p.slices_per_group;
+    const int si = blockIdx.x % p.slices_per_group;
+    const long g0 = g * p.tokens_per_group;
+    long lo = g0 + (long)si * p.rows_per_slice, hi = lo + p.rows_per_slice;
+    const long gend = g0 + p.tokens_per_group < p.nrows ? g0 + p.tokens_per_group : p.nrows;
+    hi = hi < gend ? hi : gend;
+    __shared__ float st[2];
+    float s = 0.f;
+    for (long t = lo; t < hi; ++t) {
+        float bb = 1.f;
+        if (p.mode == 1) {
+            bb = c < p.ncols ? p.b[t * p.ldb + c] : 0.f;
+        } else if (p.mode == 2) {   // LayerNorm statistics of row t (384 columns): block-wide reduction
+            const float xv = p.b[t * p.ldb + threadIdx.x];
+            __shared__ float red[6], red2[6];
+            float sm = wave_sum(xv);
+            if (lane_id() == 0) red[wave_id()] = sm;
+            __syncthreads();
+            const float mean = (red[0] + red[1] + red[2] + red[3] + red[4] + red[5]) * (1.0f / kC);
+            const float d = xv - mean;
+            float sq = wave_sum(d * d);
+            if (lane_id() == 0) red2[wave_id()] = sq;
+            __syncthreads();
+            const float var = (red2[0] + red2[1] + red2[2] + red2[3] + red2[4] + red2[5]) * (1.0f / kC);
+            bb = d / sqrtf(var + p.eps);
+            __syncthreads();
+        } else if (p.mode == 3) {
+            bb = p.roww[t];
+        }
+        if (c < p.ncols) s += p.a[t * p.lda + c] * bb;
+    }
+    (void)st;
+    if (c < p.ncols) p.partial[(long)blockIdx.x * p.ncols + c] = s;
+}
+// out[g * ldo + c] += sum_i partial[(g * spg + i)][c]
+__global__ void k32_colsum_final(const float* __restrict__ partial, int ngroups, int spg, int ncols, float* __restrict__ out,
+                                 long ldo) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ngroups * ncols) return;
+    const int g = i / ncols, c = i % ncols;
+    float s = 0.f;
+    for (int k = 0; k < spg; ++k) s += partial[((long)g * spg + k) * ncols + c];
+    out[(long)g * ldo + c] += s;
+}
+
+// ---- LayerNorm (+ modulate | affine) backward -------------------------------------------------------------------------
+// y = xhat * mult + shift, mult = 1 + scale[g] (modulate) or gamma (affine).  Given dy: dx (+)= rstd * (dxh - mean(dxh)
+// - xhat * mean(dxh * xhat)), dxh = dy * mult.  One wave per row.
+__global__ __launch_bounds__(256) void k32_ln_bwd(const float* __restrict__ x, const float* __restrict__ dy, long nrows,
+                                                  ModMap mm, int scale_chunk, int affine, float eps, float* __restrict__ dx,
+                                                  int accumulate) {
+    const long row = (long)blockIdx.x * 4 + wave_id();
+    if (row >= nrows) return;
+    const int lane = lane_id();
+    float v[6], g[6];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v[i] = x[row * kC + lane + 64 * i];
+        s += v[i];
+    }
+    const float mean = wave_sum(s) * (1.0f / kC);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v[i] -= mean;
+        q += v[i] * v[i];
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kC) + eps);
+    const float* mod = mm.mod + (affine ? 0 : mm.row_off(row));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = lane + 64 * i;
+        const float sc = mod[scale_chunk * kC + c];
+        v[i] *= rstd;                                            // xhat
+        g[i] = dy[row * kC + c] * (affine ? sc : 1.0f + sc);     // dxhat
+        s1 += g[i];
+        s2 += g[i] * v[i];
+    }
+    s1 = wave_sum(s1) * (1.0f / kC);
+    s2 = wave_sum(s2) * (1.0f / kC);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = lane + 64 * i;
+        const float d = rstd * (g[i] - s1 - v[i] * s2);
+        dx[row * kC + c] = accumulate ? dx[row * kC + c] + d : d;
+    }
+}
+
+// out[t][c] = a[t][c] * gate[g(t)][c]   (du = gate * dh; gate == null -> copy)
+__global__ void k32_gate_mul(const float* __restrict__ a, long nrows, ModMap mm, int gate_chunk, int gated,
+                             float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * kC) return;
+    const long t = i / kC;
+    const int c = (int)(i % kC);
+    const float g = gated ? mm.mod[mm.row_off(t) + gate_chunk * kC + c] : 1.0f;
+    out[i] = a[i] * g;
+}
+
+// exact-erf GELU (layers.py:77-84) from the saved pre-activation, and its derivative Phi(x) + x phi(x)
+__global__ void k32_gelu_from_pre(const float* __restrict__ pre, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = pre[i];
+    out[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+}
+__global__ void k32_gelu_bwd(const float* __restrict__ pre, long n, float* __restrict__ d) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = pre[i];
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+    d[i] *= cdf + v * pdf;
+}
+
+// ---- attention backward ------------------------------------------------------------------------------------------------
+// Shared helpers: staging of one (sequence, head) key tile as in k32_attn (bias key at position len, rotated there).
+__device__ __forceinline__ void bias_kv(const float* bias_k, const float* bias_v, const float* inv_freq, int hd, int len, int d,
+                                        float& kvv, float& vvv) {
+    const int i = d % 12;
+    const float ang = (float)len * inv_freq[i];
+    const float c = cosf(ang), s = sinf(ang);
+    const float x1 = bias_k[hd * kDH + i], x2 = bias_k[hd * kDH + i + 12];
+    kvv = d < 12 ? x1 * c - x2 * s : x2 * c + x1 * s;
+    vvv = bias_v[hd * kDH + d];
+}
+
+// Query pass: thread = query.  lse = m + log(l) is recomputed here (a first sweep over the keys), then
+// delta = dO . O, ds = p (dO . v - delta), dq = sum_j ds k_j.  Writes dq into dqkv[:, 0:384], and (lse, delta) into
+// stats[token][head][2] for the key pass.
+__global__ __launch_bounds__(256) void k32_attn_bwd_q(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
+                                                      const float* __restrict__ bias_k, const float* __restrict__ bias_v,
+                                                      const float* __restrict__ inv_freq, const float* __restrict__ o,
+                                                      const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                      float* __restrict__ stats) {
+    constexpr int KT = 64;
+    __shared__ __attribute__((aligned(16))) float sk[KT][kDH];
+    __shared__ __attribute__((aligned(16))) float sv[KT][kDH];
+    __shared__ float sm[KT];
+    const int len = ax.len;
+    const int nqb = (len + 255) / 256;
+    const int qb = blockIdx.x % nqb;
+    const int hd = (blockIdx.x / nqb) % kH;
+    const int seq = blockIdx.x / (nqb * kH);
+    const int tid = threadIdx.x;
+    const int qi = qb * 256 + tid;
+    const bool qok = qi < len;
+    const long qtok = ax.token(seq, qok ? qi : len - 1);
+    float q[kDH], dO[kDH], dq[kDH];
+    float delta = 0.f;
+#pragma unroll
+    for (int d = 0; d < kDH; ++d) {
+        q[d] = qkv[qtok * ld + hd * kDH + d];
+        dO[d] = dout[qtok * kC + hd * kDH + d];
+        delta += dO[d] * o[qtok * kC + hd * kDH + d];
+        dq[d] = 0.f;
+    }
+    float mrun = -3.0e38f, den = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        const float lse = pass ? mrun + logf(den) : 0.f;
+        for (int j0 = 0; j0 < len + 1; j0 += KT) {
+            __syncthreads();
+            for (int e = tid; e < KT * kDH; e += 256) {
+                const int jj = e / kDH, d = e % kDH;
+                const int j = j0 + jj;
+                float kvv = 0.f, vvv = 0.f;
+                if (j < len) {
+                    const long t = ax.token(seq, j);
+                    kvv = qkv[t * ld + kC + hd * kDH + d];
+                    vvv = qkv[t * ld + 2 * kC + hd * kDH + d];
+                } else if (j == len) {
+                    bias_kv(bias_k, bias_v, inv_freq, hd, len, d, kvv, vvv);
+                }
+                sk[jj][d] = kvv;
+                sv[jj][d] = vvv;
+            }
+            if (tid < KT) {
+                const int j = j0 + tid;
+                sm[tid] = j < len ? (mk.at(ax.token(seq, j)) != 0.f ? 1.f : 0.f) : (j == len ? 1.f : 0.f);
+            }
+            __syncthreads();
+            if (pass == 0) {
+                float tmax = -3.0e38f;
+                float lg[KT];
+#pragma unroll
+                for (int jj = 0; jj < KT; ++jj) {
+                    float dot = 0.f;
+#pragma unroll
+                    for (int d = 0; d < kDH; ++d) dot += q[d] * sk[jj][d];
+                    lg[jj] = sm[jj] != 0.f ? dot : -3.0e38f;
+                    tmax = fmaxf(tmax, lg[jj]);
+                }
+                const float mnew = fmaxf(mrun, tmax);
+                den *= expf(mrun - mnew);
+                mrun = mnew;
+#pragma unroll
+                for (int jj = 0; jj < KT; ++jj) den += lg[jj] > -1.0e38f ? expf(lg[jj] - mnew) : 0.f;
+            } else {
+#pragma unroll 4
+                for (int jj = 0; jj < KT; ++jj) {
+                    if (sm[jj] == 0.f) continue;
+                    float dot = 0.f, dp = 0.f;
+#pragma unroll
+                    for (int d = 0; d < kDH; ++d) {
+                        dot += q[d] * sk[jj][d];
+                        dp += dO[d] * sv[jj][d];
+                    }
+                    const float ds = expf(dot - lse) * (dp - delta);
+#pragma unroll
+                    for (int d = 0; d < kDH; ++d) dq[d] += ds * sk[jj][d];
+                }
+            }
+        }
+    }
+    if (!qok) return;
+#pragma unroll
+    for (int d = 0; d < kDH; ++d) dqkv[qtok * ld + hd * kDH + d] = dq[d];
+    stats[(qtok * kH + hd) * 2] = mrun + logf(den);
+    stats[(qtok * kH + hd) * 2 + 1] = delta;
+}
+
+// Key pass: thread = key (the bias key is key `len`), queries staged through LDS.  dk = sum_i ds_ij q_i, dv = sum_i p_ij dO_i.
+// Real keys write dqkv[:, 384:1152]; the bias key writes dbias[seq][head][48] (dk rotated | dv), reduced over sequences later.
+__global__ __launch_bounds__(256) void k32_attn_bwd_kv(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
+                                                       const float* __restrict__ bias_k, const float* __restrict__ bias_v,
+                                                       const float* __restrict__ inv_freq, const float* __restrict__ dout,
+                                                       const float* __restrict__ stats, float* __restrict__ dqkv,
+                                                       float* __restrict__ dbias) {
+    constexpr int QT = 64;
+    __shared__ __attribute__((aligned(16))) float sq[QT][kDH];
+    __shared__ __attribute__((aligned(16))) float sdo[QT][kDH];
+    __shared__ float slse[QT], sdel[QT];
+    const int len = ax.len;
+    const int nkb = (len + 1 + 255) / 256;
+    const int kb = blockIdx.x % nkb;
+    const int hd = (blockIdx.x / nkb) % kH;
+    const int seq = blockIdx.x / (nkb * kH);
+    const int tid = threadIdx.x;
+    const int j = kb * 256 + tid;
+    const bool kok = j <= len;
+    float k[kDH], v[kDH], dk[kDH], dv[kDH];
+    bool valid = false;
+    long ktok = 0;
+    if (j < len) {
+        ktok = ax.token(seq, j);
+        valid = mk.at(ktok) != 0.f;
+#pragma unroll
+        for (int d = 0; d < kDH; ++d) {
+            k[d] = qkv[ktok * ld + kC + hd * kDH + d];
+            v[d] = qkv[ktok * ld + 2 * kC + hd * kDH + d];
+        }
+    } else {
+        valid = j == len;
+#pragma unroll
+        for (int d = 0; d < kDH; ++d) bias_kv(bias_k, bias_v, inv_freq, hd, len, d, k[d], v[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < kDH; ++d) dk[d] = dv[d] = 0.f;
+    for (int i0 = 0; i0 < len; i0 += QT) {
+        __syncthreads();
+        for (int e = tid; e < QT * kDH; e += 256) {
+            const int ii = e / kDH, d = e % kDH;
+            const int i = i0 + ii;
+            float qv = 0.f, dov = 0.f;
+            if (i < len) {
+                const long t = ax.token(seq, i);
+                qv = qkv[t * ld + hd * kDH + d];
+                dov = dout[t * kC + hd * kDH + d];
+            }
+            sq[ii][d] = qv;
+            sdo[ii][d] = dov;
+        }
+        if (tid < QT) {
+            const int i = i0 + tid;
+            const long t = ax.token(seq, i < len ? i : len - 1);
+            slse[tid] = i < len ? stats[(t * kH + hd) * 2] : 3.0e38f;    // beyond len: p = exp(-inf) = 0
+            sdel[tid] = stats[(t * kH + hd) * 2 + 1];
+        }
+        __syncthreads();
+        if (valid) {
+#pragma unroll 4
+            for (int ii = 0; ii < QT; ++ii) {
+                float dot = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < kDH; ++d) {
+                    dot += sq[ii][d] * k[d];
+                    dp += sdo[ii][d] * v[d];
+                }
+                const float p = expf(dot - slse[ii]);
+                const float ds = p * (dp - sdel[ii]);
+#pragma unroll
+                for (int d = 0; d < kDH; ++d) {
+                    dk[d] += ds * sq[ii][d];
+                    dv[d] += p * sdo[ii][d];
+                }
+            }
+        }
+    }
+    if (!kok) return;
+    if (j < len) {
+#pragma unroll
+        for (int d = 0; d < kDH; ++d) {
+            dqkv[ktok * ld + kC + hd * kDH + d] = dk[d];
+            dqkv[ktok * ld + 2 * kC + hd * kDH + d] = dv[d];
+        }
+    } else {   // bias key: undo its rotation (position len) here, so that the per-sequence rows just add up
+        float* dst = dbias + ((long)seq * kH + hd) * 2 * kDH;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const float ang = (float)len * inv_freq[i];
+            const float c = cosf(ang), s = sinf(ang);
+            dst[i] = dk[i] * c + dk[i + 12] * s;            // R(-theta): d x1 = d y1 c + d y2 s
+            dst[i + 12] = dk[i + 12] * c - dk[i] * s;       //            d x2 = d y2 c - d y1 s
+        }
+#pragma unroll
+        for (int d = 0; d < kDH; ++d) dst[kDH + d] = dv[d];
+    }
+}
+
+// dq, dk (post-RoPE) -> pre-RoPE in place: inverse rotation; dq additionally times the q scale.
+__global__ void k32_rope_bwd(float* __restrict__ buf, long ntok, int ld, long pos_div, int pos_mod,
+                             const float* __restrict__ inv_freq, float qscale) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = ntok * kH * 12 * 2;
+    if (idx >= total) return;
+    const int i = (int)(idx % 12);
+    const int hd = (int)((idx / 12) % kH);
+    const int which = (int)((idx / (12 * kH)) & 1);
+    const long token = idx / (12 * kH * 2);
+    const int pos = (int)((token / pos_div) % pos_mod);
+    const float ang = (float)pos * inv_freq[i];
+    const float c = cosf(ang), s = sinf(ang);
+    float* v = buf + token * ld + which * kC + hd * kDH;
+    const float y1 = v[i], y2 = v[i + 12];
+    const float sc = which == 0 ? qscale : 1.0f;
+    v[i] = (y1 * c + y2 * s) * sc;
+    v[i + 12] = (y2 * c - y1 * s) * sc;
+}
+
+// ---- loss ----------------------------------------------------------------------------------------------------------
+// total = mean_b ( sum((pred - ut)^2 m) / sum(m) )   (transport.py:13-17, 184; wrapper.py:403 loss.mean())
+// den[b] = sum(m) from k32_colsum-free tiny kernel; dpred = 2 (pred - ut) m / den[b] / B
+__global__ __launch_bounds__(256) void k32_mask_sum(const float* __restrict__ mask, long per_sample, float* __restrict__ den) {
+    __shared__ float red[4];
+    const long base = (long)blockIdx.x * per_sample;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < per_sample; i += 256) s += mask[base + i];
+    s = wave_sum(s);
+    if (lane_id() == 0) red[wave_id()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) den[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void k32_loss_grad(const float* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ mask,
+                              const float* __restrict__ den, long per_sample, long total, float inv_b,
+                              float* __restrict__ dpred) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / per_sample;
+    dpred[i] = 2.0f * (pred[i] - target[i]) * mask[i] / den[b] * inv_b;
+}
+
+// out[(b, l)][c] (+)= sum_t a[(b, t, l)][c]   (h = h + ipa_out[:, None]: latent_model.py:245-246)
+__global__ void k32_sum_frames(const float* __restrict__ a, int B, int T, int L, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * L * kC) return;
+    const int c = (int)(i % kC);
+    const int l = (int)((i / kC) % L);
+    const int b = (int)(i / ((long)kC * L));
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += a[(((long)b * T + t) * L + l) * kC + c];
+    out[i] = s;
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------
+void launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,
+                 size_t part_floats, hipStream_t s) {
+    int nsplit = (int)((n + 2047) / 2048);
+    if (nsplit > 64) nsplit = 64;
+    if (nsplit < 1) nsplit = 1;
+    while (nsplit > 1 && (size_t)nsplit * m * k > part_floats) --nsplit;
+    hipLaunchKernelGGL(k32_dw, dim3((m + 63) / 64, (k + 63) / 64, nsplit), dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
+    const long count = (long)m * k;
+    hipLaunchKernelGGL(k32_reduce_add, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part, nsplit, count, dw);
+}
+// out[g][c] (ldo) += sum_{t in group g} a[t][c] * B(t, c); groups of tokens_per_group rows
+void launch32_colsum(const float* a, int lda, const float* b, int ldb, const float* roww, int mode, long nrows, int ncols,
+                     long tokens_per_group, float eps, float* out, long ldo, float* part, size_t part_floats, hipStream_t s) {
+    const long ng = (nrows + tokens_per_group - 1) / tokens_per_group;
+    int rps = 512;
+    int spg = (int)((tokens_per_group + rps - 1) / rps);
+    while ((size_t)ng * spg * ncols > part_floats && rps < (1 << 24)) {
+        rps *= 2;
+        spg = (int)((tokens_per_group + rps - 1) / rps);
+    }
+    ColsumParams p{a, lda, b, ldb, roww, mode, nrows, ncols, tokens_per_group, rps, spg, eps, part};
+    hipLaunchKernelGGL(k32_colsum, dim3((unsigned)(ng * spg), (unsigned)((ncols + 383) / 384)), dim3(384), 0, s, p);
+    const int tot = (int)(ng * ncols);
+    hipLaunchKernelGGL(k32_colsum_final, dim3((tot + 255) / 256), dim3(256), 0, s, part, (int)ng, spg, ncols, out, ldo);
+}
+void launch32_ln_bwd(const float* x, const float* dy, long nrows, const ModMap& mm, int scale_chunk, int affine, float eps,
+                     float* dx, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(k32_ln_bwd, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, x, dy, nrows, mm, scale_chunk, affine,
+                       eps, dx, accumulate);
+}
+void launch32_gate_mul(const float* a, long nrows, const ModMap& mm, int gate_chunk, int gated, float* out, hipStream_t s) {
+    const long n = nrows * kC;
+    hipLaunchKernelGGL(k32_gate_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, nrows, mm, gate_chunk, gated, out);
+}
+void launch32_gelu_from_pre(const float* pre, long n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k32_gelu_from_pre, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, n, out);
+}
+void launch32_gelu_bwd(const float* pre, long n, float* d, hipStream_t s) {
+    hipLaunchKernelGGL(k32_gelu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, n, d);
+}
+void launch32_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
+                       const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
+                       float* stats, float* dbias, hipStream_t s) {
+    const int nqb = (ax.len + 255) / 256, nkb = (ax.len + 1 + 255) / 256;
+    hipLaunchKernelGGL(k32_attn_bwd_q, dim3((unsigned)((long)ax.nseq * kH * nqb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k,
+                       bias_v, inv_freq, o, dout, dqkv, stats);
+    hipLaunchKernelGGL(k32_attn_bwd_kv, dim3((unsigned)((long)ax.nseq * kH * nkb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k,
+                       bias_v, inv_freq, dout, stats, dqkv, dbias);
+}
+void launch32_rope_bwd(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, float qscale,
+                       hipStream_t s) {
+    const long total = ntok * kH * 12 * 2;
+    hipLaunchKernelGGL(k32_rope_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, buf, ntok, ld, pos_div, pos_mod,
+                       inv_freq, qscale);
+}
+void launch32_loss_grad(const float* pred, const float* target, const float* mask, long per_sample, long B, float* den,
+                        float* dpred, hipStream_t s) {
+    hipLaunchKernelGGL(k32_mask_sum, dim3((unsigned)B), dim3(256), 0, s, mask, per_sample, den);
+    const long total = per_sample * B;
+    hipLaunchKernelGGL(k32_loss_grad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pred, target, mask, den,
+                       per_sample, total, 1.0f / (float)B, dpred);
+}
+void launch32_sum_frames(const float* a, int B, int T, int L, float* out, hipStream_t s) {
+    const long n = (long)B * L * kC;
+    hipLaunchKernelGGL(k32_sum_frames, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, B, T, L, out);
+}
+
+}  // namespace mdg
+
+namespace mdg {
+
+// h[t][c] += gate[g(t)][c] * u[t][c]   (the residual update kept apart from the projection so that u can be taped)
+__global__ void k32_gated_add(float* __restrict__ h, const float* __restrict__ u, long nrows, ModMap mm, int gate_chunk,
+                              int gated) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * kC) return;
+    const long t = i / kC;
+    const int c = (int)(i % kC);
+    const float g = gated ? mm.mod[mm.row_off(t) + gate_chunk * kC + c] : 1.0f;
+    h[i] += g * u[i];
+}
+void launch32_gated_add(float* h, const float* u, long nrows, const ModMap& mm, int gate_chunk, int gated, hipStream_t s) {
+    const long n = nrows * kC;
+    hipLaunchKernelGGL(k32_gated_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h, u, nrows, mm, gate_chunk, gated);
+}
+
+// ind0[t] = (cm[t] == 0), ind1[t] = (cm[t] != 0) as floats (mask_to_emb rows; latent_model.py:240-241)
+__global__ void k32_indicator(const int64_t* __restrict__ cm, long n, float* __restrict__ ind0, float* __restrict__ ind1) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool one = cm[i] != 0;
+    ind0[i] = one ? 0.f : 1.f;
+    ind1[i] = one ? 1.f : 0.f;
+}
+void launch32_indicator(const int64_t* cm, long n, float* ind0, float* ind1, hipStream_t s) {
+    hipLaunchKernelGGL(k32_indicator, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cm, n, ind0, ind1);
+}
+
+// d aatype_to_emb[v][c] += sum over rows (b, l) with aatype == v of dx0[(g, l)][c]   (rows = ngroups * L, fixed order)
+__global__ void k32_embed_rows_bwd(const float* __restrict__ dx0, const int64_t* __restrict__ aatype, int ngroups, int B, int L,
+                                   float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 21 * kC) return;
+    const int v = i / kC, c = i % kC;
+    float s = 0.f;
+    for (long r = 0; r < (long)ngroups * L; ++r) {
+        const int l = (int)(r % L), b = (int)((r / L) % B);
+        if ((int)aatype[(long)b * L + l] == v) s += dx0[r * kC + c];
+    }
+    dw[i] += s;
+}
+void launch32_embed_rows_bwd(const float* dx0, const int64_t* aatype, int ngroups, int B, int L, float* dw, hipStream_t s) {
+    hipLaunchKernelGGL(k32_embed_rows_bwd, dim3((21 * kC + 255) / 256), dim3(256), 0, s, dx0, aatype, ngroups, B, L, dw);
+}
+
+// TimestepEmbedder backward (layers.py:17-55 + the SiLU of the adaLN heads).  One block per time row r: recompute
+// emb, pre1, h1, pre2; from dst = d silu(pre2): dpre2 -> scratch, h1 -> scratch, dpre1 -> scratch, emb -> scratch
+// (the weight gradients are then plain dW / column-sum calls over the R rows).
+__device__ __forceinline__ float silu_grad(float x) {
+    const float s = 1.0f / (1.0f + expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+__global__ __launch_bounds__(384) void k32_temb_bwd(const float* __restrict__ t_rows, float tmul, const float* __restrict__ w0,
+                                                    const float* __restrict__ b0, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, const float* __restrict__ dst,
+                                                    float* __restrict__ emb_out, float* __restrict__ h1_out,
+                                                    float* __restrict__ dpre1_out, float* __restrict__ dpre2_out) {
+    __shared__ float emb[256];
+    __shared__ float h1[kC];
+    __shared__ float dp2[kC];
+    const int r = blockIdx.x, c = threadIdx.x;
+    const float t = t_rows[r] * tmul;
+    if (c < 256) {
+        const int i = c & 127;
+        const float f = expf(-9.210340371976184f * (float)i / 128.0f);
+        const float a = t * f;
+        emb[c] = (c < 128) ? cosf(a) : sinf(a);
+        emb_out[(long)r * 256 + c] = emb[c];
+    }
+    __syncthreads();
+    float pre1 = b0[c];
+    const float* wr = w0 + (long)c * 256;
+    for (int i = 0; i < 256; ++i) pre1 += wr[i] * emb[i];
+    h1[c] = pre1 / (1.0f + expf(-pre1));
+    h1_out[(long)r * kC + c] = h1[c];
+    __syncthreads();
+    float pre2 = b2[c];
+    const float* wr2 = w2 + (long)c * kC;
+    for (int i = 0; i < kC; ++i) pre2 += wr2[i] * h1[i];
+    dp2[c] = dst[(long)r * kC + c] * silu_grad(pre2);
+    dpre2_out[(long)r * kC + c] = dp2[c];
+    __syncthreads();
+    float dh1 = 0.f;
+    for (int o = 0; o < kC; ++o) dh1 += w2[(long)o * kC + c] * dp2[o];
+    dpre1_out[(long)r * kC + c] = dh1 * silu_grad(pre1);
+}
+void launch32_temb_bwd(const float* t_rows, int nrows, float tmul, const float* w0, const float* b0, const float* w2,
+                       const float* b2, const float* dst, float* emb, float* h1, float* dpre1, float* dpre2, hipStream_t s) {
+    hipLaunchKernelGGL(k32_temb_bwd, dim3(nrows), dim3(384), 0, s, t_rows, tmul, w0, b0, w2, b2, dst, emb, h1, dpre1, dpre2);
+}
+
+}  // namespace mdg

@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256) void k_ipa_attn(const IpaAttnParams p) {
         }
     }
     const float inv = 1.0f / den;
+    if (p.stats) p.stats[gi * 4 + hd] = mrun + logf(den);
     ipa_store_features(p, gi, hd, o, op, inv, Ri, ti);
 }
 
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(256) void k_ipa_attn_tiled(const IpaAttnParams p) {
     }
     if (!qok) return;
     const float inv = 1.0f / den;
+    if (p.stats) p.stats[gi * 4 + hd] = mrun + logf(den);
     ipa_store_features(p, gi, hd, o, op, inv, Ri, ti);
 }
 

@@ -108,6 +108,7 @@ struct IpaAttnParams {
     const float* head_w;    // [4]
     __bf16* feat;           // [M][256]
     float* feat32;          // fp32 mode: features written here (fp32) instead of `feat`
+    float* stats;           // training tape (nullable): [M][4 heads] log-sum-exp of the logits (m + log(sum exp))
     int ngroups, B, L;
 };
 
@@ -134,7 +135,31 @@ void launch_ipa_attn(const IpaAttnParams& p, hipStream_t s);
 void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chunk, int scale_chunk, int affine, float eps,
                      float* y, hipStream_t s);
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
-                     float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s);
+                     float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
+                     int wtrans = 0, float* c2 = nullptr);
+// backward kernels of the training step (k_fp32_bwd.hip)
+void launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,
+                 size_t part_floats, hipStream_t s);
+void launch32_colsum(const float* a, int lda, const float* b, int ldb, const float* roww, int mode, long nrows, int ncols,
+                     long tokens_per_group, float eps, float* out, long ldo, float* part, size_t part_floats, hipStream_t s);
+void launch32_ln_bwd(const float* x, const float* dy, long nrows, const ModMap& mm, int scale_chunk, int affine, float eps,
+                     float* dx, int accumulate, hipStream_t s);
+void launch32_gate_mul(const float* a, long nrows, const ModMap& mm, int gate_chunk, int gated, float* out, hipStream_t s);
+void launch32_gelu_from_pre(const float* pre, long n, float* out, hipStream_t s);
+void launch32_gelu_bwd(const float* pre, long n, float* d, hipStream_t s);
+void launch32_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
+                       const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
+                       float* stats, float* dbias, hipStream_t s);
+void launch32_rope_bwd(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, float qscale,
+                       hipStream_t s);
+void launch32_loss_grad(const float* pred, const float* target, const float* mask, long per_sample, long B, float* den,
+                        float* dpred, hipStream_t s);
+void launch32_sum_frames(const float* a, int B, int T, int L, float* out, hipStream_t s);
+void launch32_gated_add(float* h, const float* u, long nrows, const ModMap& mm, int gate_chunk, int gated, hipStream_t s);
+void launch32_indicator(const int64_t* cm, long n, float* ind0, float* ind1, hipStream_t s);
+void launch32_embed_rows_bwd(const float* dx0, const int64_t* aatype, int ngroups, int B, int L, float* dw, hipStream_t s);
+void launch32_temb_bwd(const float* t_rows, int nrows, float tmul, const float* w0, const float* b0, const float* w2,
+                       const float* b2, const float* dst, float* emb, float* h1, float* dpre1, float* dpre2, hipStream_t s);
 void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, hipStream_t s);
 void launch32_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
                    const float* inv_freq, float* out, hipStream_t s);

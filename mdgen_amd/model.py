@@ -97,6 +97,7 @@ class LatentMDGenModel:
             check(lib.mdgen_ctx_finalize(self._ctx, s))
             torch.cuda.current_stream().synchronize()   # packing kernels read `keep` asynchronously
         self._loaded = True
+        self._state_names = list(sd.keys())
         if self.precision == "fp32":
             self.set_precision("fp32")
         return self

@@ -65,8 +65,14 @@ class NewMDGenWrapper:
         args = ckpt["hyper_parameters"]["args"]
         w = cls(args, device=device, precision=precision)
         sd = {k[len("model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("model.")}
-        w.model.load_state_dict(sd)
+        w.load_model_state_dict(sd)
         return w
+
+    def load_model_state_dict(self, sd):
+        """Hand the `model.*` tensors to the library and remember them (the training step starts from them)."""
+        self.model.load_state_dict(sd)
+        self.model_state_dict = {k: v.detach().clone() for k, v in sd.items()}
+        return self
 
     def eval(self):
         return self
