@@ -16,6 +16,7 @@ constexpr int kIpaFeat = 256;  // o(128) | o_pt.x(32) | o_pt.y(32) | o_pt.z(32) 
 constexpr int kFragBytes = 1536;  // one (seq, head, 32-position tile) of Q, K or V^T fragments
 constexpr int kRopeRow = 32;   // floats per position of the rotary table: [2 halves][cos 6 | pad 2 | sin 6 | pad 2]
 constexpr int kPanel = 64;     // token rows per GEMM panel (workgroup)
+constexpr int kIpaKT = 32;     // keys per LDS tile of the tiled IPA attention kernels
 constexpr float kLog2e = 1.4426950408889634f;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -630,3 +630,326 @@ void launch32_temb_bwd(const float* t_rows, int nrows, float tmul, const float* 
 }
 
 }  // namespace mdg
+
+namespace mdg {
+
+// ---- invariant point attention backward (ipa.py:92-255 with c_z = 0; forward: k_ipa_attn / k_ipa_attn_tiled) ------------
+// logit_ij = c_qk q_i.k_j + hwh_h sum_p |Qp_ip - Kp_jp|^2 + 1e5 (m_i m_j - 1),  a = softmax_j,
+// o_i = sum_j a_ij v_j,  Op_i = sum_j a_ij Vp_j (global frame),  op_i = R_i^T (Op_i - t_i),  n_i = sqrt(|op_i|^2 + 1e-8).
+// Query pass (thread = query): from d feat -> do, d Op (global), delta_i = do.o + dOp.Op; then over key tiles
+//   dl_ij = a_ij (do.v_j + dOp.Vp_j - delta_i);  dq_i += c_qk dl_ij k_j;  dQp_i += 2 hwh dl_ij (Qp_i - Kp_j);  dhw_i += dl_ij d2_ij
+// writes dproj (q columns, q-point columns rotated back to the local frame), dhw[token][head], and the per-query record
+// qrec[token][head][49] = Qp (24) | dOp (24) | delta for the key pass.
+constexpr int kIpaRec = 49;
+__device__ __forceinline__ void stage_ipa_keys(const IpaAttnParams& p, long g, int b, int hd, int j0, int skey, int ssub,
+                                               float (*sk)[32], float (*sv)[32], float (*skp)[24], float (*svp)[24], float* sm) {
+    const int j = j0 + skey;
+    const int jc = j < p.L ? j : p.L - 1;
+    const float* pj = p.proj + (g * p.L + jc) * kIpaProj;
+    const f32x4 kk = *reinterpret_cast<const f32x4*>(pj + 128 + hd * 64 + 4 * ssub);
+    const f32x4 vv = *reinterpret_cast<const f32x4*>(pj + 128 + hd * 64 + 32 + 4 * ssub);
+    float Rj[9], tj[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rj[k] = p.rot[((long)b * p.L + jc) * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tj[k] = p.trans[((long)b * p.L + jc) * 3 + k];
+    float kx, ky, kz, vx, vy, vz;
+    {
+        const float x = pj[480 + hd * 16 + ssub], y = pj[544 + hd * 16 + ssub], z = pj[608 + hd * 16 + ssub];
+        kx = Rj[0] * x + Rj[1] * y + Rj[2] * z + tj[0];
+        ky = Rj[3] * x + Rj[4] * y + Rj[5] * z + tj[1];
+        kz = Rj[6] * x + Rj[7] * y + Rj[8] * z + tj[2];
+    }
+    {
+        const float x = pj[480 + hd * 16 + 8 + ssub], y = pj[544 + hd * 16 + 8 + ssub], z = pj[608 + hd * 16 + 8 + ssub];
+        vx = Rj[0] * x + Rj[1] * y + Rj[2] * z + tj[0];
+        vy = Rj[3] * x + Rj[4] * y + Rj[5] * z + tj[1];
+        vz = Rj[6] * x + Rj[7] * y + Rj[8] * z + tj[2];
+    }
+    *reinterpret_cast<f32x4*>(&sk[skey][4 * ssub]) = kk;
+    *reinterpret_cast<f32x4*>(&sv[skey][4 * ssub]) = vv;
+    skp[skey][3 * ssub] = kx; skp[skey][3 * ssub + 1] = ky; skp[skey][3 * ssub + 2] = kz;
+    svp[skey][3 * ssub] = vx; svp[skey][3 * ssub + 1] = vy; svp[skey][3 * ssub + 2] = vz;
+    if (ssub == 0) sm[skey] = j < p.L ? p.mask_bl[(long)b * p.L + jc] : -1.0f;
+}
+
+struct IpaBwdParams {
+    IpaAttnParams f;          // forward inputs (proj, rot, trans, mask_bl, head_w, stats = lse, feat32 = forward features)
+    const float* dfeat;       // [M][256]
+    float* dproj;             // [M][672]
+    float* dhw;               // [M][4]
+    float* qrec;              // [M][4][49]
+};
+
+__global__ __launch_bounds__(256) void k32_ipa_bwd_q(const IpaBwdParams bp) {
+    const IpaAttnParams& p = bp.f;
+    __shared__ __attribute__((aligned(16))) float sk[kIpaKT][32];
+    __shared__ __attribute__((aligned(16))) float sv[kIpaKT][32];
+    __shared__ __attribute__((aligned(16))) float skp[kIpaKT][24];
+    __shared__ __attribute__((aligned(16))) float svp[kIpaKT][24];
+    __shared__ float sm[kIpaKT];
+    const int nqt = (p.L + 255) / 256;
+    const int qt = blockIdx.x % nqt;
+    const int hd = (blockIdx.x / nqt) & 3;
+    const long g = blockIdx.x / (nqt * 4);
+    const int b = (int)(g % p.B);
+    const int tid = threadIdx.x;
+    const int i = qt * 256 + tid;
+    const bool qok = i < p.L;
+    const int ic = qok ? i : p.L - 1;
+    const long gi = g * p.L + ic;
+    const float* pi = p.proj + gi * kIpaProj;
+    float Ri[9], ti[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ri[k] = p.rot[((long)b * p.L + ic) * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ti[k] = p.trans[((long)b * p.L + ic) * 3 + k];
+    const float mi = p.mask_bl[(long)b * p.L + ic];
+    const float qk_scale = 0.10206207261596575f;
+    const float hwraw = p.head_w[hd];
+    const float sp = (hwraw > 20.f) ? hwraw : log1pf(expf(hwraw));
+    const float hwh = -0.5f * sp * 0.09622504486493763f;
+    const float lse = p.stats[gi * 4 + hd];
+    float q[32], qp[8][3], dO[32], dOp[8][3], dq[32], dqp[8][3];
+    const float* fi = p.feat32 + gi * kIpaFeat;
+    const float* dfi = bp.dfeat + gi * kIpaFeat;
+    float delta = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        q[c] = pi[hd * 32 + c] * qk_scale;
+        dO[c] = dfi[hd * 32 + c];
+        delta += dO[c] * fi[hd * 32 + c];
+        dq[c] = 0.f;
+    }
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {
+        const float x = pi[384 + hd * 8 + pt], y = pi[416 + hd * 8 + pt], z = pi[448 + hd * 8 + pt];
+        qp[pt][0] = Ri[0] * x + Ri[1] * y + Ri[2] * z + ti[0];
+        qp[pt][1] = Ri[3] * x + Ri[4] * y + Ri[5] * z + ti[1];
+        qp[pt][2] = Ri[6] * x + Ri[7] * y + Ri[8] * z + ti[2];
+        // local output point and its norm (forward features), d local = d feat + d norm * op / norm
+        const float lx = fi[128 + hd * 8 + pt], ly = fi[160 + hd * 8 + pt], lz = fi[192 + hd * 8 + pt];
+        const float nr = fi[224 + hd * 8 + pt];
+        const float dn = dfi[224 + hd * 8 + pt] / nr;
+        const float dlx = dfi[128 + hd * 8 + pt] + dn * lx, dly = dfi[160 + hd * 8 + pt] + dn * ly,
+                    dlz = dfi[192 + hd * 8 + pt] + dn * lz;
+        // global: Op = R op + t,  dOp = R d op
+        const float Ox = Ri[0] * lx + Ri[1] * ly + Ri[2] * lz + ti[0], Oy = Ri[3] * lx + Ri[4] * ly + Ri[5] * lz + ti[1],
+                    Oz = Ri[6] * lx + Ri[7] * ly + Ri[8] * lz + ti[2];
+        dOp[pt][0] = Ri[0] * dlx + Ri[1] * dly + Ri[2] * dlz;
+        dOp[pt][1] = Ri[3] * dlx + Ri[4] * dly + Ri[5] * dlz;
+        dOp[pt][2] = Ri[6] * dlx + Ri[7] * dly + Ri[8] * dlz;
+        delta += dOp[pt][0] * Ox + dOp[pt][1] * Oy + dOp[pt][2] * Oz;
+        dqp[pt][0] = dqp[pt][1] = dqp[pt][2] = 0.f;
+    }
+    float dhw = 0.f;
+    const int skey = tid >> 3, ssub = tid & 7;
+    for (int j0 = 0; j0 < p.L; j0 += kIpaKT) {
+        __syncthreads();
+        stage_ipa_keys(p, g, b, hd, j0, skey, ssub, sk, sv, skp, svp, sm);
+        __syncthreads();
+#pragma unroll 2
+        for (int jj = 0; jj < kIpaKT; ++jj) {
+            const float mj = sm[jj];
+            if (mj < 0.f) continue;
+            float dot = 0.f, da = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                dot += q[c] * sk[jj][c];
+                da += dO[c] * sv[jj][c];
+            }
+            float dif[8][3];
+#pragma unroll
+            for (int pt = 0; pt < 8; ++pt) {
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    dif[pt][x] = qp[pt][x] - skp[jj][3 * pt + x];
+                    d2 += dif[pt][x] * dif[pt][x];
+                    da += dOp[pt][x] * svp[jj][3 * pt + x];
+                }
+            }
+            const float logit = dot + hwh * d2 + 1e5f * (mi * mj - 1.0f);
+            const float dl = expf(logit - lse) * (da - delta);
+#pragma unroll
+            for (int c = 0; c < 32; ++c) dq[c] += dl * sk[jj][c];
+            const float w2 = 2.0f * hwh * dl;
+#pragma unroll
+            for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+                for (int x = 0; x < 3; ++x) dqp[pt][x] += w2 * dif[pt][x];
+            dhw += dl * d2;
+        }
+    }
+    if (!qok) return;
+    float* dp = bp.dproj + gi * kIpaProj;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) dp[hd * 32 + c] = dq[c] * qk_scale;
+    float* rec = bp.qrec + (gi * 4 + hd) * kIpaRec;
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {
+        // local q-point gradient: R^T d Qp
+        dp[384 + hd * 8 + pt] = Ri[0] * dqp[pt][0] + Ri[3] * dqp[pt][1] + Ri[6] * dqp[pt][2];
+        dp[416 + hd * 8 + pt] = Ri[1] * dqp[pt][0] + Ri[4] * dqp[pt][1] + Ri[7] * dqp[pt][2];
+        dp[448 + hd * 8 + pt] = Ri[2] * dqp[pt][0] + Ri[5] * dqp[pt][1] + Ri[8] * dqp[pt][2];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            rec[3 * pt + x] = qp[pt][x];
+            rec[24 + 3 * pt + x] = dOp[pt][x];
+        }
+    }
+    rec[48] = delta;
+    bp.dhw[gi * 4 + hd] = dhw;
+}
+
+// Key pass (thread = key j): over query tiles  dk_j += c_qk dl_ij q_i;  dv_j += a_ij do_i;  dVp_j += a_ij dOp_i;
+// dKp_j -= 2 hwh dl_ij (Qp_i - Kp_j);  then points back to the local frame of j.
+__global__ __launch_bounds__(256) void k32_ipa_bwd_kv(const IpaBwdParams bp) {
+    const IpaAttnParams& p = bp.f;
+    constexpr int QT = 32;
+    __shared__ __attribute__((aligned(16))) float sq[QT][32];
+    __shared__ __attribute__((aligned(16))) float sdo[QT][32];
+    __shared__ float srec[QT][kIpaRec + 3];   // Qp | dOp | delta | lse | m_i | valid
+    const int nkt = (p.L + 255) / 256;
+    const int kt = blockIdx.x % nkt;
+    const int hd = (blockIdx.x / nkt) & 3;
+    const long g = blockIdx.x / (nkt * 4);
+    const int b = (int)(g % p.B);
+    const int tid = threadIdx.x;
+    const int j = kt * 256 + tid;
+    const bool kok = j < p.L;
+    const int jc = kok ? j : p.L - 1;
+    const long gj = g * p.L + jc;
+    const float* pj = p.proj + gj * kIpaProj;
+    float Rj[9], tj[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rj[k] = p.rot[((long)b * p.L + jc) * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tj[k] = p.trans[((long)b * p.L + jc) * 3 + k];
+    const float mj = p.mask_bl[(long)b * p.L + jc];
+    const float qk_scale = 0.10206207261596575f;
+    const float hwraw = p.head_w[hd];
+    const float sp = (hwraw > 20.f) ? hwraw : log1pf(expf(hwraw));
+    const float hwh = -0.5f * sp * 0.09622504486493763f;
+    float k[32], v[32], kp[8][3], vp[8][3], dk[32], dv[32], dkp[8][3], dvp[8][3];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        k[c] = pj[128 + hd * 64 + c];
+        v[c] = pj[128 + hd * 64 + 32 + c];
+        dk[c] = dv[c] = 0.f;
+    }
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {
+        {
+            const float x = pj[480 + hd * 16 + pt], y = pj[544 + hd * 16 + pt], z = pj[608 + hd * 16 + pt];
+            kp[pt][0] = Rj[0] * x + Rj[1] * y + Rj[2] * z + tj[0];
+            kp[pt][1] = Rj[3] * x + Rj[4] * y + Rj[5] * z + tj[1];
+            kp[pt][2] = Rj[6] * x + Rj[7] * y + Rj[8] * z + tj[2];
+        }
+        {
+            const float x = pj[480 + hd * 16 + 8 + pt], y = pj[544 + hd * 16 + 8 + pt], z = pj[608 + hd * 16 + 8 + pt];
+            vp[pt][0] = Rj[0] * x + Rj[1] * y + Rj[2] * z + tj[0];
+            vp[pt][1] = Rj[3] * x + Rj[4] * y + Rj[5] * z + tj[1];
+            vp[pt][2] = Rj[6] * x + Rj[7] * y + Rj[8] * z + tj[2];
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) dkp[pt][x] = dvp[pt][x] = 0.f;
+    }
+    for (int i0 = 0; i0 < p.L; i0 += QT) {
+        __syncthreads();
+        for (int e = tid; e < QT * 32; e += 256) {
+            const int ii = e >> 5, c = e & 31;
+            const int i = i0 + ii;
+            const long gi = g * p.L + (i < p.L ? i : p.L - 1);
+            sq[ii][c] = p.proj[gi * kIpaProj + hd * 32 + c] * qk_scale;
+            sdo[ii][c] = bp.dfeat[gi * kIpaFeat + hd * 32 + c];
+        }
+        for (int e = tid; e < QT * (kIpaRec + 3); e += 256) {
+            const int ii = e / (kIpaRec + 3), c = e % (kIpaRec + 3);
+            const int i = i0 + ii;
+            const int icl = i < p.L ? i : p.L - 1;
+            const long gi = g * p.L + icl;
+            float val;
+            if (c < kIpaRec) val = bp.qrec[(gi * 4 + hd) * kIpaRec + c];
+            else if (c == kIpaRec) val = p.stats[gi * 4 + hd];
+            else if (c == kIpaRec + 1) val = p.mask_bl[(long)b * p.L + icl];
+            else val = i < p.L ? 1.f : 0.f;
+            srec[ii][c] = val;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ii = 0; ii < QT; ++ii) {
+            if (srec[ii][kIpaRec + 2] == 0.f) continue;
+            float dot = 0.f, da = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                dot += sq[ii][c] * k[c];
+                da += sdo[ii][c] * v[c];
+            }
+            float dif[8][3];
+#pragma unroll
+            for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    dif[pt][x] = srec[ii][3 * pt + x] - kp[pt][x];
+                    d2 += dif[pt][x] * dif[pt][x];
+                    da += srec[ii][24 + 3 * pt + x] * vp[pt][x];
+                }
+            const float logit = dot + hwh * d2 + 1e5f * (srec[ii][kIpaRec + 1] * mj - 1.0f);
+            const float a = expf(logit - srec[ii][kIpaRec]);
+            const float dl = a * (da - srec[ii][48]);
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                dk[c] += dl * sq[ii][c];
+                dv[c] += a * sdo[ii][c];
+            }
+            const float w2 = -2.0f * hwh * dl;
+#pragma unroll
+            for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    dkp[pt][x] += w2 * dif[pt][x];
+                    dvp[pt][x] += a * srec[ii][24 + 3 * pt + x];
+                }
+        }
+    }
+    if (!kok) return;
+    float* dp = bp.dproj + gj * kIpaProj;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        dp[128 + hd * 64 + c] = dk[c];          // sq already carries c_qk
+        dp[128 + hd * 64 + 32 + c] = dv[c];
+    }
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) {
+        dp[480 + hd * 16 + pt] = Rj[0] * dkp[pt][0] + Rj[3] * dkp[pt][1] + Rj[6] * dkp[pt][2];
+        dp[544 + hd * 16 + pt] = Rj[1] * dkp[pt][0] + Rj[4] * dkp[pt][1] + Rj[7] * dkp[pt][2];
+        dp[608 + hd * 16 + pt] = Rj[2] * dkp[pt][0] + Rj[5] * dkp[pt][1] + Rj[8] * dkp[pt][2];
+        dp[480 + hd * 16 + 8 + pt] = Rj[0] * dvp[pt][0] + Rj[3] * dvp[pt][1] + Rj[6] * dvp[pt][2];
+        dp[544 + hd * 16 + 8 + pt] = Rj[1] * dvp[pt][0] + Rj[4] * dvp[pt][1] + Rj[7] * dvp[pt][2];
+        dp[608 + hd * 16 + 8 + pt] = Rj[2] * dvp[pt][0] + Rj[5] * dvp[pt][1] + Rj[8] * dvp[pt][2];
+    }
+}
+
+// d head_weights[h] += (-1/2 sqrt(1/108)) sigmoid(w_h) * sum_tokens dhw[token][h]    (softplus' = sigmoid)
+__global__ void k32_ipa_headw_bwd(const float* __restrict__ dhw, long ntok, const float* __restrict__ head_w,
+                                  float* __restrict__ g) {
+    const int hd = threadIdx.x;
+    if (hd >= 4) return;
+    float s = 0.f;
+    for (long t = 0; t < ntok; ++t) s += dhw[t * 4 + hd];
+    const float w = head_w[hd];
+    const float sig = w > 20.f ? 1.0f : 1.0f / (1.0f + expf(-w));
+    g[hd] += s * (-0.5f * 0.09622504486493763f) * sig;
+}
+
+void launch32_ipa_bwd(const IpaAttnParams& f, const float* dfeat, float* dproj, float* dhw, float* qrec, float* dheadw,
+                      hipStream_t s) {
+    IpaBwdParams bp{f, dfeat, dproj, dhw, qrec};
+    const int nqt = (f.L + 255) / 256;
+    const long nblk = (long)f.ngroups * 4 * nqt;
+    hipLaunchKernelGGL(k32_ipa_bwd_q, dim3((unsigned)nblk), dim3(256), 0, s, bp);
+    hipLaunchKernelGGL(k32_ipa_bwd_kv, dim3((unsigned)nblk), dim3(256), 0, s, bp);
+    if (dheadw) hipLaunchKernelGGL(k32_ipa_headw_bwd, dim3(1), dim3(64), 0, s, dhw, (long)f.ngroups * f.L, f.head_w, dheadw);
+}
+
+}  // namespace mdg

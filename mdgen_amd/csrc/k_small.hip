@@ -368,7 +368,6 @@ __global__ __launch_bounds__(256) void k_ipa_attn(const IpaAttnParams p) {
 // the softmax is renormalised once per 32-key tile (one max, one exp per key) instead of twice per key.
 // 4.1 ms -> ~0.1 ms per launch at cfg-4 (B 1, L 256, 49 prepared steps).
 // -------------------------------------------------------------------------------------------------
-constexpr int kIpaKT = 32;   // keys per LDS tile
 __global__ __launch_bounds__(256) void k_ipa_attn_tiled(const IpaAttnParams p) {
     __shared__ __attribute__((aligned(16))) float sk[kIpaKT][32];    // k vectors of this head
     __shared__ __attribute__((aligned(16))) float sv[kIpaKT][32];    // v vectors

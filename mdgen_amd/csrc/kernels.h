@@ -155,6 +155,8 @@ void launch32_rope_bwd(float* buf, long ntok, int ld, long pos_div, int pos_mod,
 void launch32_loss_grad(const float* pred, const float* target, const float* mask, long per_sample, long B, float* den,
                         float* dpred, hipStream_t s);
 void launch32_sum_frames(const float* a, int B, int T, int L, float* out, hipStream_t s);
+void launch32_ipa_bwd(const IpaAttnParams& f, const float* dfeat, float* dproj, float* dhw, float* qrec, float* dheadw,
+                      hipStream_t s);
 void launch32_gated_add(float* h, const float* u, long nrows, const ModMap& mm, int gate_chunk, int gated, hipStream_t s);
 void launch32_indicator(const int64_t* cm, long n, float* ind0, float* ind1, hipStream_t s);
 void launch32_embed_rows_bwd(const float* dx0, const int64_t* aatype, int ngroups, int B, int L, float* dw, hipStream_t s);

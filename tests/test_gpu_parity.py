@@ -1047,6 +1047,11 @@ def test_training_step_gradients_vs_autograd(shape):
         worst.append((e, k))
     worst.sort(reverse=True)
     print("worst gradient rel-L2:", [(f"{e:.1e}", k) for e, k in worst[:6]])
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                           f"train_grad_errors_L{L}.txt"), "w") as f:
+        for e, k in worst:
+            f.write(f"{e:.3e} {k} |g_ref| {float(P[k].grad.norm()):.3e}\n")
     bad = [(e, k) for e, k in worst if not e < 2e-4]
     assert not bad, bad[:10]
     # a second call ADDS (gradient accumulation) and is bit-reproducible
