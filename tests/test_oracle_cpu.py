@@ -215,3 +215,26 @@ def test_forward_cfg4_full_size_matches_reference():
     norms = [float(out.double().norm()), float(tr["ipa_out"].double().norm()), float(tr["h0"].double().norm()),
              float(tr[f"h{nl}"].double().norm())]
     np.testing.assert_allclose(norms, g["norms"].numpy(), rtol=1e-5)
+
+
+def test_training_gradients_vs_reference_autograd():
+    """The oracle's autograd (what the GPU gradient tests compare against) pinned to the REFERENCE's own backward pass:
+    `training_losses(...)["loss"].mean().backward()` on the full-width 2-layer model (tests/golden/train_grads_sim.npz,
+    oracle/gen_golden_train.py): every parameter's gradient norm and a strided sample of its entries."""
+    g = load_golden("train_grads_sim")
+    cfg, sd = weights_for(g)
+    names = [str(n) for n in g["grad_names"]]
+    P = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    kw = dict(mask=g["mask"], start_frames=(g["start_rot"], g["start_trans"]), end_frames=(g["start_rot"], g["start_trans"]),
+              x_cond=g["x_cond"], x_cond_mask=g["x_cond_mask"], aatype=g["aatype"])
+    with torch.enable_grad():
+        out = O.training_losses(P, O.cfg_dict(cfg), g["x1"], g["loss_mask"], kw, g["t"], g["x0"])
+        out["loss"].mean().backward()
+    assert torch.allclose(out["loss"].detach(), g["loss"], rtol=2e-5)
+    assert len(names) == 124 and "pos_embed" not in names            # frozen buffer: no gradient in the reference
+    for k in names:
+        gr = P[k].grad.reshape(-1)
+        stride = int(g["gstride_" + k])
+        ref = g["gsamp_" + k]
+        assert rel_l2(gr[::stride][:2048], ref) < 1e-4, k
+        assert abs(float(gr.double().norm()) - float(g["gnorm_" + k])) <= 1e-4 * float(g["gnorm_" + k]) + 1e-9, k
