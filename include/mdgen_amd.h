@@ -99,6 +99,11 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *   "residue_l4_path"  residue-axis attention sub-layer when L == 4: 2 (default) one kernel for the whole
  *                      sub-layer, 1 attention inside the QKV kernel + separate out-projection, 0 the general
  *                      L <= 8 path.  All three compute mha.py:258-397 + latent_model.py:457-462.
+ *   "attention_path"   tiled attention (sequence > 8 positions; mha.py:359-396): 0 (default) softmax with a FIXED
+ *                      shift anchored on the first key tile, an overflow test per query row at the end and an
+ *                      automatic re-run of the affected (head, 64 queries) on the robust loop; 1 the robust loop
+ *                      (running row max, shift re-anchored as it grows) for everything.  Same results to fp32
+ *                      rounding; 1 is ~1.5x slower.
  * Returns -4 for an unknown name, -2 for a value out of range. */
 int32_t mdgen_ctx_set_option(mdgen_ctx* ctx, const char* name, int32_t value);
 /* number of state_dict keys the model needs; name of the i-th (for loaders / tests) */

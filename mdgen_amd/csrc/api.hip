@@ -95,7 +95,7 @@ struct mdgen_ctx {
     float *pos_embed = nullptr, *t_w0 = nullptr, *t_b0 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
     float *wf7 = nullptr, *bf7 = nullptr, *wr7 = nullptr, *br7 = nullptr;
     float *ada_w = nullptr, *ada_b = nullptr;
-    float *inv_freq = nullptr, *rope = nullptr, *zero_page = nullptr;
+    float *inv_freq = nullptr, *rope = nullptr;
     bf16x8* wfin = nullptr;
     float* bfin = nullptr;
     std::vector<TrunkW> trunk;
@@ -111,6 +111,7 @@ struct mdgen_ctx {
     int opt_keep_fp32 = 0;      // keep an fp32 copy of every weight handed over (required by precision 32)
     std::map<std::string, float*> w32;   // fp32 copies, natural layout, keyed by the reference's state_dict key
     int opt_streams = 2;        // concurrent sub-batch streams of the Euler rollout (1 = caller's stream only)
+    int opt_attn_path = 0;      // tiled attention: 0 fixed-anchor fast loop with overflow check + fallback, 1 robust loop always
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
     unsigned long long* phase_trace = nullptr;   // mdgen_profile_phase_trace target (device), consumed by one launch
     long phase_trace_cap = 0;
@@ -343,14 +344,6 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
         TRYHIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
     TRYHIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    TRY(c->dalloc(&c->zero_page, (size_t)512));
-    TRYHIP(hipMemset(c->zero_page, 0, 2048));
-    {   // bytes 128..143 and 896..911 (= +768, the k-step-1 offset of a V^T fragment): eight bf16 1.0 -- the all-ones
-        // V^T row that accumulates the softmax denominator
-        const uint16_t ones[8] = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
-        TRYHIP(hipMemcpy((unsigned char*)c->zero_page + 128, ones, sizeof(ones), hipMemcpyHostToDevice));
-        TRYHIP(hipMemcpy((unsigned char*)c->zero_page + 128 + 768, ones, sizeof(ones), hipMemcpyHostToDevice));
-    }
     TRY(c->dalloc(&c->wfin, (size_t)kKS * 64));
     TRY(c->dalloc(&c->bfin, (size_t)32));
     TRYHIP(hipMemset(c->bfin, 0, 32 * sizeof(float)));
@@ -520,6 +513,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
         if (value == 32 && (!c->opt_keep_fp32 || c->w32.empty()))
             return fail(-6, "precision 32 needs the fp32 weight copies: set option keep_fp32_weights = 1 before loading weights");
         c->opt_precision = value;
+    } else if (n == "attention_path") {
+        if (value != 0 && value != 1) return fail(-2, "attention_path must be 0 (auto) or 1 (robust loop always)");
+        c->opt_attn_path = value;
     } else if (n == "residue_l4_path") {
         if (value < 0 || value > 2) return fail(-2, "residue_l4_path must be 0, 1 or 2");
         c->opt_residue_l4 = value;
@@ -803,6 +799,9 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         q.bv = m.bv_flash;
         q.bias_k = m.bias_k;   // written into key slot `len` of the K / V^T fragments by the sequence's last panel
         q.bias_v = m.bias_v;
+        q.mk = mk;   // key-validity words for the attention kernel, in the slack behind the V^T fragments
+        q.vmask = (uint32_t*)(q.vf + flash_vmask_offset(ax.nseq, ax.ntile()));
+        q.vmask_stride = flash_vmask_stride(ax.ntile());
         { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv(q, false, r.s); }
         LAUNCHCHK();
         FlashParams f{};
@@ -815,7 +814,9 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         f.bias_v = m.bias_v;
         f.rope = r.c->rope;
         f.obuf = r.obufp;
-        f.zero_page = (const unsigned char*)r.c->zero_page;
+        f.force_robust = r.c->opt_attn_path;
+        f.vmask = q.vmask;
+        f.vmask_stride = q.vmask_stride;
         { ProfScope ps(r.c, c_att, r.s); launch_flash(f, r.s); }
         LAUNCHCHK();
         p.a_bf16 = f.obuf;
@@ -1237,7 +1238,8 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)c->opt_residue_l4, (uint64_t)c->opt_precision};
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)c->opt_residue_l4, (uint64_t)c->opt_precision,
+                                 (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
 
@@ -1297,7 +1299,8 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
                                  (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)c->opt_residue_l4,
-                                 (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision};
+                                 (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
+                                 (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);
 }
 

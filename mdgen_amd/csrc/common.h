@@ -13,7 +13,12 @@ constexpr int kDH = 24;        // head_dim
 constexpr int kF = 1536;       // ffn dim (4C)
 constexpr int kIpaProj = 672;  // linear_q(128) | linear_kv(256) | linear_q_points(96) | linear_kv_points(192)
 constexpr int kIpaFeat = 256;  // o(128) | o_pt.x(32) | o_pt.y(32) | o_pt.z(32) | |o_pt|(32)
-constexpr int kFragBytes = 1536;  // one (seq, head, 32-position tile) of Q, K or V^T fragments
+// Attention operand fragments of one (seq, head, 32-position tile).  Q: k-step 0 (64 lanes x 16 B) + k-step 1 (64 x 8 B).
+// K: both k-steps 64 x 16 B -- k-step 1 carries 4 features, the constant 1.0 twice (slots 4, 5) and 2 zeros.  V^T: [k-step 2]
+// [key half 2][row d 0..24][16 B], row 24 all ones (it accumulates the softmax denominator).
+constexpr int kFragQ = 1536, kFragK = 2048, kFragV = 1600;
+constexpr int kFragBytes = 2048;  // allocation size of a fragment tile (the largest of the three)
+constexpr int kMaxFlashTiles = 260;   // key tiles per sequence k_flash supports (len <= 8319)
 constexpr int kRopeRow = 32;   // floats per position of the rotary table: [2 halves][cos 6 | pad 2 | sin 6 | pad 2]
 constexpr int kPanel = 64;     // token rows per GEMM panel (workgroup)
 constexpr int kIpaKT = 32;     // keys per LDS tile of the tiled IPA attention kernels

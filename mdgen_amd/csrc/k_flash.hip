@@ -7,23 +7,33 @@
 // (mha.py:399-405) are not reproduced.
 //
 // Operand fragments are produced by k_ln_qkv in exactly the register layout the MFMAs want
-// (DESIGN.md "fragment layout"), so this kernel issues only fully-coalesced 16/8-byte loads:
+// (DESIGN.md "fragment layout"), so this kernel issues only fully-coalesced 16-byte loads:
 //   S^T[key][q] = K-frag (A) x Q-frag (B)      2 x mfma_32x32x16 (d = 24 padded to 32)
-//   O^T[d][q]  += V^T-frag (A) x P^T (B)       2 x mfma_32x32x16, P^T = exp2(S^T - m) packed in place
-// A lane owns one query column (q = lane&31) and half of the tile's keys, so the row max is lane-local plus
-// one exchange with lane^32.  One wave = one head x 64 queries (two 32-query tiles A, B); workgroup = 4 heads of
-// the same queries; three workgroups per CU (<= 168 VGPRs): per-wave issue (one instruction per ~4-5 cycles,
-// profiles/r02_issue_rate.txt) is what bounds a softmax loop, so waves per SIMD matter more than anything else.
-// Per score: max3 + exp + cvt, nothing more:
-//   * the running shift -m rides in a spare K-dim slot of Q (bf16-exact), so the score MFMA returns s - m;
-//   * an all-ones V^T row (d = 24) makes the PV MFMA accumulate the softmax denominator;
-//   * the shift is re-anchored only when a tile's max exceeds it by 2^kDefer (one scalar test per pair);
+//   O^T[d][q]  += V^T-frag (A) x P^T (B)       2 x mfma_32x32x16, P^T = exp2(S^T - M) packed in place
+// A lane owns one query column (q = lane&31) and half of the tile's keys.  One wave = one head x 64 queries (two
+// 32-query tiles A, B); workgroup = 4 heads of the same queries; three workgroups per CU (<= 168 VGPRs).
+// The loop is bound by the vector ALU (16 v_exp_f32 per (32-key, 32-query) pair cost about as much as its four
+// MFMAs, profiles/r02_issue_rate.txt), so everything else a pair does on the VALU has been removed:
+//   * the running shift -M rides in a spare K-dim slot of Q (bf16-exact), so the score MFMA returns s - M;
+//   * an all-ones V^T row (d = 24, a physical row of the fragment) makes the PV MFMA accumulate the denominator;
+//   * NO row max and no range test in the common path.  P is bf16 -- an 8-bit exponent, the same range as fp32 --
+//     so the shift only has to keep 2^(s - M) inside that range, not below 1.  M is anchored 63 above the row max of
+//     the FIRST key tile (P <= 2^-63 there) and never moves: scores may rise 190 (log2 units) above that tile's max
+//     before a P overflows, and an overflow cannot go unnoticed -- the denominator is the plain sum of all P (ones
+//     row of V^T), so one `l < inf` test per query when the loop is done covers every P of the row.  If it fails
+//     -- or if the first tile of the sequence is fully masked, so that there is nothing to anchor to -- the wave
+//     discards its result and redoes the whole (head, 64 queries) with the ROBUST loop: true row max per tile, shift
+//     re-anchored whenever the max moves up by more than 2^8, O rescaled.  Terms more than 63 below the anchor flush
+//     to zero: they are < 2^-63 of the largest term of their row;
 //   * software pipeline over (key tile, query tile) pairs A0 B0 A1 B1 ...: the block of a pair issues the score
 //     MFMAs of the NEXT pair and the PV MFMAs of the PREVIOUS pair beside its own 16 exps -- every MFMA of a block
 //     has its operands ready when the block starts, and the two neighbours belong to the other query tile;
-//   * K/V are prefetched one to two tiles ahead with unconditional loads, tiles in linear order (K: SGPR base);
+//   * K / V^T are streamed with buffer loads (SGPR descriptor + constant per-lane offset + scalar tile offset: no
+//     address arithmetic on the VALU), one tile ahead; V^T rows d > 24 are out-of-range lanes, which read zeros;
+//   * per-tile key-validity words live in one VGPR (lane i = tile i of a 64-tile window), fetched with v_readlane;
 //   * the learned bias key is an ordinary entry of the fragments (key slot len, written by k_ln_qkv).
 #include "kernels.h"
+#include <type_traits>
 
 namespace mdg {
 
@@ -35,33 +45,32 @@ __device__ __forceinline__ bf16x8 frag8(const unsigned char* p) {  // 4 real bf1
     return __builtin_bit_cast(bf16x8, w);
 }
 
-// K / V^T fragments of one 32-key tile.  They are fetched ahead with ORDINARY loads (so hipcc counts them and
-// inserts exact vmcnt waits) and pinned in place by sched_barrier(0) fences: without the fence the scheduler
-// sinks each load to its first use and every tile pays a full L2 round trip.  (Inline-asm loads are not an
-// option here: across the loop back-edge hipcc copies the asm outputs before the data lands.)
+// K / V^T fragments of one 32-key tile.  They are fetched ahead with ORDINARY (compiler-counted) buffer loads, so
+// hipcc inserts exact vmcnt waits, and pinned in place by sched_barrier(0) fences: without the fence the scheduler
+// sinks each load to its first use and every tile pays a full L2 round trip.
 struct KTile {
     u32x4 k0;   // K k-step 0: 8 bf16
-    u32x2 k1;   // K k-step 1: 4 bf16 (+ the constant-one slot and 3 implicit zeros)
+    u32x4 k1;   // K k-step 1: 4 bf16, the constant 1.0 twice (slots 4, 5: they pick up -M = -(hi + lo) from Q), 2 zeros
 };
 struct VTile {
     u32x4 v0;   // V^T k-step 0
     u32x4 v1;   // V^T k-step 1
 };
 struct QTile {
-    bf16x8 q0, q1;   // k-steps 0 / 1 of one 32-query tile; k-step-1 slot 4 of the lanes hh == 0 carries -m
+    bf16x8 q0, q1;   // k-steps 0 / 1 of one 32-query tile; k-step-1 slots 4, 5 of the lanes hh == 0 carry -M
 };
 struct PTile {
-    bf16x8 p0, p1;   // P^T = exp2(S^T - m) of one (32-key, 32-query) tile, k-steps 0 / 1 of the PV MFMAs
+    u32x4 p0, p1;   // P^T = exp2(S^T - M) of one (32-key, 32-query) tile as packed bf16, k-steps 0 / 1 of the PV MFMAs
 };
 
-// Running softmax state of ONE 32-query tile.  The row sum is NOT kept here: V^T row 24 (a padding row, d >= 24)
-// is all ones, so the PV MFMA accumulates l = sum_k P[k][q] into O^T[24][q] (register 12 of the lanes with
-// hh == 0) and every rescale of O rescales l with it.
+// Running softmax state of ONE 32-query tile.  The row sum is NOT kept here: V^T row 24 is all ones, so the PV MFMA
+// accumulates l = sum_k P[k][q] into O^T[24][q] (register 12 of the lanes with hh == 0) and every rescale of O
+// rescales l with it.
 struct Half {
     f32x16 o;
-    float m;                     // applied shift (exactly representable in bf16; rides in a spare K-dim slot of Q)
+    float m;                     // applied shift M (exactly representable in bf16; rides in a spare K-dim slot of Q)
     unsigned long long unanch;   // wave-level lane mask (SGPR pair): lanes whose shift has NOT yet been anchored to a
-                                 // finite score.  All zero after the first tile or two: then only "max moved up" matters
+                                 // finite score.  All zero after the first tile (or the first unmasked one)
 };
 
 __device__ __forceinline__ float half_max(float x) {   // max over the two half-waves (lane, lane^32)
@@ -71,22 +80,91 @@ __device__ __forceinline__ float half_max(float x) {   // max over the two half-
 
 __device__ __forceinline__ float round_bf16(float x) { return __uint_as_float(pack_bf16(x, 0.f) << 16); }
 
+// The shift M rides in two spare K-dim slots of Q as a bf16 pair hi + lo (16 significant bits: exact to < 1 log2 unit up
+// to |M| = 2^16, where a single bf16 would already be off by hundreds); K holds 1.0 in both slots, so the score MFMA
+// returns s - hi - lo.  Returns the shift actually applied.
+__device__ __forceinline__ float set_shift(QTile& q, float m, int hh) {
+    const float hi = round_bf16(m), lo = round_bf16(m - hi);
+    if (hh == 0) {
+        q.q1[4] = (__bf16)(-hi);
+        q.q1[5] = (__bf16)(-lo);
+    }
+    return hi + lo;
+}
+
+// The anchor sits kAnchor (log2 units) above the row max it was taken from: P = 2^(s - M) <= 2^-kAnchor there, scores
+// up to 127 + kAnchor above that max still give a finite P, terms more than 126 - kAnchor below it flush to zero.
+constexpr float kAnchor = 63.f;
+
+// Key-padding mask of one tile: `vm` = validity bits of its 32 keys (wave-uniform, in an SGPR).  Only ever runs for
+// the last tile of a sequence and for padded residues; the shift is asm volatile so that none of it is hoisted.
+__device__ __forceinline__ void mask_scores(f32x16& s, uint32_t vm, int hh) {
+    uint32_t vmh;
+    asm volatile("v_lshrrev_b32 %0, %1, %2" : "=v"(vmh) : "v"(4 * hh), "s"(vm));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool ok = (vmh >> ((r & 3) + 8 * (r >> 2))) & 1u;
+        s[r] = ok ? s[r] : -1e30f;
+    }
+}
+
+__device__ __forceinline__ f32x16 scores(const KTile& k, const QTile& q) {
+    const bf16x8 k0 = __builtin_bit_cast(bf16x8, k.k0), k1 = __builtin_bit_cast(bf16x8, k.k1);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q.q0, zero, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q.q1, s, 0, 0, 0);
+    asm volatile("" :: "v"(k0), "v"(k1), "v"(q.q0), "v"(q.q1));   // sources outlive the MFMAs (see block())
+    return s;
+}
+
+// The MFMA-dense block of one (key tile, query tile) pair, one straight-line region in which every MFMA has its
+// operands ready at entry:
+//   od += V^T P^T of the PREVIOUS pair            2 MFMAs (that pair belongs to the OTHER query tile, so a shift
+//                                                 moved by this pair's slow path never concerns it)
+//   n  = S^T - M of the FOLLOWING pair            K-frag (A) x Q-frag (B), 2 MFMAs
+//   pc = exp2(s) of THIS pair, packed to bf16     16 v_exp + 8 v_cvt_pk
+// i.e. 4 MFMAs (128 matrix-pipe cycles) beside 24 VALU operations, none waiting for another.  The PV MFMAs go
+// first: once they have been issued the previous pair's P registers are dead, and the packed results of this pair
+// can take their place (one P tuple live instead of two).
+// The score MFMAs take the INLINE CONSTANT 0 as C (no 16-register zero tuple to keep alive).  With that operand form
+// hipcc does not mark the destination early-clobber and may allocate it on top of a source that dies at the MFMA --
+// which corrupts results (DESIGN.md section 6.1).  Both sources are therefore kept alive across the MFMAs: Q is loop
+// invariant, K gets a no-op use after the block.  (build.py check_isa still rejects any overlap in the final ISA.)
+__device__ __forceinline__ void block(const KTile& kn, const QTile& qn, f32x16& n,
+                                      const VTile& vp, const PTile& pp, f32x16& od,
+                                      const f32x16& s, PTile& pc) {
+    const bf16x8 k0 = __builtin_bit_cast(bf16x8, kn.k0), k1 = __builtin_bit_cast(bf16x8, kn.k1);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    od = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vp.v0), __builtin_bit_cast(bf16x8, pp.p0), od, 0, 0, 0);
+    n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qn.q0, zero, 0, 0, 0);
+    od = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vp.v1), __builtin_bit_cast(bf16x8, pp.p1), od, 0, 0, 0);
+    n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qn.q1, n, 0, 0, 0);
+    float e[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) e[j] = __builtin_amdgcn_exp2f(s[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pc.p0[j] = pack_bf16(e[2 * j], e[2 * j + 1]);
+        pc.p1[j] = pack_bf16(e[8 + 2 * j], e[9 + 2 * j]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);   // six VALU / transcendental
+    }
+    // sources outlive the MFMAs (see above); the packed P is pinned HERE, inside the block: left alone hipcc sinks the
+    // exps below the block (next to their consumer, the next block's PV MFMA) and the overlap is lost
+    asm volatile("" : "+v"(pc.p0), "+v"(pc.p1) : "v"(k0), "v"(k1), "v"(qn.q0), "v"(qn.q1));
+}
+
 // How far the running shift may lag the true row max before O is rescaled (log2 units: P <= 2^kDefer).
 constexpr float kDefer = 8.f;
 
-// Softmax bookkeeping of one (key tile, query tile) pair, everything except exp: key-padding mask, row max, and
-// -- rarely -- moving the shift (which rewrites Q's -m slot and rescales O).  `vm`: validity bits of the tile's 32
+// ROBUST loop only.  Softmax bookkeeping of one (key tile, query tile) pair, everything except exp: key-padding mask,
+// row max, and -- rarely -- moving the shift (which rewrites Q's -m slot and rescales O).  `vm`: validity bits of the tile's 32
 // keys (wave-uniform, in an SGPR).
 __device__ __forceinline__ void softmax_stats(Half& st, f32x16& s, QTile& q, uint32_t vm, int hh) {
-    if (vm != 0xffffffffu) {   // rare (the last tile of a sequence, padded residues): keep ALL of it inside the branch
-        uint32_t vmh = vm >> (4 * hh);
-        asm volatile("" : "+v"(vmh));   // opaque: else the 16 bit tests are hoisted above the branch and always run
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool ok = (vmh >> ((r & 3) + 8 * (r >> 2))) & 1u;
-            s[r] = ok ? s[r] : -1e30f;
-        }
-    }
+    if (vm != 0xffffffffu) mask_scores(s, vm, hh);
     float t = fmaxf(s[0], s[1]);
 #pragma unroll
     for (int r = 2; r < 16; r += 2) t = fmaxf(fmaxf(t, s[r]), s[r + 1]);   // v_max3_f32
@@ -99,8 +177,8 @@ __device__ __forceinline__ void softmax_stats(Half& st, f32x16& s, QTile& q, uin
         const bool un = (st.unanch >> lane_id()) & 1ull;
         const bool mv = (t > kDefer) | (un & fin & (t < -kDefer));
         st.unanch &= ~__builtin_amdgcn_ballot_w64(fin);
-        // new shift = bf16(m + tile max); e = what this tile's already-shifted scores still have to lose
-        const float r = mv ? round_bf16(st.m + t) : st.m;
+        // new shift = m + tile max (as a bf16 pair); e = what this tile's already-shifted scores still have to lose
+        const float r = set_shift(q, mv ? st.m + t : st.m, hh);
         const float e = r - st.m;
         st.m = r;
         // e < 0 only while nothing has been accumulated yet (first anchoring): O is still zero, keep it so
@@ -110,56 +188,25 @@ __device__ __forceinline__ void softmax_stats(Half& st, f32x16& s, QTile& q, uin
             st.o[i] *= a;
             s[i] -= e;
         }
-        if (hh == 0) q.q1[4] = (__bf16)(-r);   // -m into Q's spare slot (k-step 1, slot 4)
     }
 }
 
-// The MFMA-dense block of one (key tile, query tile) pair, one straight-line region in which every MFMA has its
-// operands ready at entry:
-//   od += V^T P^T of the PREVIOUS pair            2 MFMAs (that pair belongs to the OTHER query tile, so a shift
-//                                                 moved by this pair's softmax_stats never concerns it)
-//   n  = S^T - m of the FOLLOWING pair            K-frag (A) x Q-frag (B), 2 MFMAs
-//   pc = exp2(s) of THIS pair, packed to bf16     16 v_exp + 8 v_cvt_pk
-// i.e. 4 MFMAs (128 matrix-pipe cycles) beside 24 VALU operations, none waiting for another.  The PV MFMAs go
-// first: once they have been issued the previous pair's P registers are dead, and the packed results of this pair
-// can take their place (one P tuple live instead of two).
-// The score MFMAs take the INLINE CONSTANT 0 as C (no 16-register zero tuple to keep alive).  With that operand form
-// hipcc does not mark the destination early-clobber and may allocate it on top of a source that dies at the MFMA --
-// which corrupts results (DESIGN.md section 6.1).  Both sources are therefore kept alive across the MFMAs: Q is loop
-// invariant, K gets a no-op use after the block.  (build.py check_isa still rejects any overlap in the final ISA.)
-__device__ __forceinline__ void block(const KTile& kn, const QTile& qn, f32x16& n,
-                                      const VTile& vp, const PTile& pp, f32x16& od,
-                                      const f32x16& s, PTile& pc) {
-    const bf16x8 k0 = __builtin_bit_cast(bf16x8, kn.k0);
-    const u32x4 k1w = u32x4{kn.k1[0], kn.k1[1], 0x00003f80u, 0u};   // slot 4 = 1.0: picks up -m from Q
-    const bf16x8 k1 = __builtin_bit_cast(bf16x8, k1w);
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    od = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vp.v0), pp.p0, od, 0, 0, 0);
-    n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qn.q0, zero, 0, 0, 0);
-    od = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vp.v1), pp.p1, od, 0, 0, 0);
-    n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qn.q1, n, 0, 0, 0);
-    float e[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) e[j] = __builtin_amdgcn_exp2f(s[j]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        pc.p0[j] = (__bf16)e[j];
-        pc.p1[j] = (__bf16)e[8 + j];
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);   // six VALU / transcendental
-    }
-    // sources outlive the MFMAs (see above); the packed P is pinned HERE, inside the block: left alone hipcc sinks the
-    // exps below the block (next to their consumer, the next block's PV MFMA) and the overlap is lost
-    asm volatile("" : "+v"(pc.p0), "+v"(pc.p1) : "v"(k0), "v"(k1), "v"(qn.q0), "v"(qn.q1));
+#ifdef MDGEN_DEV_FLASH_STAMPS   // (experiments only) per-wave s_memtime / s_memrealtime stamps: [wave][16]
+__device__ unsigned long long g_flash_stamps[32768 * 16];
+extern "C" int mdgen_dev_flash_stamps(void* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_flash_stamps), bytes);
 }
+#define FLASH_STAMP(slot, v)                                                                          \
+    if (lane == 0 && (long)blockIdx.x * 4 + w < 32768) g_flash_stamps[((long)blockIdx.x * 4 + w) * 16 + (slot)] = (v)
+#else
+#define FLASH_STAMP(slot, v)
+#endif
 
 __global__ __launch_bounds__(256, 3) void k_flash(const FlashParams p) {
     const int lane = lane_id(), hh = lane >> 5, ql = lane & 31;
-    const int w = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform, and the compiler knows it: the K stream
-                                                               // is then addressed as SGPR base + lane offset
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform, and the compiler knows it
+    FLASH_STAMP(0, __builtin_amdgcn_s_memtime());
+    FLASH_STAMP(4, __builtin_amdgcn_s_memrealtime());
     const int len = p.ax.len, nt = p.ax.ntile();   // tiles per (seq, head): they cover the len keys + the bias key
     const int nqc = (len + 63) / 64;
     // (sequence, head group) pairs are dealt to the 8 XCDs (block b runs on XCD b % 8) so that ALL q-chunks of a
@@ -169,122 +216,182 @@ __global__ __launch_bounds__(256, 3) void k_flash(const FlashParams p) {
     const int seq = pair >> 2, hg = pair & 3;
     if (seq >= p.ax.nseq) return;
     const int head = hg * 4 + w;
-    const long fbase = (long)(seq * kH + head) * nt * kFragBytes;
-    const unsigned char* qb = p.qf + fbase;
+#ifdef MDGEN_DEV_FLASH_SAMEHEAD   // (timing experiments only) all four waves stream the same head's K / V
+    const long ftile = (long)(seq * kH + hg * 4) * nt;
+#else
+    const long ftile = (long)(seq * kH + head) * nt;   // first fragment tile of this (sequence, head)
+#endif
+    const unsigned char* qb = p.qf + ftile * kFragQ;
     const long seq_base = p.ax.token(seq, 0);
     const int pstride = p.ax.pos_stride;
-
-    // ---- per-tile key validity bitmasks (key-padding mask; the bias key at position len is always valid;
-    //      positions > len are invalid), shared by the 4 waves (same sequence): wave w fills tiles w, w+4, ...
-    __shared__ uint32_t vmask[260];
-    for (int kt = w; kt < nt + 1; kt += 4) {
-        const int pos = kt * 32 + ql;
-        const bool ok = kt < nt && (pos == len || (pos < len && p.mk.at(seq_base + (long)(pos < len ? pos : 0) * pstride) != 0.f));
-        const uint32_t vm = (uint32_t)__ballot(ok && hh == 0);
-        if (lane == 0) vmask[kt] = vm;
-    }
-    __syncthreads();
 
     // ---- Q fragments of q-tiles 2qc, 2qc+1 (the second may not exist: reuse the first, never stored)
     const int qt0 = 2 * qc;
     const bool has2 = (qt0 + 1) * 32 < len;
     const int qt1 = has2 ? qt0 + 1 : qt0;
     QTile qa, qb_;
-    qa.q0 = frag16(qb + (long)qt0 * kFragBytes + lane * 16);
-    qa.q1 = frag8(qb + (long)qt0 * kFragBytes + 1024 + lane * 8);
-    qb_.q0 = frag16(qb + (long)qt1 * kFragBytes + lane * 16);
-    qb_.q1 = frag8(qb + (long)qt1 * kFragBytes + 1024 + lane * 8);
+    qa.q0 = frag16(qb + (long)qt0 * kFragQ + lane * 16);
+    qa.q1 = frag8(qb + (long)qt0 * kFragQ + 1024 + lane * 8);
+    qb_.q0 = frag16(qb + (long)qt1 * kFragQ + lane * 16);
+    qb_.q1 = frag8(qb + (long)qt1 * kFragQ + 1024 + lane * 8);
 
-    // per-lane fragment streams.  K: uniform base + lane offset.  V^T: rows d < 24 are lanes of the fragment; rows
-    // d > 24 read a zero page, row 24 a ones page (stride 0): the all-ones row accumulates the softmax denominator.
-    const bool vreal = ql < kDH;
-    const unsigned char* vptr = vreal ? p.vf + fbase + hh * 384 + ql * 16 : p.zero_page + (ql == kDH ? 128 : 0);
-    const unsigned vstep = vreal ? kFragBytes : 0;
-    const unsigned char* kbase = p.kf + fbase;   // wave-uniform
-    const unsigned ko0 = lane * 16, ko1 = 1024 + lane * 8;
-
-    Half ha, hb;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        ha.o[r] = opaque_zero();
-        hb.o[r] = opaque_zero();
-    }
-    ha.m = hb.m = 0.f;
-    ha.unanch = hb.unanch = ~0ull;
-
+    // ---- K / V^T streams: one buffer descriptor each (wave-uniform base = this (sequence, head)'s first tile), a
+    // constant per-lane byte offset, and the tile offset as the scalar offset of the load.  V^T: rows d <= 24 are
+    // lanes of the fragment (row 24 = ones); the lanes of rows d > 24 point far out of range and read zeros.
     // Loads are UNCONDITIONAL: tiles past the end of this (sequence, head) read whatever follows in the fragment
-    // buffer (finite bf16 of the next head, or the zeroed tail) and their results are dropped -- a load under `if`
-    // makes hipcc wait for the data right behind it.
+    // buffer (finite bf16 of the next head, or the tail) and their results are never used.
+    auto uniform_ptr = [](const unsigned char* q) {
+        const unsigned long long a = (unsigned long long)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return (void*)(((unsigned long long)hi << 32) | lo);
+    };
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.kf + ftile * kFragK), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.vf + ftile * kFragV), 0, 0x7fffffff, 0x00020000);
+    const int koff = lane * 16;
+    const int voff = ql <= kDH ? hh * 400 + ql * 16 : (int)0x80000000;
     auto issue_k = [&](KTile& t, int kt) {
-        const unsigned char* b = kbase + (long)kt * kFragBytes;
-        t.k0 = *reinterpret_cast<const u32x4*>(b + ko0);
-        t.k1 = *reinterpret_cast<const u32x2*>(b + ko1);
+        t.k0 = __builtin_amdgcn_raw_buffer_load_b128(krs, koff, kt * kFragK, 0);
+        t.k1 = __builtin_amdgcn_raw_buffer_load_b128(krs, koff + 1024, kt * kFragK, 0);
     };
     auto issue_v = [&](VTile& t, int kt) {
-        const unsigned char* b = vptr + (unsigned long)((unsigned)kt * vstep);
-        t.v0 = *reinterpret_cast<const u32x4*>(b);
-        t.v1 = *reinterpret_cast<const u32x4*>(b + 768);   // the constant page repeats itself at +768
+        t.v0 = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, kt * kFragV, 0);
+        t.v1 = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff + 800, kt * kFragV, 0);
     };
+    // K tile 0 is wanted first (the anchor below): requested here, together with Q, so that its round trip overlaps
+    // the mask reads
+    KTile k0t;
+    issue_k(k0t, 0);
+
+    // ---- per-tile key-validity words (key-padding mask; the bias key at position len is always valid; positions
+    //      > len are invalid): written by k_ln_qkv, read here 64 tiles at a time into ONE register (lane i = tile i of
+    //      the window) and picked out with v_readlane.  No LDS, no barrier: the four waves of a workgroup never meet.
+    const uint32_t* vmrow = p.vmask + (long)seq * p.vmask_stride;
+    uint32_t vmw = vmrow[lane];
 
     // One key tile = two (key tile, query tile) pairs, A then B.  Pipeline: the block of pair i issues the score
     // MFMAs of pair i+1 and the PV MFMAs of pair i-1 beside its own exps.  Score tuples sa / sb and P tuples pa / pb
     // belong to query tile A / B for good, so nothing is ever copied; K / V tiles alternate between two slots by
     // tile parity (kx, vx: even tiles; ky, vy: odd tiles).
+    Half ha, hb;
     f32x16 sa, sb;
     PTile pa, pb;
     KTile kx, ky;
     VTile vx, vy;
-    pb.p0 = pb.p1 = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});   // "previous pair" of the very first block: P = 0
-    uint32_t vm_next = __builtin_amdgcn_readfirstlane(vmask[0]);
-    auto tile = [&](int t, KTile& kc, KTile& kn, VTile& vc, VTile& vprev) {
-        const uint32_t vm = vm_next;
-        const uint32_t vmv = vmask[t + 1];   // the next tile's mask: requested now, moved to an SGPR at the end
+    auto tile = [&](auto robust, int t, KTile& kc, KTile& kn, VTile& vc, VTile& vprev) {
+        constexpr bool kRobust = decltype(robust)::value;
+        const uint32_t vm = __builtin_amdgcn_readlane(vmw, t & 63);
         // pair (t, A): scores in sa.  Block: sb <- scores (t, B);  hb.o += V(t-1) P_B(t-1);  pa <- exp(sa)
-        softmax_stats(ha, sa, qa, vm, hh);
+        if (kRobust) softmax_stats(ha, sa, qa, vm, hh);
+        else if (vm != 0xffffffffu) mask_scores(sa, vm, hh);
         __builtin_amdgcn_sched_barrier(0);
         block(kc, qb_, sb, vprev, pb, hb.o, sa, pa);
         __builtin_amdgcn_sched_barrier(0);
+#ifndef MDGEN_DEV_FLASH_NOLOAD   // (timing experiments only: scripts/micro/flash_variants.sh)
         issue_v(vprev, t + 1);   // V(t-1) and K(t) (for query tile B: just issued) are consumed: refill both slots
         issue_k(kc, t + 2);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // pair (t, B): scores in sb.  Block: sa <- scores (t+1, A);  ha.o += V(t) P_A(t);  pb <- exp(sb)
-        softmax_stats(hb, sb, qb_, vm, hh);
+        if (kRobust) softmax_stats(hb, sb, qb_, vm, hh);
+        else if (vm != 0xffffffffu) mask_scores(sb, vm, hh);
         __builtin_amdgcn_sched_barrier(0);
         block(kn, qa, sa, vc, pa, ha.o, sb, pb);
         __builtin_amdgcn_sched_barrier(0);
-        vm_next = __builtin_amdgcn_readfirstlane(vmv);
+    };
+    // The whole (head, 64 queries) job; returns with the last pair's PV MFMAs issued.
+    auto run = [&](auto robust) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ha.o[r] = opaque_zero();
+            hb.o[r] = opaque_zero();
+        }
+        pb.p0 = pb.p1 = u32x4{0u, 0u, 0u, 0u};   // "previous pair" of the very first block: P = 0
+        if (nt > 64) vmw = vmrow[lane];          // (a re-run after a long fast loop: back to the first window)
+        issue_k(kx, 0);
+        issue_v(vy, 0);    // stands in for "V(-1)": any finite values (its P is zero)
+        issue_k(ky, 1);
+        issue_v(vx, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        sa = scores(kx, qa);   // pair (0, A)
+        // The loop body is a PAIR of tiles with a single exit (an exit between the two makes hipcc keep O in
+        // different registers in the two halves and copy it mid-chain); an odd tile count gets a tail tile.
+        int t = 0;
+        for (; t + 1 < nt; t += 2) {
+            if ((t & 63) == 0 && t) vmw = vmrow[t + lane];
+            tile(robust, t, kx, ky, vx, vy);
+            tile(robust, t + 1, ky, kx, vy, vx);
+        }
+        if (t < nt) {
+            if ((t & 63) == 0 && t) vmw = vmrow[t + lane];
+            tile(robust, t, kx, ky, vx, vy);
+            // pending: P_B of the last tile (in pb) with V(last) = vx
+            hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vx.v0), __builtin_bit_cast(bf16x8, pb.p0), hb.o, 0, 0, 0);
+            hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vx.v1), __builtin_bit_cast(bf16x8, pb.p1), hb.o, 0, 0, 0);
+        } else {
+            hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vy.v0), __builtin_bit_cast(bf16x8, pb.p0), hb.o, 0, 0, 0);
+            hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vy.v1), __builtin_bit_cast(bf16x8, pb.p1), hb.o, 0, 0, 0);
+        }
     };
 
-    issue_k(kx, 0);
-    issue_v(vy, 0);    // stands in for "V(-1)": any finite values (its P is zero)
-    issue_k(ky, 1);
-    issue_v(vx, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    {   // scores of pair (0, A)
-        const bf16x8 k0 = __builtin_bit_cast(bf16x8, kx.k0);
-        const u32x4 k1w = u32x4{kx.k1[0], kx.k1[1], 0x00003f80u, 0u};
-        const bf16x8 k1 = __builtin_bit_cast(bf16x8, k1w);
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qa.q0, zero, 0, 0, 0);
-        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qa.q1, sa, 0, 0, 0);
-        asm volatile("" :: "v"(k0), "v"(k1), "v"(qa.q0), "v"(qa.q1));
+    // ---- FAST loop: anchor both query tiles kAnchor above the row max of key tile 0 and never move the shift.
+    bool robust_needed;
+    {
+        const uint32_t vm0 = __builtin_amdgcn_readlane(vmw, 0);
+        f32x16 s0 = scores(k0t, qa), s1 = scores(k0t, qb_);   // the -M slots are still zero: plain scores
+        if (vm0 != 0xffffffffu) {
+            mask_scores(s0, vm0, hh);
+            mask_scores(s1, vm0, hh);
+        }
+        float t0 = fmaxf(s0[0], s0[1]), t1 = fmaxf(s1[0], s1[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) {
+            t0 = fmaxf(fmaxf(t0, s0[r]), s0[r + 1]);
+            t1 = fmaxf(fmaxf(t1, s1[r]), s1[r + 1]);
+        }
+        t0 = half_max(t0);
+        t1 = half_max(t1);
+        // nothing to anchor to (all of tile 0 masked: a padded residue's temporal sequence) -> robust loop
+        robust_needed = p.force_robust != 0 || __builtin_amdgcn_ballot_w64(!(t0 > -1e29f && t1 > -1e29f)) != 0;
+        ha.m = set_shift(qa, t0 + kAnchor, hh);
+        hb.m = set_shift(qb_, t1 + kAnchor, hh);
     }
-    // The loop body is a PAIR of tiles with a single exit (an exit between the two makes hipcc keep O in
-    // different registers in the two halves and copy it mid-chain); an odd tile count gets a tail tile.
-    int t = 0;
-    for (; t + 1 < nt; t += 2) {
-        tile(t, kx, ky, vx, vy);
-        tile(t + 1, ky, kx, vy, vx);
+    FLASH_STAMP(1, __builtin_amdgcn_s_memtime());
+    FLASH_STAMP(6, (unsigned long long)robust_needed);
+    FLASH_STAMP(8, (unsigned long long)__float_as_uint(ha.m));   // lane 0's fixed anchor (first-tile row max + kAnchor)
+    if (!robust_needed) {
+        run(std::false_type{});
+        FLASH_STAMP(2, __builtin_amdgcn_s_memtime());
+        // every P of a query row is summed into its denominator (register 12 of the lanes hh == 0): finite and
+        // positive <=> no P overflowed.
+        // Bit test, not a float compare: this file is built with -fno-honor-nans.
+        const uint32_t la = __float_as_uint(ha.o[12]), lb = __float_as_uint(hb.o[12]);
+        bool bad = (la & 0x7f800000u) == 0x7f800000u || (lb & 0x7f800000u) == 0x7f800000u;   // inf or NaN
+        // a denominator that underflowed to nothing (first-tile max far above everything the bf16-pair shift resolves)
+        // (lanes hh == 1 hold row 28 there, a zero padding row: not a denominator)
+        bad |= hh == 0 && ((la & 0x7f800000u) == 0u || (lb & 0x7f800000u) == 0u);
+        // ... and a P below the overflow threshold can still push a sum of P v over it: every accumulator is checked
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            bad |= (__float_as_uint(ha.o[i]) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(hb.o[i]) & 0x7f800000u) == 0x7f800000u;
+        FLASH_STAMP(9, (unsigned long long)__builtin_amdgcn_ballot_w64(bad));
+        FLASH_STAMP(10, (unsigned long long)la | ((unsigned long long)lb << 32));
+        robust_needed = __builtin_amdgcn_ballot_w64(bad) != 0;
+#ifdef MDGEN_DEV_FLASH_NOFALLBACK   // (experiments only: shows what the fixed anchor alone does to overflowing scores)
+        robust_needed = false;
+#endif
     }
-    if (t < nt) {
-        tile(t, kx, ky, vx, vy);
-        // pending: P_B of the last tile (in pb) with V(last) = vx
-        hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vx.v0), pb.p0, hb.o, 0, 0, 0);
-        hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vx.v1), pb.p1, hb.o, 0, 0, 0);
-    } else {
-        hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vy.v0), pb.p0, hb.o, 0, 0, 0);
-        hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vy.v1), pb.p1, hb.o, 0, 0, 0);
+    if (robust_needed) {   // wave-uniform; start over with a moving shift
+        ha.m = hb.m = 0.f;
+        ha.unanch = hb.unanch = ~0ull;
+        set_shift(qa, 0.f, hh);
+        set_shift(qb_, 0.f, hh);
+        run(std::true_type{});
     }
+    FLASH_STAMP(3, __builtin_amdgcn_s_memtime());
+    FLASH_STAMP(11, (unsigned long long)__float_as_uint(ha.m));   // lane 0's final shift (robust loop: ~ the true row max)
+#ifdef MDGEN_DEV_FLASH_STAMPS
+    if (lane == 0 && (long)blockIdx.x * 4 + w < 32768) g_flash_stamps[((long)blockIdx.x * 4 + w) * 16 + 6] |= (unsigned long long)robust_needed << 1;
+#endif
     const float l0 = __shfl(ha.o[12], ql, 64);   // O^T row 24 = softmax denominator, held by lanes hh == 0
     const float l1 = __shfl(hb.o[12], ql, 64);
     const f32x16 o0 = ha.o, o1 = hb.o;
@@ -309,6 +416,7 @@ __global__ __launch_bounds__(256, 3) void k_flash(const FlashParams p) {
             d[2] = u32x2{pack_bf16(o1[8] * inv, o1[9] * inv), pack_bf16(o1[10] * inv, o1[11] * inv)};
         }
     }
+    FLASH_STAMP(5, __builtin_amdgcn_s_memrealtime());
 }
 
 void launch_flash(const FlashParams& p, hipStream_t s) {

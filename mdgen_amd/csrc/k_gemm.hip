@@ -91,9 +91,15 @@ __device__ __forceinline__ void epilogue_heads_T(const f32x16* acc /*[3 ft][2 tt
                     d[2] = u32x2{u[4], u[5]};
                 }
             } else if (tile < ntile) {
-                unsigned char* base = frag + ((long)(seq * kH + head) * ntile + tile) * kFragBytes;
-                *reinterpret_cast<u32x4*>(base + lane * 16) = u32x4{u[0], u[1], u[2], u[3]};
-                *reinterpret_cast<u32x2*>(base + 1024 + lane * 8) = u32x2{u[4], u[5]};
+                if (which == 1) {   // K: k-step 1 is a full 16-byte slot; slots 4, 5 = 1.0: they pick up Q's -M (bf16 pair)
+                    unsigned char* base = frag + ((long)(seq * kH + head) * ntile + tile) * kFragK;
+                    *reinterpret_cast<u32x4*>(base + lane * 16) = u32x4{u[0], u[1], u[2], u[3]};
+                    *reinterpret_cast<u32x4*>(base + 1024 + lane * 16) = u32x4{u[4], u[5], 0x3f803f80u, 0u};
+                } else {
+                    unsigned char* base = frag + ((long)(seq * kH + head) * ntile + tile) * kFragQ;
+                    *reinterpret_cast<u32x4*>(base + lane * 16) = u32x4{u[0], u[1], u[2], u[3]};
+                    *reinterpret_cast<u32x2*>(base + 1024 + lane * 8) = u32x2{u[4], u[5]};
+                }
             }
         }
     }
@@ -115,15 +121,22 @@ __device__ __forceinline__ void epilogue_v_flash(const f32x16* acc /*[2 tt][3 ft
         for (int tt = 0; tt < 2; ++tt) {
             const int tile = tile0 + tt;
             if (tile < ntile) {
-                unsigned char* base = vf + ((long)(seq * kH + head) * ntile + tile) * kFragBytes + hh * 384 + d * 16;
+                unsigned char* base = vf + ((long)(seq * kH + head) * ntile + tile) * kFragV + hh * 400 + d * 16;
                 const f32x16 a = acc[tt * 3 + j];
                 *reinterpret_cast<u32x4*>(base) = u32x4{pack_bf16(a[0] + b, a[1] + b), pack_bf16(a[2] + b, a[3] + b),
                                                          pack_bf16(a[4] + b, a[5] + b), pack_bf16(a[6] + b, a[7] + b)};
-                *reinterpret_cast<u32x4*>(base + 768) =
+                *reinterpret_cast<u32x4*>(base + 800) =
                     u32x4{pack_bf16(a[8] + b, a[9] + b), pack_bf16(a[10] + b, a[11] + b),
                           pack_bf16(a[12] + b, a[13] + b), pack_bf16(a[14] + b, a[15] + b)};
             }
         }
+    }
+    if (lane < 32) {   // row 24 of every fragment this wave owns: 4 heads x 2 tiles x 2 key halves x 2 k-steps, all ones
+        const int hd = lane & 3, tt = (lane >> 2) & 1, h2 = (lane >> 3) & 1, ks = lane >> 4;
+        const int tile = tile0 + tt;
+        if (tile < ntile)
+            *reinterpret_cast<u32x4*>(vf + ((long)(seq * kH + 4 * w + hd) * ntile + tile) * kFragV + ks * 800 + h2 * 400 + kDH * 16) =
+                u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     }
 }
 
@@ -136,6 +149,25 @@ __device__ __forceinline__ void write_bias_slots(const QkvParams& p, int seq, in
     const int lane = lane_id();
     const int len = p.ax.len, nt = p.ax.ntile();
     const int kt = len >> 5, sl = len & 31;
+    if (kt >= 2 * p.panels_per_seq) {
+        // len is a multiple of 64: the bias key starts a tile of its own, which no panel epilogue has touched.  Its
+        // other 31 key slots are masked, but the PV MFMA still multiplies their V^T entries by P = 0 -- stale bytes
+        // that decode to NaN / inf would poison the sum -- and the all-ones row 24 must exist for the bias key's own P
+        // to reach the denominator.  So: zero both fragments, then the ones row, then (below) the bias slots.
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) {
+            const long ft = (long)(seq * kH + 4 * w + hd) * nt + kt;
+            u32x4* kd = reinterpret_cast<u32x4*>(p.kf + ft * kFragK);
+            u32x4* vd = reinterpret_cast<u32x4*>(p.vf + ft * kFragV);
+            const u32x4 z = {0u, 0u, 0u, 0u}, ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+            kd[lane] = z;
+            kd[64 + lane] = u32x4{0u, 0u, 0x3f803f80u, 0u};
+            const int r0 = lane, r1 = 64 + lane;   // 16-byte rows of the V^T fragment: [k-step 2][key half 2][25]
+            vd[r0] = (r0 % 25) == kDH ? ones : z;
+            if (r1 < 100) vd[r1] = (r1 % 25) == kDH ? ones : z;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if (lane < 8) {   // K: (half hh, head hd) -> 12 rotated values = 16 B (k-step 0) + 8 B (k-step 1) of key slot sl
         const int hd = lane & 3, hh = lane >> 2, head = 4 * w + hd;
         const float* bk = p.bias_k + head * kDH;
@@ -148,10 +180,11 @@ __device__ __forceinline__ void write_bias_slots(const QkvParams& p, int seq, in
             e[2 * pp] = x1 * c - x2 * sn;
             e[2 * pp + 1] = x2 * c + x1 * sn;
         }
-        unsigned char* base = p.kf + ((long)(seq * kH + head) * nt + kt) * kFragBytes;
+        unsigned char* base = p.kf + ((long)(seq * kH + head) * nt + kt) * kFragK;
         *reinterpret_cast<u32x4*>(base + (hh * 32 + sl) * 16) =
             u32x4{pack_bf16(e[0], e[1]), pack_bf16(e[2], e[3]), pack_bf16(e[4], e[5]), pack_bf16(e[6], e[7])};
-        *reinterpret_cast<u32x2*>(base + 1024 + (hh * 32 + sl) * 8) = u32x2{pack_bf16(e[8], e[9]), pack_bf16(e[10], e[11])};
+        *reinterpret_cast<u32x4*>(base + 1024 + (hh * 32 + sl) * 16) =
+            u32x4{pack_bf16(e[8], e[9]), pack_bf16(e[10], e[11]), 0x3f803f80u, 0u};
     }
     if (lane < kDH) {   // V^T: row d = lane; key slot sl = register r of lane-half hk: r = (sl & 3) + 4 (sl >> 3)
         const int d = lane;
@@ -160,9 +193,9 @@ __device__ __forceinline__ void write_bias_slots(const QkvParams& p, int seq, in
 #pragma unroll
         for (int hd = 0; hd < 4; ++hd) {
             const int head = 4 * w + hd;
-            unsigned char* base = p.vf + ((long)(seq * kH + head) * nt + kt) * kFragBytes;
+            unsigned char* base = p.vf + ((long)(seq * kH + head) * nt + kt) * kFragV;
             const uint32_t v = pack_bf16(p.bias_v[head * kDH + dpsi], 0.f);
-            *reinterpret_cast<uint16_t*>(base + (r >> 3) * 768 + hk * 384 + d * 16 + (r & 7) * 2) = (uint16_t)v;
+            *reinterpret_cast<uint16_t*>(base + (r >> 3) * 800 + hk * 400 + d * 16 + (r & 7) * 2) = (uint16_t)v;
         }
     }
 }
@@ -181,6 +214,21 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
         pos0 = pn * kPanel;
         tile0 = pn * 2;
         setup_rows_axis(pr, p.ax, seq, pos0, p.mm);
+        // key-validity words of this panel's two tiles for the attention kernel (kernels.h flash_vmask_*): the 64
+        // lanes of wave 0 are the panel's 64 positions.  The sequence's last panel also writes the words behind it:
+        // zeros, except the bias key's when it starts a tile of its own (len a multiple of 64).
+        if (wave_id() == 0) {
+            const int lane = lane_id(), len = p.ax.len, pos = pos0 + lane;
+            const float mv = p.mk.at(p.ax.token(seq, pos < len ? pos : len - 1));
+            const unsigned long long bal = __ballot(pos == len || (pos < len && mv != 0.f));
+            uint32_t* vm = p.vmask + (long)seq * p.vmask_stride;
+            if (lane < 2) vm[tile0 + lane] = (uint32_t)(bal >> (32 * lane));
+            if (pn == p.panels_per_seq - 1) {
+                const int idx = tile0 + 2 + lane;
+                if (idx < p.vmask_stride) vm[idx] = idx == (len >> 5) ? 1u << (len & 31) : 0u;
+                if (idx + 64 < p.vmask_stride) vm[idx + 64] = 0u;   // (stride - 2 panels_per_seq can reach 65)
+            }
+        }
     }
     __syncthreads();
     prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);

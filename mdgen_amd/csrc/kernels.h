@@ -16,6 +16,8 @@ struct QkvParams {
     unsigned char *qf, *kf, *vf;  // FLASH layout fragment buffers
     __bf16* qkv_small;     // SMALL layout [token][3][16 head][2 half][12]
     int panels_per_seq;
+    uint32_t* vmask;       // FLASH layout: key-validity words [seq][vmask_stride], one per 32-key tile (see flash_vmask)
+    int vmask_stride;
     // k_ln_qkv_attn4 only (residue axis, L == 4: attention inside the QKV kernel)
     const float *bias_k, *bias_v;   // learned bias key / value [384]
     MaskMap mk;                     // key-padding mask
@@ -79,6 +81,15 @@ struct FinalParams {
     float* out;             // !euler: velocity
 };
 
+// Key-validity words of the tiled attention: one uint32 per (sequence, 32-key tile); bit set = the key is real (inside
+// the sequence and not padded, or the learned bias key at position len).  Per sequence `stride` words, a multiple of
+// 64 >= ntile + 1, zero beyond the last tile (k_flash reads them in 64-tile windows, one tile ahead).  They live in the
+// slack of the V^T fragment region (a tile is allocated kFragBytes, V^T uses kFragV of it), behind the last fragment.
+__host__ __device__ inline int flash_vmask_stride(int ntile) { return (ntile + 64) & ~63; }
+__host__ __device__ inline size_t flash_vmask_offset(long nseq, int ntile) {
+    return (((size_t)nseq * kH * ntile * kFragV) + 255) & ~(size_t)255;
+}
+
 struct FlashParams {
     AxisMap ax;
     MaskMap mk;
@@ -86,7 +97,9 @@ struct FlashParams {
     const float *bias_k, *bias_v;  // natural fp32 [384]
     const float* rope;
     __bf16* obuf;           // [N][384]
-    const unsigned char* zero_page;   // 2 KB: zeros (V^T padding rows d > 24); eight bf16 1.0 at +128 and +896 (row 24)
+    const uint32_t* vmask;  // [seq][vmask_stride]: bit k of word t = key 32 t + k may be attended (written by k_ln_qkv)
+    int vmask_stride;
+    int force_robust;       // option attention_path: 1 = skip the fixed-anchor loop, always run the moving-shift loop
 };
 
 struct EmbedParams {

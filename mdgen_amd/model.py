@@ -120,7 +120,7 @@ class LatentMDGenModel:
         return self
 
     def set_option(self, name: str, value: int):
-        """Library run-time options (include/mdgen_amd.h `mdgen_ctx_set_option`): "streams", "residue_l4_path"."""
+        """Library run-time options (include/mdgen_amd.h `mdgen_ctx_set_option`): "streams", "residue_l4_path", "attention_path"."""
         check(lib.mdgen_ctx_set_option(self._ctx, name.encode(), int(value)))
         return self
 

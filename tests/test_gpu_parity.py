@@ -74,10 +74,13 @@ def test_forward_vs_reference_golden(name):
 
 
 @pytest.mark.parametrize("shape", [(2, 70, 4, 0), (1, 64, 4, 0), (1, 33, 5, 2), (1, 5, 33, 3), (2, 3, 64, 0),
-                                   (1, 130, 9, 1)])
+                                   (1, 130, 9, 1), (1, 64, 64, 4), (2, 32, 96, 5)])
 def test_forward_vs_oracle_shapes(shape):
     """Edge shapes vs the CPU oracle: partial panels/tiles, T or L a multiple of 32/64 (bias key opens a
-    new tile), L in {4,5} micro path vs L>8 flash path, padded residues, per-batch t."""
+    new tile), L in {4,5} micro path vs L>8 flash path, padded residues, per-batch t.
+    The forward is run on a workspace whose every byte was set to 0xFF first (bf16 / fp32 NaN patterns): whatever
+    the kernels read from it must have been written by this call (regression: the bias-only key tile of a
+    sequence whose length is a multiple of 64 used to be multiplied in as 0 x stale bytes)."""
     from oracle import mdgen_oracle as O
     from mdgen_amd.config import ModelConfig
     from mdgen_amd.synthetic import synth_state_dict
@@ -103,8 +106,12 @@ def test_forward_vs_oracle_shapes(shape):
     aat = torch.randint(0, 20, (B, L), generator=gen)
     kw = dict(x=x, t=t, mask=mask, start_frames=(R, tr_), end_frames=(R, tr_), x_cond=xc, x_cond_mask=cm, aatype=aat)
     ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
-    out, tr = m.forward(**{k: (tuple(u.to(dev) for u in v) if isinstance(v, tuple) else v.to(dev)) for k, v in kw.items()},
-                        return_trace=True)
+    dkw = {k: (tuple(u.to(dev) for u in v) if isinstance(v, tuple) else v.to(dev)) for k, v in kw.items()}
+    m.forward(**dkw)                                   # allocates (and caches) the workspace of this shape
+    assert len(m._ws) > 0
+    for ws in m._ws.values():
+        ws.view(torch.uint8).fill_(0xFF)
+    out, tr = m.forward(**dkw, return_trace=True)
     rep = {k: rel_l2(tr[k].cpu(), rtr[k]) for k in ["ipa_out"] + [f"h{i}" for i in range(cfg.num_layers + 1)]}
     rep["out"] = rel_l2(out.cpu(), ref)
     print(shape, {k: f"{v:.2e}" for k, v in rep.items()})
@@ -314,6 +321,69 @@ def test_tps_inference_end_to_end_vs_oracle():
     assert torch.isfinite(atom14).all()
     assert e_s < 2e-2
     assert d.pow(2).mean().sqrt() < 0.05 and d.max() < 0.5
+
+
+def test_attention_fixed_anchor_and_robust_loops_agree():
+    """Tiled attention (csrc/k_flash.hip): the default loop keeps ONE softmax shift per query row, anchored on the first
+    key tile, and re-runs a (head, 64 queries) job on the moving-shift loop only if a row's denominator overflowed or
+    the first tile is fully masked.  (a) On ordinary inputs both loops give the same output up to the bf16 rounding of
+    P (the two shifts differ by a non-integer, so the mantissas of P differ): rel-L2 ~2e-3, the size of the bf16 error
+    of the whole forward.  (b) With the q / k projections scaled so that scores move by hundreds of log2 units between
+    key tiles, the fixed anchor overflows: the fallback must kick in and the result must stay finite and agree with the
+    robust loop (the experiment build -DMDGEN_DEV_FLASH_NOFALLBACK fails exactly here with non-finite outputs:
+    profiles/r02_flash_variants.txt).  (c) Padded residues (first tile fully masked on the time
+    axis) take the robust loop from the start: covered by the n_pad > 0 shapes here and in the ATLAS goldens."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict, synth_forward_inputs
+    from mdgen_amd.model import LatentMDGenModel
+    dev = _cuda()
+    B, T, L, n_pad = 2, 200, 33, 3
+    cfg = ModelConfig(crop=L, num_frames=T, num_layers=2, abs_pos_emb=False, sim_condition=True)
+    inp = synth_forward_inputs(cfg, B, T, L, n_pad, 11)
+    kw = dict(x=inp["x"].to(dev), t=inp["t"].to(dev), mask=inp["mask"].to(dev),
+              start_frames=(inp["start_rot"].to(dev), inp["start_trans"].to(dev)), x_cond=inp["x_cond"].to(dev),
+              x_cond_mask=inp["x_cond_mask"].to(dev), aatype=inp["aatype"].to(dev))
+    for scale, label in ((1.0, "ordinary"), (8.0, "partly overflowing"), (60.0, "overflowing")):
+        sd = synth_state_dict(cfg, 4)
+        for ax in ("mha_t", "mha_l"):
+            for nm in ("q_proj", "k_proj"):
+                sd[f"layers.0.{ax}.attn.{nm}.weight"] = sd[f"layers.0.{ax}.attn.{nm}.weight"] * scale
+        m = LatentMDGenModel(cfg)
+        m.load_state_dict(sd)
+        m.set_option("attention_path", 0)
+        a = m.forward(**kw).clone()
+        m.set_option("attention_path", 1)
+        b = m.forward(**kw).clone()
+        assert torch.isfinite(a).all() and torch.isfinite(b).all(), label
+        e = rel_l2(a.cpu(), b.cpu())
+        print(f"attention loops, {label} scores: rel-L2(auto, robust) {e:.2e}; bitwise equal: {torch.equal(a, b)}")
+        assert e < 5e-3, (label, e)
+        del m
+
+
+def test_rollout_on_poisoned_workspace():
+    """A 2-step rollout at T = L = 64 (both multiples of 64: the learned bias key opens a key tile of its own on both
+    axes and in the IPA attention; 4 padded residues: fully masked temporal sequences) on a workspace filled with
+    0xFF bytes: finite, and bit-identical to the run on the freshly allocated workspace."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    import bench
+    dev = _cuda()
+    B, T, L, n_pad = 1, 64, 64, 4
+    cfg = ModelConfig(crop=L, num_frames=T, num_layers=2, abs_pos_emb=False, sim_condition=True)
+    w = NewMDGenWrapper(cfg, device=dev)
+    w.model.load_state_dict(synth_state_dict(cfg, 0))
+    batch = bench.synth_batch(B, T, L, n_pad, dev, seed=100)
+    zs = torch.randn(B, T, L, cfg.latent_dim, generator=torch.Generator().manual_seed(137)).to(dev)
+    a0, _ = w.inference(batch, zs=zs, num_steps=2, use_graph=False)
+    a0 = a0.clone()
+    assert len(w.model._ws) > 0
+    for ws in w.model._ws.values():
+        ws.view(torch.uint8).fill_(0xFF)
+    a1, _ = w.inference(batch, zs=zs, num_steps=2, use_graph=False)
+    assert torch.isfinite(a1).all()
+    assert torch.equal(a0, a1)
 
 
 def test_residue_axis_paths_agree():
