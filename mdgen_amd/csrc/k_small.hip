@@ -100,31 +100,42 @@ __global__ void k_pack_rows(const float* __restrict__ w, int ld, const int* __re
 // -------------------------------------------------------------------------------------------------
 // Token embedding (latent_model.py:233-246):
 //   h = latent_to_emb(x) [+ pos_embed[l]] + cond_to_emb(x_cond) + mask_to_emb[x_cond_mask] + ipa_out[b,l]
-// block = 384 threads (one per channel), 32 tokens per block; the D<=28 wide weight rows live in VGPRs.
+// A [N x D] . [D x 384] product with D = 21 / 28: far too thin for the bf16 path's panels, and as a per-channel dot
+// product on the VALU (round 1) it ran at 0.9 TB/s of its 98 MB output.  Here it is an fp32 MFMA job:
+// v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate -- the reference's arithmetic), D = tokens x channels.
+// Workgroup = 128 tokens (4 row tiles) x 384 channels; wave w owns channels 96 w .. 96 w + 95 and keeps its slices
+// of both weight matrices in registers (2 x 3 tiles x 14 k-steps); token rows are staged once in LDS (row stride 29
+// floats: the per-k column reads are conflict-free).  cond_to_emb is skipped for row tiles whose x_cond rows are all
+// zero (every non-conditioning frame).  The epilogue adds bias, mask embedding, pos_embed / ipa_out rows (requested
+// four token rows ahead) and stores 128-byte row segments.
 // -------------------------------------------------------------------------------------------------
-// 64 tokens per block; thread = channel (384 threads).  The per-channel weight rows (2 x D <= 56 floats)
-// live in VGPRs; token inputs are broadcast from LDS as float4 (7 x ds_read_b128 per dot product); the
-// cond_to_emb product is skipped for tokens whose x_cond row is all zero (every non-conditioning frame);
-// each store is a fully coalesced 1.5 KB row.
-constexpr int kEmbTok = 64;
-// POS / IPA: pos_embed / ipa_out present (compile-time so that their loads are unconditional and can be
-// issued 8 tokens ahead; a load inside `if (ptr)` in a rolled loop paid one L2 round trip per token).
+constexpr int kEmbTok = 128, kEmbLd = 29, kEmbK = 14;
+// POS / IPA: pos_embed / ipa_out present (compile-time so that their loads are unconditional).
 template <bool POS, bool IPA>
-__global__ __launch_bounds__(384) void k_embed(const EmbedParams p) {
-    __shared__ __attribute__((aligned(16))) float xs[kEmbTok][28];
-    __shared__ __attribute__((aligned(16))) float cs[kEmbTok][28];
+__global__ __launch_bounds__(256) void k_embed(const EmbedParams p) {
+    __shared__ float xs[kEmbTok * kEmbLd];
+    __shared__ float cs[kEmbTok * kEmbLd];
     __shared__ int ms[kEmbTok];     // bit0: x_cond_mask, bit1: x_cond row has a non-zero
-    const int c = threadIdx.x;
+    __shared__ int tpos[kEmbTok];   // l * kC                 (row of pos_embed)
+    __shared__ int tipa[kEmbTok];   // (b * L + l) * kC       (row of ipa_out)
+    const int tid = threadIdx.x;
     const long tok0 = (long)blockIdx.x * kEmbTok;
-    if (threadIdx.x < kEmbTok) ms[threadIdx.x] = 0;
+    if (tid < kEmbTok) {
+        long t = tok0 + tid;
+        t = t < p.N ? t : p.N - 1;
+        const int l = (int)(t % p.L), b = (int)(t / ((long)p.T * p.L));
+        ms[tid] = 0;
+        tpos[tid] = l * kC;
+        tipa[tid] = (b * p.L + l) * kC;
+    }
     __syncthreads();
     {   // stage x / x_cond rows: unconditional clamped loads, all in flight together
-        constexpr int NIT = (kEmbTok * 28 + 383) / 384;
+        constexpr int NIT = kEmbTok * 28 / 256;
         float a[NIT], b[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = threadIdx.x + 384 * it;
-            const int tk = (i / 28) & (kEmbTok - 1), d = i % 28;
+            const int i = tid + 256 * it;
+            const int tk = i / 28, d = i % 28;
             long t = tok0 + tk;
             t = t < p.N ? t : p.N - 1;
             const int dc = d < p.D ? d : 0;
@@ -133,81 +144,93 @@ __global__ __launch_bounds__(384) void k_embed(const EmbedParams p) {
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = threadIdx.x + 384 * it;
-            if (i < kEmbTok * 28) {
-                const int tk = i / 28, d = i % 28;
-                const bool ok = tok0 + tk < p.N && d < p.D;
-                xs[tk][d] = ok ? a[it] : 0.f;
-                cs[tk][d] = ok ? b[it] : 0.f;
-                if (ok && b[it] != 0.f) atomicOr(&ms[tk], 2);
-            }
+            const int i = tid + 256 * it;
+            const int tk = i / 28, d = i % 28;
+            const bool ok = tok0 + tk < p.N && d < p.D;
+            xs[tk * kEmbLd + d] = ok ? a[it] : 0.f;
+            cs[tk * kEmbLd + d] = ok ? b[it] : 0.f;
+            if (ok && b[it] != 0.f) atomicOr(&ms[tk], 2);
         }
     }
-    __syncthreads();
-    if (threadIdx.x < kEmbTok) {
-        const long t = tok0 + threadIdx.x;
-        if (t < p.N && p.x_cond_mask[t]) ms[threadIdx.x] |= 1;
-    }
-    float wl[28], wc[28];
+    const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id(), hh = lane >> 5, j = lane & 31;
+    const int nk = (p.D + 1) >> 1;
+    // B operands (k = 2 ks + hh, column = channel): this wave's three channel tiles of both weight matrices
+    float wl[3][kEmbK], wc[3][kEmbK], b0[3], me0[3], me1[3];
 #pragma unroll
-    for (int d = 0; d < 28; ++d) {
-        wl[d] = p.wl[(long)c * p.D + (d < p.D ? d : 0)];
-        wc[d] = p.wc[(long)c * p.D + (d < p.D ? d : 0)];
-        if (d >= p.D) wl[d] = wc[d] = 0.f;
-    }
-    const float b0 = p.bl[c] + p.bc[c];
-    const float me0 = p.mask_emb[c], me1 = p.mask_emb[kC + c];
-    __syncthreads();
-    const int TL = p.T * p.L;
-    const int ntok = (p.N - tok0 < kEmbTok) ? (int)(p.N - tok0) : kEmbTok;
-    // (b, l) of the block's first token; consecutive tokens advance l, then the frame, then b (wave-uniform)
-    int l = (int)(tok0 % p.L);
-    int fl = (int)(tok0 % TL);          // position inside sample b: frame*L + l
-    int bidx = (int)(tok0 / TL);
-    for (int tk0 = 0; tk0 < ntok; tk0 += 8) {
-        float add[8];
+    for (int ct = 0; ct < 3; ++ct) {
+        const int c = 96 * w + 32 * ct + j;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            float v = 0.f;
-            if (POS) v += p.pos_embed[(long)l * kC + c];
-            if (IPA) v += p.ipa_out[((long)bidx * p.L + l) * kC + c];
-            add[u] = v;
-            if (++l == p.L) l = 0;
-            if (++fl == TL) {
-                fl = 0;
-                ++bidx;
-            }
-            // past the last sample the indices would run out of ipa_out: clamp (those tokens are not stored)
-            if ((long)bidx * TL + fl >= p.N) {
-                bidx = 0;
-                fl = 0;
-                l = 0;
+        for (int ks = 0; ks < kEmbK; ++ks) {
+            const int d = 2 * ks + hh;
+            const float a = p.wl[(long)c * p.D + (d < p.D ? d : 0)], b = p.wc[(long)c * p.D + (d < p.D ? d : 0)];
+            wl[ct][ks] = d < p.D ? a : 0.f;
+            wc[ct][ks] = d < p.D ? b : 0.f;
+        }
+        b0[ct] = p.bl[c] + p.bc[c];
+        me0[ct] = p.mask_emb[c];
+        me1[ct] = p.mask_emb[kC + c];
+    }
+    __syncthreads();
+    if (tid < kEmbTok) {
+        const long t = tok0 + tid;
+        if (t < p.N && p.x_cond_mask[t]) ms[tid] |= 1;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int rt = 0; rt < kEmbTok / 32; ++rt) {
+        if (tok0 + rt * 32 >= p.N) break;
+        f32x16 acc[3];
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        const float* xr = xs + (rt * 32 + j) * kEmbLd + hh;
+#pragma unroll
+        for (int ks = 0; ks < kEmbK; ++ks) {
+            if (ks < nk) {
+                const float a = xr[2 * ks];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wl[ct][ks], acc[ct], 0, 0, 0);
             }
         }
+        if (__builtin_amdgcn_ballot_w64((ms[rt * 32 + j] & 2) != 0) != 0) {   // some token of this tile is conditioned
+            const float* cr = cs + (rt * 32 + j) * kEmbLd + hh;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int tk = tk0 + u;
-            if (tk < ntok) {
-                float a = b0;
-                const f32x4* xr = reinterpret_cast<const f32x4*>(&xs[tk][0]);
+            for (int ks = 0; ks < kEmbK; ++ks) {
+                if (ks < nk) {
+                    const float a = cr[2 * ks];
 #pragma unroll
-                for (int d4 = 0; d4 < 7; ++d4) {
-                    const f32x4 v = xr[d4];
-                    a += wl[4 * d4] * v[0] + wl[4 * d4 + 1] * v[1] + wl[4 * d4 + 2] * v[2] + wl[4 * d4 + 3] * v[3];
+                    for (int ct = 0; ct < 3; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wc[ct][ks], acc[ct], 0, 0, 0);
                 }
-                const int m = ms[tk];
-                if (m & 2) {
-                    const f32x4* cr = reinterpret_cast<const f32x4*>(&cs[tk][0]);
-                    float a2 = 0.f;
+            }
+        }
+        // epilogue: register r of lane-half hh is token row mfma_row(r, hh) of the tile, lane j its channel
 #pragma unroll
-                    for (int d4 = 0; d4 < 7; ++d4) {
-                        const f32x4 v = cr[d4];
-                        a2 += wc[4 * d4] * v[0] + wc[4 * d4 + 1] * v[1] + wc[4 * d4 + 2] * v[2] + wc[4 * d4 + 3] * v[3];
-                    }
-                    a += a2;
+        for (int r0 = 0; r0 < 16; r0 += 4) {
+            float add[4][3];
+            int mrow[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tk = rt * 32 + mfma_row(r0 + u, hh);
+                mrow[u] = ms[tk];
+                const int op = tpos[tk], oi = tipa[tk];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    const int c = 96 * w + 32 * ct + j;
+                    float v = 0.f;
+                    if (POS) v += p.pos_embed[op + c];
+                    if (IPA) v += p.ipa_out[oi + c];
+                    add[u][ct] = v;
                 }
-                a += (m & 1) ? me1 : me0;
-                p.h[(tok0 + tk) * kC + c] = a + add[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long t = tok0 + rt * 32 + mfma_row(r0 + u, hh);
+                if (t < p.N) {
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct)
+                        p.h[t * kC + 96 * w + 32 * ct + j] = acc[ct][r0 + u] + b0[ct] + ((mrow[u] & 1) ? me1[ct] : me0[ct]) + add[u][ct];
+                }
             }
         }
     }
@@ -571,7 +594,7 @@ void launch_masked_mse(const float* pred, const float* target, const float* mask
     hipLaunchKernelGGL(k_masked_mse, dim3((unsigned)B), dim3(256), 0, s, pred, target, mask, loss, per_sample);
 }
 void launch_embed(const EmbedParams& p, hipStream_t s) {
-    const dim3 g((unsigned)((p.N + kEmbTok - 1) / kEmbTok)), b(384);
+    const dim3 g((unsigned)((p.N + kEmbTok - 1) / kEmbTok)), b(256);
     if (p.pos_embed && p.ipa_out) hipLaunchKernelGGL((k_embed<true, true>), g, b, 0, s, p);
     else if (p.pos_embed) hipLaunchKernelGGL((k_embed<true, false>), g, b, 0, s, p);
     else if (p.ipa_out) hipLaunchKernelGGL((k_embed<false, true>), g, b, 0, s, p);
