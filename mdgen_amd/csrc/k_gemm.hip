@@ -754,11 +754,7 @@ __device__ __forceinline__ void stage_x(const unsigned char* panel, const bf16x8
     aring[0][1] = pre.a[1];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-#ifdef MDGEN_DEV_MLP_HALFW   // (timing experiment only: every other weight fragment is a register copy, not a load)
-        if (ks + PF < KS) wring[(ks + PF) % (PF + 1)] = ((ks + PF) & 1) ? wring[(ks + PF - 1) % (PF + 1)] : w1c[(ks + PF) * 64];
-#else
         if (ks + PF < KS) wring[(ks + PF) % (PF + 1)] = w1c[(ks + PF) * 64];
-#endif
         if (ks + 1 < KS) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) aring[(ks + 1) & 1][t] = panel_frag(panel, kRowB, t, ks + 1);
@@ -802,11 +798,7 @@ __device__ __forceinline__ void stage_y(const unsigned char* hr, const bf16x8* _
     for (int ks = 0; ks < KS; ++ks) {
         if (ks + PF < KS) {
 #pragma unroll
-#ifdef MDGEN_DEV_MLP_HALFW
-            for (int f = 0; f < 3; ++f) wring[(ks + PF) % (PF + 1)][f] = ((ks + PF) & 1) ? wring[(ks + PF - 1) % (PF + 1)][f] : w2c[(size_t)f * kW2S + (ks + PF) * 64];
-#else
             for (int f = 0; f < 3; ++f) wring[(ks + PF) % (PF + 1)][f] = w2c[(size_t)f * kW2S + (ks + PF) * 64];
-#endif
         }
         if (ks + 1 < KS) {
 #pragma unroll
