@@ -216,11 +216,7 @@ __global__ __launch_bounds__(256, 3) void k_flash(const FlashParams p) {
     const int seq = pair >> 2, hg = pair & 3;
     if (seq >= p.ax.nseq) return;
     const int head = hg * 4 + w;
-#ifdef MDGEN_DEV_FLASH_SAMEHEAD   // (timing experiments only) all four waves stream the same head's K / V
-    const long ftile = (long)(seq * kH + hg * 4) * nt;
-#else
     const long ftile = (long)(seq * kH + head) * nt;   // first fragment tile of this (sequence, head)
-#endif
     const unsigned char* qb = p.qf + ftile * kFragQ;
     const long seq_base = p.ax.token(seq, 0);
     const int pstride = p.ax.pos_stride;
