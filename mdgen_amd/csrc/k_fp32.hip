@@ -11,8 +11,8 @@
 //                   h += gate * y (latent_model.py:462,476,481), Euler update / velocity (integrators.py:106)
 //   k32_rope        q * dh^-1/2 and rotate-half RoPE of q, k in place (mha.py:260-263, 356-357)
 //   k32_attn        softmax(q k^T [+ bias key] with key padding) v, streaming over key tiles (mha.py:265-268, 359-396)
-// It is a tolerance mode, not a fast path: ~10x slower than the bf16 kernels (157 TFLOP/s fp32 MFMA peak vs 2.5
-// PFLOP/s bf16, and an unfused structure).  It shares everything that is fp32 already: time embedding, adaLN table,
+// It is a tolerance mode, not a fast path: ~30x slower than the bf16 kernels at cfg-2 (157 TFLOP/s fp32 MFMA peak vs
+// 2.5 PFLOP/s bf16, an unfused structure, and a simple attention kernel).  It shares everything that is fp32 already: time embedding, adaLN table,
 // token embedding, IPA point attention, SE(3) kernels.
 #include "kernels.h"
 
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k32_ln_mod(const float* __restrict__ x, l
     }
 }
 
-// C[n][col0 + m] (ldc) = sum_k A[n][k] (lda) W[m][k] (ldw) + bias[m], 64 x 64 tile per workgroup, 32 x 32 per wave.
+// C[n][col0 + m] (ldc) = sum_k A[n][k] (lda) W[m][k] (ldw) + bias[m].
 struct LinearParams {
     const float* a; int lda;
     const float* w; int ldw;
@@ -64,71 +64,148 @@ struct LinearParams {
     float* c2;                              // mode 6: GELU output
 };
 
+// Workgroup tile 128 rows x 128 columns, wave tile 64 x 64 (2 x 2 MFMA tiles: every LDS operand read feeds two MFMAs),
+// k in steps of 16; the next k-step's global loads are issued before the current one's MFMAs (register prefetch), so a
+// k-step costs max(MFMA, memory) instead of their sum.  Loads are unconditional with clamped indices.
 __global__ __launch_bounds__(256) void k32_linear(const LinearParams p) {
-    constexpr int BK = 16, LD = BK + 1;
-    __shared__ float As[64 * LD];
-    __shared__ float Ws[64 * LD];
+    constexpr int BK = 16, LD = BK + 1, TM = 128;
+    __shared__ float As[TM * LD];
+    __shared__ float Ws[TM * LD];
     const int lane = lane_id(), w = wave_id();
-    const long row0 = (long)blockIdx.x * 64;
-    const int colt = blockIdx.y * 64;
-    const int wr = w >> 1, wc = w & 1;   // wave -> 32 x 32 sub-tile
-    f32x16 acc;
+    const long row0 = (long)blockIdx.x * TM;
+    const int colt = blockIdx.y * TM;
+    const int wr = w >> 1, wc = w & 1;   // wave -> 64 x 64 sub-tile
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = opaque_zero();   // a real zero tuple, not the inline constant (common.h)
-    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 4;   // staging: 64 rows x 4 float4 per tile
-    for (int k0 = 0; k0 < p.k; k0 += BK) {
-        {
-            const long ar = row0 + lr < p.n ? row0 + lr : p.n - 1;
-            const int wrow = colt + lr < p.m ? colt + lr : p.m - 1;
-            float av[4], wv[4];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kk = k0 + lk + j;
-                av[j] = kk < p.k ? p.a[ar * p.lda + kk] : 0.f;
-                wv[j] = kk < p.k ? (p.wtrans ? p.w[(long)kk * p.ldw + wrow] : p.w[(long)wrow * p.ldw + kk]) : 0.f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = opaque_zero();   // a real zero tuple, not the inline constant (common.h)
+    // staging: thread -> rows lr, lr + 64 and four consecutive k of the 16 (one 16-byte load each when the operand
+    // allows it); a transposed weight operand ([k][m], the dX = dY W products) is staged k-major instead: thread ->
+    // k index tid / 16 and eight consecutive columns, so that its loads are contiguous too
+    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 4;
+    const int tk = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 8;
+    long ar[2];
+    int wrow[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        ar[h] = row0 + lr + 64 * h < p.n ? row0 + lr + 64 * h : p.n - 1;
+        wrow[h] = colt + lr + 64 * h < p.m ? colt + lr + 64 * h : p.m - 1;
+    }
+    const bool veca = ((p.lda | p.k) & 3) == 0 && ((unsigned long long)p.a & 15) == 0;
+    const bool vecw = p.wtrans ? ((p.ldw | p.m) & 7) == 0 && ((unsigned long long)p.w & 15) == 0
+                               : ((p.ldw | p.k) & 3) == 0 && ((unsigned long long)p.w & 15) == 0;
+    float av[2][4], wv[2][4];
+    auto fetch = [&](int k0) {
+        if (veca) {
+            const int kc = k0 + lk < p.k ? k0 + lk : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p.a + ar[h] * p.lda + kc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[h][j] = k0 + lk < p.k ? v[j] : 0.f;
             }
-            __syncthreads();   // previous tile consumed
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                As[lr * LD + lk + j] = av[j];
-                Ws[lr * LD + lk + j] = wv[j];
-            }
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = k0 + lk + j, kc = kk < p.k ? kk : p.k - 1;
+                    const float a = p.a[ar[h] * p.lda + kc];
+                    av[h][j] = kk < p.k ? a : 0.f;
+                }
         }
+        if (vecw && p.wtrans) {          // wv[h][j] = W^T[k0 + tk][colt + tc + 4 h + j]
+            const int kc = k0 + tk < p.k ? k0 + tk : 0;
+            const int cc = colt + tc < p.m ? colt + tc : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + (long)kc * p.ldw + cc + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wv[h][j] = (k0 + tk < p.k && colt + tc < p.m) ? v[j] : 0.f;
+            }
+        } else if (vecw) {
+            const int kc = k0 + lk < p.k ? k0 + lk : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + (long)wrow[h] * p.ldw + kc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wv[h][j] = k0 + lk < p.k ? v[j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = k0 + lk + j, kc = kk < p.k ? kk : p.k - 1;
+                    const float b = p.wtrans ? p.w[(long)kc * p.ldw + wrow[h]] : p.w[(long)wrow[h] * p.ldw + kc];
+                    wv[h][j] = kk < p.k ? b : 0.f;
+                }
+        }
+    };
+    const bool wkmajor = vecw && p.wtrans;
+    fetch(0);
+    const int i = lane & 31, kh = lane >> 5;
+    for (int k0 = 0; k0 < p.k; k0 += BK) {
+        __syncthreads();   // previous tile consumed
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                As[(lr + 64 * h) * LD + lk + j] = av[h][j];
+                if (wkmajor) Ws[(tc + 4 * h + j) * LD + tk] = wv[h][j];
+                else Ws[(lr + 64 * h) * LD + lk + j] = wv[h][j];
+            }
         __syncthreads();
-        const int i = lane & 31, kh = lane >> 5;
+        if (k0 + BK < p.k) fetch(k0 + BK);   // in flight under the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a = As[(wr * 32 + i) * LD + kk + kh];
-            const float b = Ws[(wc * 32 + i) * LD + kk + kh];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = As[(wr * 64 + t * 32 + i) * LD + kk + kh];
+                b[t] = Ws[(wc * 64 + t * 32 + i) * LD + kk + kh];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
         }
     }
-    const int col = colt + wc * 32 + (lane & 31);
-    if (col >= p.m) return;
-    const float bias = p.bias ? p.bias[col] : 0.f;
     const int hh = lane >> 5;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const long row = row0 + wr * 32 + mfma_row(r, hh);
-        if (row >= p.n) continue;
-        float v = acc[r] + bias;
-        float* dst = p.c + row * p.ldc + p.col0 + col;
-        if (p.mode == 0) {
-            *dst = v;
-        } else if (p.mode == 1) {
-            *dst = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-        } else if (p.mode == 2) {
-            const float g = p.gated ? p.mm.mod[p.mm.row_off(row) + p.gate_chunk * kC + col] : 1.0f;
-            *dst = *dst + g * v;
-        } else if (p.mode == 3) {
-            *dst = *dst + p.scalar * v;
-        } else if (p.mode == 4) {
-            *dst = v * p.scalar;
-        } else if (p.mode == 5) {
-            *dst = *dst + v;
-        } else {
-            *dst = v;
-            p.c2[row * p.ldc + p.col0 + col] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    for (int u = 0; u < 2; ++u) {
+        const int col = colt + wc * 64 + u * 32 + (lane & 31);
+        if (col >= p.m) continue;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + wr * 64 + t * 32 + mfma_row(r, hh);
+                if (row >= p.n) continue;
+                float v = acc[t][u][r] + bias;
+                float* dst = p.c + row * p.ldc + p.col0 + col;
+                if (p.mode == 0) {
+                    *dst = v;
+                } else if (p.mode == 1) {
+                    *dst = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                } else if (p.mode == 2) {
+                    const float g = p.gated ? p.mm.mod[p.mm.row_off(row) + p.gate_chunk * kC + col] : 1.0f;
+                    *dst = *dst + g * v;
+                } else if (p.mode == 3) {
+                    *dst = *dst + p.scalar * v;
+                } else if (p.mode == 4) {
+                    *dst = v * p.scalar;
+                } else if (p.mode == 5) {
+                    *dst = *dst + v;
+                } else {
+                    *dst = v;
+                    p.c2[row * p.ldc + p.col0 + col] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                }
+            }
         }
     }
 }
@@ -253,7 +330,7 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
                      int wtrans, float* c2) {
     LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, wtrans, c, ldc, col0, mm, gate_chunk, gated, scalar, c2};
-    hipLaunchKernelGGL(k32_linear, dim3((unsigned)((n + 63) / 64), (unsigned)((m + 63) / 64)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k32_linear, dim3((unsigned)((n + 127) / 128), (unsigned)((m + 127) / 128)), dim3(256), 0, s, p);
 }
 void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, hipStream_t s) {
     const long total = ntok * kH * 12 * 2;

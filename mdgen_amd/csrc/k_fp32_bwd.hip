@@ -91,50 +91,97 @@ struct ColsumParams {
     float* partial;
 };
 __global__ __launch_bounds__(384) void k32_colsum(const ColsumParams p) {
-    const int c = blockIdx.y * 384 + threadIdx.x;   // column chunks of 384 (mode 2: exactly one chunk)
     const long g = blockIdx.x / p.slices_per_group;
     const int si = blockIdx.x % p.slices_per_group;
     const long g0 = g * p.tokens_per_group;
     long lo = g0 + (long)si * p.rows_per_slice, hi = lo + p.rows_per_slice;
     const long gend = g0 + p.tokens_per_group < p.nrows ? g0 + p.tokens_per_group : p.nrows;
     hi = hi < gend ? hi : gend;
-    __shared__ float st[2];
-    float s = 0.f;
-    for (long t = lo; t < hi; ++t) {
-        float bb = 1.f;
-        if (p.mode == 1) {
-            bb = c < p.ncols ? p.b[t * p.ldb + c] : 0.f;
-        } else if (p.mode == 2) {   // LayerNorm statistics of row t (384 columns): block-wide reduction
-            const float xv = p.b[t * p.ldb + threadIdx.x];
-            __shared__ float red[6], red2[6];
-            float sm = wave_sum(xv);
-            if (lane_id() == 0) red[wave_id()] = sm;
-            __syncthreads();
-            const float mean = (red[0] + red[1] + red[2] + red[3] + red[4] + red[5]) * (1.0f / kC);
-            const float d = xv - mean;
-            float sq = wave_sum(d * d);
-            if (lane_id() == 0) red2[wave_id()] = sq;
-            __syncthreads();
-            const float var = (red2[0] + red2[1] + red2[2] + red2[3] + red2[4] + red2[5]) * (1.0f / kC);
-            bb = d / sqrtf(var + p.eps);
-            __syncthreads();
-        } else if (p.mode == 3) {
-            bb = p.roww[t];
+    if (p.mode == 2) {
+        // b = LayerNorm-normalised row (384 columns): one WAVE per row (lane holds columns lane + 64 i), so the row
+        // statistics are wave reductions and six rows are in flight per workgroup; the six waves' column sums are
+        // combined in a fixed order at the end.
+        __shared__ float red[6 * kC];
+        const int w = wave_id(), lane = lane_id();
+        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (long t = lo + w; t < hi; t += 6) {
+            float xv[6], av[6];
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                xv[i] = p.b[t * p.ldb + lane + 64 * i];
+                av[i] = p.a[t * p.lda + lane + 64 * i];
+                sm += xv[i];
+            }
+            const float mean = wave_sum(sm) * (1.0f / kC);
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                xv[i] -= mean;
+                sq += xv[i] * xv[i];
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(sq) * (1.0f / kC) + p.eps);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) s[i] += av[i] * (xv[i] * rstd);
         }
-        if (c < p.ncols) s += p.a[t * p.lda + c] * bb;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) red[w * kC + lane + 64 * i] = s[i];
+        __syncthreads();
+        const int c = threadIdx.x;
+        p.partial[(long)blockIdx.x * p.ncols + c] =
+            ((red[c] + red[kC + c]) + (red[2 * kC + c] + red[3 * kC + c])) + (red[4 * kC + c] + red[5 * kC + c]);
+        return;
     }
-    (void)st;
+    const int c = blockIdx.y * 384 + threadIdx.x;   // column chunks of 384
+    const int cc = c < p.ncols ? c : p.ncols - 1;   // loads are unconditional (clamped column), eight rows in flight
+    float s = 0.f;
+    long t = lo;
+    for (; t + 8 <= hi; t += 8) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            av[u] = p.a[(t + u) * p.lda + cc];
+            bv[u] = p.mode == 1 ? p.b[(t + u) * p.ldb + cc] : p.mode == 3 ? p.roww[t + u] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += av[u] * bv[u];
+    }
+    for (; t < hi; ++t) {
+        const float bb = p.mode == 1 ? p.b[t * p.ldb + cc] : p.mode == 3 ? p.roww[t] : 1.f;
+        s += p.a[t * p.lda + cc] * bb;
+    }
     if (c < p.ncols) p.partial[(long)blockIdx.x * p.ncols + c] = s;
 }
-// out[g * ldo + c] += sum_i partial[(g * spg + i)][c]
-__global__ void k32_colsum_final(const float* __restrict__ partial, int ngroups, int spg, int ncols, float* __restrict__ out,
-                                 long ldo) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ngroups * ncols) return;
-    const int g = i / ncols, c = i % ncols;
+// out[g * ldo + c] += sum_i partial[(g * spg + i)][c].  Workgroup = 16 columns x 16 slice lanes: lane s sums slices
+// s, s + 16, ... (four loads in flight), the sixteen lane sums are added in a fixed order -- bit-reproducible, and
+// 16 x the parallelism of one thread per column (at B = 1 a bias gradient is ONE group of ~1000 slices).
+__global__ __launch_bounds__(256) void k32_colsum_final(const float* __restrict__ partial, int ngroups, int spg, int ncols,
+                                                        float* __restrict__ out, long ldo) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int ncb = (ncols + 15) / 16;
+    const int g = blockIdx.x / ncb, c = (blockIdx.x % ncb) * 16 + cl;
+    const int cc = c < ncols ? c : ncols - 1;
+    const float* base = partial + (long)g * spg * ncols + cc;
     float s = 0.f;
-    for (int k = 0; k < spg; ++k) s += partial[((long)g * spg + k) * ncols + c];
-    out[(long)g * ldo + c] += s;
+    int k = sl;
+    for (; k + 48 < spg; k += 64) {
+        const float v0 = base[(long)k * ncols], v1 = base[(long)(k + 16) * ncols], v2 = base[(long)(k + 32) * ncols],
+                    v3 = base[(long)(k + 48) * ncols];
+        s += v0;
+        s += v1;
+        s += v2;
+        s += v3;
+    }
+    for (; k < spg; k += 16) s += base[(long)k * ncols];
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cl];
+        out[(long)g * ldo + c] += t;
+    }
 }
 
 // ---- LayerNorm (+ modulate | affine) backward -------------------------------------------------------------------------
@@ -440,7 +487,15 @@ __global__ __launch_bounds__(256) void k32_mask_sum(const float* __restrict__ ma
     __shared__ float red[4];
     const long base = (long)blockIdx.x * per_sample;
     float s = 0.f;
-    for (long i = threadIdx.x; i < per_sample; i += 256) s += mask[base + i];
+    long i = threadIdx.x;
+    for (; i + 7 * 256 < per_sample; i += 8 * 256) {
+        float mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = mask[base + i + 256 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += mv[u];
+    }
+    for (; i < per_sample; i += 256) s += mask[base + i];
     s = wave_sum(s);
     if (lane_id() == 0) red[wave_id()] = s;
     __syncthreads();
@@ -482,7 +537,7 @@ void launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int 
 void launch32_colsum(const float* a, int lda, const float* b, int ldb, const float* roww, int mode, long nrows, int ncols,
                      long tokens_per_group, float eps, float* out, long ldo, float* part, size_t part_floats, hipStream_t s) {
     const long ng = (nrows + tokens_per_group - 1) / tokens_per_group;
-    int rps = 512;
+    int rps = 64;   // rows per slice: ~1000 workgroups per call at cfg-5's per-GPU size, each with 8 (mode 2: 6) rows in flight
     int spg = (int)((tokens_per_group + rps - 1) / rps);
     while ((size_t)ng * spg * ncols > part_floats && rps < (1 << 24)) {
         rps *= 2;
@@ -490,8 +545,7 @@ void launch32_colsum(const float* a, int lda, const float* b, int ldb, const flo
     }
     ColsumParams p{a, lda, b, ldb, roww, mode, nrows, ncols, tokens_per_group, rps, spg, eps, part};
     hipLaunchKernelGGL(k32_colsum, dim3((unsigned)(ng * spg), (unsigned)((ncols + 383) / 384)), dim3(384), 0, s, p);
-    const int tot = (int)(ng * ncols);
-    hipLaunchKernelGGL(k32_colsum_final, dim3((tot + 255) / 256), dim3(256), 0, s, part, (int)ng, spg, ncols, out, ldo);
+    hipLaunchKernelGGL(k32_colsum_final, dim3((unsigned)(ng * ((ncols + 15) / 16))), dim3(256), 0, s, part, (int)ng, spg, ncols, out, ldo);
 }
 void launch32_ln_bwd(const float* x, const float* dy, long nrows, const ModMap& mm, int scale_chunk, int affine, float eps,
                      float* dx, int accumulate, hipStream_t s) {

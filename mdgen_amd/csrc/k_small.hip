@@ -548,7 +548,23 @@ __global__ __launch_bounds__(256) void k_masked_mse(const float* __restrict__ pr
     __shared__ float red[2][4];
     const long base = (long)blockIdx.x * per_sample;
     float num = 0.f, den = 0.f;
-    for (long i = threadIdx.x; i < per_sample; i += 256) {
+    long i = threadIdx.x;
+    for (; i + 7 * 256 < per_sample; i += 8 * 256) {   // eight independent load triples in flight (B = 1: one workgroup
+        float pv[8], tv[8], mv[8];                      // walks the whole sample; one load per trip cost 2 ms at cfg-5 size)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            pv[u] = pred[base + i + 256 * u];
+            tv[u] = target[base + i + 256 * u];
+            mv[u] = mask[base + i + 256 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float d = pv[u] - tv[u];
+            num += d * d * mv[u];
+            den += mv[u];
+        }
+    }
+    for (; i < per_sample; i += 256) {
         const float d = pred[base + i] - target[base + i], m = mask[base + i];
         num += d * d * m;
         den += m;
