@@ -16,57 +16,107 @@
 namespace mdg {
 
 // ---- dW ---------------------------------------------------------------------------------------------------------------
-// part[z][m][k] = sum_{n in slice z} dY[n][m] * X[n][k];  grid (ceil(M/64), ceil(K/64), nsplit), 256 threads.
+// part[z][m][k] = sum_{n in slice z} dY[n][m] * X[n][k];  grid (ceil(M/128), ceil(K/128), nsplit), 256 threads.
+// Workgroup tile 128 x 128, wave tile 64 x 64 (2 x 2 MFMA tiles), sixteen token rows per step, the next step's rows
+// requested before the current step's MFMAs.  Both operands are read along their contiguous dimension (thread -> token
+// row tid / 16, eight consecutive columns: two 16-byte loads each) and transposed on their way into LDS.
 __global__ __launch_bounds__(256) void k32_dw(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
                                               long n, int m, int k, float* __restrict__ part) {
-    constexpr int BN = 16, LD = BN + 1;
-    __shared__ float As[64 * LD];   // dY^T tile: [m][n]
-    __shared__ float Bs[64 * LD];   // X^T  tile: [k][n]
+    constexpr int BN = 16, LD = BN + 1, TM = 128;
+    __shared__ float As[TM * LD];   // dY^T tile: [m][n]
+    __shared__ float Bs[TM * LD];   // X^T  tile: [k][n]
     const int lane = lane_id(), w = wave_id();
-    const int m0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int m0 = blockIdx.x * TM, k0 = blockIdx.y * TM;
     const long per = ((n + gridDim.z - 1) / gridDim.z + BN - 1) / BN * BN;
     const long nlo = (long)blockIdx.z * per, nhi = nlo + per < n ? nlo + per : n;
     const int wr = w >> 1, wc = w & 1;
-    f32x16 acc;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = opaque_zero();
-    const int ln = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 4;   // staging: 16 n-rows x 64 columns (4 per thread)
-    for (long n0 = nlo; n0 < nhi; n0 += BN) {
-        float av[4], bv[4];
-        const long row = n0 + ln;
-        const bool rok = row < nhi;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int mc = m0 + lc + j, kc = k0 + lc + j;
-            av[j] = (rok && mc < m) ? dy[row * ldy + mc] : 0.f;
-            bv[j] = (rok && kc < k) ? x[row * ldx + kc] : 0.f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = opaque_zero();
+    const int ln = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 8;   // staging: 16 token rows x 128 columns (8 per thread)
+    const bool veca = ((ldy | m) & 7) == 0 && ((unsigned long long)dy & 15) == 0;
+    const bool vecb = ((ldx | k) & 7) == 0 && ((unsigned long long)x & 15) == 0;
+    float av[8], bv[8];
+    auto fetch = [&](long n0) {
+        const long row = n0 + ln < nhi ? n0 + ln : (nhi > 0 ? nhi - 1 : 0);
+        const bool rok = n0 + ln < nhi;
+        if (veca) {
+            const int mc = m0 + lc < m ? m0 + lc : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(dy + row * ldy + mc + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[4 * h + j] = (rok && m0 + lc < m) ? v[j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int mc = m0 + lc + j;
+                const float v = dy[row * ldy + (mc < m ? mc : m - 1)];
+                av[j] = (rok && mc < m) ? v : 0.f;
+            }
         }
+        if (vecb) {
+            const int kc = k0 + lc < k ? k0 + lc : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + kc + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[4 * h + j] = (rok && k0 + lc < k) ? v[j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kc = k0 + lc + j;
+                const float v = x[row * ldx + (kc < k ? kc : k - 1)];
+                bv[j] = (rok && kc < k) ? v : 0.f;
+            }
+        }
+    };
+    if (nlo < nhi) fetch(nlo);
+    const int i = lane & 31, kh = lane >> 5;
+    for (long n0 = nlo; n0 < nhi; n0 += BN) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
             As[(lc + j) * LD + ln] = av[j];
             Bs[(lc + j) * LD + ln] = bv[j];
         }
         __syncthreads();
-        const int i = lane & 31, kh = lane >> 5;
+        if (n0 + BN < nhi) fetch(n0 + BN);
 #pragma unroll
         for (int kk = 0; kk < BN; kk += 2) {
-            const float a = As[(wr * 32 + i) * LD + kk + kh];
-            const float b = Bs[(wc * 32 + i) * LD + kk + kh];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = As[(wr * 64 + t * 32 + i) * LD + kk + kh];
+                b[t] = Bs[(wc * 64 + t * 32 + i) * LD + kk + kh];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
         }
     }
-    const int col = k0 + wc * 32 + (lane & 31);
-    if (col >= k) return;
     const int hh = lane >> 5;
     float* dst = part + (long)blockIdx.z * m * k;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 32 + mfma_row(r, hh);
-        if (row < m) dst[(long)row * k + col] = acc[r];
+    for (int u = 0; u < 2; ++u) {
+        const int col = k0 + wc * 64 + u * 32 + (lane & 31);
+        if (col >= k) continue;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + t * 32 + mfma_row(r, hh);
+                if (row < m) dst[(long)row * k + col] = acc[t][u][r];
+            }
     }
 }
-// dst[i] += sum_z part[z][i]  (fixed order)
 __global__ void k32_reduce_add(const float* __restrict__ part, int nsplit, long count, float* __restrict__ dst) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -525,11 +575,15 @@ __global__ void k32_sum_frames(const float* __restrict__ a, int B, int T, int L,
 // ---- launchers ------------------------------------------------------------------------------------------------------
 void launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,
                  size_t part_floats, hipStream_t s) {
-    int nsplit = (int)((n + 2047) / 2048);
-    if (nsplit > 64) nsplit = 64;
+    // enough slices to fill the chip with 128 x 128 tiles (a 384 x 384 weight is only 9 of them)
+    const int tiles = ((m + 127) / 128) * ((k + 127) / 128);
+    int nsplit = (int)((n + 511) / 512);
+    const int want = (1024 + tiles - 1) / tiles;
+    if (nsplit > want) nsplit = want;
+    if (nsplit > 128) nsplit = 128;
     if (nsplit < 1) nsplit = 1;
     while (nsplit > 1 && (size_t)nsplit * m * k > part_floats) --nsplit;
-    hipLaunchKernelGGL(k32_dw, dim3((m + 63) / 64, (k + 63) / 64, nsplit), dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
+    hipLaunchKernelGGL(k32_dw, dim3((m + 127) / 128, (k + 127) / 128, nsplit), dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
     const long count = (long)m * k;
     hipLaunchKernelGGL(k32_reduce_add, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part, nsplit, count, dw);
 }
