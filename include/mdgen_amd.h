@@ -292,10 +292,13 @@ int32_t mdgen_ema_update(int64_t n, float* ema, const float* params, float decay
  * context's i-th state_dict key (mdgen_ctx_weight_name; -1 = do not compute / frozen).  Runs the fp32-operand form of
  * the network (option keep_fp32_weights must have been set before the weights were handed over), with a tape in
  * `tape` (mdgen_train_workspace_bytes; 256-byte aligned); `workspace` as for mdgen_denoiser_forward (n_steps 1,
- * t_shared 0).  Forward-simulation models only.  xt, target, loss_mask, pred: (B,T,L,D); t, loss: (B). */
+ * t_shared 0).  Forward-simulation models (end_rot / end_trans NULL) and the two-sided TPS model (end frames
+ * required; its IPA stack runs twice on shared weights, latent_model.py:193-205).  xt, target, loss_mask, pred:
+ * (B,T,L,D); t, loss: (B). */
 int32_t mdgen_train_workspace_bytes(const mdgen_ctx* ctx, const mdgen_shape* shape, size_t* bytes);
 int32_t mdgen_train_forward_backward(mdgen_ctx* ctx, const mdgen_shape* shape, const float* xt, const float* t,
                                      const float* mask, const float* start_rot, const float* start_trans,
+                                     const float* end_rot, const float* end_trans,
                                      const float* x_cond, const int64_t* x_cond_mask, const int64_t* aatype,
                                      const float* target, const float* loss_mask, float* loss, float* pred,
                                      float* grads, const int64_t* grad_offsets, void* workspace, size_t workspace_bytes,

@@ -86,7 +86,7 @@ def _load():
     lib.mdgen_adam_step.argtypes = [i64, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp, f32, vp]
     lib.mdgen_ema_update.argtypes = [i64, vp, vp, f32, vp]
     lib.mdgen_train_workspace_bytes.argtypes = [vp, C.POINTER(Shape), C.POINTER(sz)]
-    lib.mdgen_train_forward_backward.argtypes = [vp, C.POINTER(Shape)] + [vp] * 14 + [vp, sz, vp, sz, vp]
+    lib.mdgen_train_forward_backward.argtypes = [vp, C.POINTER(Shape)] + [vp] * 16 + [vp, sz, vp, sz, vp]
     for n in EXPORTS:
         getattr(lib, n)
         if n not in ("mdgen_last_error", "mdgen_ctx_weight_name"):

@@ -34,8 +34,6 @@ class TrainableModel:
     parameters back to the library (bf16 repack for the sampler kernels + fp32 copies for the training kernels)."""
 
     def __init__(self, cfg: ModelConfig, device="cuda"):
-        if cfg.tps_condition:
-            raise L.MdgenError("the training step is built for forward-simulation models (sim_condition)")
         self.cfg = cfg
         self.model = LatentMDGenModel(cfg, device, precision="fp32")
         self.device = self.model.device
@@ -65,8 +63,9 @@ class TrainableModel:
     def zero_grad(self):
         self.grads.zero_()
 
-    def forward_backward(self, xt, t, target, loss_mask, mask, start_frames, x_cond, x_cond_mask, aatype):
-        """loss[b] and pred; d mean_b(loss) / d theta is ADDED into self.grads."""
+    def forward_backward(self, xt, t, target, loss_mask, mask, start_frames, x_cond, x_cond_mask, aatype, end_frames=None):
+        """loss[b] and pred; d mean_b(loss) / d theta is ADDED into self.grads.  `end_frames`: the two-sided (TPS) model's
+        second conditioning frames (latent_model.py:193-205)."""
         m = self.model
         B, T, L_, D = xt.shape
         xt = xt.to(torch.float32).contiguous()
@@ -75,6 +74,9 @@ class TrainableModel:
         loss_mask = loss_mask.to(torch.float32).expand_as(xt).contiguous()
         mask = mask.to(torch.float32).contiguous()
         sr, st = _frames(start_frames)
+        if self.cfg.tps_condition and end_frames is None:
+            raise L.MdgenError("tps_condition requires end_frames")
+        er, et = _frames(end_frames) if self.cfg.tps_condition else (None, None)
         x_cond = x_cond.to(torch.float32).contiguous()
         x_cond_mask = x_cond_mask.to(torch.int64).contiguous()
         aatype = aatype.to(torch.int64).contiguous()
@@ -90,7 +92,8 @@ class TrainableModel:
         pred = torch.empty_like(xt)
         with torch.cuda.device(self.device):
             check(lib.mdgen_train_forward_backward(
-                m._ctx, C.byref(sh), ptr(xt), ptr(t), ptr(mask), ptr(sr), ptr(st), ptr(x_cond), ptr(x_cond_mask), ptr(aatype),
+                m._ctx, C.byref(sh), ptr(xt), ptr(t), ptr(mask), ptr(sr), ptr(st), ptr(er), ptr(et), ptr(x_cond), ptr(x_cond_mask),
+                ptr(aatype),
                 ptr(target), ptr(loss_mask), ptr(loss), ptr(pred), ptr(self.grads), self._goff, ptr(ws), ws.numel(),
                 ptr(self._tape), self._tape.numel(), L.stream_ptr()))
         return loss, pred
@@ -124,7 +127,7 @@ class Trainer:
         self.tm.zero_grad()
         self.buckets.reset()
         loss, _ = self.tm.forward_backward(xt, t, ut, prep["loss_mask"], kw["mask"], kw["start_frames"], kw["x_cond"],
-                                           kw["x_cond_mask"], kw["aatype"])
+                                           kw["x_cond_mask"], kw["aatype"], end_frames=kw.get("end_frames"))
         for name in list(self.tm.params.shapes)[::-1]:     # the whole backward is one library call: all ready at once
             self.buckets.mark_ready(name)
         scale = self.buckets.finish()

@@ -1131,6 +1131,62 @@ def test_training_step_gradients_vs_autograd(shape):
     assert torch.allclose(tm.grads, 2 * g1, rtol=1e-6, atol=1e-12)
 
 
+@pytest.mark.parametrize("shape", [(2, 6, 5, 2), (1, 24, 33, 1)])
+def test_training_step_gradients_tps_vs_autograd(shape):
+    """The two-sided (TPS) model's training step: D = 28 latents, the IPA stack run twice on shared weights (x_r stream on
+    the start frames, x_f stream on the end frames, latent_model.py:193-205) -- two tapes, two backward passes into the
+    same gradients, plus latent_to_emb_f / _r.  Against torch autograd through the oracle run with the kernel's
+    quaternion convention (w >= 0; the oracle itself is pinned to the reference's TPS gradients with the reference's
+    own sign in tests/test_oracle_cpu.py): every one of the 128 trainable tensors to 2e-4."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict
+    from mdgen_amd.train import TrainableModel, trainable_shapes
+    dev = _cuda()
+    B, T, L, nl = shape
+    cfg = ModelConfig(crop=L, num_frames=T, num_layers=nl, abs_pos_emb=True, sim_condition=False, tps_condition=True)
+    assert cfg.latent_dim == 28
+    sd = synth_state_dict(cfg, 19)
+    c = _train_case(cfg, B, T, L, 2000 + T)
+    gen = torch.Generator().manual_seed(77)
+    q = torch.randn(B, L, 4, generator=gen)
+    eR = O.quat_to_rot(q / q.norm(dim=-1, keepdim=True))
+    et = c["st"] + 0.7 * torch.randn(B, L, 3, generator=gen)
+    cm = c["cm"].clone()
+    cm[:, -1] = 1
+    x_cond = torch.where(cm.unsqueeze(-1).bool(), c["x1"], torch.zeros(()))
+    names = list(trainable_shapes(cfg))
+    assert len(names) == 128 if nl == 2 else True
+    P = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    kw = dict(mask=c["mask"], start_frames=(c["sR"], c["st"]), end_frames=(eR, et), x_cond=x_cond, x_cond_mask=cm,
+              aatype=c["aatype"])
+    with torch.enable_grad():
+        ref = O.training_losses(P, dict(O.cfg_dict(cfg), quat_sign="w_nonneg"), c["x1"], c["loss_mask"], kw, c["t"], c["x0"])
+        ref["loss"].mean().backward()
+    xt, ut = O.path_plan(c["t"], c["x0"], c["x1"], "GVP")
+    tm = TrainableModel(cfg, dev).load_state_dict(sd)
+    tm.zero_grad()
+    loss, pred = tm.forward_backward(xt.to(dev), c["t"].to(dev), ut.to(dev), c["loss_mask"].to(dev), c["mask"].to(dev),
+                                     (c["sR"].to(dev), c["st"].to(dev)), x_cond.to(dev), cm.to(dev), c["aatype"].to(dev),
+                                     end_frames=(eR.to(dev), et.to(dev)))
+    torch.cuda.synchronize()
+    assert torch.allclose(loss.cpu(), ref["loss"].detach(), rtol=1e-5)
+    assert rel_l2(pred.cpu(), ref["pred"].detach()) < 1e-5
+    got = tm.params.state_dict(tm.grads)
+    worst = []
+    for k in names:
+        g_ref = P[k].grad
+        assert g_ref is not None, k
+        e = rel_l2(got[k].cpu(), g_ref) if float(g_ref.norm()) > 0 else float(got[k].abs().max())
+        worst.append((e, k))
+    worst.sort(reverse=True)
+    print("TPS worst gradient rel-L2:", [(f"{e:.1e}", k) for e, k in worst[:6]])
+    bad = [(e, k) for e, k in worst if not e < 2e-4]
+    assert not bad, bad[:10]
+    for k in ("latent_to_emb_f.weight", "latent_to_emb_r.weight", "latent_to_emb_f.bias", "latent_to_emb_r.bias"):
+        assert float(got[k].abs().max()) > 0
+
+
 def test_training_gradients_vs_reference_fixture():
     """The same gradients against the REFERENCE's own backward pass directly (tests/golden/train_grads_sim.npz: norms and
     strided samples of every parameter's gradient from `loss.mean().backward()` in the reference)."""
@@ -1224,6 +1280,42 @@ def test_trainer_steps_vs_torch_adam():
                                               aatype=prep["model_kwargs"]["aatype"]).items()})
     assert torch.isfinite(out).all()
     assert tr.ema is not None and not torch.equal(tr.ema.data, tr.tm.params.data)
+
+
+def test_trainer_step_tps():
+    """One `Trainer.training_step` of the two-sided (TPS) model on the reference-generated TPS batch (prep_tps.npz:
+    prep_batch -> plan -> forward / backward over both IPA streams -> clip -> AdamW -> weights handed back): loss equals
+    the oracle's (kernel quaternion convention) to 1e-4, every tensor moved, sampler still finite on the new weights."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict
+    from mdgen_amd.train import Trainer, trainable_shapes
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    dev = _cuda()
+    g0 = load_golden("prep_tps")
+    batch = {k[3:]: v for k, v in g0.items() if k.startswith("in_")}
+    B, T, L = batch["torsions"].shape[:3]
+    cfg = ModelConfig(crop=L, num_frames=T, num_layers=1, abs_pos_emb=True, sim_condition=False, tps_condition=True)
+    sd = synth_state_dict(cfg, 29)
+    w = NewMDGenWrapper(cfg)
+    w.load_model_state_dict(sd)
+    tr = Trainer(w, lr=1e-3, adamw=True, grad_clip=1.0, ema_decay=0.99)
+    gen = torch.Generator().manual_seed(4)
+    t = torch.rand(B, generator=gen)
+    x0 = torch.randn(B, T, L, cfg.latent_dim, generator=gen)
+    before = tr.tm.params.data.clone()
+    loss = tr.training_step({k: v.to(dev) for k, v in batch.items()}, t=t.to(dev), x0=x0.to(dev))
+    cd = dict(O.cfg_dict(cfg), quat_sign="w_nonneg")
+    prep = O.prep_batch(batch, cd)
+    ref = O.training_losses(sd, cd, prep["latents"], prep["loss_mask"], prep["model_kwargs"], t, x0)
+    print(f"TPS training step: loss {float(loss):.6f} (oracle {float(ref['loss'].mean()):.6f})")
+    assert abs(float(loss) - float(ref["loss"].mean())) < 1e-4 * abs(float(ref["loss"].mean()))
+    after = tr.tm.params.state_dict()
+    b4 = tr.tm.params.state_dict(before)
+    still = [k for k in trainable_shapes(cfg) if torch.equal(after[k], b4[k])]
+    assert not still, still
+    out, _ = w.inference({k: v.to(dev) for k, v in batch.items()}, num_steps=2)
+    assert torch.isfinite(out).all()
 
 
 def test_training_step_cfg5_size():

@@ -217,21 +217,25 @@ def test_forward_cfg4_full_size_matches_reference():
     np.testing.assert_allclose(norms, g["norms"].numpy(), rtol=1e-5)
 
 
-def test_training_gradients_vs_reference_autograd():
+@pytest.mark.parametrize("name,nparams", [("train_grads_sim", 124), ("train_grads_tps", 128)])
+def test_training_gradients_vs_reference_autograd(name, nparams):
     """The oracle's autograd (what the GPU gradient tests compare against) pinned to the REFERENCE's own backward pass:
-    `training_losses(...)["loss"].mean().backward()` on the full-width 2-layer model (tests/golden/train_grads_sim.npz,
-    oracle/gen_golden_train.py): every parameter's gradient norm and a strided sample of its entries."""
-    g = load_golden("train_grads_sim")
+    `training_losses(...)["loss"].mean().backward()` on the full-width 2-layer model (tests/golden/train_grads_{sim,tps}.npz,
+    oracle/gen_golden_train.py): every parameter's gradient norm and a strided sample of its entries.  The two-sided (TPS)
+    fixture has distinct end frames and four more tensors (latent_to_emb_f / _r); the oracle runs it with the reference's
+    own quaternion sign (quat_sign "eigh": same torch build, same LAPACK signs)."""
+    g = load_golden(name)
     cfg, sd = weights_for(g)
     names = [str(n) for n in g["grad_names"]]
     P = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
-    kw = dict(mask=g["mask"], start_frames=(g["start_rot"], g["start_trans"]), end_frames=(g["start_rot"], g["start_trans"]),
+    end = (g["end_rot"], g["end_trans"]) if "end_rot" in g else (g["start_rot"], g["start_trans"])
+    kw = dict(mask=g["mask"], start_frames=(g["start_rot"], g["start_trans"]), end_frames=end,
               x_cond=g["x_cond"], x_cond_mask=g["x_cond_mask"], aatype=g["aatype"])
     with torch.enable_grad():
         out = O.training_losses(P, O.cfg_dict(cfg), g["x1"], g["loss_mask"], kw, g["t"], g["x0"])
         out["loss"].mean().backward()
     assert torch.allclose(out["loss"].detach(), g["loss"], rtol=2e-5)
-    assert len(names) == 124 and "pos_embed" not in names            # frozen buffer: no gradient in the reference
+    assert len(names) == nparams and "pos_embed" not in names        # frozen buffer: no gradient in the reference
     for k in names:
         gr = P[k].grad.reshape(-1)
         stride = int(g["gstride_" + k])
