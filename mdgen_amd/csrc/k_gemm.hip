@@ -677,7 +677,9 @@ __global__ __launch_bounds__(256, 2) void k_proj(const ProjParams p) {
 // 11 VALU ops per element (the MLP kernel's GELU phase is VALU-bound): libm erff ~40, A&S 7.1.26 rational ~17.
 // Coefficients carry the factor -log2(e) so that the exponential is a bare v_exp_f32.
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+    // No clamp of x: P(x^2) < 0 everywhere (asserted on a grid by scripts/fit_gelu.py), so for large |x| the exponent
+    // x P(x^2) runs off to -inf (x > 0: e = 0, result x) or +inf (x < 0: e = inf, rcp = 0, result -0) on its own.
+    const float xc = x;
     const float x2 = xc * xc;
     float p = -3.936969279e-06f;
     p = p * x2 + 1.012880530e-04f;
@@ -714,12 +716,12 @@ __device__ __forceinline__ void stamp(const MlpParams& p, int slot) {
 constexpr int kHC = 128, kHRowB = kHC * 2, kNChunk = kF / kHC;
 
 // GELU of one (a, tt) group: hidden units 32 w + 8 a + 4 hh .. +3 of token row tt * 32 + tk -> 8 bytes of hbuf
-__device__ __forceinline__ void gelu_group(const f32x16* a1, const f32x4 (&b)[4], unsigned char* hw, int g, int w,
+__device__ __forceinline__ void gelu_group(const f32x16* a1, const f32x4& ba, unsigned char* hw, int g, int w,
                                            int hh, int tk) {
     const int a = g >> 1, tt = g & 1;
     float v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(a1[tt][4 * a + i] + b[a][i]);
+    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(a1[tt][4 * a + i] + ba[i]);
     *reinterpret_cast<u32x2*>(hw + panel_off(tt * 32 + tk, (32 * w + 8 * a + 4 * hh) * 2, kHRowB)) =
         u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
 }
@@ -728,8 +730,9 @@ __device__ __forceinline__ void gelu_group(const f32x16* a1, const f32x4 (&b)[4]
 // are L2-resident but an L2 round trip is several hundred cycles, and both waves of a SIMD start their stages
 // together: with the first loads issued at the stage's own start every stage -- 24 per panel -- began with that
 // bubble; phase stamps showed both stage kinds at ~55 % of their MFMA / VALU bound).
+constexpr int kPFX = 5;  // W1 fragments in flight per wave in the fc1 stage (see stage_x)
 struct XPre {            // fc1 stage
-    bf16x8 w[3];         // W1 fragments of k-steps 0..2
+    bf16x8 w[kPFX];      // W1 fragments of k-steps 0..kPFX-1
     bf16x8 a[2];         // panel fragments (two 32-token tiles) of k-step 0
 };
 struct YPre {            // fc2 stage
@@ -743,9 +746,12 @@ constexpr int kW2S = 96 * 64;   // bf16x8 elements between two feature tiles of 
 // It also requests the fc1 bias of its own 32 hidden units (b1c), consumed by the GELU of that Y stage.
 template <bool NEXT>
 __device__ __forceinline__ void stage_x(const unsigned char* panel, const bf16x8* __restrict__ w1c, const XPre& pre, f32x16* a1,
-                                        const float* b1c, f32x4 (&b)[4], const bf16x8* __restrict__ w2n,
+                                        const float* b1c, f32x4& b0, const bf16x8* __restrict__ w2n,
                                         const unsigned char* hrn, YPre& nxt) {
-    constexpr int KS = 24, PF = 3;
+    // Weight fragments come from L2 with ~600 cycles of latency under load (in-kernel stamps: a k-step took 210 cycles
+    // with three fragments in flight, 64 of them matrix-pipe time; with five 170), so the number in flight sets the
+    // pace: kPFX, as many as the register file allows (six spill).
+    constexpr int KS = 24, PF = kPFX;
     bf16x8 wring[PF + 1];
     bf16x8 aring[2][2];
 #pragma unroll
@@ -767,10 +773,7 @@ __device__ __forceinline__ void stage_x(const unsigned char* panel, const bf16x8
 #pragma unroll
             for (int t = 0; t < 2; ++t) nxt.a[t] = panel_frag(hrn, kHRowB, t, 0);
         }
-        if (ks == KS - 4) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) b[a] = *reinterpret_cast<const f32x4*>(b1c + 8 * a);
-        }
+        if (ks == KS - 4) b0 = *reinterpret_cast<const f32x4*>(b1c);   // bias of GELU group pair 0; the others just in time
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -783,8 +786,8 @@ __device__ __forceinline__ void stage_x(const unsigned char* panel, const bf16x8
 // hbuf[c&1]); its last k-steps request what the following X stage starts with.
 template <bool NEXT>
 __device__ __forceinline__ void stage_y(const unsigned char* hr, const bf16x8* __restrict__ w2c, const YPre& pre, f32x16* y,
-                                        const f32x16* a1, const f32x4 (&b)[4], unsigned char* hw, int w, int hh, int tk,
-                                        const unsigned char* panel, const bf16x8* __restrict__ w1n, XPre& nxt) {
+                                        const f32x16* a1, const f32x4& b0, const float* b1c, unsigned char* hw, int w, int hh,
+                                        int tk, const unsigned char* panel, const bf16x8* __restrict__ w1n, XPre& nxt) {
     constexpr int KS = 8, PF = 2;
     bf16x8 wring[PF + 1][3];
     bf16x8 aring[2][2];
@@ -794,8 +797,13 @@ __device__ __forceinline__ void stage_y(const unsigned char* hr, const bf16x8* _
         for (int f = 0; f < 3; ++f) wring[i][f] = pre.w[i][f];
     aring[0][0] = pre.a[0];
     aring[0][1] = pre.a[1];
+    // fc1 bias of the GELU group pair in flight / of the next one, requested one k-step early: four live registers
+    // instead of sixteen -- what pays for the deeper W1 ring of stage_x
+    f32x4 bcur = b0, bnext = b0;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
+        if ((ks & 1) == 0 && ks) bcur = bnext;
+        if ((ks & 1) && ks + 1 < KS) bnext = *reinterpret_cast<const f32x4*>(b1c + 8 * ((ks + 1) >> 1));
         if (ks + PF < KS) {
 #pragma unroll
             for (int f = 0; f < 3; ++f) wring[(ks + PF) % (PF + 1)][f] = w2c[(size_t)f * kW2S + (ks + PF) * 64];
@@ -804,7 +812,7 @@ __device__ __forceinline__ void stage_y(const unsigned char* hr, const bf16x8* _
 #pragma unroll
             for (int t = 0; t < 2; ++t) aring[(ks + 1) & 1][t] = panel_frag(hr, kHRowB, t, ks + 1);
         }
-        if (NEXT && ks >= KS - 3) nxt.w[ks - (KS - 3)] = w1n[(ks - (KS - 3)) * 64];
+        if (NEXT && ks >= KS - kPFX) nxt.w[ks - (KS - kPFX)] = w1n[(ks - (KS - kPFX)) * 64];
         if (NEXT && ks == KS - 1) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) nxt.a[t] = panel_frag(panel, kRowB, t, 0);
@@ -815,7 +823,7 @@ __device__ __forceinline__ void stage_y(const unsigned char* hr, const bf16x8* _
 #pragma unroll
             for (int f = 0; f < 3; ++f)
                 y[t * 3 + f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aring[ks & 1][t], wring[ks % (PF + 1)][f], y[t * 3 + f], 0, 0, 0);
-        gelu_group(a1, b, hw, ks, w, hh, tk);
+        gelu_group(a1, bcur, hw, ks, w, hh, tk);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
@@ -856,21 +864,24 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
     YPre yp;
     {   // what X(0) starts with: nothing ran before it that could have prefetched
 #pragma unroll
-        for (int i = 0; i < 3; ++i) xp.w[i] = w1l[i * 64];
+        for (int i = 0; i < kPFX; ++i) xp.w[i] = w1l[i * 64];
 #pragma unroll
         for (int t = 0; t < 2; ++t) xp.a[t] = panel_frag(panel, kRowB, t, 0);
     }
-    f32x4 b[4];
+    f32x4 b0;
     zero_acc<2>(a1);
-    stage_x<false>(panel, w1l, xp, a1, b1l, b, nullptr, nullptr, yp);
+    stage_x<false>(panel, w1l, xp, a1, b1l, b0, nullptr, nullptr, yp);
     {   // chunk 0: nothing to overlap its GELU with yet; request X(1)'s first operands under it
 #pragma unroll
-        for (int i = 0; i < 3; ++i) xp.w[i] = w1l[W1C + i * 64];
+        for (int i = 0; i < kPFX; ++i) xp.w[i] = w1l[W1C + i * 64];
 #pragma unroll
         for (int t = 0; t < 2; ++t) xp.a[t] = panel_frag(panel, kRowB, t, 0);
+        f32x4 b4[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) b4[a] = *reinterpret_cast<const f32x4*>(b1l + 8 * a);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) gelu_group(a1, b, hb0, g, w, hh, tk);
+        for (int g = 0; g < 8; ++g) gelu_group(a1, b4[g >> 1], hb0, g, w, hh, tk);
     }
     stamp(p, 2);
     lds_barrier();   // hbuf[0] is complete
@@ -880,11 +891,11 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
         const unsigned char* hr = (c & 1) ? hb0 : hb1;     // fc2(c - 1) reads it
         // X(c): fc1 of chunk c; requests the first fc2(c - 1) operands
         zero_acc<2>(a1);
-        stage_x<true>(panel, w1l + (size_t)c * W1C, xp, a1, b1l + c * kHC, b, w2l + (size_t)8 * (c - 1) * 64, hr, yp);
+        stage_x<true>(panel, w1l + (size_t)c * W1C, xp, a1, b1l + c * kHC, b0, w2l + (size_t)8 * (c - 1) * 64, hr, yp);
         stamp(p, 1 + 2 * c);
         // Y(c): GELU(c) -> hw  ||  fc2(c - 1) from hr; requests the first operands of X(c + 1) (clamped at the end)
         const int cn = c + 1 < kNChunk ? c + 1 : c;
-        stage_y<true>(hr, w2l + (size_t)8 * (c - 1) * 64, yp, y, a1, b, hw, w, hh, tk, panel, w1l + (size_t)cn * W1C, xp);
+        stage_y<true>(hr, w2l + (size_t)8 * (c - 1) * 64, yp, y, a1, b0, b1l + c * kHC, hw, w, hh, tk, panel, w1l + (size_t)cn * W1C, xp);
         stamp(p, 2 + 2 * c);
         lds_barrier();   // hbuf[c & 1] is complete; every wave has left hbuf[(c - 1) & 1]
     }
