@@ -747,7 +747,7 @@ constexpr int kW2S = 96 * 64;   // bf16x8 elements between two feature tiles of 
 template <bool NEXT>
 __device__ __forceinline__ void stage_x(const unsigned char* panel, const bf16x8* __restrict__ w1c, const XPre& pre, f32x16* a1,
                                         const float* b1c, f32x4& b0, const bf16x8* __restrict__ w2n,
-                                        const unsigned char* hrn, YPre& nxt) {
+                                        const unsigned char* hrn, YPre& nxt, unsigned long long* midstamp = nullptr) {
     // Weight fragments come from L2 with ~600 cycles of latency under load (in-kernel stamps: a k-step took 210 cycles
     // with three fragments in flight, 64 of them matrix-pipe time; with five 170), so the number in flight sets the
     // pace: kPFX, as many as the register file allows (six spill).
@@ -779,6 +779,9 @@ __device__ __forceinline__ void stage_x(const unsigned char* panel, const bf16x8
         for (int t = 0; t < 2; ++t)
             a1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[ks % (PF + 1)], aring[ks & 1][t], a1[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MDGEN_DEV_MLP_STAMPX   // (experiment build, scripts/micro/mlp_stampx.py: a stamp half-way through one fc1 stage)
+        if (midstamp && ks == 11) *midstamp = __builtin_amdgcn_s_memtime();
+#endif
     }
 }
 
@@ -891,7 +894,15 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
         const unsigned char* hr = (c & 1) ? hb0 : hb1;     // fc2(c - 1) reads it
         // X(c): fc1 of chunk c; requests the first fc2(c - 1) operands
         zero_acc<2>(a1);
+#ifdef MDGEN_DEV_MLP_STAMPX
+        unsigned long long mid = 0;
+        if (c == 5) stamp(p, 25);   // after the barrier, before fc1(5)
+        stage_x<true>(panel, w1l + (size_t)c * W1C, xp, a1, b1l + c * kHC, b0, w2l + (size_t)8 * (c - 1) * 64, hr, yp,
+                      c == 5 ? &mid : nullptr);
+        if (c == 5) stamp(p, 30, mid);
+#else
         stage_x<true>(panel, w1l + (size_t)c * W1C, xp, a1, b1l + c * kHC, b0, w2l + (size_t)8 * (c - 1) * 64, hr, yp);
+#endif
         stamp(p, 1 + 2 * c);
         // Y(c): GELU(c) -> hw  ||  fc2(c - 1) from hr; requests the first operands of X(c + 1) (clamped at the end)
         const int cn = c + 1 < kNChunk ? c + 1 : c;
