@@ -202,13 +202,26 @@ extern "C" int mdgen_dev_flash_stamps(void* host, size_t bytes) {
 #define FLASH_STAMP(slot, v)
 #endif
 
-__global__ __launch_bounds__(256, 3) void k_flash(const FlashParams p) {
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., so that h[j], q[j], s[j & 1] are constant-indexed and stay
+// in registers (a runtime-looking index inside the lambdas sent the whole state to scratch)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// NQ = 32-query tiles per wave.  NQ = 2 (three waves per SIMD) or NQ = 4 (two waves per SIMD, <= 256 VGPRs): with four
+// tiles a K / V^T fragment load and a wave's prologue serve twice as many (key tile, query tile) pairs.
+template <int NQ>
+__global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParams p) {
     const int lane = lane_id(), hh = lane >> 5, ql = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform, and the compiler knows it
     FLASH_STAMP(0, __builtin_amdgcn_s_memtime());
     FLASH_STAMP(4, __builtin_amdgcn_s_memrealtime());
     const int len = p.ax.len, nt = p.ax.ntile();   // tiles per (seq, head): they cover the len keys + the bias key
-    const int nqc = (len + 63) / 64;
+    const int nqc = (len + 32 * NQ - 1) / (32 * NQ);
     // (sequence, head group) pairs are dealt to the 8 XCDs (block b runs on XCD b % 8) so that ALL q-chunks of a
     // pair -- which stream the same K/V -- share one L2: K/V leave HBM once.
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
@@ -221,23 +234,26 @@ __global__ __launch_bounds__(256, 3) void k_flash(const FlashParams p) {
     const long seq_base = p.ax.token(seq, 0);
     const int pstride = p.ax.pos_stride;
 
-    // ---- Q fragments of q-tiles 2qc, 2qc+1 (the second may not exist: reuse the first, never stored)
-    const int qt0 = 2 * qc;
-    const bool has2 = (qt0 + 1) * 32 < len;
-    const int qt1 = has2 ? qt0 + 1 : qt0;
-    QTile qa, qb_;
-    qa.q0 = frag16(qb + (long)qt0 * kFragQ + lane * 16);
-    qa.q1 = frag8(qb + (long)qt0 * kFragQ + 1024 + lane * 8);
-    qb_.q0 = frag16(qb + (long)qt1 * kFragQ + lane * 16);
-    qb_.q1 = frag8(qb + (long)qt1 * kFragQ + 1024 + lane * 8);
+    // ---- Q fragments of q-tiles NQ qc .. NQ qc + NQ - 1 (tiles past the end of the sequence reuse the first one and are
+    //      never stored)
+    const int qt0 = NQ * qc;
+    QTile q[NQ];
+    bool qvalid[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        qvalid[j] = (qt0 + j) * 32 < len;
+        const int qt = qvalid[j] ? qt0 + j : qt0;
+        q[j].q0 = frag16(qb + (long)qt * kFragQ + lane * 16);
+        q[j].q1 = frag8(qb + (long)qt * kFragQ + 1024 + lane * 8);
+    }
 
     // ---- K / V^T streams: one buffer descriptor each (wave-uniform base = this (sequence, head)'s first tile), a
     // constant per-lane byte offset, and the tile offset as the scalar offset of the load.  V^T: rows d <= 24 are
     // lanes of the fragment (row 24 = ones); the lanes of rows d > 24 point far out of range and read zeros.
     // Loads are UNCONDITIONAL: tiles past the end of this (sequence, head) read whatever follows in the fragment
     // buffer (finite bf16 of the next head, or the tail) and their results are never used.
-    auto uniform_ptr = [](const unsigned char* q) {
-        const unsigned long long a = (unsigned long long)q;
+    auto uniform_ptr = [](const unsigned char* q_) {
+        const unsigned long long a = (unsigned long long)q_;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
         return (void*)(((unsigned long long)hi << 32) | lo);
     };
@@ -245,16 +261,16 @@ __global__ __launch_bounds__(256, 3) void k_flash(const FlashParams p) {
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.vf + ftile * kFragV), 0, 0x7fffffff, 0x00020000);
     const int koff = lane * 16;
     const int voff = ql <= kDH ? hh * 400 + ql * 16 : (int)0x80000000;
-    auto issue_k = [&](KTile& t, int kt) {
+    auto issue_k = [&](KTile& t, int kt) __attribute__((always_inline)) {
         t.k0 = __builtin_amdgcn_raw_buffer_load_b128(krs, koff, kt * kFragK, 0);
         t.k1 = __builtin_amdgcn_raw_buffer_load_b128(krs, koff + 1024, kt * kFragK, 0);
     };
-    auto issue_v = [&](VTile& t, int kt) {
+    auto issue_v = [&](VTile& t, int kt) __attribute__((always_inline)) {
         t.v0 = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, kt * kFragV, 0);
         t.v1 = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff + 800, kt * kFragV, 0);
     };
     // K tile 0 is wanted first (the anchor below): requested here, together with Q, so that its round trip overlaps
-    // the mask reads
+    // the validity-word read
     KTile k0t;
     issue_k(k0t, 0);
 
@@ -264,51 +280,51 @@ __global__ __launch_bounds__(256, 3) void k_flash(const FlashParams p) {
     const uint32_t* vmrow = p.vmask + (long)seq * p.vmask_stride;
     uint32_t vmw = vmrow[lane];
 
-    // One key tile = two (key tile, query tile) pairs, A then B.  Pipeline: the block of pair i issues the score
-    // MFMAs of pair i+1 and the PV MFMAs of pair i-1 beside its own exps.  Score tuples sa / sb and P tuples pa / pb
-    // belong to query tile A / B for good, so nothing is ever copied; K / V tiles alternate between two slots by
-    // tile parity (kx, vx: even tiles; ky, vy: odd tiles).
-    Half ha, hb;
-    f32x16 sa, sb;
-    PTile pa, pb;
+    // One key tile = NQ (key tile, query tile) pairs, query tiles 0 .. NQ-1 in turn.  Pipeline: the block of pair i
+    // issues the score MFMAs of pair i+1 and the PV MFMAs of pair i-1 beside its own exps.  Two score tuples and two P
+    // tuples alternate by pair parity (NQ is even, so a query tile always meets the same ones); K / V tiles alternate
+    // between two slots by tile parity (kx, vx: even tiles; ky, vy: odd tiles).
+    Half h[NQ];
+    f32x16 s[2];
+    PTile pt[2];
     KTile kx, ky;
     VTile vx, vy;
-    auto tile = [&](auto robust, int t, KTile& kc, KTile& kn, VTile& vc, VTile& vprev) {
+    // (always_inline: a lambda that is NOT inlined keeps everything it captures by reference in scratch memory)
+    auto tile = [&](auto robust, int t, KTile& kc, KTile& kn, VTile& vc, VTile& vprev) __attribute__((always_inline)) {
         constexpr bool kRobust = decltype(robust)::value;
         const uint32_t vm = __builtin_amdgcn_readlane(vmw, t & 63);
-        // pair (t, A): scores in sa.  Block: sb <- scores (t, B);  hb.o += V(t-1) P_B(t-1);  pa <- exp(sa)
-        if (kRobust) softmax_stats(ha, sa, qa, vm, hh);
-        else if (vm != 0xffffffffu) mask_scores(sa, vm, hh);
-        __builtin_amdgcn_sched_barrier(0);
-        block(kc, qb_, sb, vprev, pb, hb.o, sa, pa);
-        __builtin_amdgcn_sched_barrier(0);
+        static_for<NQ>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            // pair (t, j): scores in s[j & 1].  Block: s[(j+1) & 1] <- scores of the next pair; O of the previous
+            // pair's query tile += its V P; pt[j & 1] <- exp(s[j & 1])
+            if constexpr (kRobust) softmax_stats(h[j], s[j & 1], q[j], vm, hh);
+            else if (vm != 0xffffffffu) mask_scores(s[j & 1], vm, hh);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j == 0) block(kc, q[1], s[1], vprev, pt[(NQ - 1) & 1], h[NQ - 1].o, s[0], pt[0]);
+            else if constexpr (j < NQ - 1) block(kc, q[j + 1], s[(j + 1) & 1], vc, pt[(j - 1) & 1], h[j - 1].o, s[j & 1], pt[j & 1]);
+            else block(kn, q[0], s[0], vc, pt[(j - 1) & 1], h[j - 1].o, s[j & 1], pt[j & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #ifndef MDGEN_DEV_FLASH_NOLOAD   // (timing experiments only: scripts/micro/flash_variants.sh)
-        issue_v(vprev, t + 1);   // V(t-1) and K(t) (for query tile B: just issued) are consumed: refill both slots
-        issue_k(kc, t + 2);
+            if constexpr (j == 0) issue_v(vprev, t + 1);      // V(t-1) is consumed: refill its slot
+            if constexpr (j == NQ - 2) issue_k(kc, t + 2);    // K(t) has served its last query tile
+            if constexpr (j == 0 || j == NQ - 2) __builtin_amdgcn_sched_barrier(0);
 #endif
-        __builtin_amdgcn_sched_barrier(0);
-        // pair (t, B): scores in sb.  Block: sa <- scores (t+1, A);  ha.o += V(t) P_A(t);  pb <- exp(sb)
-        if (kRobust) softmax_stats(hb, sb, qb_, vm, hh);
-        else if (vm != 0xffffffffu) mask_scores(sb, vm, hh);
-        __builtin_amdgcn_sched_barrier(0);
-        block(kn, qa, sa, vc, pa, ha.o, sb, pb);
-        __builtin_amdgcn_sched_barrier(0);
+        });
     };
-    // The whole (head, 64 queries) job; returns with the last pair's PV MFMAs issued.
-    auto run = [&](auto robust) {
+    // The whole (head, 32 NQ queries) job; returns with the last pair's PV MFMAs issued.
+    auto run = [&](auto robust) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            ha.o[r] = opaque_zero();
-            hb.o[r] = opaque_zero();
-        }
-        pb.p0 = pb.p1 = u32x4{0u, 0u, 0u, 0u};   // "previous pair" of the very first block: P = 0
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[j].o[r] = opaque_zero();
+        pt[(NQ - 1) & 1].p0 = pt[(NQ - 1) & 1].p1 = u32x4{0u, 0u, 0u, 0u};   // "previous pair" of the very first block: P = 0
         if (nt > 64) vmw = vmrow[lane];          // (a re-run after a long fast loop: back to the first window)
         issue_k(kx, 0);
         issue_v(vy, 0);    // stands in for "V(-1)": any finite values (its P is zero)
         issue_k(ky, 1);
         issue_v(vx, 0);
         __builtin_amdgcn_sched_barrier(0);
-        sa = scores(kx, qa);   // pair (0, A)
+        s[0] = scores(kx, q[0]);   // pair (0, 0)
         // The loop body is a PAIR of tiles with a single exit (an exit between the two makes hipcc keep O in
         // different registers in the two halves and copy it mid-chain); an odd tile count gets a tail tile.
         int t = 0;
@@ -317,108 +333,104 @@ __global__ __launch_bounds__(256, 3) void k_flash(const FlashParams p) {
             tile(robust, t, kx, ky, vx, vy);
             tile(robust, t + 1, ky, kx, vy, vx);
         }
+        const bf16x8 lp0 = __builtin_bit_cast(bf16x8, pt[(NQ - 1) & 1].p0), lp1 = __builtin_bit_cast(bf16x8, pt[(NQ - 1) & 1].p1);
         if (t < nt) {
             if ((t & 63) == 0 && t) vmw = vmrow[t + lane];
             tile(robust, t, kx, ky, vx, vy);
-            // pending: P_B of the last tile (in pb) with V(last) = vx
-            hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vx.v0), __builtin_bit_cast(bf16x8, pb.p0), hb.o, 0, 0, 0);
-            hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vx.v1), __builtin_bit_cast(bf16x8, pb.p1), hb.o, 0, 0, 0);
+            // pending: P of the last tile's last pair with V(last) = vx
+            h[NQ - 1].o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vx.v0), __builtin_bit_cast(bf16x8, pt[(NQ - 1) & 1].p0), h[NQ - 1].o, 0, 0, 0);
+            h[NQ - 1].o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vx.v1), __builtin_bit_cast(bf16x8, pt[(NQ - 1) & 1].p1), h[NQ - 1].o, 0, 0, 0);
         } else {
-            hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vy.v0), __builtin_bit_cast(bf16x8, pb.p0), hb.o, 0, 0, 0);
-            hb.o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vy.v1), __builtin_bit_cast(bf16x8, pb.p1), hb.o, 0, 0, 0);
+            h[NQ - 1].o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vy.v0), lp0, h[NQ - 1].o, 0, 0, 0);
+            h[NQ - 1].o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vy.v1), lp1, h[NQ - 1].o, 0, 0, 0);
         }
     };
 
-    // ---- FAST loop: anchor both query tiles kAnchor above the row max of key tile 0 and never move the shift.
-    bool robust_needed;
+    // ---- FAST loop: anchor every query tile kAnchor above the row max of key tile 0 and never move the shift.
+    bool robust_needed = p.force_robust != 0;
     {
         const uint32_t vm0 = __builtin_amdgcn_readlane(vmw, 0);
-        f32x16 s0 = scores(k0t, qa), s1 = scores(k0t, qb_);   // the -M slots are still zero: plain scores
-        if (vm0 != 0xffffffffu) {
-            mask_scores(s0, vm0, hh);
-            mask_scores(s1, vm0, hh);
-        }
-        float t0 = fmaxf(s0[0], s0[1]), t1 = fmaxf(s1[0], s1[1]);
 #pragma unroll
-        for (int r = 2; r < 16; r += 2) {
-            t0 = fmaxf(fmaxf(t0, s0[r]), s0[r + 1]);
-            t1 = fmaxf(fmaxf(t1, s1[r]), s1[r + 1]);
+        for (int j = 0; j < NQ; ++j) {
+            f32x16 s0 = scores(k0t, q[j]);   // the -M slots are still zero: plain scores
+            if (vm0 != 0xffffffffu) mask_scores(s0, vm0, hh);
+            float t0 = fmaxf(s0[0], s0[1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) t0 = fmaxf(fmaxf(t0, s0[r]), s0[r + 1]);
+            t0 = half_max(t0);
+            // nothing to anchor to (all of tile 0 masked: a padded residue's temporal sequence) -> robust loop
+            robust_needed |= __builtin_amdgcn_ballot_w64(!(t0 > -1e29f)) != 0;
+            h[j].m = set_shift(q[j], t0 + kAnchor, hh);
         }
-        t0 = half_max(t0);
-        t1 = half_max(t1);
-        // nothing to anchor to (all of tile 0 masked: a padded residue's temporal sequence) -> robust loop
-        robust_needed = p.force_robust != 0 || __builtin_amdgcn_ballot_w64(!(t0 > -1e29f && t1 > -1e29f)) != 0;
-        ha.m = set_shift(qa, t0 + kAnchor, hh);
-        hb.m = set_shift(qb_, t1 + kAnchor, hh);
     }
     FLASH_STAMP(1, __builtin_amdgcn_s_memtime());
     FLASH_STAMP(6, (unsigned long long)robust_needed);
-    FLASH_STAMP(8, (unsigned long long)__float_as_uint(ha.m));   // lane 0's fixed anchor (first-tile row max + kAnchor)
+    FLASH_STAMP(8, (unsigned long long)__float_as_uint(h[0].m));   // lane 0's fixed anchor (first-tile row max + kAnchor)
     if (!robust_needed) {
         run(std::false_type{});
         FLASH_STAMP(2, __builtin_amdgcn_s_memtime());
         // every P of a query row is summed into its denominator (register 12 of the lanes hh == 0): finite and
-        // positive <=> no P overflowed.
-        // Bit test, not a float compare: this file is built with -fno-honor-nans.
-        const uint32_t la = __float_as_uint(ha.o[12]), lb = __float_as_uint(hb.o[12]);
-        bool bad = (la & 0x7f800000u) == 0x7f800000u || (lb & 0x7f800000u) == 0x7f800000u;   // inf or NaN
-        // a denominator that underflowed to nothing (first-tile max far above everything the bf16-pair shift resolves)
-        // (lanes hh == 1 hold row 28 there, a zero padding row: not a denominator)
-        bad |= hh == 0 && ((la & 0x7f800000u) == 0u || (lb & 0x7f800000u) == 0u);
-        // ... and a P below the overflow threshold can still push a sum of P v over it: every accumulator is checked
+        // positive <=> no P overflowed.  Bit tests, not float compares: this file is built with -fno-honor-nans.
+        bool bad = false;
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            bad |= (__float_as_uint(ha.o[i]) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(hb.o[i]) & 0x7f800000u) == 0x7f800000u;
+        for (int j = 0; j < NQ; ++j) {
+            const uint32_t lj = __float_as_uint(h[j].o[12]);
+            bad |= (lj & 0x7f800000u) == 0x7f800000u;   // inf or NaN
+            // a denominator that underflowed to nothing (first-tile max far above everything the bf16-pair shift
+            // resolves); lanes hh == 1 hold row 28 there, a zero padding row: not a denominator
+            bad |= hh == 0 && (lj & 0x7f800000u) == 0u;
+            // ... and a P below the overflow threshold can still push a sum of P v over it: every accumulator is checked
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bad |= (__float_as_uint(h[j].o[i]) & 0x7f800000u) == 0x7f800000u;
+        }
         FLASH_STAMP(9, (unsigned long long)__builtin_amdgcn_ballot_w64(bad));
-        FLASH_STAMP(10, (unsigned long long)la | ((unsigned long long)lb << 32));
         robust_needed = __builtin_amdgcn_ballot_w64(bad) != 0;
 #ifdef MDGEN_DEV_FLASH_NOFALLBACK   // (experiments only: shows what the fixed anchor alone does to overflowing scores)
         robust_needed = false;
 #endif
     }
     if (robust_needed) {   // wave-uniform; start over with a moving shift
-        ha.m = hb.m = 0.f;
-        ha.unanch = hb.unanch = ~0ull;
-        set_shift(qa, 0.f, hh);
-        set_shift(qb_, 0.f, hh);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            h[j].m = 0.f;
+            h[j].unanch = ~0ull;
+            set_shift(q[j], 0.f, hh);
+        }
         run(std::true_type{});
     }
     FLASH_STAMP(3, __builtin_amdgcn_s_memtime());
-    FLASH_STAMP(11, (unsigned long long)__float_as_uint(ha.m));   // lane 0's final shift (robust loop: ~ the true row max)
+    FLASH_STAMP(11, (unsigned long long)__float_as_uint(h[0].m));   // lane 0's final shift (robust loop: ~ the true row max)
 #ifdef MDGEN_DEV_FLASH_STAMPS
     if (lane == 0 && (long)blockIdx.x * 4 + w < 32768) g_flash_stamps[((long)blockIdx.x * 4 + w) * 16 + 6] |= (unsigned long long)robust_needed << 1;
 #endif
-    const float l0 = __shfl(ha.o[12], ql, 64);   // O^T row 24 = softmax denominator, held by lanes hh == 0
-    const float l1 = __shfl(hb.o[12], ql, 64);
-    const f32x16 o0 = ha.o, o1 = hb.o;
-    // ---- epilogue: registers 0..11 of lane-half hh are features 12*hh .. 12*hh+11 of this head
-    {
-        const int pos = qt0 * 32 + ql;
-        if (pos < len) {
-            const float inv = 1.0f / l0;
+    // ---- epilogue: O^T row 24 = softmax denominator (held by lanes hh == 0); registers 0..11 of lane-half hh are
+    //      features 12 hh .. 12 hh + 11 of this head
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const float l = __shfl(h[j].o[12], ql, 64);
+        const int pos = (qt0 + j) * 32 + ql;
+        if (qvalid[j] && pos < len) {
+            const float inv = 1.0f / l;
+            const f32x16 o = h[j].o;
             u32x2* d = reinterpret_cast<u32x2*>(p.obuf + (seq_base + (long)pos * pstride) * kC + head * kDH + hh * 12);
-            d[0] = u32x2{pack_bf16(o0[0] * inv, o0[1] * inv), pack_bf16(o0[2] * inv, o0[3] * inv)};
-            d[1] = u32x2{pack_bf16(o0[4] * inv, o0[5] * inv), pack_bf16(o0[6] * inv, o0[7] * inv)};
-            d[2] = u32x2{pack_bf16(o0[8] * inv, o0[9] * inv), pack_bf16(o0[10] * inv, o0[11] * inv)};
-        }
-    }
-    if (has2) {
-        const int pos = qt1 * 32 + ql;
-        if (pos < len) {
-            const float inv = 1.0f / l1;
-            u32x2* d = reinterpret_cast<u32x2*>(p.obuf + (seq_base + (long)pos * pstride) * kC + head * kDH + hh * 12);
-            d[0] = u32x2{pack_bf16(o1[0] * inv, o1[1] * inv), pack_bf16(o1[2] * inv, o1[3] * inv)};
-            d[1] = u32x2{pack_bf16(o1[4] * inv, o1[5] * inv), pack_bf16(o1[6] * inv, o1[7] * inv)};
-            d[2] = u32x2{pack_bf16(o1[8] * inv, o1[9] * inv), pack_bf16(o1[10] * inv, o1[11] * inv)};
+            d[0] = u32x2{pack_bf16(o[0] * inv, o[1] * inv), pack_bf16(o[2] * inv, o[3] * inv)};
+            d[1] = u32x2{pack_bf16(o[4] * inv, o[5] * inv), pack_bf16(o[6] * inv, o[7] * inv)};
+            d[2] = u32x2{pack_bf16(o[8] * inv, o[9] * inv), pack_bf16(o[10] * inv, o[11] * inv)};
         }
     }
     FLASH_STAMP(5, __builtin_amdgcn_s_memrealtime());
 }
 
+// Measured (cfg-2 / cfg-4, same box, back to back): NQ = 4 runs 160-162 / 76 us, NQ = 2 160-164 / 76 us -- a tie; 2 keeps
+// three waves per SIMD and is faster on short sequences (IPA stack: 10 vs 14 us).
+#ifndef MDGEN_FLASH_NQ
+#define MDGEN_FLASH_NQ 2
+#endif
 void launch_flash(const FlashParams& p, hipStream_t s) {
-    const int nqc = (p.ax.len + 63) / 64;
+    constexpr int NQ = MDGEN_FLASH_NQ;
+    const int nqc = (p.ax.len + 32 * NQ - 1) / (32 * NQ);
     const int npair8 = (p.ax.nseq * 4 + 7) / 8;   // (sequence, head group) pairs, in groups of 8 (one per XCD)
-    hipLaunchKernelGGL(k_flash, dim3(npair8 * nqc * 8), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_flash<NQ>, dim3(npair8 * nqc * 8), dim3(256), 0, s, p);
 }
 
 }  // namespace mdg
