@@ -85,6 +85,8 @@ struct FinalParams {
 // the sequence and not padded, or the learned bias key at position len).  Per sequence `stride` words, a multiple of
 // 64 >= ntile + 1, zero beyond the last tile (k_flash reads them in 64-tile windows, one tile ahead).  They live in the
 // slack of the V^T fragment region (a tile is allocated kFragBytes, V^T uses kFragV of it), behind the last fragment.
+static_assert((kFragBytes - kFragV) * kH >= 4 * 64 + 4 * 1 + 256,
+              "the key-validity words (<= ntile + 64 of them per sequence, 256-byte aligned) must fit the slack the V^T fragments leave");
 __host__ __device__ inline int flash_vmask_stride(int ntile) { return (ntile + 64) & ~63; }
 __host__ __device__ inline size_t flash_vmask_offset(long nseq, int ntile) {
     return (((size_t)nseq * kH * ntile * kFragV) + 255) & ~(size_t)255;
