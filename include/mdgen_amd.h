@@ -296,6 +296,14 @@ int32_t mdgen_ema_update(int64_t n, float* ema, const float* params, float decay
  * required; its IPA stack runs twice on shared weights, latent_model.py:193-205).  xt, target, loss_mask, pred:
  * (B,T,L,D); t, loss: (B). */
 int32_t mdgen_train_workspace_bytes(const mdgen_ctx* ctx, const mdgen_shape* shape, size_t* bytes);
+/* Gradient milestones, for overlapping the DDP all-reduce with the backward pass (Lightning DDP's bucketed hooks,
+ * train.py:46-77): the backward pass completes parameter groups in the order
+ *   0: emb_to_latent.* | 1 .. nl: layers.{nl-1 .. 0}.* | nl+1: latent_to_emb, cond_to_emb, mask_to_emb |
+ *   nl+2 .. 2nl+1: ipa_layers.{nl-1 .. 0}.* | 2nl+2: everything else (aatype_to_emb, latent_to_emb_f/_r, t_embedder)
+ * and records the caller's hipEvent_t events[k] (NULL = skip) on the training stream when group k's gradients are
+ * final.  The list stays in force until replaced (n = 0 clears it); the events remain the caller's. */
+int32_t mdgen_train_num_milestones(const mdgen_ctx* ctx);
+int32_t mdgen_train_set_milestone_events(mdgen_ctx* ctx, void* const* events, int32_t n);
 int32_t mdgen_train_forward_backward(mdgen_ctx* ctx, const mdgen_shape* shape, const float* xt, const float* t,
                                      const float* mask, const float* start_rot, const float* start_trans,
                                      const float* end_rot, const float* end_trans,

@@ -4,7 +4,7 @@
 What is here: flat fp32 parameter / gradient / moment buffers (`FlatParams`), gradient-norm clipping + Adam / AdamW
 (`Adam`, kernels in csrc/k_optim.hip, no host round trip for the clip coefficient), the weight EMA (`EMA`) and the
 bucketed gradient all-reduce over `torch.distributed` (`GradBucketer`; backend "nccl" is RCCL on ROCm).
-What is NOT here: the backward kernels that would fill the gradient buffer ("training step").
+The backward pass that fills the gradient buffer is `mdgen_train_forward_backward` (mdgen_amd/train.py).
 
 All arithmetic runs in libmdgen_amd.so; torch carries memory, streams and the process group."""
 from __future__ import annotations
@@ -165,6 +165,28 @@ class GradBucketer:
                 self._handles.append(self.dist.all_reduce(self.grads[b["lo"]:b["hi"]], op=self.dist.ReduceOp.SUM,
                                                           async_op=True))
 
+    # ---- overlap with a backward pass that runs as ONE library call (mdgen_train_forward_backward) -----------------
+    def launch_on_events(self, milestone_of: Callable[[str], int], events, comm_stream, on_bucket=None):
+        """The library records `events[k]` on the training stream when the gradients of parameter group k are final
+        (include/mdgen_amd.h `mdgen_train_set_milestone_events`).  Every bucket's all-reduce is enqueued on
+        `comm_stream` behind the event of the LAST group it contains, in backward order -- so it runs while the
+        training stream is still differentiating earlier layers.  `on_bucket(i, view)` (tests) is called inside the
+        comm-stream context after the wait.  Call `finish()` afterwards."""
+        order = sorted(range(len(self.buckets)), key=lambda i: max(milestone_of(n) for n in self.buckets[i]["names"]))
+        for i in order:
+            b = self.buckets[i]
+            m = max(milestone_of(n) for n in b["names"])
+            comm_stream.wait_event(events[m])
+            with torch.cuda.stream(comm_stream):
+                view = self.grads[b["lo"]:b["hi"]]
+                if on_bucket is not None:
+                    on_bucket(i, view)
+                if self.world() > 1:
+                    self._handles.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, async_op=True))
+            self._pending[i] = set()
+            self.launch_order.append(i)
+        self._comm_stream = comm_stream
+
     def finish(self) -> float:
         """Wait for all buckets; returns the `grad_scale` (1 / world_size) the optimiser should apply."""
         missing = [i for i, p in enumerate(self._pending) if p]
@@ -172,4 +194,8 @@ class GradBucketer:
             raise MdgenError(f"gradients of buckets {missing} were never marked ready")
         for h in self._handles:
             h.wait()
+        cs = getattr(self, "_comm_stream", None)
+        if cs is not None:                       # the optimiser (training stream) must see the reduced buckets
+            torch.cuda.current_stream(self.grads.device).wait_stream(cs)
+            self._comm_stream = None
         return 1.0 / self.world()

@@ -28,6 +28,33 @@ def trainable_shapes(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
     return OrderedDict((k, v) for k, v in state_shapes(cfg).items() if not k.endswith("inv_freq") and k not in FROZEN)
 
 
+def grad_milestone(name: str, num_layers: int) -> int:
+    """Parameter group of the library's backward pass whose completion makes `name`'s gradient final
+    (include/mdgen_amd.h `mdgen_train_set_milestone_events`): 0 emb_to_latent | 1 .. nl layers nl-1 .. 0 | nl+1 token
+    embedders | nl+2 .. 2nl+1 ipa_layers nl-1 .. 0 | 2nl+2 the rest."""
+    nl = num_layers
+    head = name.split(".")[0]
+    if head == "emb_to_latent":
+        return 0
+    if head == "layers":
+        return 1 + (nl - 1 - int(name.split(".")[1]))
+    if head in ("latent_to_emb", "cond_to_emb", "mask_to_emb"):
+        return nl + 1
+    if head == "ipa_layers":
+        return nl + 2 + (nl - 1 - int(name.split(".")[1]))
+    return 2 * nl + 2
+
+
+def flat_order(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
+    """`trainable_shapes` re-ordered for the flat parameter / gradient buffers: groups that the backward pass finishes
+    LAST come first, so that walking the buffer from its end (what `GradBucketer` does) meets the gradients in the order
+    they become final and every bucket can start its all-reduce as early as possible.  (The reference's registration
+    order puts `t_embedder` -- final only at the very end -- behind `emb_to_latent`, the first to be ready.)"""
+    sh = trainable_shapes(cfg)
+    names = sorted(sh, key=lambda k: -grad_milestone(k, cfg.num_layers))   # stable: the reference's order inside a group
+    return OrderedDict((k, sh[k]) for k in names)
+
+
 class TrainableModel:
     """A `LatentMDGenModel` whose trainable tensors live in one flat fp32 buffer (`self.params`) next to a flat
     gradient buffer (`self.grads`); `forward_backward` fills the gradients, `sync_weights` hands the (updated)
@@ -37,7 +64,7 @@ class TrainableModel:
         self.cfg = cfg
         self.model = LatentMDGenModel(cfg, device, precision="fp32")
         self.device = self.model.device
-        self.params = FlatParams(trainable_shapes(cfg), device=self.device)
+        self.params = FlatParams(flat_order(cfg), device=self.device)
         self.grads = self.params.like()
         self._buffers = {}
         names = self.model.weight_names()
@@ -113,6 +140,22 @@ class Trainer:
         self.opt = Adam(self.tm.params, lr=lr, adamw=adamw, grad_clip=grad_clip)
         self.ema = EMA(self.tm.params, ema_decay) if ema_decay else None
         self.buckets = GradBucketer(self.tm.params, self.tm.grads, dist=dist)
+        # gradient milestones of the library's backward pass (include/mdgen_amd.h): one event per parameter group, the
+        # buckets' all-reduces wait for them on a communication stream of their own
+        nl = wrapper.cfg.num_layers
+        self._n_milestones = lib.mdgen_train_num_milestones(self.tm.model._ctx)
+        assert self._n_milestones == 2 * nl + 3
+        self._events = [torch.cuda.Event() for _ in range(self._n_milestones)]
+        with torch.cuda.device(self.tm.device):
+            for ev in self._events:
+                ev.record()                       # creates the underlying hipEvent_t
+            arr = (C.c_void_p * self._n_milestones)(*[ev.cuda_event for ev in self._events])
+            check(lib.mdgen_train_set_milestone_events(self.tm.model._ctx, arr, self._n_milestones))
+            self._comm_stream = torch.cuda.Stream(device=self.tm.device)
+        self.on_bucket = None                     # test hook: called as on_bucket(i, view) on the communication stream
+
+    def milestone_of(self, name: str) -> int:
+        return grad_milestone(name, self.wrapper.cfg.num_layers)
 
     def training_step(self, batch, t=None, x0=None):
         w = self.wrapper
@@ -128,8 +171,9 @@ class Trainer:
         self.buckets.reset()
         loss, _ = self.tm.forward_backward(xt, t, ut, prep["loss_mask"], kw["mask"], kw["start_frames"], kw["x_cond"],
                                            kw["x_cond_mask"], kw["aatype"], end_frames=kw.get("end_frames"))
-        for name in list(self.tm.params.shapes)[::-1]:     # the whole backward is one library call: all ready at once
-            self.buckets.mark_ready(name)
+        # forward_backward has only ENQUEUED the step: the buckets' all-reduces queue up behind the milestone events and
+        # overlap with the part of the backward pass that is still running
+        self.buckets.launch_on_events(self.milestone_of, self._events, self._comm_stream, on_bucket=self.on_bucket)
         scale = self.buckets.finish()
         self.opt.step(self.tm.grads, grad_scale=scale)
         self.tm.sync_weights()

@@ -1318,6 +1318,42 @@ def test_trainer_step_tps():
     assert torch.isfinite(out).all()
 
 
+def test_gradient_buckets_are_final_at_their_milestones():
+    """DDP overlap: the library records an event per parameter group as soon as that group's gradients are final, and
+    `Trainer` enqueues every bucket's all-reduce on a communication stream behind the event of the last group the
+    bucket contains.  Here (one GPU) the all-reduce is replaced by a snapshot of the bucket taken at that point of the
+    communication stream: every snapshot must equal the bucket's content after the whole backward pass bit for bit --
+    nothing the backward pass does after a milestone touches a gradient released by it -- for the one-sided and the
+    two-sided model (whose IPA weights collect gradients from two passes)."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict
+    from mdgen_amd.train import Trainer
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    dev = _cuda()
+    for name, tps in (("prep_sim", False), ("prep_tps", True)):
+        g0 = load_golden(name)
+        batch = {k[3:]: v.to(dev) for k, v in g0.items() if k.startswith("in_")}
+        B, T, L = batch["torsions"].shape[:3]
+        cfg = ModelConfig(crop=L, num_frames=T, num_layers=3, abs_pos_emb=True, sim_condition=not tps, tps_condition=tps)
+        w = NewMDGenWrapper(cfg)
+        w.load_model_state_dict(synth_state_dict(cfg, 31))
+        tr = Trainer(w, lr=1e-3, grad_clip=1.0)
+        from mdgen_amd.optim import GradBucketer
+        tr.buckets = GradBucketer(tr.tm.params, tr.tm.grads, dist=None, bucket_bytes=4 << 20)   # ~20 buckets
+        snaps = {}
+        tr.on_bucket = lambda i, view: snaps.__setitem__(i, view.clone())
+        gen = torch.Generator().manual_seed(8)
+        tr.training_step(batch, t=torch.rand(B, generator=gen).to(dev), x0=torch.randn(B, T, L, cfg.latent_dim, generator=gen).to(dev))
+        torch.cuda.synchronize()
+        assert len(snaps) == len(tr.buckets.buckets) >= 10
+        ms = [max(tr.milestone_of(n) for n in b["names"]) for b in tr.buckets.buckets]
+        assert ms == sorted(ms), "buckets in backward order become ready in backward order"
+        assert tr.buckets.launch_order == sorted(range(len(ms)), key=lambda i: ms[i])
+        for i, b in enumerate(tr.buckets.buckets):
+            assert torch.equal(snaps[i], tr.tm.grads[b["lo"]:b["hi"]]), (name, i, b["names"][:2])
+        assert float(tr.tm.grads.abs().max()) > 0
+
+
 def test_training_step_cfg5_size():
     """BASELINE.json configs[4] at its per-GPU size: ATLAS crop 256 x 250 frames, batch 1 per GPU, the full 5-layer
     model (34.15 M parameters): one forward + backward.  Size-independent checks: loss equals the fp32 forward's loss,
