@@ -306,62 +306,6 @@ __device__ __forceinline__ void epilogue_gate_residual(const f32x16* acc, const 
     }
 }
 
-// Same update straight from the accumulator layout, but with every load UNCONDITIONAL and issued up front:
-// one instruction covers two rows x 128 contiguous bytes (lanes 0-31 / 32-63), i.e. whole cache lines, and a
-// wave issues 96 h loads, 96 gate loads and 96 stores per panel -- a few hundred cycles of address processing.
-// (The form above is slow only because its loads sit under `if (tk >= 0)`: one HBM round trip per row.)
-// No LDS staging: used where no free LDS slab exists (k_mlp_ws).  TT = 2, FT = 3.
-__device__ __forceinline__ void epilogue_gate_residual_direct(f32x16* acc, const PanelRows* pr, int col0,
-                                                              const float* __restrict__ bias, const ModMap mm,
-                                                              int gate_chunk, float* __restrict__ h,
-                                                              const int lane = lane_id()) {
-    const int hh = lane >> 5, n = lane & 31;
-    float b[3];
-#pragma unroll
-    for (int f = 0; f < 3; ++f) b[f] = bias[col0 + f * 32 + n];
-    unsigned char* hb = reinterpret_cast<unsigned char*>(h);
-    const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
-    const unsigned colb = (unsigned)(col0 + n) * 4u;
-    // One 32-row half at a time.  The 48 h values (HBM) are requested first; while they fly, the gate values
-    // (L2-resident table) arrive in groups of 4 rows and the accumulators are turned IN PLACE into the update
-    // gate * (acc + bias) -- so the registers in flight next to the 96 accumulators stay at 48 + 12.  (Both
-    // halves' h values at once would save one HBM round trip but needs 96 + 96 + 12 registers: it spills.)
-    // Addresses are a uniform base + 32-bit byte offsets (no 64-bit address VGPRs to keep alive or spill).
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float hv[16][3];
-        int tk[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            tk[r] = pr->tok[t * 32 + mfma_row(r, hh)];
-            const unsigned ho = (unsigned)(tk[r] < 0 ? 0 : tk[r]) * (unsigned)(kC * 4) + colb;
-#pragma unroll
-            for (int f = 0; f < 3; ++f) hv[r][f] = *reinterpret_cast<const float*>(hb + ho + 128u * f);
-        }
-#pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 4) {
-            float gv[4][3];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned go = ((unsigned)pr->moff[t * 32 + mfma_row(r0 + r, hh)] + (unsigned)(gate_chunk * kC)) * 4u + colb;
-#pragma unroll
-                for (int f = 0; f < 3; ++f) gv[r][f] = *reinterpret_cast<const float*>(mb + go + 128u * f);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int f = 0; f < 3; ++f) acc[t * 3 + f][r0 + r] = gv[r][f] * (acc[t * 3 + f][r0 + r] + b[f]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (tk[r] >= 0) {
-                const unsigned ho = (unsigned)tk[r] * (unsigned)(kC * 4) + colb;
-#pragma unroll
-                for (int f = 0; f < 3; ++f) *reinterpret_cast<float*>(hb + ho + 128u * f) = hv[r][f] + acc[t * 3 + f][r];
-            }
-    }
-}
-
 // Same update, staged through a wave-private 12 KiB LDS slab so that the read-modify-write of h uses 16-byte
 // accesses on whole 384-byte row segments: the direct form above issues 288 dword memory instructions per
 // lane and measured 100 of the 128 us of the out-projection kernel; this one issues 32 loads + 32 stores.
