@@ -235,7 +235,8 @@ __global__ void k32_rope(float* __restrict__ buf, long ntok, int ld, long pos_di
 // key / value (rotated at position len) is the last key; padded keys are excluded (mha.py:367-373 -inf fill).
 __global__ __launch_bounds__(256) void k32_attn(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
                                                 const float* __restrict__ bias_k, const float* __restrict__ bias_v,
-                                                const float* __restrict__ inv_freq, float* __restrict__ out) {
+                                                const float* __restrict__ inv_freq, float* __restrict__ out,
+                                                float* __restrict__ lse_out) {
     constexpr int KT = 64;
     __shared__ __attribute__((aligned(16))) float sk[KT][kDH];
     __shared__ __attribute__((aligned(16))) float sv[KT][kDH];
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(256) void k32_attn(const float* __restrict__ qkv, i
     const float inv = 1.0f / den;
 #pragma unroll
     for (int d = 0; d < kDH; ++d) out[qtok * kC + hd * kDH + d] = o[d] * inv;
+    if (lse_out) lse_out[qtok * kH + hd] = mrun + logf(den);   // training tape: the backward pass starts from it
 }
 
 // x += dt * v (Euler) is mode 3 of k32_linear; bf16 IPA features -> fp32 is avoided by the fp32 feature output of the
@@ -338,10 +340,10 @@ void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, con
                        inv_freq);
 }
 void launch32_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
-                   const float* inv_freq, float* out, hipStream_t s) {
+                   const float* inv_freq, float* out, hipStream_t s, float* lse_out) {
     const int nqb = (ax.len + 255) / 256;
     hipLaunchKernelGGL(k32_attn, dim3((unsigned)((long)ax.nseq * kH * nqb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
-                       inv_freq, out);
+                       inv_freq, out, lse_out);
 }
 
 }  // namespace mdg

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k32_attn_bwd_q(const float* __restrict__ 
                                                       const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                       const float* __restrict__ inv_freq, const float* __restrict__ o,
                                                       const float* __restrict__ dout, float* __restrict__ dqkv,
-                                                      float* __restrict__ stats) {
+                                                      float* __restrict__ stats, const float* __restrict__ lse_in) {
     constexpr int KT = 64;
     __shared__ __attribute__((aligned(16))) float sk[KT][kDH];
     __shared__ __attribute__((aligned(16))) float sv[KT][kDH];
@@ -349,8 +349,11 @@ __global__ __launch_bounds__(256) void k32_attn_bwd_q(const float* __restrict__ 
         dq[d] = 0.f;
     }
     float mrun = -3.0e38f, den = 0.f;
-    for (int pass = 0; pass < 2; ++pass) {
-        const float lse = pass ? mrun + logf(den) : 0.f;
+    // pass 0 recomputes the row's log-sum-exp; with the forward pass's own value on the tape (lse_in, the same
+    // arithmetic in the same order) it is skipped
+    const float lse_tape = lse_in ? lse_in[qtok * kH + hd] : 0.f;
+    for (int pass = lse_in ? 1 : 0; pass < 2; ++pass) {
+        const float lse = lse_in ? lse_tape : (pass ? mrun + logf(den) : 0.f);
         for (int j0 = 0; j0 < len + 1; j0 += KT) {
             __syncthreads();
             for (int e = tid; e < KT * kDH; e += 256) {
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256) void k32_attn_bwd_q(const float* __restrict__ 
     if (!qok) return;
 #pragma unroll
     for (int d = 0; d < kDH; ++d) dqkv[qtok * ld + hd * kDH + d] = dq[d];
-    stats[(qtok * kH + hd) * 2] = mrun + logf(den);
+    stats[(qtok * kH + hd) * 2] = lse_in ? lse_tape : mrun + logf(den);
     stats[(qtok * kH + hd) * 2 + 1] = delta;
 }
 
@@ -618,10 +621,10 @@ void launch32_gelu_bwd(const float* pre, long n, float* d, hipStream_t s) {
 }
 void launch32_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
                        const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
-                       float* stats, float* dbias, hipStream_t s) {
+                       float* stats, float* dbias, hipStream_t s, const float* lse_in) {
     const int nqb = (ax.len + 255) / 256, nkb = (ax.len + 1 + 255) / 256;
     hipLaunchKernelGGL(k32_attn_bwd_q, dim3((unsigned)((long)ax.nseq * kH * nqb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k,
-                       bias_v, inv_freq, o, dout, dqkv, stats);
+                       bias_v, inv_freq, o, dout, dqkv, stats, lse_in);
     hipLaunchKernelGGL(k32_attn_bwd_kv, dim3((unsigned)((long)ax.nseq * kH * nkb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k,
                        bias_v, inv_freq, dout, stats, dqkv, dbias);
 }

@@ -164,7 +164,7 @@ void launch32_gelu_from_pre(const float* pre, long n, float* out, hipStream_t s)
 void launch32_gelu_bwd(const float* pre, long n, float* d, hipStream_t s);
 void launch32_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
                        const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
-                       float* stats, float* dbias, hipStream_t s);
+                       float* stats, float* dbias, hipStream_t s, const float* lse_in = nullptr);
 void launch32_rope_bwd(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, float qscale,
                        hipStream_t s);
 void launch32_loss_grad(const float* pred, const float* target, const float* mask, long per_sample, long B, float* den,
@@ -179,7 +179,7 @@ void launch32_temb_bwd(const float* t_rows, int nrows, float tmul, const float* 
                        const float* b2, const float* dst, float* emb, float* h1, float* dpre1, float* dpre2, hipStream_t s);
 void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, hipStream_t s);
 void launch32_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
-                   const float* inv_freq, float* out, hipStream_t s);
+                   const float* inv_freq, float* out, hipStream_t s, float* lse_out = nullptr);
 
 // optimiser (k_optim.hip)
 void launch_sumsq(const float* g, long n, float scale, float* partial, int nblocks, float* out, hipStream_t s);
