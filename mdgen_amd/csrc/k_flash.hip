@@ -14,13 +14,15 @@
 // 32-query tiles A, B); workgroup = 4 heads of the same queries; three workgroups per CU (<= 168 VGPRs).
 // The loop is bound by the vector ALU (16 v_exp_f32 per (32-key, 32-query) pair cost about as much as its four
 // MFMAs, profiles/r02_issue_rate.txt), so everything else a pair does on the VALU has been removed:
-//   * the running shift -M rides in a spare K-dim slot of Q (bf16-exact), so the score MFMA returns s - M;
+//   * the running shift -M rides in two spare K-dim slots of Q (a bf16 pair hi + lo against 1.0 in K), so the score
+//     MFMA returns s - M;
 //   * an all-ones V^T row (d = 24, a physical row of the fragment) makes the PV MFMA accumulate the denominator;
 //   * NO row max and no range test in the common path.  P is bf16 -- an 8-bit exponent, the same range as fp32 --
 //     so the shift only has to keep 2^(s - M) inside that range, not below 1.  M is anchored 63 above the row max of
 //     the FIRST key tile (P <= 2^-63 there) and never moves: scores may rise 190 (log2 units) above that tile's max
 //     before a P overflows, and an overflow cannot go unnoticed -- the denominator is the plain sum of all P (ones
-//     row of V^T), so one `l < inf` test per query when the loop is done covers every P of the row.  If it fails
+//     row of V^T), so exponent-bit tests on the accumulators when the loop is done (inf / NaN anywhere, or a
+//     denominator that underflowed) cover every P of the row.  If they fire
 //     -- or if the first tile of the sequence is fully masked, so that there is nothing to anchor to -- the wave
 //     discards its result and redoes the whole (head, 64 queries) with the ROBUST loop: true row max per tile, shift
 //     re-anchored whenever the max moves up by more than 2^8, O rescaled.  Terms more than 63 below the anchor flush
