@@ -200,6 +200,18 @@ __device__ __forceinline__ void write_bias_slots(const QkvParams& p, int seq, in
     }
 }
 
+#ifdef MDGEN_DEV_QKV_STAMPS   // (experiment build, scripts/micro/qkv_stamps.py: per-wave s_memtime stamps of k_ln_qkv<false>)
+__device__ unsigned long long g_qkv_stamps[16384 * 8];
+extern "C" int mdgen_dev_qkv_stamps(void* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_qkv_stamps), bytes);
+}
+#define QKV_STAMP(slot)                                                                                      \
+    if (!SMALL && lane_id() == 0 && (long)blockIdx.x * 4 + wave_id() < 16384)                                  \
+    g_qkv_stamps[((long)blockIdx.x * 4 + wave_id()) * 8 + (slot)] = __builtin_amdgcn_s_memtime()
+#else
+#define QKV_STAMP(slot)
+#endif
+
 template <bool SMALL>
 __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
@@ -230,9 +242,11 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
             }
         }
     }
+    QKV_STAMP(0);
     __syncthreads();
     prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
     __syncthreads();
+    QKV_STAMP(1);
     const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id();
     const int ntile = p.ax.ntile();
     const int len = p.ax.len;
@@ -240,13 +254,17 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
     // ---- Q (heads 4w..4w+3), transposed
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    QKV_STAMP(2);
     epilogue_heads_T<true>(acc, pr, w, p.bq, p.rope, SMALL, pos0, len, seq, ntile, tile0, p.qf, p.qkv_small, 0);
     __builtin_amdgcn_sched_barrier(0);
+    QKV_STAMP(3);
     // ---- K
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    QKV_STAMP(4);
     epilogue_heads_T<true>(acc, pr, w, p.bk, p.rope, SMALL, pos0, len, seq, ntile, tile0, p.kf, p.qkv_small, 1);
     __builtin_amdgcn_sched_barrier(0);
+    QKV_STAMP(5);
     // ---- V
     zero_acc<6>(acc);
     if (SMALL) {
@@ -254,11 +272,13 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
         epilogue_heads_T<false>(acc, pr, w, p.bv, nullptr, true, pos0, len, seq, ntile, tile0, nullptr, p.qkv_small, 2);
     } else {
         wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        QKV_STAMP(6);
         epilogue_v_flash(acc, w, p.bv, seq, ntile, tile0, p.vf);
         if ((int)blockIdx.x - seq * p.panels_per_seq == p.panels_per_seq - 1) {   // the sequence's last panel
             __builtin_amdgcn_sched_barrier(0);   // after this wave's own K / V stores
             write_bias_slots(p, seq, w);
         }
+        QKV_STAMP(7);
     }
 }
 
