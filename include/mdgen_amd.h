@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define MDGEN_ABI_VERSION 1
+/* Bumped whenever a public struct or signature changes; mdgen_amd/_lib.py refuses a library whose version differs. */
+#define MDGEN_ABI_VERSION 3
 
 typedef struct mdgen_ctx mdgen_ctx;
 
@@ -207,6 +208,11 @@ int32_t mdgen_debug_view_plan(const mdgen_shape* shape, int32_t streams, int32_t
  *   perm_qk[((w*2+h)*4+hd)*12+e], perm_vsmall[...] = source feature of lane-ordered bias slot. */
 int32_t mdgen_debug_layout_maps(int32_t* map_qk, int32_t* map_vflash, int32_t* map_vsmall,
                                 int32_t* perm_qk, int32_t* perm_vsmall);
+
+/* Host-only (no GPU): the weight-fragment stream of the row-owner MLP kernel (csrc/k_rows.hip), for layout tests.
+ * out[f] = mat << 16 | row_tile << 8 | k_step for fragment f (2304 of them); mat 0 = fc1 (layers.py:77-84 `fc1`), 1 = fc2.
+ * Returns the number of entries, or a negative status. */
+int32_t mdgen_debug_mlp_stream_table(int32_t* out, int32_t capacity);
 
 /* ---- SE(3) frame algebra, fp32 (mdgen/rigid_utils.py) --------------------------------------
  * n = number of frames; rot: [n][3][3]; trans/pts: [n][3]; quat: [n][4] (w,x,y,z). */

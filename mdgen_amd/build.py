@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmdgen_amd.so")
-SOURCES = ["api.hip", "k_gemm.hip", "k_flash.hip", "k_small.hip", "k_se3.hip", "k_fp32.hip", "k_optim.hip", "k_fp32_bwd.hip"]
-HEADERS = ["common.h", "panel.h", "kernels.h", "train.inc", os.path.join("..", "..", "include", "mdgen_amd.h")]
+SOURCES = ["api.hip", "k_gemm.hip", "k_rows.hip", "k_flash.hip", "k_small.hip", "k_se3.hip", "k_fp32.hip", "k_optim.hip", "k_fp32_bwd.hip"]
+HEADERS = ["common.h", "panel.h", "rows.h", "kernels.h", "train.inc", os.path.join("..", "..", "include", "mdgen_amd.h")]
 # -fno-slp-vectorize: keeps hipcc from fusing scalar fp32 math into v_pk_{mul,add,fma}_f32.  On MI355X those
 # packed ops (a) are an anti-lever beside MFMAs (MI355X_MICROARCH "price of one filler") and (b) produced
 # intermittently wrong results in lanes 48-63 when two waves shared a SIMD (DESIGN.md "packed-fp32 hazard").
@@ -52,7 +52,7 @@ def check_isa(cc: str, src: str) -> None:
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("ISA check failed to compile " + src + "\n" + r.stderr)
-        pat = re.compile(r"v_mfma_\w+ [va]\[(\d+):(\d+)\], [va]\[(\d+):(\d+)\], [va]\[(\d+):(\d+)\], (.*)$")
+        pat = re.compile(r"v_mfma_\w+ ([va])\[(\d+):(\d+)\], ([va])\[(\d+):(\d+)\], ([va])\[(\d+):(\d+)\], (.*)$")
         n = 0
         for line in open(out):
             if re.search(r"\bv_pk_(mul|add|fma)_f32\b", line):
@@ -61,8 +61,10 @@ def check_isa(cc: str, src: str) -> None:
             if not m:
                 continue
             n += 1
-            d0, d1, a0, a1, b0, b1 = map(int, m.groups()[:6])
-            if not (a1 < d0 or a0 > d1) or not (b1 < d0 or b0 > d1):
+            g = m.groups()
+            dc, ac, bc = g[0], g[3], g[6]   # register file of each operand: v = VGPR, a = accumulation register
+            d0, d1, a0, a1, b0, b1 = int(g[1]), int(g[2]), int(g[4]), int(g[5]), int(g[7]), int(g[8])
+            if (ac == dc and not (a1 < d0 or a0 > d1)) or (bc == dc and not (b1 < d0 or b0 > d1)):
                 raise RuntimeError(f"{os.path.basename(src)}: MFMA destination overlaps a source operand: {line.strip()}")
     return n
 

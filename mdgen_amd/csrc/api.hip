@@ -55,6 +55,7 @@ struct MhaW {
 struct FfnW {
     bf16x8 *w1 = nullptr, *w2 = nullptr;
     float *b1 = nullptr, *b2 = nullptr;
+    bf16x8* wstream = nullptr;   // both matrices as ONE fragment stream in the consumption order of k_mlp_rows (mlp_stream_table)
 };
 struct TrunkW {
     MhaW mha_l, mha_t;
@@ -103,6 +104,7 @@ struct mdgen_ctx {
     // device index maps
     int *map_nat = nullptr, *map_qk = nullptr, *map_vflash = nullptr, *map_vsmall = nullptr, *map_fin = nullptr;
     int *perm_qk = nullptr, *perm_vsmall = nullptr;
+    int* mlp_tab = nullptr;     // device copy of mlp_stream_table()
     std::vector<GraphEntry> graphs;
     bool inv_freq_set = false;
     bool prof_on = false;
@@ -112,6 +114,8 @@ struct mdgen_ctx {
     std::map<std::string, float*> w32;   // fp32 copies, natural layout, keyed by the reference's state_dict key
     int opt_streams = 2;        // concurrent sub-batch streams of the Euler rollout (1 = caller's stream only)
     int opt_attn_path = 0;      // tiled attention: 0 fixed-anchor fast loop with overflow check + fallback, 1 robust loop always
+    int opt_mlp_path = 1;       // MLP block: 0 resident-panel kernel (k_mlp), 1 row-owner kernel (k_mlp_rows) when the launch
+                                // fills the chip, 2 row-owner kernel always
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
     std::vector<void*> milestone_events;          // mdgen_train_set_milestone_events (hipEvent_t handles, caller-owned)
     unsigned long long* phase_trace = nullptr;   // mdgen_profile_phase_trace target (device), consumed by one launch
@@ -214,6 +218,39 @@ extern "C" int32_t mdgen_debug_layout_maps(int32_t* map_qk, int32_t* map_vflash,
     return 0;
 }
 
+// Weight stream of k_mlp_rows (csrc/k_rows.hip): 2304 fragments, entry = mat << 16 | row tile << 8 | k-step with mat 0 = fc1
+// (48 hidden tiles x 24 k-steps), 1 = fc2 (12 feature tiles x 96 k-steps).  Chunk c = hidden units 64 c .. 64 c + 63 =
+// fc1 tiles 2c, 2c + 1 = fc2 k-steps 4c .. 4c + 3.  Order = the kernel's software pipeline:
+//   [X(0)] [X(1)] { X(c+1) ks 0-5 | Y(c-1) kk 0 | X ks 6-11 | Y kk 1 | X ks 12-17 | Y kk 2 | X ks 18-23 | Y kk 3 } c = 1..22 [Y(22)] [Y(23)]
+// X block: (k-step, tile) pairs, tile fastest; Y block: the 12 feature tiles of one k-step.
+static std::vector<int> mlp_stream_table() {
+    std::vector<int> t;
+    auto xblock = [&](int c, int kx) {
+        for (int q = 0; q < 12; ++q) t.push_back(0 << 16 | (2 * c + (q & 1)) << 8 | (6 * kx + (q >> 1)));
+    };
+    auto yblock = [&](int c, int kk) {
+        for (int ft = 0; ft < 12; ++ft) t.push_back(1 << 16 | ft << 8 | (4 * c + kk));
+    };
+    for (int c = 0; c < 2; ++c)
+        for (int kx = 0; kx < 4; ++kx) xblock(c, kx);
+    for (int c = 1; c < 23; ++c)
+        for (int b = 0; b < 4; ++b) {
+            xblock(c + 1, b);
+            yblock(c - 1, b);
+        }
+    for (int c = 22; c < 24; ++c)
+        for (int kk = 0; kk < 4; ++kk) yblock(c, kk);
+    return t;
+}
+constexpr int kMlpFrags = 2304;
+
+extern "C" int32_t mdgen_debug_mlp_stream_table(int32_t* out, int32_t capacity) {
+    const std::vector<int> t = mlp_stream_table();
+    if (!out || capacity < (int)t.size()) return fail(-1, "need room for %d entries", (int)t.size());
+    for (size_t i = 0; i < t.size(); ++i) out[i] = t[i];
+    return (int32_t)t.size();
+}
+
 static int upload_ints(mdgen_ctx* c, int** dst, const std::vector<int>& v) {
     if (int r = c->dalloc(dst, v.size())) return r;
     HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -279,9 +316,18 @@ static int register_ffn(mdgen_ctx* c, const std::string& pre, FfnW* f) {
     if (int r = c->dalloc(&f->w2, (size_t)12 * 96 * 64)) return r;
     if (int r = c->dalloc(&f->b1, (size_t)kF)) return r;
     if (int r = c->dalloc(&f->b2, (size_t)kC)) return r;
-    SETTER(pre + "fc1.weight", { WANT(kF, kC); launch_pack_rows(data, kC, c->map_nat, 48, kKS, 1.f, f->w1, s); });
+    if (int r = c->dalloc(&f->wstream, (size_t)kMlpFrags * 64)) return r;
+    SETTER(pre + "fc1.weight", {
+        WANT(kF, kC);
+        launch_pack_rows(data, kC, c->map_nat, 48, kKS, 1.f, f->w1, s);
+        launch_pack_stream(data, kC, 0, c->mlp_tab, kMlpFrags, 1.f, f->wstream, s);
+    });
     SETTER(pre + "fc1.bias", { WANT(kF); if (int r = copy_f32(f->b1, data, kF, s)) return r; });
-    SETTER(pre + "fc2.weight", { WANT(kC, kF); launch_pack_rows(data, kF, c->map_nat, 12, 96, 1.f, f->w2, s); });
+    SETTER(pre + "fc2.weight", {
+        WANT(kC, kF);
+        launch_pack_rows(data, kF, c->map_nat, 12, 96, 1.f, f->w2, s);
+        launch_pack_stream(data, kF, 1, c->mlp_tab, kMlpFrags, 1.f, f->wstream, s);
+    });
     SETTER(pre + "fc2.bias", { WANT(kC); if (int r = copy_f32(f->b2, data, kC, s)) return r; });
     return 0;
 }
@@ -315,6 +361,7 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     TRY(upload_ints(c, &c->map_vflash, vf));
     TRY(upload_ints(c, &c->map_vsmall, vs));
     TRY(upload_ints(c, &c->map_fin, fin));
+    TRY(upload_ints(c, &c->mlp_tab, mlp_stream_table()));
     TRY(upload_ints(c, &c->perm_qk, pqk));
     TRY(upload_ints(c, &c->perm_vsmall, pvs));
     TRY(c->dalloc(&c->wl, (size_t)kC * D));
@@ -517,6 +564,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "attention_path") {
         if (value != 0 && value != 1) return fail(-2, "attention_path must be 0 (auto) or 1 (robust loop always)");
         c->opt_attn_path = value;
+    } else if (n == "mlp_path") {
+        if (value < 0 || value > 2) return fail(-2, "mlp_path must be 0 (panel kernel), 1 (row-owner kernel when it fills the chip) or 2 (always)");
+        c->opt_mlp_path = value;
     } else if (n == "residue_l4_path") {
         if (value < 0 || value > 2) return fail(-2, "residue_l4_path must be 0, 1 or 2");
         c->opt_residue_l4 = value;
@@ -829,6 +879,29 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
 
 static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const ModMap& mm, int shift, int scale,
                         int gate, bool trunk) {
+    // Row-owner kernel: one workgroup = 4 waves x 32 rows and one workgroup per CU, so it needs ~200 workgroups to fill the
+    // chip; smaller launches (IPA stack, B = 1 tetrapeptides) stay on the 64-row panel kernel.
+    const long tiles = (nrows + 31) / 32;
+    if (r.c->opt_mlp_path == 2 || (r.c->opt_mlp_path == 1 && tiles >= 4 * 192)) {
+        MlpRowsParams q{};
+        q.h = h;
+        q.nrows = nrows;
+        q.mm = mm;
+        q.shift_chunk = shift;
+        q.scale_chunk = scale;
+        q.gate_chunk = gate;
+        q.wstream = (const unsigned char*)f.wstream;
+        q.b1 = f.b1;
+        q.b2 = f.b2;
+        if (trunk && r.c->phase_trace) {
+            q.trace = r.c->phase_trace;
+            q.trace_cap = r.c->phase_trace_cap;
+            r.c->phase_trace = nullptr;
+        }
+        { ProfScope ps(r.c, trunk ? "mlp" : "ipa.mlp", r.s); launch_mlp_rows(q, 4, r.s); }
+        LAUNCHCHK();
+        return 0;
+    }
     MlpParams p{};
     p.h = h;
     p.nrows = nrows;
@@ -1239,7 +1312,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)c->opt_residue_l4, (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1299,7 +1372,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)c->opt_residue_l4,
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

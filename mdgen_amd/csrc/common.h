@@ -115,6 +115,27 @@ __device__ __forceinline__ float opaque_zero() {
     return z;
 }
 
+// gelu(x) = x * Phi(x), Phi = standard normal CDF = 0.5 * (1 + erf(x / sqrt 2))   (layers.py:77-84, exact-erf GELU).
+// Phi is evaluated as a logistic function of an odd polynomial, Phi(x) = 1 / (1 + exp(-x * P(x^2))), with the
+// degree-4 P fitted to the exact CDF on |x| <= 8 (beyond that Phi is 0 or 1 to fp32 precision, hence the clamp
+// of the polynomial's argument).  Maximum absolute error of gelu over all x, evaluated in fp32: 6.2e-6
+// (checked by scripts/fit_gelu.py), two orders of magnitude below the bf16 rounding applied to the result right after.
+// 11 VALU ops per element (the MLP kernel's GELU phase is VALU-bound): libm erff ~40, A&S 7.1.26 rational ~17.
+// Coefficients carry the factor -log2(e) so that the exponential is a bare v_exp_f32.
+__device__ __forceinline__ float gelu_erf(float x) {
+    // No clamp of x: P(x^2) < 0 everywhere (asserted on a grid by scripts/fit_gelu.py), so for large |x| the exponent
+    // x P(x^2) runs off to -inf (x > 0: e = 0, result x) or +inf (x < 0: e = inf, rcp = 0, result -0) on its own.
+    const float xc = x;
+    const float x2 = xc * xc;
+    float p = -3.936969279e-06f;
+    p = p * x2 + 1.012880530e-04f;
+    p = p * x2 + 2.890509495e-04f;
+    p = p * x2 - 1.051034182e-01f;
+    p = p * x2 - 2.302086592e+00f;
+    const float e = __builtin_amdgcn_exp2f(xc * p);         // exp(-x P(x^2)); +inf for very negative x -> result -0
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 // D-layout row of accumulator register r for lane-half h of a 32x32 MFMA tile
 __host__ __device__ constexpr int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

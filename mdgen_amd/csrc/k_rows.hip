@@ -1,0 +1,275 @@
+// k_rows.hip -- row-owner token-local kernels (rows.h): the fused MLP block with activations in registers and the
+// weights arriving as one LDS-DMA stream shared by the waves of a workgroup.  gfx950 only.
+#include "kernels.h"
+#include "rows.h"
+
+namespace mdg {
+
+// =================================================================================================
+// Fused MLP block:  h += gate_m * ( W2 gelu_erf( W1 (LN(h)(1+scale)+shift) + b1 ) + b2 )
+// (latent_model.py:478-481, layers.py:77-84), row-owner form.
+//
+// Per wave (32 tokens): X = LN rows as 24 B-operand fragments (96 registers); the hidden dimension is processed in 24
+// chunks of 64 units: stage X(c) = fc1 of chunk c (2 hidden tiles x 24 k-steps = 48 MFMAs, accumulators a1[c & 1]),
+// GELU(c) (32 values per lane -> the 4 B-operand fragments hf[c & 1] of fc2's k-steps 4c .. 4c + 3, no data
+// movement), stage Y(c) = fc2 partial sums (4 k-steps x 12 feature tiles = 48 MFMAs into y[12], 192 registers).
+// Software pipeline: iteration c runs the MFMAs of X(c + 1) and Y(c - 1) -- eight blocks of 12, alternating -- with
+// GELU(c) riding beside them, one group of four values per block (~4 VALU per MFMA).  The weight stream
+// (api.hip mlp_stream_table) is laid out in exactly that order:
+//     [X(0)] [X(1)] { [X(c+1) ks 0-5] [Y(c-1) kk 0] [X ks 6-11] [Y kk 1] [X ks 12-17] [Y kk 2] [X ks 18-23] [Y kk 3] } c = 1..22 [Y(22)] [Y(23)]
+// 2304 fragments = 96 ring slots; one iteration = 96 fragments = the whole ring, so every LDS address in the loop
+// body is a compile-time constant.
+// =================================================================================================
+struct MlpPipe {
+    f32x16 y[12];
+    f32x16 a1[2][2];
+    bf16x8 hf[2][4];
+    bf16x8 wr[kWRing];
+    f32x4 bias;       // fc1 bias (LDS copy of b1) the accumulator registers of the GELU group in flight are re-armed with
+    float gx[4], gp[4], gq[4];   // GELU state of the four values of the group in flight
+};
+
+// GELU of group g (0..7) of a chunk = hidden tile g >> 2, accumulator registers 4 (g & 3) .. + 3 -> half of the fragment
+// hf[2 (g >> 2) + ((g & 3) >> 1)].  gelu(x) = x * Phi(x) exactly as common.h gelu_erf, cut into three slices per value
+// so that every MFMA of a block carries a few VALU instructions of it (one wave per SIMD: the matrix pipe hides at
+// most ~5 single-issue instructions per MFMA, MI355X_MICROARCH "one wave per SIMD").  The fc1 bias is not added here:
+// the accumulators START from it (see rearm).
+template <int PH>
+__device__ __forceinline__ void gelu_slice(MlpPipe& m, const f32x16 (&a1r)[2], int g, int j, bf16x8 (&hfw)[4]) {
+    const int tile = g >> 2, a = g & 3;
+    if (PH == 0) {
+        // explicit accumulator-file read: left to hipcc, the whole 16-register tuple is copied to VGPRs at its first use (32
+        // reads in one burst per chunk and 32 VGPRs held for the copy)
+        float x;
+        asm("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a1r[tile][4 * a + j]));
+        const float x2 = x * x;
+        float p = -3.936969279e-06f;
+        p = p * x2 + 1.012880530e-04f;
+        p = p * x2 + 2.890509495e-04f;
+        m.gx[j] = x;
+        m.gq[j] = x2;
+        m.gp[j] = p;
+    } else if (PH == 1) {
+        float p = m.gp[j];
+        p = p * m.gq[j] - 1.051034182e-01f;
+        p = p * m.gq[j] - 2.302086592e+00f;
+        m.gp[j] = __builtin_amdgcn_exp2f(m.gx[j] * p);
+    } else {
+        const float v = m.gx[j] * __builtin_amdgcn_rcpf(1.0f + m.gp[j]);
+        m.gx[j] = v;
+        if (j & 1) {   // a pair is complete: one v_cvt_pk_bf16_f32
+            const int kk = 2 * tile + (a >> 1), e0 = 4 * (a & 1) + (j & 2);
+            hfw[kk][e0] = (__bf16)m.gx[j - 1];
+            hfw[kk][e0 + 1] = (__bf16)v;
+        }
+    }
+}
+// The four accumulator registers a GELU group has consumed start their next accumulation (the chunk two further on, which
+// lands in the same registers) from the fc1 bias of that chunk: no zeroing, no bias add.
+__device__ __forceinline__ void rearm(f32x16 (&a1r)[2], int g, const f32x4& b) {
+    const int tile = g >> 2, a = g & 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float z;
+        asm("v_accvgpr_write_b32 %0, %1" : "=a"(z) : "v"(b[j]));
+        a1r[tile][4 * a + j] = z;
+    }
+}
+// all 32 accumulator registers of a chunk <- its fc1 bias (pipeline fill); b1c = LDS bias row of the chunk + 4 hh
+__device__ __forceinline__ void arm_chunk(f32x16 (&a1)[2], const float* b1c) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) rearm(a1, g, *reinterpret_cast<const f32x4*>(b1c + 32 * (g >> 2) + 8 * (g & 3)));
+}
+
+// One block of 12 fragments, one fenced scheduling region per fragment: [look-ahead LDS read of fragment I + PF]
+// [MFMA of fragment I] [a slice of the GELU group] (+ this wave's share of the ring refill).
+//   I0    ring-relative index of its first fragment (multiple of 12)
+//   KIND  0: X block (k-steps 6 KI .. 6 KI + 5 of both hidden tiles -> a1w), 1: Y block (k-step KI of the chunk, 12 feature tiles)
+//   GG    GELU group riding along (reads a1r, writes hfw), or -1.  REARM: afterwards its four accumulator registers are
+//         re-armed with the bias at b1n (LDS; the same group of the chunk two further on)
+//   BARVM >= 0: the block opens a ring slot: barrier with that vmcnt first
+//   FILL  issue this wave's DMAs of slot `fill_slot` (half of them per block: a slot is two blocks)
+//   NLOOK look-ahead reads are issued for the first NLOOK fragments only (end of the stream)
+template <int NW, int I0, int KIND, int KI, int GG, bool REARM, int BARVM, bool FILL, int NLOOK = 12>
+__device__ __forceinline__ void pipe_block(MlpPipe& m, const bf16x8 (&xf)[24], f32x16 (&a1w)[2], f32x16 (&a1r)[2],
+                                           bf16x8 (&hfw)[4], const bf16x8 (&hfr)[4], const float* b1n,
+                                           const unsigned char* ring_lane, const WStream<NW>& ws, long fill_slot) {
+    constexpr int FPW = WStream<NW>::FPW, DPB = FPW / 2, STRIDE = 12 / DPB;
+    if (BARVM >= 0) ring_barrier<BARVM>();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        const int I = I0 + q;
+        if (FILL && q % STRIDE == 0) ws.issue(fill_slot, ((I0 / 12) & 1) * DPB + q / STRIDE);
+        if (q < NLOOK) m.wr[(I + kWPF) % kWRing] = *reinterpret_cast<const bf16x8*>(ring_lane + ((I + kWPF) % kRingFrags) * 1024);
+        if (GG >= 0 && REARM && q == 5) m.bias = *reinterpret_cast<const f32x4*>(b1n + 32 * (GG >> 2) + 8 * (GG & 3));
+        if (KIND == 0) {
+            const int ks = 6 * KI + (q >> 1), tile = q & 1;
+            a1w[tile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], xf[ks], a1w[tile], 0, 0, 0);
+        } else {
+            m.y[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], hfr[KI], m.y[q], 0, 0, 0);
+        }
+        if (GG >= 0) {
+            if (q % 3 == 0) gelu_slice<0>(m, a1r, GG, q / 3, hfw);
+            else if (q % 3 == 1) gelu_slice<1>(m, a1r, GG, q / 3, hfw);
+            else gelu_slice<2>(m, a1r, GG, q / 3, hfw);
+            if (REARM && q == 11) rearm(a1r, GG, m.bias);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// a whole GELU group without MFMAs beside it (pipeline fill / drain only)
+template <bool REARM>
+__device__ __forceinline__ void gelu_group_plain(MlpPipe& m, f32x16 (&a1r)[2], const float* b1n, int g, bf16x8 (&hfw)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        gelu_slice<0>(m, a1r, g, j, hfw);
+        gelu_slice<1>(m, a1r, g, j, hfw);
+        gelu_slice<2>(m, a1r, g, j, hfw);
+    }
+    if (REARM) rearm(a1r, g, *reinterpret_cast<const f32x4*>(b1n + 32 * (g >> 2) + 8 * (g & 3)));
+}
+
+// Phase stamps (measurement only, p.trace null in normal operation): s_memtime values are collected in SGPRs and
+// written by ONE branch at the very end -- an `if (p.trace)` store per stamp splits the kernel into basic blocks around
+// which hipcc's register allocator spilled 170 registers per lane.
+#define ROWS_STAMP(i)                                  \
+    st[i] = __builtin_amdgcn_s_memtime();              \
+    __builtin_amdgcn_sched_barrier(0)
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kRingBytes + kF * 4 + 512];   // ring | fc1 bias | slack: the last re-arm reads the (non-existent) chunk 24
+    constexpr int FPW = WStream<NW>::FPW;
+    const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id(), hh = lane >> 5, n = lane & 31;
+    unsigned long long st[6];
+    ROWS_STAMP(0);
+    WStream<NW> ws{p.wstream, lds_addr(smem), (unsigned)lane * 16u, w};
+    ws.issue_slot(0);
+    ws.issue_slot(1);
+    ws.issue_slot(2);
+    float* b1s = reinterpret_cast<float*>(smem + kRingBytes);
+    for (int i = threadIdx.x; i < kF / 4; i += NW * 64)
+        reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
+    const long t = ((long)blockIdx.x * NW + w) * 32 + n;
+    const int tok = t < p.nrows ? (int)t : -1;
+    bf16x8 xf[24];
+    rows_ln(p.h, tok, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, xf);
+    ROWS_STAMP(1);
+    MlpPipe m;
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m.y[i][r] = acc_zero();
+    const unsigned char* ring_lane = smem + lane * 16;
+    const float* b1l = b1s + 4 * hh;   // LDS bias row of chunk c: + 64 c (this lane half's four units of every group of 8)
+    // ---- P0: X(0).  Barrier 0 certifies slots 0 and 1 (only the FPW DMAs of slot 2 may be in flight) and the LDS copy of b1.
+    ring_barrier<FPW>();
+#pragma unroll
+    for (int i = 0; i < kWPF; ++i) m.wr[i] = *reinterpret_cast<const bf16x8*>(ring_lane + i * 1024);
+    arm_chunk(m.a1[0], b1l);
+    arm_chunk(m.a1[1], b1l + 64);
+    pipe_block<NW, 0, 0, 0, -1, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 3);
+    pipe_block<NW, 12, 0, 1, -1, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 3);
+    pipe_block<NW, 24, 0, 2, -1, false, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 4);
+    pipe_block<NW, 36, 0, 3, -1, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 4);
+    // ---- P1: X(1) -> a1[1] with GELU(0): a1[0] -> hf[0] (even groups ride in the blocks, odd ones run between them);
+    //          a1[0] is re-armed with the bias of chunk 2
+    pipe_block<NW, 48, 0, 0, 0, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], b1l + 128, ring_lane, ws, 5);
+    gelu_group_plain<true>(m, m.a1[0], b1l + 128, 1, m.hf[0]);
+    pipe_block<NW, 60, 0, 1, 2, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], b1l + 128, ring_lane, ws, 5);
+    gelu_group_plain<true>(m, m.a1[0], b1l + 128, 3, m.hf[0]);
+    pipe_block<NW, 72, 0, 2, 4, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], b1l + 128, ring_lane, ws, 6);
+    gelu_group_plain<true>(m, m.a1[0], b1l + 128, 5, m.hf[0]);
+    pipe_block<NW, 84, 0, 3, 6, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], b1l + 128, ring_lane, ws, 6);
+    gelu_group_plain<true>(m, m.a1[0], b1l + 128, 7, m.hf[0]);
+    ROWS_STAMP(2);
+    // ---- iterations c = 1 .. 22 (two per trip: the register double buffers a1 / hf alternate)
+#pragma unroll 1
+    for (int c = 1; c < 23; c += 2) {
+        {   // odd c: X(c + 1) -> a1[0], GELU(c): a1[1] -> hf[1] (a1[1] re-armed for chunk c + 2), Y(c - 1) <- hf[0]
+            const long s0 = 4 * c;
+            const float* bn = b1l + 64 * (c + 2);
+            pipe_block<NW, 0, 0, 0, 0, true, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 3);
+            pipe_block<NW, 12, 1, 0, 1, true, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 3);
+            pipe_block<NW, 24, 0, 1, 2, true, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 4);
+            pipe_block<NW, 36, 1, 1, 3, true, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 4);
+            pipe_block<NW, 48, 0, 2, 4, true, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 5);
+            pipe_block<NW, 60, 1, 2, 5, true, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 5);
+            pipe_block<NW, 72, 0, 3, 6, true, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 6);
+            pipe_block<NW, 84, 1, 3, 7, true, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 6);
+        }
+        {   // even c + 1: X(c + 2) -> a1[1], GELU(c + 1): a1[0] -> hf[0] (a1[0] re-armed for chunk c + 3), Y(c) <- hf[1]
+            const long s0 = 4 * (c + 1);
+            const float* bn = b1l + 64 * (c + 3);   // c + 3 = 24 on the last trip: slack behind the table, never consumed
+            pipe_block<NW, 0, 0, 0, 0, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 3);
+            pipe_block<NW, 12, 1, 0, 1, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 3);
+            pipe_block<NW, 24, 0, 1, 2, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 4);
+            pipe_block<NW, 36, 1, 1, 3, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 4);
+            pipe_block<NW, 48, 0, 2, 4, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 5);
+            pipe_block<NW, 60, 1, 2, 5, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 5);
+            pipe_block<NW, 72, 0, 3, 6, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 6);
+            pipe_block<NW, 84, 1, 3, 7, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 6);
+        }
+    }
+    ROWS_STAMP(3);
+    // ---- E0: Y(22) <- hf[0] with GELU(23): a1[1] -> hf[1] (slots 92, 93; slot 95 is the last one to fetch)
+    pipe_block<NW, 0, 1, 0, 0, false, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], b1l, ring_lane, ws, 95);
+    gelu_group_plain<false>(m, m.a1[1], b1l, 1, m.hf[1]);
+    pipe_block<NW, 12, 1, 1, 2, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], b1l, ring_lane, ws, 95);
+    gelu_group_plain<false>(m, m.a1[1], b1l, 3, m.hf[1]);
+    pipe_block<NW, 24, 1, 2, 4, false, FPW, false>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], b1l, ring_lane, ws, 0);
+    gelu_group_plain<false>(m, m.a1[1], b1l, 5, m.hf[1]);
+    pipe_block<NW, 36, 1, 3, 6, false, -1, false>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], b1l, ring_lane, ws, 0);
+    gelu_group_plain<false>(m, m.a1[1], b1l, 7, m.hf[1]);
+    // ---- E1: Y(23) <- hf[1] (slots 94, 95: everything has been requested; barrier 94 waits for all of it)
+    pipe_block<NW, 48, 1, 0, -1, false, 0, false>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 0);
+    pipe_block<NW, 60, 1, 1, -1, false, -1, false>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 0);
+    pipe_block<NW, 72, 1, 2, -1, false, 0, false>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 0);
+    pipe_block<NW, 84, 1, 3, -1, false, -1, false, 12 - kWPF>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 0);
+    ROWS_STAMP(4);
+    // ---- gated residual
+    rows_gate_residual<0, 6>(m.y, tok, p.b2, p.mm, p.gate_chunk, p.h);
+    rows_gate_residual<6, 12>(m.y, tok, p.b2, p.mm, p.gate_chunk, p.h);
+    ROWS_STAMP(5);
+    if (p.trace && lane == 0) {
+        const long i = ((long)blockIdx.x * NW + w) * 8;
+        if (i + 8 <= p.trace_cap) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) p.trace[i + k] = st[k];
+        }
+    }
+}
+
+// ---- weight-stream packing ------------------------------------------------------------------------------------------
+// dst fragment f (1 KiB = 64 lanes x 8 bf16) <- rows 32 tile .. + 31 of the matrix tab[f] names, K slice of k-step ks in
+// kappa order (rows.h).  tab[f] = mat << 16 | tile << 8 | ks; only entries with mat == which are written.
+__global__ void k_pack_stream(const float* __restrict__ wsrc, int ld, int which, const int* __restrict__ tab, int nfrag,
+                              float scale, bf16x8* __restrict__ dst) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)nfrag * 64) return;
+    const int lane = (int)(i & 63), f = (int)(i >> 6);
+    const int e = tab[f];
+    if ((e >> 16) != which) return;
+    const int tile = (e >> 8) & 255, ks = e & 255;
+    const int row = tile * 32 + (lane & 31), hh = lane >> 5;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)(wsrc[(long)row * ld + 16 * ks + 8 * (j >> 2) + 4 * hh + (j & 3)] * scale);
+    dst[i] = v;
+}
+
+void launch_pack_stream(const float* w, int ld, int which, const int* tab, int nfrag, float scale, bf16x8* dst, hipStream_t s) {
+    const long total = (long)nfrag * 64;
+    hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, ld, which, tab, nfrag, scale, dst);
+}
+
+void launch_mlp_rows(const MlpRowsParams& p, int nw, hipStream_t s) {
+    const long tiles = (p.nrows + 31) / 32;
+    if (nw == 4) hipLaunchKernelGGL((k_mlp_rows<4>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, p);
+    else if (nw == 2) hipLaunchKernelGGL((k_mlp_rows<2>), dim3((unsigned)((tiles + 1) / 2)), dim3(128), 0, s, p);
+    else hipLaunchKernelGGL((k_mlp_rows<1>), dim3((unsigned)tiles), dim3(64), 0, s, p);
+}
+
+}  // namespace mdg

@@ -57,6 +57,19 @@ struct MlpParams {
     long trace_cap;              // capacity of `trace` in 64-bit words
 };
 
+// k_mlp_rows (k_rows.hip): the MLP block in row-owner form; `wstream` = both weight matrices as one fragment stream in
+// consumption order (api.hip mlp_stream_table)
+struct MlpRowsParams {
+    float* h;
+    long nrows;
+    ModMap mm;
+    int shift_chunk, scale_chunk, gate_chunk;
+    const unsigned char* wstream;   // 2304 fragments of 1 KiB
+    const float *b1, *b2;
+    unsigned long long* trace;      // measurement only: [wave][8] s_memtime stamps, or null
+    long trace_cap;
+};
+
 struct LnLinearParams {
     const float* h;
     long nrows;
@@ -136,6 +149,8 @@ void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s);
 void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
 void launch_mlp(const MlpParams& p, hipStream_t s);
+void launch_mlp_rows(const MlpRowsParams& p, int nw, hipStream_t s);
+void launch_pack_stream(const float* w, int ld, int which, const int* tab, int nfrag, float scale, bf16x8* dst, hipStream_t s);
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s);
 void launch_final(const FinalParams& p, hipStream_t s);
 void launch_flash(const FlashParams& p, hipStream_t s);

@@ -1,0 +1,203 @@
+// rows.h -- device building blocks of the "row-owner" token-local kernels (gfx950).
+//
+// Design (DESIGN.md "row-owner family"): a WAVE owns 32 token rows for the whole kernel and keeps every activation of
+// those rows in registers, in MFMA operand layout:
+//   * all GEMMs are computed transposed, D[feature][token] = W (A operand) x X^T (B operand): a lane IS a token
+//     (n = lane & 31) and holds, per 32-feature tile, the features 8a + 4hh + i (a = r >> 2, i = r & 3, hh = lane >> 5);
+//   * the K dimension of every weight matrix is packed in the order
+//         kappa(ks, hh, j) = 16 ks + 8 (j >> 2) + 4 hh + (j & 3)          (k-step ks, lane half hh, element j of 8)
+//     which makes the accumulator registers 8s .. 8s + 7 of an output tile -- after the activation function and a
+//     bf16 pack -- BE the B operand of k-step s of the next GEMM.  Activations never visit LDS, there is no
+//     cross-wave exchange and hence no barrier tied to the data flow;
+//   * one wave per SIMD with the whole 512-entry register file (256 arch VGPRs + 256 accumulation registers);
+//   * the weights are one linear stream of 1 KiB MFMA fragments in consumption order.  The NW waves of a workgroup
+//     consume the SAME stream in lock step, so it is fetched once per workgroup: LDS-DMA (global_load_lds_dwordx4,
+//     no registers involved) into a ring of four 24 KiB slots, each wave issuing 1/NW of every slot; `ds_read_b128`
+//     (lane-linear, conflict-free) feeds the MFMAs.  One `s_barrier` per slot (24 MFMAs per wave).
+//
+// Ring protocol.  Slot s (global index) lives at ring position s & 3.  Before the first MFMA of slot s every wave runs
+//     s_waitcnt vmcnt(FPW) lgkmcnt(0); s_barrier            ("barrier s")
+// which certifies (a) slot s + 1 has landed for every wave (each wave's own DMAs complete in order; only the FPW
+// DMAs of slot s + 2 may still be in flight), (b) every wave has finished reading slot s - 1 (lgkmcnt(0): the
+// look-ahead `ds_read`s run at most PF fragments ahead of the MFMAs, i.e. inside slots s and s + 1).  After barrier s
+// the waves issue the DMAs of slot s + 3 into the position slot s - 1 has just vacated.  The DMAs are inline asm
+// (hipcc neither counts nor drains them); the main loop contains no other vector-memory instruction, so the hand
+// count is exact.
+#pragma once
+#include "common.h"
+
+namespace mdg {
+
+constexpr int kSlotFrags = 24;                       // 1 KiB weight fragments per ring slot
+constexpr int kSlotBytes = kSlotFrags * 1024;
+constexpr int kRingSlots = 4;
+constexpr int kRingFrags = kRingSlots * kSlotFrags;  // 96: one pipeline iteration of the MLP kernel
+constexpr int kRingBytes = kRingSlots * kSlotBytes;  // 96 KiB
+constexpr int kWPF = 5;                              // look-ahead of the LDS -> register fragment reads (fragments)
+constexpr int kWRing = kWPF + 1;                     // register ring; divides 12, so ring indices are static
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(const lds_u8*)p; }
+
+__device__ __forceinline__ float half_sum2(float x) {   // x(lane) + x(lane ^ 32)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// A zero written straight into an accumulation register (common.h opaque_zero yields a VGPR: 192 of them at once, waiting
+// to be copied into the accumulator file, is exactly the register pressure the row-owner kernels cannot afford).
+__device__ __forceinline__ float acc_zero() {
+    float z;
+    asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z));
+    return z;
+}
+
+// One LDS-DMA: 64 lanes x 16 bytes, global (uniform base + per-lane 32-bit offset) -> LDS [dst + lane * 16].
+// M0 is written in the same statement that reads it (hipcc reserves it and does not preserve it across statements).
+__device__ __forceinline__ void dma_frag(const unsigned char* src, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(src), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int VM>
+__device__ __forceinline__ void ring_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
+}
+
+template <int NW>
+struct WStream {
+    static constexpr int FPW = kSlotFrags / NW;   // DMAs per wave per slot
+    const unsigned char* src;   // stream base (uniform)
+    unsigned ring;              // LDS byte address of the ring
+    unsigned voff;              // lane * 16
+    int w;                      // wave index (uniform)
+    // the d-th (0 .. FPW - 1) DMA of this wave for global slot `slot`
+    __device__ __forceinline__ void issue(long slot, int d) const {
+        const int f = w * FPW + d;
+        dma_frag(src + slot * kSlotBytes + f * 1024, voff, ring + ((unsigned)slot & 3u) * kSlotBytes + f * 1024);
+    }
+    __device__ __forceinline__ void issue_slot(long slot) const {
+#pragma unroll
+        for (int d = 0; d < FPW; ++d) issue(slot, d);
+    }
+};
+
+// fragment I (ring-relative index; the ring holds exactly kRingFrags consecutive fragments of the stream)
+template <int I>
+__device__ __forceinline__ bf16x8 ring_frag(const unsigned char* ring_lane) {
+    return *reinterpret_cast<const bf16x8*>(ring_lane + (I % kRingFrags) * 1024);
+}
+
+// ---- LayerNorm + adaLN modulate of the wave's 32 rows, straight into B-operand fragments -------------------------
+// y = LN(x) * (1 + scale) + shift (layers.py:14-15; no affine, eps) for token `tok` (-1: padding row -> zeros).
+// Lane (n, hh) reads the 192 features kappa(ks, hh, .) of its row as 48 unconditional 16-byte loads (all in flight
+// together: 48 KiB per wave), reduces them locally and with its partner lane n + 32 (one permlane32 swap per
+// statistic), and packs xf[ks] = the B operand of k-step ks.  The modulation vectors are read through per-lane row
+// offsets, so a tile may straddle samples.
+__device__ __forceinline__ void rows_ln(const float* __restrict__ x, int tok, const ModMap mm, int shift_chunk,
+                                        int scale_chunk, float eps, bf16x8 (&xf)[24]) {
+    const int hh = lane_id() >> 5;
+    const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
+    const unsigned off = tokc * (unsigned)(kC * 4) + (unsigned)hh * 16u;
+    f32x4 v[48];
+#pragma unroll
+    for (int i = 0; i < 48; ++i) v[i] = *reinterpret_cast<const f32x4*>(xb + off + 32u * i);
+    const unsigned mo = tok < 0 ? 0u : (unsigned)mm.row_off(tokc);
+    const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
+    const unsigned osc = (mo + (unsigned)(scale_chunk * kC)) * 4u + (unsigned)hh * 16u;
+    const unsigned osh = (mo + (unsigned)(shift_chunk * kC)) * 4u + (unsigned)hh * 16u;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 48; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = half_sum2(s) * (1.0f / kC);
+    // (the loaded tuples are never modified: an in-place `v -= mean` makes hipcc rename 192 registers tuple by tuple and
+    // spill the originals; the centred values are recomputed where they are used)
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[i][j] - mean;
+            q += d * d;
+        }
+    }
+    const float rstd = tok < 0 ? 0.f : 1.0f / sqrtf(half_sum2(q) * (1.0f / kC) + eps);
+    const float live = tok < 0 ? 0.f : 1.f;   // padding rows enter every GEMM as zeros
+    float mean2 = mean;
+    asm volatile("" : "+v"(mean2));   // opaque copy: keeps hipcc from holding on to the 192 centred values of the variance pass
+    // modulate + pack, k-step by k-step; the (L2-resident) modulation vectors are requested kModPF k-steps ahead and the
+    // loop is fenced so that hipcc neither sinks those loads to their use nor hoists all 96 of them (384 registers)
+    constexpr int kModPF = 1;
+    f32x4 sc[kModPF + 1][2], sh[kModPF + 1][2];
+#pragma unroll
+    for (int ks = 0; ks < kModPF; ++ks)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            sc[ks][h2] = *reinterpret_cast<const f32x4*>(mb + osc + 32u * (2 * ks + h2));
+            sh[ks][h2] = *reinterpret_cast<const f32x4*>(mb + osh + 32u * (2 * ks + h2));
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) {
+        if (ks + kModPF < 24) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                sc[(ks + kModPF) % (kModPF + 1)][h2] = *reinterpret_cast<const f32x4*>(mb + osc + 32u * (2 * (ks + kModPF) + h2));
+                sh[(ks + kModPF) % (kModPF + 1)][h2] = *reinterpret_cast<const f32x4*>(mb + osh + 32u * (2 * (ks + kModPF) + h2));
+            }
+        }
+        uint32_t u[4];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const f32x4 c = sc[ks % (kModPF + 1)][h2], d = sh[ks % (kModPF + 1)][h2];
+            const f32x4 a = v[2 * ks + h2];
+            const float y0 = (a[0] - mean2) * (rstd * c[0] + rstd) + live * d[0];
+            const float y1 = (a[1] - mean2) * (rstd * c[1] + rstd) + live * d[1];
+            const float y2 = (a[2] - mean2) * (rstd * c[2] + rstd) + live * d[2];
+            const float y3 = (a[3] - mean2) * (rstd * c[3] + rstd) + live * d[3];
+            u[2 * h2] = pack_bf16(y0, y1);
+            u[2 * h2 + 1] = pack_bf16(y2, y3);
+        }
+        xf[ks] = __builtin_bit_cast(bf16x8, u32x4{u[0], u[1], u[2], u[3]});
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- gated residual epilogue of the wave's 32 rows ----------------------------------------------------------------
+// h[tok][32 ft + 8 a + 4 hh + i] += gate * (y[ft][4 a + i] + bias)   (latent_model.py:462,476,481): 16-byte accesses,
+// the same address pattern as rows_ln; loads unconditional, stores predicated on the row being real.
+template <int FT0, int FT1>
+__device__ __forceinline__ void rows_gate_residual(const f32x16 (&y)[12], int tok, const float* __restrict__ bias,
+                                                   const ModMap mm, int gate_chunk, float* __restrict__ h) {
+    const int hh = lane_id() >> 5;
+    const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
+    unsigned char* hb = reinterpret_cast<unsigned char*>(h);
+    const unsigned off = tokc * (unsigned)(kC * 4) + (unsigned)hh * 16u;
+    const unsigned mo = tok < 0 ? 0u : (unsigned)mm.row_off(tokc);
+    const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
+    const unsigned og = (mo + (unsigned)(gate_chunk * kC)) * 4u + (unsigned)hh * 16u;
+    const unsigned char* bb = reinterpret_cast<const unsigned char*>(bias);
+    constexpr int NV = (FT1 - FT0) * 4;
+    f32x4 hv[NV], g[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const unsigned fo = 32u * (unsigned)(FT0 * 4 + i);   // byte offset of feature 32 ft + 8 a (+ 4 hh via off / og)
+        hv[i] = *reinterpret_cast<const f32x4*>(hb + off + fo);
+        g[i] = *reinterpret_cast<const f32x4*>(mb + og + fo);
+        b[i] = *reinterpret_cast<const f32x4*>(bb + (unsigned)hh * 16u + fo);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int ft = FT0 + (i >> 2), a = i & 3;
+        f32x4 o = hv[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += g[i][j] * (y[ft][4 * a + j] + b[i][j]);
+        if (tok >= 0) *reinterpret_cast<f32x4*>(hb + off + 32u * (unsigned)(FT0 * 4 + i)) = o;
+    }
+}
+
+}  // namespace mdg

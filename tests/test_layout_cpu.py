@@ -130,3 +130,119 @@ def test_fragment_pipeline_reproduces_attention():
                 qq = np.concatenate([qf[hd, tt][0][l], qf[hd, tt][1][l, :4]])
                 feats = pqk[((w * 2 + hh) * 4 + hd) * 12: ((w * 2 + hh) * 4 + hd) * 12 + 12]
                 assert np.allclose(qq, q[tok, feats])
+
+
+# ---- row-owner MLP kernel (csrc/k_rows.hip, rows.h) ---------------------------------------------------------------
+def kappa(ks, hh, j):
+    """K order of every row-owner weight fragment (rows.h): element j of lane half hh in k-step ks."""
+    return 16 * ks + 8 * (j >> 2) + 4 * hh + (j & 3)
+
+
+def stream_frag(W, tile, ks):
+    """A-operand fragment [64 lanes][8] of weight rows 32 tile .. + 31, K slice of k-step ks in kappa order
+    (what k_pack_stream writes)."""
+    return np.stack([[W[tile * 32 + (l & 31), kappa(ks, l >> 5, j)] for j in range(8)] for l in range(64)])
+
+
+def mlp_stream_table():
+    import mdgen_amd._lib as L
+    buf = (ctypes.c_int32 * 2304)()
+    assert L.lib.mdgen_debug_mlp_stream_table(buf, 2304) == 2304
+    return np.array(buf)
+
+
+def test_mlp_stream_table_covers_every_fragment_once():
+    t = mlp_stream_table()
+    mat, tile, ks = t >> 16, (t >> 8) & 255, t & 255
+    fc1 = set(zip(tile[mat == 0].tolist(), ks[mat == 0].tolist()))
+    fc2 = set(zip(tile[mat == 1].tolist(), ks[mat == 1].tolist()))
+    assert len(fc1) == 48 * 24 == (mat == 0).sum() and fc1 == {(a, b) for a in range(48) for b in range(24)}
+    assert len(fc2) == 12 * 96 == (mat == 1).sum() and fc2 == {(a, b) for a in range(12) for b in range(96)}
+
+
+def test_row_owner_mlp_pipeline_reproduces_the_mlp():
+    """Replays k_mlp_rows for one wave (32 tokens) with the library's stream table: fragments are consumed strictly in
+    stream order by the kernel's block schedule (P0, P1, 22 pipelined iterations, E0, E1); the fc1 accumulators start
+    from the bias (re-armed per GELU group), GELU output registers 8s .. 8s + 7 are the B operand of k-step s of fc2, and
+    the residual epilogue reads feature 32 ft + 8 a + 4 hh + i from accumulator register 4 a + i."""
+    tab = mlp_stream_table()
+    rng = np.random.default_rng(1)
+    C, F = 384, 1536
+    X = rng.standard_normal((32, C))                 # LN'd + modulated rows of the wave
+    W1 = rng.standard_normal((F, C)) / 20
+    W2 = rng.standard_normal((C, F)) / 40
+    b1 = rng.standard_normal(F) / 4
+    act = np.tanh                                   # any elementwise function (the kernel's is the erf GELU)
+    mats = {0: W1, 1: W2}
+    frags = iter(range(2304))
+
+    def next_frag(expect_mat):
+        f = next(frags)
+        e = int(tab[f])
+        assert e >> 16 == expect_mat
+        return stream_frag(mats[e >> 16], (e >> 8) & 255, e & 255), (e >> 8) & 255, e & 255
+
+    # B-operand fragments of the rows: lane (n, hh), element j = feature kappa(ks, hh, j)  (rows.h rows_ln)
+    xf = [np.stack([[X[l & 31, kappa(ks, l >> 5, j)] for j in range(8)] for l in range(64)]) for ks in range(24)]
+    hh = np.arange(64) >> 5
+
+    def arm(c):   # accumulators of chunk c start from its bias: register r of tile t <- b1[64 c + 32 t + row(r, hh)]
+        a = np.zeros((2, 64, 16))
+        for t in range(2):
+            for r in range(16):
+                a[t, :, r] = b1[64 * c + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh] if c < 24 else 0.0
+        return a
+
+    a1 = [arm(0), arm(1)]
+    hf = [np.zeros((4, 64, 8)), np.zeros((4, 64, 8))]
+    y = np.zeros((12, 64, 16))
+
+    def xblock(c, kx, buf):
+        for q in range(12):
+            w, tile, ks = next_frag(0)
+            assert (tile, ks) == (2 * c + (q & 1), 6 * kx + (q >> 1))
+            a1[buf][q & 1] = mfma(w, xf[ks], a1[buf][q & 1])
+
+    def yblock(c, kk, buf):
+        for q in range(12):
+            w, tile, ks = next_frag(1)
+            assert (tile, ks) == (q, 4 * c + kk)
+            y[q] = mfma(w, hf[buf][kk], y[q])
+
+    def gelu_group(c, g, abuf, hbuf, rearm_chunk):
+        tile, a = g >> 2, g & 3
+        kk, e0 = 2 * tile + (a >> 1), 4 * (a & 1)
+        for j in range(4):
+            hf[hbuf][kk][:, e0 + j] = act(a1[abuf][tile][:, 4 * a + j])
+            if rearm_chunk is not None and rearm_chunk < 24:
+                a1[abuf][tile][:, 4 * a + j] = b1[64 * rearm_chunk + 32 * tile + 8 * a + 4 * hh + j]
+
+    for kx in range(4):
+        xblock(0, kx, 0)                                      # P0
+    for kx in range(4):                                       # P1: X(1) with GELU(0), a1[0] re-armed for chunk 2
+        xblock(1, kx, 1)
+        gelu_group(0, 2 * kx, 0, 0, 2)
+        gelu_group(0, 2 * kx + 1, 0, 0, 2)
+    for c in range(1, 23):                                    # X(c+1) -> a1[(c+1)&1], GELU(c): a1[c&1] -> hf[c&1], Y(c-1) <- hf[(c-1)&1]
+        for b in range(8):
+            if b % 2 == 0:
+                xblock(c + 1, b // 2, (c + 1) & 1)
+            else:
+                yblock(c - 1, b // 2, (c - 1) & 1)
+            gelu_group(c, b, c & 1, c & 1, c + 2)
+    for kk in range(4):                                       # E0: Y(22) with GELU(23)
+        yblock(22, kk, 0)
+        gelu_group(23, 2 * kk, 1, 1, None)
+        gelu_group(23, 2 * kk + 1, 1, 1, None)
+    for kk in range(4):
+        yblock(23, kk, 1)                                     # E1
+    assert next(frags, None) is None
+    # epilogue addressing: token n = lane & 31, feature 32 ft + 8 a + 4 hh + i <- y[ft][lane][4 a + i]
+    out = np.zeros((32, C))
+    for l in range(64):
+        for ft in range(12):
+            for a in range(4):
+                for i in range(4):
+                    out[l & 31, 32 * ft + 8 * a + 4 * (l >> 5) + i] = y[ft][l, 4 * a + i]
+    ref = act(X @ W1.T + b1) @ W2.T
+    np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-9)
