@@ -54,7 +54,16 @@ def check_isa(cc: str, src: str) -> None:
             raise RuntimeError("ISA check failed to compile " + src + "\n" + r.stderr)
         pat = re.compile(r"v_mfma_\w+ ([va])\[(\d+):(\d+)\], ([va])\[(\d+):(\d+)\], ([va])\[(\d+):(\d+)\], (.*)$")
         n = 0
+        own_m0 = os.path.basename(src) == "k_rows.hip"   # rows.h dma_frag owns M0 there (not saved / restored)
+        in_asm = False
         for line in open(out):
+            if own_m0:
+                if "#ASMSTART" in line:
+                    in_asm = True
+                elif "#ASMEND" in line:
+                    in_asm = False
+                elif not in_asm and re.search(r"\bm0\b", line.split(";")[0]):
+                    raise RuntimeError(f"{os.path.basename(src)}: compiler-generated M0 access: {line.strip()}")
             if re.search(r"\bv_pk_(mul|add|fma)_f32\b", line):
                 raise RuntimeError(f"{os.path.basename(src)}: packed fp32 VALU op emitted: {line.strip()}")
             m = pat.search(line)

@@ -30,55 +30,110 @@ struct MlpPipe {
 };
 
 // GELU of group g (0..7) of a chunk = hidden tile g >> 2, accumulator registers 4 (g & 3) .. + 3 -> half of the fragment
-// hf[2 (g >> 2) + ((g & 3) >> 1)].  gelu(x) = x * Phi(x) exactly as common.h gelu_erf, cut into three slices per value
-// so that every MFMA of a block carries a few VALU instructions of it (one wave per SIMD: the matrix pipe hides at
-// most ~5 single-issue instructions per MFMA, MI355X_MICROARCH "one wave per SIMD").  The fc1 bias is not added here:
-// the accumulators START from it (see rearm).
-template <int PH>
-__device__ __forceinline__ void gelu_slice(MlpPipe& m, const f32x16 (&a1r)[2], int g, int j, bf16x8 (&hfw)[4]) {
+// hf[2 (g >> 2) + ((g & 3) >> 1)].  gelu(x) = x * Phi(x) exactly as common.h gelu_erf, cut into TWELVE stages, each of
+// which advances all four values by one operation: the instructions of a stage are independent of each other (a lone
+// wave has nobody to hide a dependent VALU chain behind: with one value per stage the measured pace was 52 cycles per
+// MFMA), at most two of them transcendental, and every MFMA of a block carries one stage (4-5 VALU instructions; the
+// matrix pipe hides ~5, MI355X_MICROARCH "one wave per SIMD").  The fc1 bias is not added here: the accumulators
+// START from it -- stages 7, 10, 11 re-arm the four registers with the bias of the chunk two further on (REARM).
+__device__ __forceinline__ void acc_rearm(f32x16& t, int r, float b) {
+    float z;
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(z) : "v"(b));
+    t[r] = z;
+}
+template <int ST, bool REARM>
+__device__ __forceinline__ void gelu_stage(MlpPipe& m, f32x16 (&a1r)[2], int g, bf16x8 (&hfw)[4]) {
     const int tile = g >> 2, a = g & 3;
-    if (PH == 0) {
-        // explicit accumulator-file read: left to hipcc, the whole 16-register tuple is copied to VGPRs at its first use (32
-        // reads in one burst per chunk and 32 VGPRs held for the copy)
-        float x;
-        asm("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a1r[tile][4 * a + j]));
-        const float x2 = x * x;
-        float p = -3.936969279e-06f;
-        p = p * x2 + 1.012880530e-04f;
-        p = p * x2 + 2.890509495e-04f;
-        m.gx[j] = x;
-        m.gq[j] = x2;
-        m.gp[j] = p;
-    } else if (PH == 1) {
-        float p = m.gp[j];
-        p = p * m.gq[j] - 1.051034182e-01f;
-        p = p * m.gq[j] - 2.302086592e+00f;
-        m.gp[j] = __builtin_amdgcn_exp2f(m.gx[j] * p);
-    } else {
-        const float v = m.gx[j] * __builtin_amdgcn_rcpf(1.0f + m.gp[j]);
-        m.gx[j] = v;
-        if (j & 1) {   // a pair is complete: one v_cvt_pk_bf16_f32
-            const int kk = 2 * tile + (a >> 1), e0 = 4 * (a & 1) + (j & 2);
-            hfw[kk][e0] = (__bf16)m.gx[j - 1];
-            hfw[kk][e0 + 1] = (__bf16)v;
+    if (ST == 0) {
+        // explicit accumulator-file reads: left to hipcc, the whole 16-register tuple is copied to VGPRs at its first use
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm("v_accvgpr_read_b32 %0, %1" : "=v"(m.gx[j]) : "a"(a1r[tile][4 * a + j]));
+    } else if (ST == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m.gq[j] = m.gx[j] * m.gx[j];
+    } else if (ST == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m.gp[j] = -3.936969279e-06f * m.gq[j] + 1.012880530e-04f;
+    } else if (ST == 3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m.gp[j] = m.gp[j] * m.gq[j] + 2.890509495e-04f;
+    } else if (ST == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m.gp[j] = m.gp[j] * m.gq[j] - 1.051034182e-01f;
+    } else if (ST == 5) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m.gp[j] = m.gp[j] * m.gq[j] - 2.302086592e+00f;
+    } else if (ST == 6) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m.gp[j] = m.gx[j] * m.gp[j];
+    } else if (ST == 7) {
+        m.gp[0] = __builtin_amdgcn_exp2f(m.gp[0]);
+        m.gp[1] = __builtin_amdgcn_exp2f(m.gp[1]);
+        if (REARM) {
+            acc_rearm(a1r[tile], 4 * a + 0, m.bias[0]);
+            acc_rearm(a1r[tile], 4 * a + 1, m.bias[1]);
         }
+    } else if (ST == 8) {
+        m.gp[2] = __builtin_amdgcn_exp2f(m.gp[2]);
+        m.gp[3] = __builtin_amdgcn_exp2f(m.gp[3]);
+        m.gp[0] = 1.0f + m.gp[0];
+        m.gp[1] = 1.0f + m.gp[1];
+    } else if (ST == 9) {
+        m.gp[0] = __builtin_amdgcn_rcpf(m.gp[0]);
+        m.gp[1] = __builtin_amdgcn_rcpf(m.gp[1]);
+        m.gp[2] = 1.0f + m.gp[2];
+        m.gp[3] = 1.0f + m.gp[3];
+    } else if (ST == 10) {
+        m.gp[2] = __builtin_amdgcn_rcpf(m.gp[2]);
+        m.gp[3] = __builtin_amdgcn_rcpf(m.gp[3]);
+        m.gx[0] = m.gx[0] * m.gp[0];
+        m.gx[1] = m.gx[1] * m.gp[1];
+        if (REARM) acc_rearm(a1r[tile], 4 * a + 2, m.bias[2]);
+    } else {
+        m.gx[2] = m.gx[2] * m.gp[2];
+        m.gx[3] = m.gx[3] * m.gp[3];
+        const int kk = 2 * tile + (a >> 1), e0 = 4 * (a & 1);
+        hfw[kk][e0 + 0] = (__bf16)m.gx[0];   // two v_cvt_pk_bf16_f32
+        hfw[kk][e0 + 1] = (__bf16)m.gx[1];
+        hfw[kk][e0 + 2] = (__bf16)m.gx[2];
+        hfw[kk][e0 + 3] = (__bf16)m.gx[3];
+        if (REARM) acc_rearm(a1r[tile], 4 * a + 3, m.bias[3]);
     }
+}
+template <bool REARM, int ST = 0>
+__device__ __forceinline__ void gelu_stages_from(MlpPipe& m, f32x16 (&a1r)[2], int g, bf16x8 (&hfw)[4]) {
+    gelu_stage<ST, REARM>(m, a1r, g, hfw);
+    if constexpr (ST < 11) gelu_stages_from<REARM, ST + 1>(m, a1r, g, hfw);
 }
 // The four accumulator registers a GELU group has consumed start their next accumulation (the chunk two further on, which
 // lands in the same registers) from the fc1 bias of that chunk: no zeroing, no bias add.
 __device__ __forceinline__ void rearm(f32x16 (&a1r)[2], int g, const f32x4& b) {
     const int tile = g >> 2, a = g & 3;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float z;
-        asm("v_accvgpr_write_b32 %0, %1" : "=a"(z) : "v"(b[j]));
-        a1r[tile][4 * a + j] = z;
-    }
+    for (int j = 0; j < 4; ++j) acc_rearm(a1r[tile], 4 * a + j, b[j]);
 }
 // all 32 accumulator registers of a chunk <- its fc1 bias (pipeline fill); b1c = LDS bias row of the chunk + 4 hh
 __device__ __forceinline__ void arm_chunk(f32x16 (&a1)[2], const float* b1c) {
 #pragma unroll
     for (int g = 0; g < 8; ++g) rearm(a1, g, *reinterpret_cast<const f32x4*>(b1c + 32 * (g >> 2) + 8 * (g & 3)));
+}
+
+template <bool REARM>
+__device__ __forceinline__ void gelu_stage_q(MlpPipe& m, f32x16 (&a1r)[2], int g, int q, bf16x8 (&hfw)[4]) {
+    switch (q) {   // q is a constant after unrolling
+        case 0: gelu_stage<0, REARM>(m, a1r, g, hfw); break;
+        case 1: gelu_stage<1, REARM>(m, a1r, g, hfw); break;
+        case 2: gelu_stage<2, REARM>(m, a1r, g, hfw); break;
+        case 3: gelu_stage<3, REARM>(m, a1r, g, hfw); break;
+        case 4: gelu_stage<4, REARM>(m, a1r, g, hfw); break;
+        case 5: gelu_stage<5, REARM>(m, a1r, g, hfw); break;
+        case 6: gelu_stage<6, REARM>(m, a1r, g, hfw); break;
+        case 7: gelu_stage<7, REARM>(m, a1r, g, hfw); break;
+        case 8: gelu_stage<8, REARM>(m, a1r, g, hfw); break;
+        case 9: gelu_stage<9, REARM>(m, a1r, g, hfw); break;
+        case 10: gelu_stage<10, REARM>(m, a1r, g, hfw); break;
+        default: gelu_stage<11, REARM>(m, a1r, g, hfw); break;
+    }
 }
 
 // One block of 12 fragments, one fenced scheduling region per fragment: [look-ahead LDS read of fragment I + PF]
@@ -102,19 +157,14 @@ __device__ __forceinline__ void pipe_block(MlpPipe& m, const bf16x8 (&xf)[24], f
         const int I = I0 + q;
         if (FILL && q % STRIDE == 0) ws.issue(fill_slot, ((I0 / 12) & 1) * DPB + q / STRIDE);
         if (q < NLOOK) m.wr[(I + kWPF) % kWRing] = *reinterpret_cast<const bf16x8*>(ring_lane + ((I + kWPF) % kRingFrags) * 1024);
-        if (GG >= 0 && REARM && q == 5) m.bias = *reinterpret_cast<const f32x4*>(b1n + 32 * (GG >> 2) + 8 * (GG & 3));
+        if (GG >= 0 && REARM && q == 0) m.bias = *reinterpret_cast<const f32x4*>(b1n + 32 * (GG >> 2) + 8 * (GG & 3));
         if (KIND == 0) {
             const int ks = 6 * KI + (q >> 1), tile = q & 1;
             a1w[tile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], xf[ks], a1w[tile], 0, 0, 0);
         } else {
             m.y[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], hfr[KI], m.y[q], 0, 0, 0);
         }
-        if (GG >= 0) {
-            if (q % 3 == 0) gelu_slice<0>(m, a1r, GG, q / 3, hfw);
-            else if (q % 3 == 1) gelu_slice<1>(m, a1r, GG, q / 3, hfw);
-            else gelu_slice<2>(m, a1r, GG, q / 3, hfw);
-            if (REARM && q == 11) rearm(a1r, GG, m.bias);
-        }
+        if (GG >= 0) gelu_stage_q<REARM>(m, a1r, GG, q, hfw);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -122,13 +172,8 @@ __device__ __forceinline__ void pipe_block(MlpPipe& m, const bf16x8 (&xf)[24], f
 // a whole GELU group without MFMAs beside it (pipeline fill / drain only)
 template <bool REARM>
 __device__ __forceinline__ void gelu_group_plain(MlpPipe& m, f32x16 (&a1r)[2], const float* b1n, int g, bf16x8 (&hfw)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        gelu_slice<0>(m, a1r, g, j, hfw);
-        gelu_slice<1>(m, a1r, g, j, hfw);
-        gelu_slice<2>(m, a1r, g, j, hfw);
-    }
-    if (REARM) rearm(a1r, g, *reinterpret_cast<const f32x4*>(b1n + 32 * (g >> 2) + 8 * (g & 3)));
+    if (REARM) m.bias = *reinterpret_cast<const f32x4*>(b1n + 32 * (g >> 2) + 8 * (g & 3));
+    gelu_stages_from<REARM>(m, a1r, g, hfw);
 }
 
 // Phase stamps (measurement only, p.trace null in normal operation): s_memtime values are collected in SGPRs and

@@ -53,13 +53,11 @@ __device__ __forceinline__ float acc_zero() {
 }
 
 // One LDS-DMA: 64 lanes x 16 bytes, global (uniform base + per-lane 32-bit offset) -> LDS [dst + lane * 16].
-// M0 is written in the same statement that reads it (hipcc reserves it and does not preserve it across statements).
+// M0 (the DMA's LDS base) is written in the same statement that reads it.  It is NOT saved / restored: hipcc reserves M0
+// but uses it for nothing in these kernels (no LDS-direct, GWS or movrel); build.py check_isa fails the build if it ever
+// emits an M0 access of its own in k_rows.hip.  Five issue slots per DMA instead of seven.
 __device__ __forceinline__ void dma_frag(const unsigned char* src, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(src), "s"(lds_dst)
-                 : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lds_dst) : "memory");
 }
 
 template <int VM>
