@@ -41,6 +41,11 @@ __device__ __forceinline__ void acc_rearm(f32x16& t, int r, float b) {
     asm("v_accvgpr_write_b32 %0, %1" : "=a"(z) : "v"(b));
     t[r] = z;
 }
+// Phi as a logistic of an odd polynomial with THREE coefficients (the panel kernel's gelu_erf has five): max abs error of
+// gelu 2.9e-5 (scripts/fit_gelu.py --rows), against the bf16 rounding applied right after (relative 2^-9).  The leading
+// coefficient has the wrong sign for large |x|, hence the clamp of x^2 at 64 (|x| > 8: Phi is 0 or 1 in fp32 anyway).
+// Constants carry the factor -log2(e): the exponential is a bare v_exp_f32.
+constexpr float kGelu3C0 = -2.301208258e+00f, kGelu3C1 = -1.066924557e-01f, kGelu3C2 = 1.000115648e-03f;
 template <int ST, bool REARM>
 __device__ __forceinline__ void gelu_stage(MlpPipe& m, f32x16 (&a1r)[2], int g, bf16x8 (&hfw)[4]) {
     const int tile = g >> 2, a = g & 3;
@@ -53,51 +58,51 @@ __device__ __forceinline__ void gelu_stage(MlpPipe& m, f32x16 (&a1r)[2], int g, 
         for (int j = 0; j < 4; ++j) m.gq[j] = m.gx[j] * m.gx[j];
     } else if (ST == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m.gp[j] = -3.936969279e-06f * m.gq[j] + 1.012880530e-04f;
+        for (int j = 0; j < 4; ++j) m.gq[j] = fminf(m.gq[j], 64.0f);
     } else if (ST == 3) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m.gp[j] = m.gp[j] * m.gq[j] + 2.890509495e-04f;
+        for (int j = 0; j < 4; ++j) m.gp[j] = kGelu3C2 * m.gq[j] + kGelu3C1;
     } else if (ST == 4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m.gp[j] = m.gp[j] * m.gq[j] - 1.051034182e-01f;
+        for (int j = 0; j < 4; ++j) m.gp[j] = m.gp[j] * m.gq[j] + kGelu3C0;
     } else if (ST == 5) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m.gp[j] = m.gp[j] * m.gq[j] - 2.302086592e+00f;
-    } else if (ST == 6) {
-#pragma unroll
         for (int j = 0; j < 4; ++j) m.gp[j] = m.gx[j] * m.gp[j];
-    } else if (ST == 7) {
+    } else if (ST == 6) {
         m.gp[0] = __builtin_amdgcn_exp2f(m.gp[0]);
         m.gp[1] = __builtin_amdgcn_exp2f(m.gp[1]);
         if (REARM) {
             acc_rearm(a1r[tile], 4 * a + 0, m.bias[0]);
             acc_rearm(a1r[tile], 4 * a + 1, m.bias[1]);
         }
-    } else if (ST == 8) {
+    } else if (ST == 7) {
         m.gp[2] = __builtin_amdgcn_exp2f(m.gp[2]);
         m.gp[3] = __builtin_amdgcn_exp2f(m.gp[3]);
         m.gp[0] = 1.0f + m.gp[0];
         m.gp[1] = 1.0f + m.gp[1];
-    } else if (ST == 9) {
+    } else if (ST == 8) {
         m.gp[0] = __builtin_amdgcn_rcpf(m.gp[0]);
         m.gp[1] = __builtin_amdgcn_rcpf(m.gp[1]);
         m.gp[2] = 1.0f + m.gp[2];
         m.gp[3] = 1.0f + m.gp[3];
-    } else if (ST == 10) {
+    } else if (ST == 9) {
         m.gp[2] = __builtin_amdgcn_rcpf(m.gp[2]);
         m.gp[3] = __builtin_amdgcn_rcpf(m.gp[3]);
         m.gx[0] = m.gx[0] * m.gp[0];
         m.gx[1] = m.gx[1] * m.gp[1];
-        if (REARM) acc_rearm(a1r[tile], 4 * a + 2, m.bias[2]);
-    } else {
+    } else if (ST == 10) {
         m.gx[2] = m.gx[2] * m.gp[2];
         m.gx[3] = m.gx[3] * m.gp[3];
+        if (REARM) {
+            acc_rearm(a1r[tile], 4 * a + 2, m.bias[2]);
+            acc_rearm(a1r[tile], 4 * a + 3, m.bias[3]);
+        }
+    } else {
         const int kk = 2 * tile + (a >> 1), e0 = 4 * (a & 1);
         hfw[kk][e0 + 0] = (__bf16)m.gx[0];   // two v_cvt_pk_bf16_f32
         hfw[kk][e0 + 1] = (__bf16)m.gx[1];
         hfw[kk][e0 + 2] = (__bf16)m.gx[2];
         hfw[kk][e0 + 3] = (__bf16)m.gx[3];
-        if (REARM) acc_rearm(a1r[tile], 4 * a + 3, m.bias[3]);
     }
 }
 template <bool REARM, int ST = 0>
@@ -116,6 +121,25 @@ __device__ __forceinline__ void rearm(f32x16 (&a1r)[2], int g, const f32x4& b) {
 __device__ __forceinline__ void arm_chunk(f32x16 (&a1)[2], const float* b1c) {
 #pragma unroll
     for (int g = 0; g < 8; ++g) rearm(a1, g, *reinterpret_cast<const f32x4*>(b1c + 32 * (g >> 2) + 8 * (g & 3)));
+}
+
+// DMA number D0 + q / STRIDE of the wave's share of a slot (q is a constant after unrolling)
+template <int NW, int D0, int STRIDE>
+__device__ __forceinline__ void issue_q(const WStream<NW>& ws, long slot, int q) {
+    switch (q / STRIDE) {
+        case 0: ws.template issue<D0 + 0>(slot); break;
+        case 1: ws.template issue<D0 + 1>(slot); break;
+        case 2: ws.template issue<D0 + 2>(slot); break;
+        case 3: if constexpr (12 / STRIDE > 3) ws.template issue<D0 + 3>(slot); break;
+        case 4: if constexpr (12 / STRIDE > 4) ws.template issue<D0 + 4>(slot); break;
+        case 5: if constexpr (12 / STRIDE > 5) ws.template issue<D0 + 5>(slot); break;
+        case 6: if constexpr (12 / STRIDE > 6) ws.template issue<D0 + 6>(slot); break;
+        case 7: if constexpr (12 / STRIDE > 7) ws.template issue<D0 + 7>(slot); break;
+        case 8: if constexpr (12 / STRIDE > 8) ws.template issue<D0 + 8>(slot); break;
+        case 9: if constexpr (12 / STRIDE > 9) ws.template issue<D0 + 9>(slot); break;
+        case 10: if constexpr (12 / STRIDE > 10) ws.template issue<D0 + 10>(slot); break;
+        default: if constexpr (12 / STRIDE > 11) ws.template issue<D0 + 11>(slot); break;
+    }
 }
 
 template <bool REARM>
@@ -155,7 +179,7 @@ __device__ __forceinline__ void pipe_block(MlpPipe& m, const bf16x8 (&xf)[24], f
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
         const int I = I0 + q;
-        if (FILL && q % STRIDE == 0) ws.issue(fill_slot, ((I0 / 12) & 1) * DPB + q / STRIDE);
+        if (FILL && q % STRIDE == 0) issue_q<NW, ((I0 / 12) & 1) * DPB, STRIDE>(ws, fill_slot, q);
         if (q < NLOOK) m.wr[(I + kWPF) % kWRing] = *reinterpret_cast<const bf16x8*>(ring_lane + ((I + kWPF) % kRingFrags) * 1024);
         if (GG >= 0 && REARM && q == 0) m.bias = *reinterpret_cast<const f32x4*>(b1n + 32 * (GG >> 2) + 8 * (GG & 3));
         if (KIND == 0) {
@@ -191,12 +215,17 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
     unsigned long long st[6];
     ROWS_STAMP(0);
     WStream<NW> ws{p.wstream, lds_addr(smem), (unsigned)lane * 16u, w};
+    // fc1 bias -> LDS, six 1 KiB DMAs (wave w: pieces w, w + NW, ...), BEFORE the stream's: barrier 0 then certifies them too.
+    // (A load + ds_write loop here cost two serialised memory round trips ahead of the row loads.)
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (i % NW == w)
+            dma_frag<0, true>(reinterpret_cast<const unsigned char*>(p.b1) + i * 1024, (unsigned)lane * 16u,
+                              lds_addr(smem) + kRingBytes + i * 1024);
     ws.issue_slot(0);
     ws.issue_slot(1);
     ws.issue_slot(2);
     float* b1s = reinterpret_cast<float*>(smem + kRingBytes);
-    for (int i = threadIdx.x; i < kF / 4; i += NW * 64)
-        reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
     const long t = ((long)blockIdx.x * NW + w) * 32 + n;
     const int tok = t < p.nrows ? (int)t : -1;
     bf16x8 xf[24];

@@ -52,12 +52,18 @@ __device__ __forceinline__ float acc_zero() {
     return z;
 }
 
-// One LDS-DMA: 64 lanes x 16 bytes, global (uniform base + per-lane 32-bit offset) -> LDS [dst + lane * 16].
-// M0 (the DMA's LDS base) is written in the same statement that reads it.  It is NOT saved / restored: hipcc reserves M0
-// but uses it for nothing in these kernels (no LDS-direct, GWS or movrel); build.py check_isa fails the build if it ever
-// emits an M0 access of its own in k_rows.hip.  Five issue slots per DMA instead of seven.
+// One LDS-DMA: 64 lanes x 16 bytes, global (uniform base + per-lane 32-bit offset + OFF) -> LDS [M0 + OFF + lane * 16]:
+// the instruction offset moves BOTH ends (measured: scripts/micro/dma_offset.hip), so consecutive fragments of a slot
+// need one M0 write per four DMAs.  SETM0: write M0 (= LDS destination of the group) in the same statement.  M0 is NOT
+// saved / restored: hipcc reserves it but uses it for nothing in these kernels (no LDS-direct, GWS or movrel);
+// build.py check_isa fails the build if it ever emits an M0 access of its own in k_rows.hip.
+template <int OFF, bool SETM0>
 __device__ __forceinline__ void dma_frag(const unsigned char* src, unsigned voff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lds_dst) : "memory");
+    static_assert(OFF >= 0 && OFF < 4096, "13-bit signed instruction offset");
+    if (SETM0)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(src), "s"(lds_dst), "n"(OFF) : "memory");
+    else
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(src), "n"(OFF) : "memory");
 }
 
 template <int VM>
@@ -72,14 +78,18 @@ struct WStream {
     unsigned ring;              // LDS byte address of the ring
     unsigned voff;              // lane * 16
     int w;                      // wave index (uniform)
-    // the d-th (0 .. FPW - 1) DMA of this wave for global slot `slot`
-    __device__ __forceinline__ void issue(long slot, int d) const {
-        const int f = w * FPW + d;
-        dma_frag(src + slot * kSlotBytes + f * 1024, voff, ring + ((unsigned)slot & 3u) * kSlotBytes + f * 1024);
+    // the D-th (0 .. FPW - 1) DMA of this wave for global slot `slot`; DMAs are grouped in fours that share an M0 value
+    // and a source base (the statements of a group must follow each other with no other M0 writer in between)
+    template <int D>
+    __device__ __forceinline__ void issue(long slot) const {
+        const int f = w * FPW + (D & ~3);
+        dma_frag<(D & 3) * 1024, (D & 3) == 0>(src + slot * kSlotBytes + f * 1024, voff,
+                                               ring + ((unsigned)slot & 3u) * kSlotBytes + f * 1024);
     }
+    template <int D0 = 0>
     __device__ __forceinline__ void issue_slot(long slot) const {
-#pragma unroll
-        for (int d = 0; d < FPW; ++d) issue(slot, d);
+        issue<D0>(slot);
+        if constexpr (D0 + 1 < FPW) issue_slot<D0 + 1>(slot);
     }
 };
 
