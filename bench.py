@@ -14,7 +14,12 @@ The JSON line also carries
   roofline     -- the dominant kernel (largest share of hipEvent time), its ALGORITHMIC flops per launch
                   divided by its average hipEvent-measured launch duration, vs the dense bf16 MFMA peak;
   cpu_baseline -- the CPU oracle (a port of the reference's PyTorch path, oracle/mdgen_oracle.py) timed on
-                  this box's host cores on a bounded sample of the same workload.
+                  this box's host cores on a bounded sample of the same workload;
+  extra        -- (1 GPU, default run) short legs for the other headline numbers, so that the driver's one bench line
+                  carries them: ATLAS crop 256 x 250 frames (north_star's second target), the TPS shard of configs[2],
+                  the reference CLI's own B = 1 shape, the 10-block rollout rate (the region sim_inference.py:109-115
+                  times), one DDP-less training step of configs[4]'s per-GPU shape, and a box probe (HBM copy rate,
+                  bf16 GEMM rate) that makes a slow box recognisable.  `--no-extra` skips them.
 """
 from __future__ import annotations
 
@@ -166,6 +171,156 @@ def pmc_traffic(kernel_class, workload):
     return None, None
 
 
+def _dominant(rep, B, T, L, workload):
+    """roofline object of the kernel class with the largest share of hipEvent time (classes with known algorithmic flops)."""
+    tot = sum(v["ms"] for v in rep.values())
+    known = [k for k in rep if algorithmic_flops(k, B, T, L)]
+    if not known:
+        return None
+    dom = max(known, key=lambda k: rep[k]["ms"])
+    avg_ms = rep[dom]["ms"] / rep[dom]["count"]
+    ach = algorithmic_flops(dom, B, T, L) / (avg_ms * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic(dom, workload)
+    return {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": rep[dom]["count"],
+            "share_of_event_time": round(rep[dom]["ms"] / tot, 3),
+            "by_kernel_ms_per_call": {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}}
+
+
+def box_probe(dev):
+    """~0.2 s: sustained HBM copy rate and a library bf16 GEMM rate of THIS box (torch = plumbing here, not the product):
+    round 2 saw boxes whose HBM-touching kernels ran 1.5x slower than the pool's norm with the same build."""
+    a = torch.empty(1 << 28, dtype=torch.float32, device=dev)   # 1 GiB
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(8):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_tbs = 8 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    del a, b
+    m = torch.randn(8192, 8192, device=dev).to(torch.bfloat16)
+    n = torch.randn(8192, 8192, device=dev).to(torch.bfloat16)
+    (m @ n)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(8):
+        m @ n
+    e1.record()
+    torch.cuda.synchronize()
+    gemm_tf = 8 * 2 * 8192 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    return {"hbm_copy_TBps": round(copy_tbs, 2), "library_bf16_gemm_8192_TFLOPs": round(gemm_tf, 1),
+            "device": torch.cuda.get_device_name(dev)}
+
+
+def sampler_leg(workload, dev, steps, warmup, S, options, roofline=False, rollouts=0):
+    """One workload through `inference()` (or, rollouts > 0, `rollout()`): frames/s with inputs resident in HBM."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    B, T, L, abs_pos, n_pad = WORKLOADS[workload]
+    tps = "_tps_" in workload
+    cfg = ModelConfig(crop=L, num_frames=T, abs_pos_emb=abs_pos, sim_condition=not tps, tps_condition=tps)
+    w = NewMDGenWrapper(cfg, device=dev)
+    w.model.load_state_dict(synth_state_dict(cfg, 0))
+    for k, v in options.items():
+        w.model.set_option(k, v)
+    batch = synth_batch(B, T if not rollouts else 1, L, n_pad, dev, seed=100, tps=tps)
+    g = torch.Generator().manual_seed(137)
+    if rollouts:
+        zs = torch.randn(rollouts, B, T, L, cfg.latent_dim, generator=g).to(dev)
+        step = lambda: w.rollout(batch, T, rollouts, num_steps=S, zs=zs)
+    else:
+        zs = torch.randn(B, T, L, cfg.latent_dim, generator=g).to(dev)
+        step = lambda: w.inference(batch, zs=zs, num_steps=S)[0]
+    for _ in range(warmup):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(out).all(), workload
+    frames = B * T * max(rollouts, 1)
+    res = {"value": round(frames / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+           "batch": B, "num_frames": T, "crop": L, "euler_steps": S}
+    if rollouts:
+        res["num_rollouts"] = rollouts
+    if roofline and not rollouts:
+        w.model.profile(True)
+        step()
+        rep = w.model.profile_report()
+        w.model.profile(False)
+        res["roofline"] = _dominant(rep, B, T, L, workload)
+        fl = sum(algorithmic_flops(k, B, T, L) * v["count"] for k, v in rep.items() if algorithmic_flops(k, B, T, L))
+        res["whole_step_frac_of_mfma_peak"] = round(fl / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
+    del w
+    torch.cuda.empty_cache()
+    return res
+
+
+def training_leg(dev, reps=2):
+    """One training step (forward + backward + clip + Adam + weight hand-back) at configs[4]'s per-GPU shape (ATLAS crop 256 x
+    250 frames, B = 1), no gradient exchange (1 GPU).  flops = 3 x the forward's algorithmic flops."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.optim import Adam
+    from mdgen_amd.synthetic import synth_state_dict, synth_forward_inputs
+    from mdgen_amd.train import TrainableModel
+    B, T, L = 1, 250, 256
+    cfg = ModelConfig.atlas(num_frames=T, crop=L)
+    inp = synth_forward_inputs(cfg, B, T, L, 16, 27)
+    gen = torch.Generator().manual_seed(5)
+    ut = torch.randn(B, T, L, cfg.latent_dim, generator=gen)
+    lm = (torch.rand(B, T, L, cfg.latent_dim, generator=gen) > 0.1).float() * inp["mask"][..., None]
+    tm = TrainableModel(cfg, dev).load_state_dict(synth_state_dict(cfg, 6))
+    args = (inp["x"].to(dev), inp["t"].to(dev), ut.to(dev), lm.to(dev), inp["mask"].to(dev),
+            (inp["start_rot"].to(dev), inp["start_trans"].to(dev)), inp["x_cond"].to(dev), inp["x_cond_mask"].to(dev),
+            inp["aatype"].to(dev))
+    opt = Adam(tm.params, lr=1e-4, grad_clip=1.0)
+
+    def step():
+        tm.zero_grad()
+        loss, _ = tm.forward_backward(*args)
+        opt.step(tm.grads)
+        tm.mark_updated()   # no hand-back: the training kernels read the flat parameter buffer
+        return loss
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert torch.isfinite(loss).all()
+    N, C = B * T * L, 384
+    fwd = N * (6 * 21 * C + 5 * (32 * C * C + 4 * C * (L + 1) + 4 * C * (T + 1)))
+    return {"workload": "atlas_train_crop256_T250_B1", "ms_per_step": round(dt * 1e3, 2), "frames_per_s": round(B * T / dt, 1),
+            "TFLOPs": round(3 * fwd / dt / 1e12, 1), "arithmetic": "fp32 operands (exact mode)", "steps": reps}
+
+
+def extra_legs(dev, options):
+    ex = {}
+    t0 = time.perf_counter()
+    def run(name, fn):
+        try:
+            ex[name] = fn()
+        except Exception as e:   # an extra leg must never take the headline number down with it
+            ex[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    run("box_probe", lambda: box_probe(dev))
+    run("atlas_crop256_T250_B1", lambda: sampler_leg("atlas_crop256_T250_B1", dev, 2, 1, 49, options, roofline=True))
+    run("tetrapeptide_tps_crop4_T100_B32", lambda: sampler_leg("tetrapeptide_tps_crop4_T100_B32", dev, 3, 1, 49, options))
+    run("tetrapeptide_fwdsim_crop4_T1000_B1", lambda: sampler_leg("tetrapeptide_fwdsim_crop4_T1000_B1", dev, 3, 1, 49, options))
+    run("rollout_10_blocks_T1000_B16", lambda: sampler_leg("tetrapeptide_fwdsim_crop4_T1000_B16", dev, 1, 1, 49, options, rollouts=10))
+    run("atlas_train_crop256_T250_B1", lambda: training_leg(dev))
+    ex["seconds"] = round(time.perf_counter() - t0, 1)
+    return ex
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,7 +334,11 @@ def main():
     ap.add_argument("--streams", type=int, default=None, help="library option 'streams' (default 2; 1 = single stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (ATLAS, TPS, B = 1, rollout, training step, box probe)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="library run-time option (mdgen_ctx_set_option), e.g. mlp_path=1; repeatable")
     a = ap.parse_args()
+    options = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.option}
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -209,6 +368,8 @@ def main():
     w.model.load_state_dict(sd)
     if a.streams is not None:
         w.model.set_option("streams", a.streams)
+    for k, v in options.items():
+        w.model.set_option(k, v)
     batch = synth_batch(B, T, L, n_pad, dev, seed=100 + rank, tps=tps)   # every rank: its own peptides (weak scaling)
     zs = torch.randn(B, T, L, cfg.latent_dim, generator=torch.Generator().manual_seed(137 + rank)).to(dev)
     use_graph = not a.no_graph
@@ -266,30 +427,21 @@ def main():
 
     roof = None
     if rank == 0 and not a.no_roofline:
-        # per-kernel-class durations measured with hipEvents on the launch stream (eager pass, graphs bypassed)
+        # per-kernel-class durations measured with hipEvents on the launch stream (eager pass, graphs bypassed);
+        # fp32 tolerance mode: its kernels (csrc/k_fp32.hip) are not priced against the bf16 MFMA peak -> None
         w.model.profile(True)
         step()
         rep = w.model.profile_report()
         w.model.profile(False)
-        tot = sum(v["ms"] for v in rep.values())
-        known = [k for k in rep if algorithmic_flops(k, B, T, L)]
-        if not known:   # fp32 tolerance mode: its kernels (csrc/k_fp32.hip) are not priced against the bf16 MFMA peak
-            known = None
-    if rank == 0 and not a.no_roofline and known:
-        dom = max(known, key=lambda k: rep[k]["ms"])
-        avg_ms = rep[dom]["ms"] / rep[dom]["count"]
-        fl = algorithmic_flops(dom, B, T, L)
-        ach = fl / (avg_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(dom, a.workload)
-        roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_source": traffic_src,
-                "avg_launch_ms": round(avg_ms, 4), "launches": rep[dom]["count"],
-                "share_of_event_time": round(rep[dom]["ms"] / tot, 3),
-                "by_kernel_ms_per_call": {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}}
+        roof = _dominant(rep, B, T, L, a.workload)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(cfg, sd, B, T, L, S, n_pad)
+    extra = None
+    if rank == 0 and world == 1 and not a.no_extra and a.precision == "bf16" and a.workload == "tetrapeptide_fwdsim_crop4_T1000_B16":
+        del w
+        torch.cuda.empty_cache()
+        extra = extra_legs(dev, dict(options, **({"streams": a.streams} if a.streams is not None else {})))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -302,7 +454,7 @@ def main():
             "data": "synthetic (seeded random-init weights, synthetic peptide frames/torsions, CPU-seeded noise)",
             "config": {"workload": a.workload, "batch_per_gpu": B, "num_frames": T, "crop": L,
                        "euler_steps": S, "hipgraph": use_graph, "parallelism": f"batch-sharded x{world}, no collective"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(out))
 

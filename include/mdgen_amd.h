@@ -308,6 +308,10 @@ int32_t mdgen_train_workspace_bytes(const mdgen_ctx* ctx, const mdgen_shape* sha
  *   nl+2 .. 2nl+1: ipa_layers.{nl-1 .. 0}.* | 2nl+2: everything else (aatype_to_emb, latent_to_emb_f/_r, t_embedder)
  * and records the caller's hipEvent_t events[k] (NULL = skip) on the training stream when group k's gradients are
  * final.  The list stays in force until replaced (n = 0 clears it); the events remain the caller's. */
+/* Point the fp32 weights the training kernels read at `flat + offsets[i]` (i = index of mdgen_ctx_weight_name; -1: keep the
+ * context's own copy, e.g. frozen buffers): the optimiser then updates what the next step reads, with no hand-back.
+ * Needs keep_fp32_weights = 1 and loaded weights.  The caller keeps `flat` alive as long as the context trains. */
+int32_t mdgen_train_bind_params(mdgen_ctx* ctx, float* flat, const int64_t* offsets);
 int32_t mdgen_train_num_milestones(const mdgen_ctx* ctx);
 int32_t mdgen_train_set_milestone_events(mdgen_ctx* ctx, void* const* events, int32_t n);
 int32_t mdgen_train_forward_backward(mdgen_ctx* ctx, const mdgen_shape* shape, const float* xt, const float* t,

@@ -21,7 +21,7 @@ EXPORTS = [
     "mdgen_samples_to_atom14", "mdgen_atom14_to_cond", "mdgen_path_plan", "mdgen_masked_mse", "mdgen_from_3_points",
     "mdgen_grad_sumsq", "mdgen_adam_step", "mdgen_ema_update", "mdgen_train_workspace_bytes",
     "mdgen_train_forward_backward",
-    "mdgen_train_num_milestones",
+    "mdgen_train_num_milestones", "mdgen_train_bind_params",
     "mdgen_train_set_milestone_events",
 ]
 
@@ -92,6 +92,7 @@ def _load():
     lib.mdgen_ema_update.argtypes = [i64, vp, vp, f32, vp]
     lib.mdgen_train_workspace_bytes.argtypes = [vp, C.POINTER(Shape), C.POINTER(sz)]
     lib.mdgen_train_num_milestones.argtypes = [vp]
+    lib.mdgen_train_bind_params.argtypes = [vp, vp, C.POINTER(i64)]
     lib.mdgen_train_set_milestone_events.argtypes = [vp, C.POINTER(vp), i32]
     lib.mdgen_train_forward_backward.argtypes = [vp, C.POINTER(Shape)] + [vp] * 16 + [vp, sz, vp, sz, vp]
     for n in EXPORTS:

@@ -529,7 +529,8 @@ extern "C" int32_t mdgen_ctx_set_weight(mdgen_ctx* c, const char* key, const flo
         float*& dst = c->w32[key];
         if (!dst)
             if (int e = c->dalloc(&dst, n)) return e;
-        HIPCHK(hipMemcpyAsync(dst, data, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        if (dst != data)   // (bound parameters, mdgen_train_bind_params: the refresh hands the flat buffer's own views over)
+            HIPCHK(hipMemcpyAsync(dst, data, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     c->provided[key] = true;
     c->finalized = false;

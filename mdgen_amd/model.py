@@ -63,6 +63,7 @@ class LatentMDGenModel:
         self.poison_workspace = False     # tests: fill new workspaces with 0xFF (NaN in fp32 and bf16)
         self._side = None
         self._loaded = False
+        self._pre_run = None              # optional hook run before every network evaluation (train.TrainableModel: lazy weight refresh)
 
     def __del__(self):
         try:
@@ -120,7 +121,8 @@ class LatentMDGenModel:
         return self
 
     def set_option(self, name: str, value: int):
-        """Library run-time options (include/mdgen_amd.h `mdgen_ctx_set_option`): "streams", "residue_l4_path", "attention_path"."""
+        """Library run-time options (include/mdgen_amd.h `mdgen_ctx_set_option`): "streams", "residue_l4_path",
+        "attention_path", "mlp_path", "precision", "keep_fp32_weights"."""
         check(lib.mdgen_ctx_set_option(self._ctx, name.encode(), int(value)))
         return self
 
@@ -181,6 +183,8 @@ class LatentMDGenModel:
     def forward(self, x, t, mask, start_frames=None, end_frames=None, x_cond=None, x_cond_mask=None, aatype=None,
                 return_trace: bool = False):
         """latent_model.py:212-260 (non-design path).  Returns the velocity (B,T,L,D) fp32."""
+        if self._pre_run is not None:
+            self._pre_run()
         B, T, L_ = self._check_inputs(x, mask, x_cond, x_cond_mask, aatype)
         require_cuda(x, t, mask, x_cond, x_cond_mask, aatype)
         sr, st = _frames(start_frames)
@@ -219,6 +223,8 @@ class LatentMDGenModel:
                      x_cond_mask=None, aatype=None, use_graph: bool = True):
         """x <- zs; for i < S: x += (t[i+1]-t[i]) * model(x, t[i]) on t = linspace(0,1,S+1); returns x.
         (transport.py:408-451 + integrators.py:95-114 + torchdiffeq fixed-grid Euler.)"""
+        if self._pre_run is not None:
+            self._pre_run()
         B, T, L_ = self._check_inputs(zs, mask, x_cond, x_cond_mask, aatype)
         require_cuda(zs, mask, x_cond, x_cond_mask, aatype)
         S = int(num_steps)
@@ -280,6 +286,8 @@ class LatentMDGenModel:
         of sim_inference.py:100-113.  zs (R,B,T,L,D) noise; mask (B,T,L); cond_* the first conditioning frame
         (B,L,...); seqres (B,L) int64; tables: dict of residue tables on the device (geometry.residue_tables).
         Returns (atom14 (B, R*T, L, 14, 3), samples (R,B,T,L,D), next conditioning frame dict)."""
+        if self._pre_run is not None:
+            self._pre_run()
         if zs.dim() != 5 or zs.shape[-1] != self.cfg.latent_dim:
             raise L.MdgenError(f"zs must be (R,B,T,L,{self.cfg.latent_dim}), got {tuple(zs.shape)}")
         R, B, T, L_, D = zs.shape

@@ -74,6 +74,20 @@ class Adam:
         self._scratch = torch.empty(1024, dtype=torch.float32, device=params.device)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=params.device)
 
+    def state_dict(self):
+        """torch.optim-style: per-parameter moments by name + the step count (resume)."""
+        return {"step": self.step_count, "lr": self.lr, "betas": self.betas, "eps": self.eps, "adamw": self.adamw,
+                "weight_decay": self.weight_decay,
+                "exp_avg": OrderedDict((k, v.detach().cpu().clone()) for k, v in self.params.state_dict(self.exp_avg).items()),
+                "exp_avg_sq": OrderedDict((k, v.detach().cpu().clone()) for k, v in self.params.state_dict(self.exp_avg_sq).items())}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        for name, buf in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+            for k in self.params.shapes:
+                self.params.view(buf, k).copy_(sd[name][k].to(torch.float32))
+        return self
+
     def grad_norm(self, grads: torch.Tensor, grad_scale: float = 1.0) -> torch.Tensor:
         """Device scalar: || grads * grad_scale ||_2 (no host synchronisation)."""
         launch(lib.mdgen_grad_sumsq, grads, grads.numel(), ptr(grads), float(grad_scale), ptr(self._scratch), 1024,
@@ -97,17 +111,32 @@ class Adam:
 
 
 class EMA:
-    """ema.py:17-58: `stored -= (stored - param) * (1 - decay)` over every entry of the state dict."""
+    """ema.py:17-58: `stored -= (stored - param) * (1 - decay)` over every entry of the state dict.
 
-    def __init__(self, params: FlatParams, decay: float):
+    `buffers` / `order`: the model's non-trainable state-dict entries (`pos_embed`, `rot_emb.inv_freq`) and the
+    reference's key order.  The reference's ExponentialMovingAverage clones the FULL `model.state_dict()` and
+    `load_ema_weights` loads it back strictly (wrapper.py:120-130): with them `state_dict()["params"]` can be dropped into a
+    reference checkpoint's `'ema'` entry (the buffers never change, so their average is themselves)."""
+
+    def __init__(self, params: FlatParams, decay: float, buffers=None, order=None):
         self.params, self.decay = params, float(decay)
         self.data = params.data.clone()
+        self.buffers = dict(buffers or {})
+        self.order = list(order) if order is not None else list(params.shapes) + list(self.buffers)
 
     def update(self):
         launch(lib.mdgen_ema_update, self.data, self.params.numel, ptr(self.data), ptr(self.params.data), self.decay)
 
     def state_dict(self):
-        return OrderedDict(params=self.params.state_dict(self.data), decay=self.decay)
+        own = self.params.state_dict(self.data)
+        full = OrderedDict((k, own[k] if k in own else self.buffers[k]) for k in self.order if k in own or k in self.buffers)
+        return OrderedDict(params=full, decay=self.decay)
+
+    def load_state_dict(self, sd):
+        for k in self.params.shapes:
+            self.params.view(self.data, k).copy_(sd["params"][k].to(torch.float32))
+        self.decay = float(sd.get("decay", self.decay))
+        return self
 
 
 class GradBucketer:

@@ -4,7 +4,9 @@ all-reduce -> gradient clipping + Adam -> EMA, with every piece of arithmetic in
 
 Forward and backward run the fp32-operand form of the network (csrc/k_fp32.hip, k_fp32_bwd.hip, train.inc): the
 gradients are checked against the reference's autograd at fp32 tolerance.  It is a correct training step, not yet a fast
-one (the bf16 MFMA kernels of the sampler have no backward counterparts); see DESIGN.md."""
+one (the bf16 MFMA kernels of the sampler have no backward counterparts); see DESIGN.md.
+
+`python -m mdgen_amd.train` is the launcher (reference: train.py:46-77), one process per GPU under torch.distributed.run."""
 from __future__ import annotations
 
 import ctypes as C
@@ -57,8 +59,10 @@ def flat_order(cfg: ModelConfig) -> "OrderedDict[str, tuple]":
 
 class TrainableModel:
     """A `LatentMDGenModel` whose trainable tensors live in one flat fp32 buffer (`self.params`) next to a flat
-    gradient buffer (`self.grads`); `forward_backward` fills the gradients, `sync_weights` hands the (updated)
-    parameters back to the library (bf16 repack for the sampler kernels + fp32 copies for the training kernels)."""
+    gradient buffer (`self.grads`).  After the first load the library's training kernels read their fp32 weights
+    straight out of that buffer (`mdgen_train_bind_params`): an optimiser step needs NO hand-back.  The sampler's
+    bf16 fragment-packed weights go stale instead; they are re-packed lazily, right before the next network
+    evaluation through `self.model` (`mark_updated` / `sync_weights`)."""
 
     def __init__(self, cfg: ModelConfig, device="cuda"):
         self.cfg = cfg
@@ -71,11 +75,16 @@ class TrainableModel:
         self._goff = (C.c_int64 * len(names))(*[self.params.offsets[n][0] if n in self.params.offsets else -1 for n in names])
         self._tape = None
         self._tape_key = None
+        self._stale = False
+        self.model._pre_run = self._refresh_if_stale
 
     def load_state_dict(self, sd):
         self.params.load_state_dict(sd)
         self._buffers = {k: v for k, v in sd.items() if k not in self.params.offsets}
-        return self.sync_weights()
+        self.sync_weights()
+        with torch.cuda.device(self.device):
+            check(lib.mdgen_train_bind_params(self.model._ctx, ptr(self.params.data), self._goff))
+        return self
 
     def state_dict(self):
         out = OrderedDict(self.params.state_dict())
@@ -83,9 +92,19 @@ class TrainableModel:
         return out
 
     def sync_weights(self):
+        """Re-pack the sampler's bf16 weights from the flat parameters (the training kernels never need this)."""
         self.model.load_state_dict(self.state_dict())
         self.model.set_precision("bf16")          # the sampler's default; forward_backward selects fp32 itself
+        self._stale = False
         return self
+
+    def mark_updated(self):
+        """The flat parameters changed (optimiser step, checkpoint load): the packed sampler weights are stale."""
+        self._stale = True
+
+    def _refresh_if_stale(self):
+        if self._stale:
+            self.sync_weights()
 
     def zero_grad(self):
         self.grads.zero_()
@@ -129,17 +148,30 @@ class TrainableModel:
 class Trainer:
     """`training_step` of the reference (wrapper.py:82-86 -> general_step :367-403) + what Lightning does around it
     (train.py:46-77): zero_grad -> forward/backward -> DDP gradient averaging (bucketed all-reduce over RCCL) ->
-    clip_grad_norm_(grad_clip) -> Adam / AdamW step -> EMA update (`on_before_zero_grad`, wrapper.py:78-80)."""
+    clip_grad_norm_(grad_clip) -> Adam / AdamW step -> EMA update (`on_before_zero_grad`, wrapper.py:78-80).
+
+    `dist`: an initialised `torch.distributed` module (backend "nccl" = RCCL on the GPUs; gloo works on CUDA tensors too and
+    is what the 2-process test on one GPU uses).  At construction rank 0's parameters, Adam moments and EMA are broadcast
+    -- what torch DDP / Lightning do -- so that ranks started from different states cannot silently diverge."""
 
     def __init__(self, wrapper, lr: float = 1e-4, adamw: bool = False, grad_clip: Optional[float] = 1.0,
-                 ema_decay: Optional[float] = None, dist=None):
+                 ema_decay: Optional[float] = None, dist=None, state_dict=None):
         self.wrapper = wrapper                    # a NewMDGenWrapper whose .model is replaced by the trainable model's
+        sd = state_dict if state_dict is not None else getattr(wrapper, "model_state_dict", None)
+        if sd is None:
+            raise L.MdgenError("Trainer needs the model's state dict: load the wrapper with load_model_state_dict() / "
+                               "load_from_checkpoint(), or pass state_dict=...")
         self.tm = TrainableModel(wrapper.cfg, wrapper.device)
-        self.tm.load_state_dict(wrapper.model_state_dict)
+        self.tm.load_state_dict(sd)
         wrapper.model = self.tm.model
         self.opt = Adam(self.tm.params, lr=lr, adamw=adamw, grad_clip=grad_clip)
-        self.ema = EMA(self.tm.params, ema_decay) if ema_decay else None
-        self.buckets = GradBucketer(self.tm.params, self.tm.grads, dist=dist)
+        self.ema = EMA(self.tm.params, ema_decay, buffers=self.tm._buffers, order=list(sd.keys())) if ema_decay else None
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        if self.dist is not None:
+            for buf in [self.tm.params.data, self.opt.exp_avg, self.opt.exp_avg_sq] + ([self.ema.data] if self.ema else []):
+                self.dist.broadcast(buf, 0)
+            self.tm.mark_updated()
+        self.buckets = GradBucketer(self.tm.params, self.tm.grads, dist=self.dist)
         # gradient milestones of the library's backward pass (include/mdgen_amd.h): one event per parameter group, the
         # buckets' all-reduces wait for them on a communication stream of their own
         nl = wrapper.cfg.num_layers
@@ -153,11 +185,28 @@ class Trainer:
             check(lib.mdgen_train_set_milestone_events(self.tm.model._ctx, arr, self._n_milestones))
             self._comm_stream = torch.cuda.Stream(device=self.tm.device)
         self.on_bucket = None                     # test hook: called as on_bucket(i, view) on the communication stream
+        self.exposed_comm_ms = 0.0                # host-side wait for the all-reduces after the backward pass was enqueued
+        self.global_step = 0
+
+    def close(self):
+        """Detach the milestone events from the context: the context (it lives on in `wrapper.model`) must not record on
+        hipEvents whose torch owners have been destroyed."""
+        ctx = getattr(getattr(self, "tm", None), "model", None)
+        if ctx is not None and getattr(ctx, "_ctx", None) and getattr(self, "_events", None):
+            lib.mdgen_train_set_milestone_events(ctx._ctx, None, 0)
+        self._events = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def milestone_of(self, name: str) -> int:
         return grad_milestone(name, self.wrapper.cfg.num_layers)
 
     def training_step(self, batch, t=None, x0=None):
+        import time
         w = self.wrapper
         prep = w.prep_batch(batch)
         x1 = prep["latents"]
@@ -174,9 +223,146 @@ class Trainer:
         # forward_backward has only ENQUEUED the step: the buckets' all-reduces queue up behind the milestone events and
         # overlap with the part of the backward pass that is still running
         self.buckets.launch_on_events(self.milestone_of, self._events, self._comm_stream, on_bucket=self.on_bucket)
+        t0 = time.perf_counter()
         scale = self.buckets.finish()
+        self.exposed_comm_ms = (time.perf_counter() - t0) * 1e3
         self.opt.step(self.tm.grads, grad_scale=scale)
-        self.tm.sync_weights()
+        self.tm.mark_updated()                    # no hand-back: the training kernels read the flat buffer (bind_params)
         if self.ema is not None:
             self.ema.update()
+        self.global_step += 1
         return loss.mean()
+
+    # ---- checkpoint / resume (the Lightning layout `NewMDGenWrapper.load_from_checkpoint` reads) ----
+    def save_checkpoint(self, path):
+        sd = self.tm.state_dict()
+        ckpt = {"state_dict": OrderedDict(("model." + k, v.detach().cpu().clone()) for k, v in sd.items()),
+                "hyper_parameters": {"args": self.wrapper.args},
+                "optimizer_states": [self.opt.state_dict()], "global_step": self.global_step}
+        if self.ema is not None:
+            e = self.ema.state_dict()
+            ckpt["ema"] = {"params": OrderedDict((k, v.detach().cpu().clone()) for k, v in e["params"].items()),
+                           "decay": e["decay"]}
+        torch.save(ckpt, path)
+
+    def load_checkpoint(self, path):
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        sd = {k[len("model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("model.")}
+        self.tm.params.load_state_dict(sd)
+        self.tm.mark_updated()
+        if ckpt.get("optimizer_states"):
+            self.opt.load_state_dict(ckpt["optimizer_states"][0])
+        if self.ema is not None and "ema" in ckpt:
+            self.ema.load_state_dict(ckpt["ema"])
+        self.global_step = int(ckpt.get("global_step", 0))
+        return self
+
+
+def main(argv=None):
+    """`python -m mdgen_amd.train ...` -- counterpart of the reference's launcher (train.py:46-77): the flags of
+    `parse_train_args` that concern this path, one process per GPU under `torch.distributed.run` (RANK / LOCAL_RANK /
+    WORLD_SIZE from the environment, backend nccl = RCCL), DistributedSampler-style sharding of the shuffled epoch,
+    checkpoint per epoch in the Lightning layout.  `--synthetic N`: no dataset, N random-trajectory steps per epoch at
+    (`--batch_size`, `--num_frames`, `--crop`) -- what the bench's training leg and the multi-GPU smoke run use."""
+    import argparse
+    import os
+    import time
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--ckpt", default=None)
+    ap.add_argument("--epochs", type=int, default=100)
+    ap.add_argument("--train_batches", type=int, default=None)
+    ap.add_argument("--batch_size", type=int, default=8, help="per process (Lightning DDP semantics)")
+    ap.add_argument("--grad_clip", type=float, default=1.0)
+    ap.add_argument("--adamW", action="store_true")
+    ap.add_argument("--ema", action="store_true")
+    ap.add_argument("--ema_decay", type=float, default=0.999)
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--train_split", default=None)
+    ap.add_argument("--data_dir", default=None)
+    ap.add_argument("--num_frames", type=int, default=50)
+    ap.add_argument("--crop", type=int, default=256)
+    ap.add_argument("--suffix", default="")
+    ap.add_argument("--atlas", action="store_true")
+    ap.add_argument("--copy_frames", action="store_true")
+    ap.add_argument("--frame_interval", type=int, default=None)
+    ap.add_argument("--overfit", action="store_true")
+    ap.add_argument("--overfit_frame", action="store_true")
+    ap.add_argument("--num_layers", type=int, default=5)
+    ap.add_argument("--abs_pos_emb", action="store_true")
+    ap.add_argument("--prepend_ipa", action="store_true")
+    ap.add_argument("--sim_condition", action="store_true")
+    ap.add_argument("--tps_condition", action="store_true")
+    ap.add_argument("--out_dir", default=os.environ.get("MODEL_DIR", "."))
+    ap.add_argument("--ckpt_freq", type=int, default=1)
+    ap.add_argument("--print_freq", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=137)
+    ap.add_argument("--synthetic", type=int, default=0, metavar="N", help="N synthetic steps per epoch instead of a dataset")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    a = ap.parse_args(argv)
+    if not a.prepend_ipa or a.sim_condition == a.tps_condition:
+        raise SystemExit("the accelerated path trains the prepend_ipa models with exactly one of --sim_condition / --tps_condition")
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist_.init_process_group(a.backend, **({"device_id": dev} if a.backend == "nccl" else {}))
+        dist = dist_
+    from .synthetic import synth_state_dict
+    from .wrapper import NewMDGenWrapper
+    cfg = ModelConfig(crop=a.crop, num_frames=a.num_frames, abs_pos_emb=a.abs_pos_emb, num_layers=a.num_layers,
+                      sim_condition=a.sim_condition, tps_condition=a.tps_condition)
+    if a.ckpt:
+        w = NewMDGenWrapper.load_from_checkpoint(a.ckpt, device=dev)
+    else:
+        w = NewMDGenWrapper(cfg, device=dev)
+        w.load_model_state_dict(synth_state_dict(cfg, a.seed))    # (every rank: same seed; rank 0's values are broadcast anyway)
+    tr = Trainer(w, lr=a.lr, adamw=a.adamW, grad_clip=a.grad_clip, ema_decay=a.ema_decay if a.ema else None, dist=dist)
+    if a.ckpt:
+        tr.load_checkpoint(a.ckpt)
+    import numpy as np
+    np.random.seed(a.seed + rank)
+    torch.manual_seed(a.seed + rank)
+    if a.synthetic:
+        import bench as _bench   # repository root: synthetic conditioning batch (frames, torsions) shared with bench.py
+        def batches(epoch):
+            for i in range(a.synthetic):
+                yield _bench.synth_batch(a.batch_size, a.num_frames, a.crop, 16 if a.crop >= 64 else 0, dev,
+                                         seed=1000 * epoch + 10 * i + rank, tps=a.tps_condition)
+    else:
+        from .dataset import MDGenDataset
+        ds = MDGenDataset(a, split=a.train_split, device=dev)
+        def batches(epoch):
+            g = torch.Generator().manual_seed(a.seed + epoch)      # same permutation on every rank, disjoint strided shards
+            order = torch.randperm(len(ds), generator=g).tolist()[rank::world]
+            n = len(order) // a.batch_size
+            if a.train_batches:
+                n = min(n, a.train_batches)
+            for i in range(n):
+                items = [ds[j] for j in order[i * a.batch_size:(i + 1) * a.batch_size]]
+                yield {k: torch.stack([it[k] for it in items]) for k in ("torsions", "torsion_mask", "trans", "rots", "seqres", "mask")}
+    for epoch in range(a.epochs):
+        t0, n, comm = time.perf_counter(), 0, 0.0
+        for batch in batches(epoch):
+            loss = tr.training_step(batch)
+            n += 1
+            comm += tr.exposed_comm_ms
+            if rank == 0 and n % a.print_freq == 0:
+                print(f"epoch {epoch} step {n}: loss {float(loss):.4f}", flush=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            print(f"epoch {epoch}: {n} steps, {dt / max(n, 1) * 1e3:.1f} ms/step, exposed all-reduce wait {comm / max(n, 1):.2f} ms/step, "
+                  f"world {world}", flush=True)
+            if (epoch + 1) % a.ckpt_freq == 0:
+                os.makedirs(a.out_dir, exist_ok=True)
+                tr.save_checkpoint(os.path.join(a.out_dir, f"epoch={epoch}.ckpt"))
+    tr.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -210,7 +210,7 @@ def gen_prep(name, cfg, B, T, L, data_seed):
          end_rot=kw["end_frames"]._rots.get_rot_mats(), end_trans=kw["end_frames"]._trans)
 
 
-def gen_inference(name, cfg, seed, B, T, L, steps, data_seed, n_blocks=1):
+def gen_inference(name, cfg, seed, B, T, L, steps, data_seed, n_blocks=1, slim=False):
     """End-to-end inference() (wrapper.py:405-484) with explicit zs, S steps, plus the rollout glue
     (sim_inference.py:61-98) chaining `n_blocks` blocks."""
     g = torch.Generator().manual_seed(data_seed)
@@ -243,7 +243,8 @@ def gen_inference(name, cfg, seed, B, T, L, steps, data_seed, n_blocks=1):
                 torch.randn = orig_randn
                 del m.transport_sampler.sample_ode
             out[f"S{S}_b{blk}_zs"] = zs
-            out[f"S{S}_b{blk}_samples"] = samples
+            if not slim:
+                out[f"S{S}_b{blk}_samples"] = samples
             out[f"S{S}_b{blk}_atom14"] = atom14
             # rollout glue (sim_inference.py:91-96)
             fr = G.atom14_to_frames(atom14[:, -1])
@@ -253,9 +254,10 @@ def gen_inference(name, cfg, seed, B, T, L, steps, data_seed, n_blocks=1):
             cur["trans"] = fr._trans[:, None]
             cur["rots"] = fr._rots._rot_mats[:, None]
             cur["torsions"] = tors[:, None]
-            out[f"S{S}_b{blk}_next_trans"] = cur["trans"]
-            out[f"S{S}_b{blk}_next_rots"] = cur["rots"]
-            out[f"S{S}_b{blk}_next_torsions"] = cur["torsions"]
+            if not slim:
+                out[f"S{S}_b{blk}_next_trans"] = cur["trans"]
+                out[f"S{S}_b{blk}_next_rots"] = cur["rots"]
+                out[f"S{S}_b{blk}_next_torsions"] = cur["torsions"]
     save(name, **out)
 
 
@@ -325,6 +327,9 @@ if __name__ == "__main__":
         # S = 49 is the reference's hard-coded step count (wrapper.py:441-442) and the product default
         "inference_sim": lambda: gen_inference("inference_sim", ModelConfig.forward_sim(num_frames=12, crop=4), 8, B=2,
                                                T=12, L=4, steps=[1, 10, 49], data_seed=41, n_blocks=2),
+        # the README run chains 10 blocks (sim_inference.py:110-113, README.md:72 --num_rollouts 10): error growth per block
+        "rollout10_sim": lambda: gen_inference("rollout10_sim", ModelConfig.forward_sim(num_frames=8, crop=4), 8, B=1,
+                                               T=8, L=4, steps=[10], data_seed=43, n_blocks=10, slim=True),
         "inference_tiny": lambda: gen_inference("inference_tiny", ModelConfig(crop=4, num_frames=10, **tiny), 9, B=1,
                                                 T=10, L=4, steps=[10, 49], data_seed=42, n_blocks=1),
     }

@@ -26,7 +26,7 @@ for _ in range(reps):
     tm.zero_grad()
     loss, _ = tm.forward_backward(*args)
     opt.step(tm.grads)
-    tm.sync_weights()
+    tm.mark_updated()   # no hand-back: the training kernels read the flat parameter buffer
 torch.cuda.synchronize()
 dt = (time.time() - t0) / reps
 print(f"training step B{B} T{T} L{L}: {dt * 1e3:.1f} ms  ({B * T / dt:.0f} frames/s); loss {float(loss):.4f}; "
