@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParam
 #endif
         });
     };
-    // The whole (head, 32 NQ queries) job; returns with the last pair's PV MFMAs issued.
-    auto run = [&](auto robust) __attribute__((always_inline)) {
+    // The whole (head, 32 NQ queries) job over key tiles 0 .. nt - 1; returns with the last pair's PV MFMAs issued.
+    auto run = [&](auto robust, const int nt) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j)
 #pragma unroll
@@ -348,6 +348,61 @@ __global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParam
         }
     };
 
+    // ---- a sequence with NO valid key but the learned bias key (a padded residue's temporal sequence: 6 % of the waves of
+    //      the ATLAS config, which used to take the robust loop to compute a softmax over one key): the output of every
+    //      query is exactly bias_v (rounded to bf16 as the V^T fragment holds it).  Written directly.
+    if (nt <= 64 && !p.force_robust) {
+        const uint32_t want = lane == (len >> 5) ? 1u << (len & 31) : 0u;
+        const bool only_bias = __builtin_amdgcn_ballot_w64(lane < nt && vmw != want) == 0;
+        if (only_bias) {
+            const f32x4* bv = reinterpret_cast<const f32x4*>(p.bias_v + head * kDH + hh * 12);
+            const f32x4 b0 = bv[0], b1 = bv[1], b2 = bv[2];
+            const u32x2 d0 = {pack_bf16(b0[0], b0[1]), pack_bf16(b0[2], b0[3])}, d1 = {pack_bf16(b1[0], b1[1]), pack_bf16(b1[2], b1[3])},
+                        d2 = {pack_bf16(b2[0], b2[1]), pack_bf16(b2[2], b2[3])};
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int pos = (qt0 + j) * 32 + ql;
+                if (qvalid[j] && pos < len) {
+                    u32x2* d = reinterpret_cast<u32x2*>(p.obuf + (seq_base + (long)pos * pstride) * kC + head * kDH + hh * 12);
+                    d[0] = d0;
+                    d[1] = d1;
+                    d[2] = d2;
+                }
+            }
+            return;
+        }
+    }
+    // ---- len a multiple of 32: the bias key sits ALONE in the last tile (key slot 0 of tile len / 32).  The fixed-anchor
+    //      loop then skips that tile (one of nine at L = 256) and adds the key as a rank-1 term afterwards; its score is the
+    //      plain dot product of this lane's q values with the key's (both bf16, as the MFMA sees them).  The robust loop
+    //      keeps walking all nt tiles.
+    const bool bias_alone = (len & 31) == 0 && len >= 32;
+    const int nt_fast = bias_alone ? nt - 1 : nt;
+    float sbias[NQ], vbias[12];
+    if (bias_alone) {
+        const unsigned char* kb = p.kf + (ftile + (len >> 5)) * kFragK + hh * 32 * 16;   // key slot 0 of this lane half
+        const u32x4 kb0 = *reinterpret_cast<const u32x4*>(kb);
+        const u32x2 kb1 = *reinterpret_cast<const u32x2*>(kb + 1024);
+        const f32x4* bv = reinterpret_cast<const f32x4*>(p.bias_v + head * kDH + hh * 12);
+        const f32x4 b0 = bv[0], b1 = bv[1], b2 = bv[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vbias[i] = round_bf16(b0[i]);
+            vbias[4 + i] = round_bf16(b1[i]);
+            vbias[8 + i] = round_bf16(b2[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const u32x4 qa = __builtin_bit_cast(u32x4, q[j].q0);
+            const u32x4 qb_ = __builtin_bit_cast(u32x4, q[j].q1);   // elements 0..3 real, 4..7 the -M slots / zeros: not used
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d += bf16_lo(qa[i]) * bf16_lo(kb0[i]) + bf16_hi(qa[i]) * bf16_hi(kb0[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) d += bf16_lo(qb_[i]) * bf16_lo(kb1[i]) + bf16_hi(qb_[i]) * bf16_hi(kb1[i]);
+            sbias[j] = d + __shfl_xor(d, 32, 64);
+        }
+    }
     // ---- FAST loop: anchor every query tile kAnchor above the row max of key tile 0 and never move the shift.
     bool robust_needed = p.force_robust != 0;
     {
@@ -369,7 +424,17 @@ __global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParam
     FLASH_STAMP(6, (unsigned long long)robust_needed);
     FLASH_STAMP(8, (unsigned long long)__float_as_uint(h[0].m));   // lane 0's fixed anchor (first-tile row max + kAnchor)
     if (!robust_needed) {
-        run(std::false_type{});
+        run(std::false_type{}, nt_fast);
+        if (bias_alone) {
+            // the learned bias key as a rank-1 term: P_b = 2^(q . k_b - M), O += P_b v_b, denominator += P_b
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const float pb = __builtin_amdgcn_exp2f(sbias[j] - h[j].m);
+#pragma unroll
+                for (int r = 0; r < 12; ++r) h[j].o[r] += pb * vbias[r];
+                if (hh == 0) h[j].o[12] += pb;
+            }
+        }
         FLASH_STAMP(2, __builtin_amdgcn_s_memtime());
         // every P of a query row is summed into its denominator (register 12 of the lanes hh == 0): finite and
         // positive <=> no P overflowed.  Bit tests, not float compares: this file is built with -fno-honor-nans.
@@ -398,7 +463,7 @@ __global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParam
             h[j].unanch = ~0ull;
             set_shift(q[j], 0.f, hh);
         }
-        run(std::true_type{});
+        run(std::true_type{}, nt);
     }
     FLASH_STAMP(3, __builtin_amdgcn_s_memtime());
     FLASH_STAMP(11, (unsigned long long)__float_as_uint(h[0].m));   // lane 0's final shift (robust loop: ~ the true row max)

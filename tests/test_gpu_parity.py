@@ -49,7 +49,7 @@ def _kw(g, dev):
 def test_native_library_is_loaded():
     import mdgen_amd._lib as L
     assert os.path.exists(L.LIB_PATH)
-    assert L.lib.mdgen_abi_version() == 1
+    assert L.lib.mdgen_abi_version() == L.ABI_VERSION
     with open("/proc/self/maps") as f:
         assert "libmdgen_amd.so" in f.read()
 
