@@ -264,9 +264,10 @@ def sampler_leg(workload, dev, steps, warmup, S, options, roofline=False, rollou
     return res
 
 
-def training_leg(dev, reps=2):
-    """One training step (forward + backward + clip + Adam + weight hand-back) at configs[4]'s per-GPU shape (ATLAS crop 256 x
-    250 frames, B = 1), no gradient exchange (1 GPU).  flops = 3 x the forward's algorithmic flops."""
+def training_leg(dev, reps=2, train_precision=32):
+    """One training step (forward + backward + clip + Adam) at configs[4]'s per-GPU shape (ATLAS crop 256 x 250 frames,
+    B = 1), no gradient exchange (1 GPU).  flops = 3 x the forward's algorithmic flops.  train_precision: 32 =
+    fp32 operands (exact mode), 16 = bf16 operands in the linear layers / weight gradients (the reference's `medium`)."""
     from mdgen_amd.config import ModelConfig
     from mdgen_amd.optim import Adam
     from mdgen_amd.synthetic import synth_state_dict, synth_forward_inputs
@@ -278,6 +279,7 @@ def training_leg(dev, reps=2):
     ut = torch.randn(B, T, L, cfg.latent_dim, generator=gen)
     lm = (torch.rand(B, T, L, cfg.latent_dim, generator=gen) > 0.1).float() * inp["mask"][..., None]
     tm = TrainableModel(cfg, dev).load_state_dict(synth_state_dict(cfg, 6))
+    tm.model.set_option("train_precision", train_precision)
     args = (inp["x"].to(dev), inp["t"].to(dev), ut.to(dev), lm.to(dev), inp["mask"].to(dev),
             (inp["start_rot"].to(dev), inp["start_trans"].to(dev)), inp["x_cond"].to(dev), inp["x_cond_mask"].to(dev),
             inp["aatype"].to(dev))
@@ -300,7 +302,9 @@ def training_leg(dev, reps=2):
     N, C = B * T * L, 384
     fwd = N * (6 * 21 * C + 5 * (32 * C * C + 4 * C * (L + 1) + 4 * C * (T + 1)))
     return {"workload": "atlas_train_crop256_T250_B1", "ms_per_step": round(dt * 1e3, 2), "frames_per_s": round(B * T / dt, 1),
-            "TFLOPs": round(3 * fwd / dt / 1e12, 1), "arithmetic": "fp32 operands (exact mode)", "steps": reps}
+            "TFLOPs": round(3 * fwd / dt / 1e12, 1), "steps": reps,
+            "arithmetic": "fp32 operands (exact mode)" if train_precision == 32 else
+                          "bf16 operands in linear layers / weight gradients, fp32 accumulate + master weights; rest fp32"}
 
 
 def extra_legs(dev, options):
@@ -316,7 +320,8 @@ def extra_legs(dev, options):
     run("tetrapeptide_tps_crop4_T100_B32", lambda: sampler_leg("tetrapeptide_tps_crop4_T100_B32", dev, 3, 1, 49, options))
     run("tetrapeptide_fwdsim_crop4_T1000_B1", lambda: sampler_leg("tetrapeptide_fwdsim_crop4_T1000_B1", dev, 3, 1, 49, options))
     run("rollout_10_blocks_T1000_B16", lambda: sampler_leg("tetrapeptide_fwdsim_crop4_T1000_B16", dev, 1, 1, 49, options, rollouts=10))
-    run("atlas_train_crop256_T250_B1", lambda: training_leg(dev))
+    run("atlas_train_crop256_T250_B1", lambda: training_leg(dev, train_precision=16))
+    run("atlas_train_crop256_T250_B1_fp32", lambda: training_leg(dev, train_precision=32))
     ex["seconds"] = round(time.perf_counter() - t0, 1)
     return ex
 

@@ -116,6 +116,7 @@ struct mdgen_ctx {
     int opt_attn_path = 0;      // tiled attention: 0 fixed-anchor fast loop with overflow check + fallback, 1 robust loop always
     int opt_mlp_path = 1;       // MLP block: 0 resident-panel kernel (k_mlp), 1 row-owner kernel (k_mlp_rows) when the launch
                                 // fills the chip, 2 row-owner kernel always
+    int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
     std::vector<void*> milestone_events;          // mdgen_train_set_milestone_events (hipEvent_t handles, caller-owned)
     unsigned long long* phase_trace = nullptr;   // mdgen_profile_phase_trace target (device), consumed by one launch
@@ -568,6 +569,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "mlp_path") {
         if (value < 0 || value > 2) return fail(-2, "mlp_path must be 0 (panel kernel), 1 (row-owner kernel when it fills the chip) or 2 (always)");
         c->opt_mlp_path = value;
+    } else if (n == "train_precision") {
+        if (value != 16 && value != 32) return fail(-2, "train_precision must be 32 (fp32 operands, exact) or 16 (bf16 operands, fp32 accumulate)");
+        c->opt_train_precision = value;
     } else if (n == "residue_l4_path") {
         if (value < 0 || value > 2) return fail(-2, "residue_l4_path must be 0, 1 or 2");
         c->opt_residue_l4 = value;

@@ -98,9 +98,29 @@ class TrainableModel:
         self._stale = False
         return self
 
+    # weights whose only consumers in the TRAINING path are the bound fp32 views (attention / MLP / IPA / final linear layers,
+    # k_fp32.hip reads them through the context's key -> pointer table); their bf16 fragment packs feed the sampler only
+    _PACKED = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "out_proj.weight", "fc1.weight", "fc2.weight",
+               "linear_q.weight", "linear_kv.weight", "linear_q_points.weight", "linear_kv_points.weight",
+               "linear_out.weight", "emb_to_latent.linear.weight")
+
     def mark_updated(self):
-        """The flat parameters changed (optimiser step, checkpoint load): the packed sampler weights are stale."""
+        """The flat parameters changed (optimiser step, checkpoint load).  The tensors the training kernels read from the
+        context's OWN fp32 tables (time embedder, the concatenated adaLN table, token / residue embeddings, IPA norm and head
+        weights, permuted biases) are handed over again right away -- plain device copies from the flat buffer's views, enqueued
+        on the stream, no host synchronisation; the bf16 fragment packs of the big matrices (90 % of the bytes, sampler only) are
+        left stale until the next network evaluation through `self.model`."""
         self._stale = True
+        m = self.model
+        sd = self.params.state_dict()
+        with torch.cuda.device(self.device):
+            s = L.stream_ptr()
+            for k, v in sd.items():
+                if k.endswith(self._PACKED):
+                    continue
+                shp = (C.c_int64 * v.dim())(*v.shape)
+                check(lib.mdgen_ctx_set_weight(m._ctx, k.encode(), ptr(v), shp, v.dim(), s))
+            check(lib.mdgen_ctx_finalize(m._ctx, s))
 
     def _refresh_if_stale(self):
         if self._stale:

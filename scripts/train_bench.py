@@ -9,6 +9,7 @@ from mdgen_amd.train import TrainableModel
 dev = torch.device("cuda")
 B, T, L = [int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (1, 250, 256))]
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+prec = int(sys.argv[5]) if len(sys.argv) > 5 else 32   # train_precision: 32 exact fp32 operands, 16 bf16 operands
 cfg = ModelConfig.atlas(num_frames=T, crop=L)
 sd = synth_state_dict(cfg, 6)
 inp = synth_forward_inputs(cfg, B, T, L, 16 if L >= 64 else 0, 27)
@@ -16,6 +17,7 @@ gen = torch.Generator().manual_seed(5)
 ut = torch.randn(B, T, L, cfg.latent_dim, generator=gen)
 lm = (torch.rand(B, T, L, cfg.latent_dim, generator=gen) > 0.1).float() * inp["mask"][..., None]
 tm = TrainableModel(cfg, dev).load_state_dict(sd)
+tm.model.set_option("train_precision", prec)
 args = (inp["x"].to(dev), inp["t"].to(dev), ut.to(dev), lm.to(dev), inp["mask"].to(dev),
         (inp["start_rot"].to(dev), inp["start_trans"].to(dev)), inp["x_cond"].to(dev), inp["x_cond_mask"].to(dev),
         inp["aatype"].to(dev))
@@ -29,5 +31,5 @@ for _ in range(reps):
     tm.mark_updated()   # no hand-back: the training kernels read the flat parameter buffer
 torch.cuda.synchronize()
 dt = (time.time() - t0) / reps
-print(f"training step B{B} T{T} L{L}: {dt * 1e3:.1f} ms  ({B * T / dt:.0f} frames/s); loss {float(loss):.4f}; "
+print(f"training step B{B} T{T} L{L} train_precision {prec}: {dt * 1e3:.1f} ms  ({B * T / dt:.0f} frames/s); loss {float(loss):.4f}; "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")

@@ -1468,7 +1468,7 @@ def test_ten_chained_blocks_error_growth():
     gated: tests/test_oracle_cpu.py::test_ten_chained_blocks_vs_reference shows that on these (random-weight, unphysical)
     structures the rollout glue amplifies even fp32 summation-order noise to ~0.1 A max by block 2 and ~0.4 A by block 9 --
     the reference does not track ITSELF more closely than that -- so the per-block bounds below are the single-block bf16
-    bound for block 0, fp32-tight bounds for the fp32 mode's first two blocks, and an rms bound afterwards."""
+    bound for block 0, an fp32-tight bound for the fp32 mode's block 0, and an rms bound afterwards."""
     from mdgen_amd.wrapper import NewMDGenWrapper
     dev = _cuda()
     g = load_golden("rollout10_sim")
@@ -1490,8 +1490,8 @@ def test_ten_chained_blocks_error_growth():
             if left is None and mx > 0.5:
                 left = r
             print(f"{prec} operands, block {r}: atom14 rms {rms:.4f} A max {mx:.4f} A")
-            if prec == "fp32":
-                assert (mx < 1e-3 if r < 2 else rms < 0.1), (prec, r, rms, mx)
+            if prec == "fp32":   # block 1 already starts from OUR block-0 end frame: the glue's amplification applies from there on
+                assert (mx < 1e-3 if r < 1 else rms < 0.1), (prec, r, rms, mx)
             else:
                 assert (rms < 0.05 and mx < 0.5) if r == 0 else rms < 0.25, (prec, r, rms, mx)
         print(f"{prec} operands: first block whose max deviation exceeds 0.5 A: {left}")
@@ -1527,7 +1527,7 @@ def test_time_embedding_and_adaln_table_all_steps():
     modrow = nl * 15 * C_ + 2 * C_
     tab = ws[lay.mod:lay.mod + S * modrow * 4].view(torch.float32).view(S, modrow).cpu()
     tg = torch.linspace(0, 1, S + 1)[:S]
-    temb = O.t_embedder(sd, tg)                                    # (S, C)
+    temb = O.t_embedder(sd, tg * cfg.time_multiplier)              # (S, C); latent_model.py:243
     act = F.silu(temb)
     worst = 0.0
     for i in range(nl):                                            # library row layout: trunk i at 9C i, IPA i at 9C nl + 6C i, final at 15C nl
@@ -1539,3 +1539,43 @@ def test_time_embedding_and_adaln_table_all_steps():
     worst = max(worst, rel_l2(tab[:, nl * 15 * C_:], ref))
     print(f"adaLN table, {S} steps x {modrow} floats: worst block rel-L2 vs the oracle {worst:.2e}")
     assert worst < 1e-5
+
+
+def test_training_gradients_bf16_operands_vs_reference_fixture():
+    """Option train_precision = 16: the training step's linear layers and weight gradients multiply bf16-rounded operands on
+    the bf16 MFMA with fp32 accumulation and fp32 master weights -- the precision class the reference trains with (train.py:13
+    `set_float32_matmul_precision('medium')`); LayerNorm, softmax / attention, GELU, reductions stay fp32.  Gate against the
+    reference's own fp32 autograd gradients (train_grads_sim.npz): loss to 1e-2 relative, every tensor's gradient samples to
+    rel-L2 5e-2 and cosine 0.999 (tensors whose gradient is at the noise floor excepted), the exact mode (32) stays as tested
+    above."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.train import TrainableModel
+    dev = _cuda()
+    g = load_golden("train_grads_sim")
+    cfg, sd = weights_for(g)
+    xt, ut = O.path_plan(g["t"], g["x0"], g["x1"], "GVP")
+    tm = TrainableModel(cfg, dev).load_state_dict(sd)
+    tm.model.set_option("train_precision", 16)
+    tm.zero_grad()
+    loss, _ = tm.forward_backward(xt.to(dev), g["t"].to(dev), ut.to(dev), g["loss_mask"].to(dev), g["mask"].to(dev),
+                                  (g["start_rot"].to(dev), g["start_trans"].to(dev)), g["x_cond"].to(dev),
+                                  g["x_cond_mask"].to(dev), g["aatype"].to(dev))
+    assert torch.allclose(loss.cpu(), g["loss"], rtol=1e-2), (loss.cpu(), g["loss"])
+    got = tm.params.state_dict(tm.grads)
+    names = [str(n) for n in g["grad_names"]]
+    gmax = max(float(g["gnorm_" + k]) for k in names)
+    rep = []
+    for k in names:
+        gr = got[k].reshape(-1).cpu()
+        ref = g["gsamp_" + k]
+        mine = gr[::int(g["gstride_" + k])][:2048]
+        e = rel_l2(mine, ref)
+        cos = float((mine.double() @ ref.double()) / (mine.double().norm() * ref.double().norm() + 1e-300))
+        rep.append((e, cos, k, float(g["gnorm_" + k])))
+    rep.sort(reverse=True)
+    print("bf16-operand training step, worst gradients (rel-L2, cosine, tensor):", [(f"{e:.1e}", f"{c:.4f}", k) for e, c, k, _ in rep[:6]])
+    for e, cos, k, nrm in rep:
+        if nrm < 1e-4 * gmax:   # a gradient at the noise floor (e.g. an attention's key bias: softmax is invariant to it)
+            continue
+        assert e < 5e-2 and cos > 0.999, (k, e, cos)
+    tm.model.set_option("train_precision", 32)
