@@ -249,6 +249,23 @@ __global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParam
         q[j].q1 = frag8(qb + (long)qt * kFragQ + 1024 + lane * 8);
     }
 
+    // len a multiple of 32: the learned bias key sits ALONE in the last tile and is handled as a rank-1 term (below); its K
+    // slot and value row are requested here, with Q, so that their round trip is hidden (requested at their use they cost
+    // more than the tile they save)
+    const bool bias_alone = (len & 31) == 0 && len >= 32;
+    u32x4 kb0 = {0u, 0u, 0u, 0u};
+    u32x2 kb1 = {0u, 0u};
+    f32x4 bvl[3] = {};
+    {
+        const unsigned char* kb = p.kf + (ftile + (bias_alone ? (len >> 5) : 0)) * kFragK + hh * 32 * 16;   // key slot 0 of this lane half
+        kb0 = *reinterpret_cast<const u32x4*>(kb);
+        kb1 = *reinterpret_cast<const u32x2*>(kb + 1024);
+        const f32x4* bv = reinterpret_cast<const f32x4*>(p.bias_v + head * kDH + hh * 12);
+        bvl[0] = bv[0];
+        bvl[1] = bv[1];
+        bvl[2] = bv[2];
+    }
+
     // ---- K / V^T streams: one buffer descriptor each (wave-uniform base = this (sequence, head)'s first tile), a
     // constant per-lane byte offset, and the tile offset as the scalar offset of the load.  V^T: rows d <= 24 are
     // lanes of the fragment (row 24 = ones); the lanes of rows d > 24 point far out of range and read zeros.
@@ -355,8 +372,7 @@ __global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParam
         const uint32_t want = lane == (len >> 5) ? 1u << (len & 31) : 0u;
         const bool only_bias = __builtin_amdgcn_ballot_w64(lane < nt && vmw != want) == 0;
         if (only_bias) {
-            const f32x4* bv = reinterpret_cast<const f32x4*>(p.bias_v + head * kDH + hh * 12);
-            const f32x4 b0 = bv[0], b1 = bv[1], b2 = bv[2];
+            const f32x4 b0 = bvl[0], b1 = bvl[1], b2 = bvl[2];
             const u32x2 d0 = {pack_bf16(b0[0], b0[1]), pack_bf16(b0[2], b0[3])}, d1 = {pack_bf16(b1[0], b1[1]), pack_bf16(b1[2], b1[3])},
                         d2 = {pack_bf16(b2[0], b2[1]), pack_bf16(b2[2], b2[3])};
 #pragma unroll
@@ -376,15 +392,10 @@ __global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParam
     //      loop then skips that tile (one of nine at L = 256) and adds the key as a rank-1 term afterwards; its score is the
     //      plain dot product of this lane's q values with the key's (both bf16, as the MFMA sees them).  The robust loop
     //      keeps walking all nt tiles.
-    const bool bias_alone = (len & 31) == 0 && len >= 32;
     const int nt_fast = bias_alone ? nt - 1 : nt;
     float sbias[NQ], vbias[12];
     if (bias_alone) {
-        const unsigned char* kb = p.kf + (ftile + (len >> 5)) * kFragK + hh * 32 * 16;   // key slot 0 of this lane half
-        const u32x4 kb0 = *reinterpret_cast<const u32x4*>(kb);
-        const u32x2 kb1 = *reinterpret_cast<const u32x2*>(kb + 1024);
-        const f32x4* bv = reinterpret_cast<const f32x4*>(p.bias_v + head * kDH + hh * 12);
-        const f32x4 b0 = bv[0], b1 = bv[1], b2 = bv[2];
+        const f32x4 b0 = bvl[0], b1 = bvl[1], b2 = bvl[2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             vbias[i] = round_bf16(b0[i]);

@@ -188,7 +188,9 @@ __device__ __forceinline__ void pipe_block(MlpPipe& m, const bf16x8 (&xf)[24], f
         } else {
             m.y[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], hfr[KI], m.y[q], 0, 0, 0);
         }
+#ifndef MDGEN_DEV_ROWS_NOGELU   // (experiment build, timing only: the main loop without its VALU work)
         if (GG >= 0) gelu_stage_q<REARM>(m, a1r, GG, q, hfw);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }

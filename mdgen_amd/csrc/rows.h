@@ -112,8 +112,15 @@ __device__ __forceinline__ void rows_ln(const float* __restrict__ x, int tok, co
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
     const unsigned off = tokc * (unsigned)(kC * 4) + (unsigned)hh * 16u;
     f32x4 v[48];
+#ifdef MDGEN_DEV_ROWS_COALESCED   // (experiment build: the same 48 KiB per wave read as 48 fully coalesced 1 KiB requests -- WRONG values,
+                                  // timing only: does the 32-byte-per-row request pattern cost HBM efficiency?)
+    const unsigned offc = (tokc & ~31u) * (unsigned)(kC * 4) + (unsigned)lane_id() * 16u;
+#pragma unroll
+    for (int i = 0; i < 48; ++i) v[i] = *reinterpret_cast<const f32x4*>(xb + offc + 1024u * i);
+#else
 #pragma unroll
     for (int i = 0; i < 48; ++i) v[i] = *reinterpret_cast<const f32x4*>(xb + off + 32u * i);
+#endif
     const unsigned mo = tok < 0 ? 0u : (unsigned)mm.row_off(tokc);
     const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
     const unsigned osc = (mo + (unsigned)(scale_chunk * kC)) * 4u + (unsigned)hh * 16u;
