@@ -36,16 +36,10 @@ struct MlpPipe {
 // MFMA), at most two of them transcendental, and every MFMA of a block carries one stage (4-5 VALU instructions; the
 // matrix pipe hides ~5, MI355X_MICROARCH "one wave per SIMD").  The fc1 bias is not added here: the accumulators
 // START from it -- stages 7, 10, 11 re-arm the four registers with the bias of the chunk two further on (REARM).
-__device__ __forceinline__ void acc_rearm(f32x16& t, int r, float b) { t[r] = b; }
-// fc1 accumulators live in ARCHITECTURAL VGPRs: the GELU reads them and the re-arm writes them with plain VALU operands
-// (in the accumulation file every access costs a v_accvgpr_read / _write: 8 of the 46 VALU instructions of a GELU group,
-// and the main loop is bound by exactly those -- without its VALU work it runs at 31.3 cycles per MFMA, with it at 43).
-// hipcc selects the accumulation-file form for every MFMA of a kernel that uses that file at all, hence inline asm.
-// Hazards hipcc does not pad for an asm statement (cdna_hip_programming.md 5.7): result -> VALU read needs 18 wait states,
-// VALU write -> srcC 2 -- here the GELU stage that reads a tile's registers runs >= 12 MFMAs after the tile's last MFMA
-// and the re-arm >= 12 MFMAs before its first, by construction of the pipeline (asserted by the block schedule below).
-__device__ __forceinline__ void mfma_vgpr(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+__device__ __forceinline__ void acc_rearm(f32x16& t, int r, float b) {
+    float z;
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(z) : "v"(b));
+    t[r] = z;
 }
 // Phi as a logistic of an odd polynomial with THREE coefficients (the panel kernel's gelu_erf has five): max abs error of
 // gelu 2.9e-5 (scripts/fit_gelu.py --rows), against the bf16 rounding applied right after (relative 2^-9).  The leading
@@ -56,8 +50,9 @@ template <int ST, bool REARM>
 __device__ __forceinline__ void gelu_stage(MlpPipe& m, f32x16 (&a1r)[2], int g, bf16x8 (&hfw)[4]) {
     const int tile = g >> 2, a = g & 3;
     if (ST == 0) {
+        // explicit accumulator-file reads: left to hipcc, the whole 16-register tuple is copied to VGPRs at its first use
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m.gx[j] = a1r[tile][4 * a + j];
+        for (int j = 0; j < 4; ++j) asm("v_accvgpr_read_b32 %0, %1" : "=v"(m.gx[j]) : "a"(a1r[tile][4 * a + j]));
     } else if (ST == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) m.gq[j] = m.gx[j] * m.gx[j];
@@ -187,12 +182,9 @@ __device__ __forceinline__ void pipe_block(MlpPipe& m, const bf16x8 (&xf)[24], f
         if (FILL && q % STRIDE == 0) issue_q<NW, ((I0 / 12) & 1) * DPB, STRIDE>(ws, fill_slot, q);
         if (q < NLOOK) m.wr[(I + kWPF) % kWRing] = *reinterpret_cast<const bf16x8*>(ring_lane + ((I + kWPF) % kRingFrags) * 1024);
         if (GG >= 0 && REARM && q == 0) m.bias = *reinterpret_cast<const f32x4*>(b1n + 32 * (GG >> 2) + 8 * (GG & 3));
-#ifdef MDGEN_DEV_ROWS_PAIRWAIT   // (experiment build: one s_waitcnt per TWO fragments -- the even step also waits for the odd step's fragment)
-        if ((q & 1) == 0) asm volatile("" ::"v"(m.wr[(I + 1) % kWRing]));
-#endif
         if (KIND == 0) {
             const int ks = 6 * KI + (q >> 1), tile = q & 1;
-            mfma_vgpr(a1w[tile], m.wr[I % kWRing], xf[ks]);
+            a1w[tile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], xf[ks], a1w[tile], 0, 0, 0);
         } else {
             m.y[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], hfr[KI], m.y[q], 0, 0, 0);
         }
