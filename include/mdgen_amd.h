@@ -35,6 +35,10 @@ extern "C" {
 
 typedef struct mdgen_ctx mdgen_ctx;
 
+/* 0 for a product library; 1 if the .so was built with a kernel experiment switch (csrc/dev.h, scripts/micro/): timing-only
+ * builds whose results may be wrong.  mdgen_amd/_lib.py loads such a library only when MDGEN_AMD_LIB names it explicitly. */
+int32_t mdgen_dev_build(void);
+
 /* Model hyper-parameters (reference argparse flags, mdgen/parsing.py:79-120). */
 typedef struct mdgen_model_desc {
     int32_t embed_dim;      /* must be 384 */

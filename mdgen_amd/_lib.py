@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MDGEN_AMD_LIB", os.path.join(_HERE, "libmdgen_amd.so"
 ABI_VERSION = 3   # include/mdgen_amd.h MDGEN_ABI_VERSION
 
 EXPORTS = [
-    "mdgen_last_error", "mdgen_abi_version", "mdgen_ctx_create", "mdgen_ctx_destroy", "mdgen_ctx_set_weight",
+    "mdgen_last_error", "mdgen_abi_version", "mdgen_dev_build", "mdgen_ctx_create", "mdgen_ctx_destroy", "mdgen_ctx_set_weight",
     "mdgen_ctx_finalize", "mdgen_ctx_set_option", "mdgen_debug_view_plan", "mdgen_ctx_num_weights", "mdgen_ctx_weight_name", "mdgen_workspace_layout",
     "mdgen_denoiser_forward", "mdgen_sample_euler", "mdgen_rollout_euler", "mdgen_profile_enable", "mdgen_profile_report", "mdgen_profile_phase_trace", "mdgen_debug_layout_maps", "mdgen_debug_mlp_stream_table",
     "mdgen_rigid_compose", "mdgen_rigid_invert",
@@ -99,6 +99,8 @@ def _load():
         getattr(lib, n)
         if n not in ("mdgen_last_error", "mdgen_ctx_weight_name"):
             getattr(lib, n).restype = i32
+    if lib.mdgen_dev_build() and "MDGEN_AMD_LIB" not in os.environ:
+        raise ImportError(f"{LIB_PATH} is an experiment build (csrc/dev.h switches): rebuild with `python -m mdgen_amd.build --force`")
     got = lib.mdgen_abi_version()
     if got != ABI_VERSION:   # a stale .so would take struct writes / argument lists of another layout
         raise ImportError(f"{LIB_PATH} has ABI version {got}, this package expects {ABI_VERSION}: "

@@ -39,6 +39,14 @@ static int fail(int code, const char* fmt, ...) {
 
 extern "C" const char* mdgen_last_error(void) { return g_err; }
 extern "C" int32_t mdgen_abi_version(void) { return MDGEN_ABI_VERSION; }
+// 0 for a product library; 1 when this .so was built with an experiment switch (csrc/dev.h) -- its results may be wrong
+extern "C" int32_t mdgen_dev_build(void) {
+#ifdef MDGEN_DEV_BUILD
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 // ---------------------------------------------------------------------------------------------
 // context

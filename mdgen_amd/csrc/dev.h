@@ -1,0 +1,24 @@
+// dev.h -- the ONE place that knows the experiment switches of the kernels (included by common.h).
+//
+// Product builds (mdgen_amd/build.py) define none of them.  The experiment builds of scripts/micro/flash_variants.sh pass
+// -DMDGEN_DEV_BUILD together with the switch; a switch without it is a build error, so a stray -D cannot silently turn a
+// correctness path off (MDGEN_DEV_FLASH_NOFALLBACK) or produce wrong values (MDGEN_DEV_ROWS_COALESCED) in a product
+// library, and mdgen_dev_switches() (api.hip) lets a loader see what a given .so was built with.
+//
+//   MDGEN_DEV_FLASH_STAMPS      k_flash: per-wave s_memtime stamps            (scripts/micro/flash_stamps.py)
+//   MDGEN_DEV_FLASH_NOLOAD      k_flash: K / V loads left out, timing only
+//   MDGEN_DEV_FLASH_NOFALLBACK  k_flash: no re-run with the robust loop: shows what the fixed anchor alone does
+//   MDGEN_DEV_QKV_STAMPS        k_ln_qkv: phase stamps                         (scripts/micro/qkv_stamps.py)
+//   MDGEN_DEV_MLP_STAMPX        k_mlp: stamp inside one fc1 stage              (scripts/micro/mlp_stampx.py)
+//   MDGEN_DEV_ROWS_NOGELU       k_mlp_rows: main loop without its VALU work, timing only (values wrong)
+//   MDGEN_DEV_ROWS_COALESCED    k_mlp_rows: row loads as coalesced 1 KiB requests, timing only (values wrong)
+#pragma once
+
+#if defined(MDGEN_DEV_FLASH_STAMPS) || defined(MDGEN_DEV_FLASH_NOLOAD) || defined(MDGEN_DEV_FLASH_NOFALLBACK) || \
+    defined(MDGEN_DEV_QKV_STAMPS) || defined(MDGEN_DEV_MLP_STAMPX) || defined(MDGEN_DEV_ROWS_NOGELU) ||           \
+    defined(MDGEN_DEV_ROWS_COALESCED)
+#ifndef MDGEN_DEV_BUILD
+#error "an MDGEN_DEV_* experiment switch is set without -DMDGEN_DEV_BUILD: product libraries are built with none of them"
+#endif
+#define MDGEN_DEV_ANY 1
+#endif

@@ -49,7 +49,7 @@ class Transport:
     def training_losses(self, model, x1, aatype1=None, mask=None, model_kwargs=None, t=None, x0=None):
         """transport.py:138-189 for the velocity model (non-design path): returns {'t', 'pred', 'loss'} with
         loss = mean_flat((model(xt, t) - ut)^2, mask).  `t` / `x0` may be given to reproduce a reference run
-        (the reference draws them inside, :126-136).  Forward only: no backward kernels exist in this build."""
+        (the reference draws them inside, :126-136).  Forward value only; the differentiated step is `mdgen_amd.train.Trainer.training_step`."""
         from ._lib import lib, launch, ptr, require_cuda
         model_kwargs = model_kwargs or {}
         if t is None or x0 is None:

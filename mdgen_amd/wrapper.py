@@ -1,7 +1,8 @@
 """`NewMDGenWrapper` -- drop-in for the inference surface of `mdgen.wrapper.NewMDGenWrapper`
 (wrapper.py:175-221 `__init__`, :283-365 `prep_batch`, :405-484 `inference`) plus
 `load_from_checkpoint` for Lightning-format checkpoints (SURVEY.md section 5 "Checkpoint / resume"),
-without Lightning.  Training hooks / EMA / logging are out of scope."""
+without Lightning.  The training step (`general_step` forward half here; backward, optimiser, EMA, DDP in
+`mdgen_amd/train.py`) runs in the same library; Lightning's logging hooks are out of scope."""
 from __future__ import annotations
 
 import argparse
@@ -126,8 +127,8 @@ class NewMDGenWrapper:
     def general_step(self, batch, stage="val", t=None, x0=None):
         """The forward half of wrapper.py:367-384 `general_step`: `prep_batch` -> `transport.training_losses`
         (flow-matching target, model forward, masked MSE).  Returns the loss per sample (B,) and the term dict.
-        No backward / optimiser step exists in this build, so `stage` is informational; `t` and
-        `x0` may be fixed for reproducibility (the reference draws them inside the transport)."""
+        The backward pass + optimiser step of the same quantities is `mdgen_amd.train.Trainer.training_step`; `stage` is
+        informational; `t` and `x0` may be fixed for reproducibility (the reference draws them inside the transport)."""
         prep = self.prep_batch(batch)
         out = self.transport.training_losses(model=self.model.forward, x1=prep["latents"], aatype1=None,
                                              mask=prep["loss_mask"], model_kwargs=prep["model_kwargs"], t=t, x0=x0)

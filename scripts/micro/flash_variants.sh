@@ -9,11 +9,14 @@ python -m mdgen_amd.build >/dev/null
 mkdir -p scripts/micro/dev_libs
 KFILE=${KFILE:-k_flash}; KPFX=${KPFX:-FLASH}
 EXTRA=""; [ $KFILE = k_flash ] && EXTRA="-fno-honor-nans"
+# api.hip of every variant library reports mdgen_dev_build() = 1 (csrc/dev.h)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -fno-slp-vectorize -Wno-unused-function \
+    -Wno-pass-failed -DMDGEN_DEV_BUILD -c mdgen_amd/csrc/api.hip -o scripts/micro/dev_libs/api_dev.o
 for v in "$@"; do
   o=scripts/micro/dev_libs/${KFILE}_$v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -fno-slp-vectorize $EXTRA \
-      -Wno-unused-function -Wno-pass-failed -DMDGEN_DEV_${KPFX}_$v -c mdgen_amd/csrc/$KFILE.hip -o $o
-  objs=$(ls mdgen_amd/build/*.o | grep -v $KFILE.o)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/micro/dev_libs/libmdgen_amd_$v.so $objs $o
+      -Wno-unused-function -Wno-pass-failed -DMDGEN_DEV_BUILD -DMDGEN_DEV_${KPFX}_$v -c mdgen_amd/csrc/$KFILE.hip -o $o
+  objs=$(ls mdgen_amd/build/*.o | grep -v "/$KFILE.o" | grep -v "/api.o")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/micro/dev_libs/libmdgen_amd_$v.so $objs scripts/micro/dev_libs/api_dev.o $o
   echo built scripts/micro/dev_libs/libmdgen_amd_$v.so
 done
