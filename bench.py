@@ -99,6 +99,8 @@ def algorithmic_flops(cls, B, T, L):
         return 4.0 * N * C * (L + 1)
     if cls == "mlp":
         return 16.0 * N * C * C
+    if cls == "proj_mlp":   # temporal out-projection + MLP block in one row-owner kernel (k_mlp_rows<NW, true>)
+        return 18.0 * N * C * C
     return None
 
 
@@ -143,7 +145,7 @@ def cpu_baseline(cfg, sd, B, T, L, S, n_pad, budget_s=20.0):
 
 
 # kernel class (hipEvent profile name) -> substring of the rocprof kernel name
-_KERNEL_OF_CLASS = {"mlp": "k_mlp", "flash_T": "k_flash", "flash_L": "k_flash", "ln_qkv_T": "k_ln_qkv<false>",
+_KERNEL_OF_CLASS = {"mlp": "k_mlp", "proj_mlp": "k_mlp_rows", "flash_T": "k_flash", "flash_L": "k_flash", "ln_qkv_T": "k_ln_qkv<false>",
                     "ln_qkv_L": "k_ln_qkv<true>", "proj_T": "k_proj<0>", "proj_L": "k_proj<2>",
                     "attn_L_fused": "k_ln_qkv_attn4<true>"}
 

@@ -57,6 +57,7 @@ constexpr size_t kPackCC = (size_t)12 * kKS * 64;  // bf16x8 elements of a packe
 
 struct MhaW {
     bf16x8 *wq = nullptr, *wk = nullptr, *wv_flash = nullptr, *wv_small = nullptr, *wo = nullptr;
+    bf16x8* wo_stream = nullptr;   // W_o as the 288-fragment prefix of the row-owner MLP kernel's weight stream (proj_stream_table)
     float *bq = nullptr, *bk = nullptr, *bv_flash = nullptr, *bv_small = nullptr, *bo = nullptr;
     float *bias_k = nullptr, *bias_v = nullptr;
 };
@@ -113,6 +114,7 @@ struct mdgen_ctx {
     int *map_nat = nullptr, *map_qk = nullptr, *map_vflash = nullptr, *map_vsmall = nullptr, *map_fin = nullptr;
     int *perm_qk = nullptr, *perm_vsmall = nullptr;
     int* mlp_tab = nullptr;     // device copy of mlp_stream_table()
+    int* proj_tab = nullptr;    // device copy of proj_stream_table()
     std::vector<GraphEntry> graphs;
     bool inv_freq_set = false;
     bool prof_on = false;
@@ -124,6 +126,7 @@ struct mdgen_ctx {
     int opt_attn_path = 0;      // tiled attention: 0 fixed-anchor fast loop with overflow check + fallback, 1 robust loop always
     int opt_mlp_path = 1;       // MLP block: 0 resident-panel kernel (k_mlp), 1 row-owner kernel (k_mlp_rows) when the launch
                                 // fills the chip, 2 row-owner kernel always
+    int opt_fuse_proj = 1;      // with the row-owner MLP kernel: run the temporal attention's out-projection inside it
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
     std::vector<void*> milestone_events;          // mdgen_train_set_milestone_events (hipEvent_t handles, caller-owned)
@@ -252,6 +255,15 @@ static std::vector<int> mlp_stream_table() {
     return t;
 }
 constexpr int kMlpFrags = 2304;
+// Out-projection prefix of the fused kernel (k_mlp_rows<NW, true>): 288 fragments, k-step major (one block = the 12 feature
+// tiles of one k-step), natural k order inside a fragment.  Entry = 2 << 16 | feature tile << 8 | k-step.
+static std::vector<int> proj_stream_table() {
+    std::vector<int> t;
+    for (int ks = 0; ks < 24; ++ks)
+        for (int ft = 0; ft < 12; ++ft) t.push_back(2 << 16 | ft << 8 | ks);
+    return t;
+}
+constexpr int kProjFrags = 288;
 
 extern "C" int32_t mdgen_debug_mlp_stream_table(int32_t* out, int32_t capacity) {
     const std::vector<int> t = mlp_stream_table();
@@ -308,7 +320,12 @@ static int register_mha(mdgen_ctx* c, const std::string& pre, MhaW* m) {
         launch_gather_f32(data, c->map_vflash, 1.f, m->bv_flash, kC, s);
         launch_gather_f32(data, c->perm_vsmall, 1.f, m->bv_small, kC, s);
     });
-    SETTER(pre + "out_proj.weight", { WANT(kC, kC); launch_pack_rows(data, kC, c->map_nat, 12, kKS, 1.f, m->wo, s); });
+    if (int r = c->dalloc(&m->wo_stream, (size_t)kProjFrags * 64)) return r;
+    SETTER(pre + "out_proj.weight", {
+        WANT(kC, kC);
+        launch_pack_rows(data, kC, c->map_nat, 12, kKS, 1.f, m->wo, s);
+        launch_pack_stream(data, kC, 2, c->proj_tab, kProjFrags, 1.f, 0, m->wo_stream, s);
+    });
     SETTER(pre + "out_proj.bias", { WANT(kC); if (int r = copy_f32(m->bo, data, kC, s)) return r; });
     SETTER(pre + "bias_k", { WANT(kC); if (int r = copy_f32(m->bias_k, data, kC, s)) return r; });
     SETTER(pre + "bias_v", { WANT(kC); if (int r = copy_f32(m->bias_v, data, kC, s)) return r; });
@@ -329,13 +346,13 @@ static int register_ffn(mdgen_ctx* c, const std::string& pre, FfnW* f) {
     SETTER(pre + "fc1.weight", {
         WANT(kF, kC);
         launch_pack_rows(data, kC, c->map_nat, 48, kKS, 1.f, f->w1, s);
-        launch_pack_stream(data, kC, 0, c->mlp_tab, kMlpFrags, 1.f, f->wstream, s);
+        launch_pack_stream(data, kC, 0, c->mlp_tab, kMlpFrags, 1.f, 1, f->wstream, s);
     });
     SETTER(pre + "fc1.bias", { WANT(kF); if (int r = copy_f32(f->b1, data, kF, s)) return r; });
     SETTER(pre + "fc2.weight", {
         WANT(kC, kF);
         launch_pack_rows(data, kF, c->map_nat, 12, 96, 1.f, f->w2, s);
-        launch_pack_stream(data, kF, 1, c->mlp_tab, kMlpFrags, 1.f, f->wstream, s);
+        launch_pack_stream(data, kF, 1, c->mlp_tab, kMlpFrags, 1.f, 1, f->wstream, s);
     });
     SETTER(pre + "fc2.bias", { WANT(kC); if (int r = copy_f32(f->b2, data, kC, s)) return r; });
     return 0;
@@ -371,6 +388,7 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     TRY(upload_ints(c, &c->map_vsmall, vs));
     TRY(upload_ints(c, &c->map_fin, fin));
     TRY(upload_ints(c, &c->mlp_tab, mlp_stream_table()));
+    TRY(upload_ints(c, &c->proj_tab, proj_stream_table()));
     TRY(upload_ints(c, &c->perm_qk, pqk));
     TRY(upload_ints(c, &c->perm_vsmall, pvs));
     TRY(c->dalloc(&c->wl, (size_t)kC * D));
@@ -574,6 +592,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "attention_path") {
         if (value != 0 && value != 1) return fail(-2, "attention_path must be 0 (auto) or 1 (robust loop always)");
         c->opt_attn_path = value;
+    } else if (n == "fuse_proj") {
+        if (value != 0 && value != 1) return fail(-2, "fuse_proj must be 0 or 1");
+        c->opt_fuse_proj = value;
     } else if (n == "mlp_path") {
         if (value < 0 || value > 2) return fail(-2, "mlp_path must be 0 (panel kernel), 1 (row-owner kernel when it fills the chip) or 2 (always)");
         c->opt_mlp_path = value;
@@ -792,8 +813,11 @@ static int mlp_sublayer_fp32(const Run& r, const std::string& pre, float* h, lon
     return 0;
 }
 
+// `defer`: when non-null and the sub-layer takes the tiled-attention path, its out-projection is NOT launched; *defer receives
+// what the fused kernel (k_mlp_rows<NW, true>) needs to run it ahead of the MLP (a_bf16 stays null otherwise).
 static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, const AxisMap& ax, const ModMap& mm,
-                         int shift, int scale, int gate, const MaskMap& mk, bool residue_axis, bool trunk) {
+                         int shift, int scale, int gate, const MaskMap& mk, bool residue_axis, bool trunk,
+                         ProjParams* defer = nullptr) {
     const char* c_qkv = !trunk ? "ipa.ln_qkv" : residue_axis ? "ln_qkv_L" : "ln_qkv_T";
     const char* c_att = !trunk ? "ipa.flash" : residue_axis ? "flash_L" : "flash_T";
     const char* c_prj = !trunk ? "ipa.proj" : residue_axis ? "proj_L" : "proj_T";
@@ -884,18 +908,27 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         { ProfScope ps(r.c, c_att, r.s); launch_flash(f, r.s); }
         LAUNCHCHK();
         p.a_bf16 = f.obuf;
+        if (defer) {
+            *defer = p;
+            return 0;
+        }
         { ProfScope ps(r.c, c_prj, r.s); launch_proj(p, 0, r.s); }
         LAUNCHCHK();
     }
     return 0;
 }
 
-static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const ModMap& mm, int shift, int scale,
-                        int gate, bool trunk) {
-    // Row-owner kernel: one workgroup = 4 waves x 32 rows and one workgroup per CU, so it needs ~200 workgroups to fill the
-    // chip; smaller launches (IPA stack, B = 1 tetrapeptides) stay on the 64-row panel kernel.
+// Row-owner kernel: one workgroup = 4 waves x 32 rows and one workgroup per CU, so it needs ~200 workgroups to fill the
+// chip; smaller launches (IPA stack, B = 1 tetrapeptides) stay on the 64-row panel kernel.
+static bool mlp_uses_rows(const mdgen_ctx* c, long nrows) {
     const long tiles = (nrows + 31) / 32;
-    if (r.c->opt_mlp_path == 2 || (r.c->opt_mlp_path == 1 && tiles >= 4 * 192)) {
+    return c->opt_mlp_path == 2 || (c->opt_mlp_path == 1 && tiles >= 4 * 192);
+}
+
+// `proj`: a deferred out-projection (attn_sublayer) to run inside the row-owner kernel, ahead of the MLP
+static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const ModMap& mm, int shift, int scale,
+                        int gate, bool trunk, const ProjParams* proj = nullptr, const bf16x8* wo_stream = nullptr) {
+    if (mlp_uses_rows(r.c, nrows)) {
         MlpRowsParams q{};
         q.h = h;
         q.nrows = nrows;
@@ -906,15 +939,22 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
         q.wstream = (const unsigned char*)f.wstream;
         q.b1 = f.b1;
         q.b2 = f.b2;
+        if (proj && proj->a_bf16) {
+            q.o = proj->a_bf16;
+            q.wo_stream = (const unsigned char*)wo_stream;
+            q.bo = proj->bias;
+            q.gate_chunk_o = proj->gate_chunk;
+        }
         if (trunk && r.c->phase_trace) {
             q.trace = r.c->phase_trace;
             q.trace_cap = r.c->phase_trace_cap;
             r.c->phase_trace = nullptr;
         }
-        { ProfScope ps(r.c, trunk ? "mlp" : "ipa.mlp", r.s); launch_mlp_rows(q, 4, r.s); }
+        { ProfScope ps(r.c, !trunk ? "ipa.mlp" : q.o ? "proj_mlp" : "mlp", r.s); launch_mlp_rows(q, 4, r.s); }
         LAUNCHCHK();
         return 0;
     }
+    if (proj && proj->a_bf16) return fail(-7, "internal: deferred out-projection without the row-owner MLP kernel");
     MlpParams p{};
     p.h = h;
     p.nrows = nrows;
@@ -1117,8 +1157,10 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
         const TrunkW& w = c->trunk[i];
         ModMap mm{modstep + c->trunk_off(i), r.T * r.L, r.B, 0, r.mod_group_stride};
         if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true)) return er;
-        if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true)) return er;
-        if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true)) return er;
+        ProjParams deferred{};
+        const bool fuse = c->opt_fuse_proj && mlp_uses_rows(c, r.N);
+        if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true, fuse ? &deferred : nullptr)) return er;
+        if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true, &deferred, w.mha_t.wo_stream)) return er;
         if (trace_h) HIPCHK(hipMemcpyAsync(trace_h + (size_t)(i + 1) * r.N * kC, h, hbytes, hipMemcpyDeviceToDevice, r.s));
     }
     FinalParams f{};
@@ -1325,7 +1367,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1385,7 +1427,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

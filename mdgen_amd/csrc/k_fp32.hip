@@ -83,8 +83,11 @@ __global__ __launch_bounds__(256) void k32_linear(const LinearParams p) {
     __shared__ __attribute__((aligned(16))) float As[BF ? TM * ROWB / 4 : TM * LD];
     __shared__ __attribute__((aligned(16))) float Ws[BF ? TM * ROWB / 4 : TM * LD];
     const int lane = lane_id(), w = wave_id();
-    const long row0 = (long)blockIdx.x * TM;
-    const int colt = blockIdx.y * TM;
+    // grid = (column tiles, row tiles): the workgroups that share a 128-row slice of A are dispatched back to back, so that
+    // slice leaves HBM once and the other column tiles find it in the Infinity Cache (with row tiles fastest A was re-read
+    // m / 128 = 3 .. 12 times from HBM: 1.2 GB per fc1 / fc2 launch at cfg-5's size)
+    const long row0 = (long)blockIdx.y * TM;
+    const int colt = blockIdx.x * TM;
     const int wr = w >> 1, wc = w & 1;   // wave -> 64 x 64 sub-tile
     f32x16 acc[2][2];
 #pragma unroll
@@ -396,7 +399,7 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
                      int wtrans, float* c2) {
     LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, wtrans, c, ldc, col0, mm, gate_chunk, gated, scalar, c2};
-    const dim3 grid((unsigned)((n + 127) / 128), (unsigned)((m + 127) / 128));
+    const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128));
     if (g_k32_bf16_operands) hipLaunchKernelGGL(k32_linear<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k32_linear<false>, grid, dim3(256), 0, s, p);
 }

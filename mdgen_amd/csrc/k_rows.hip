@@ -124,8 +124,8 @@ __device__ __forceinline__ void arm_chunk(f32x16 (&a1)[2], const float* b1c) {
 }
 
 // DMA number D0 + q / STRIDE of the wave's share of a slot (q is a constant after unrolling)
-template <int NW, int D0, int STRIDE>
-__device__ __forceinline__ void issue_q(const WStream<NW>& ws, long slot, int q) {
+template <class WS, int D0, int STRIDE>
+__device__ __forceinline__ void issue_q(const WS& ws, long slot, int q) {
     switch (q / STRIDE) {
         case 0: ws.template issue<D0 + 0>(slot); break;
         case 1: ws.template issue<D0 + 1>(slot); break;
@@ -163,30 +163,33 @@ __device__ __forceinline__ void gelu_stage_q(MlpPipe& m, f32x16 (&a1r)[2], int g
 // One block of 12 fragments, one fenced scheduling region per fragment: [look-ahead LDS read of fragment I + PF]
 // [MFMA of fragment I] [a slice of the GELU group] (+ this wave's share of the ring refill).
 //   I0    ring-relative index of its first fragment (multiple of 12)
-//   KIND  0: X block (k-steps 6 KI .. 6 KI + 5 of both hidden tiles -> a1w), 1: Y block (k-step KI of the chunk, 12 feature tiles)
+//   KIND  0: X block (k-steps 6 KI .. 6 KI + 5 of both hidden tiles -> a1w), 1: Y block (k-step KI of the chunk, 12 feature tiles),
+//         2: out-projection block (k-step KI of the 24, 12 feature tiles, B operand = xf[KI])
 //   GG    GELU group riding along (reads a1r, writes hfw), or -1.  REARM: afterwards its four accumulator registers are
 //         re-armed with the bias at b1n (LDS; the same group of the chunk two further on)
 //   BARVM >= 0: the block opens a ring slot: barrier with that vmcnt first
 //   FILL  issue this wave's DMAs of slot `fill_slot` (half of them per block: a slot is two blocks)
 //   NLOOK look-ahead reads are issued for the first NLOOK fragments only (end of the stream)
-template <int NW, int I0, int KIND, int KI, int GG, bool REARM, int BARVM, bool FILL, int NLOOK = 12>
+template <int NW, int I0, int KIND, int KI, int GG, bool REARM, int BARVM, bool FILL, int NLOOK = 12, class WS>
 __device__ __forceinline__ void pipe_block(MlpPipe& m, const bf16x8 (&xf)[24], f32x16 (&a1w)[2], f32x16 (&a1r)[2],
                                            bf16x8 (&hfw)[4], const bf16x8 (&hfr)[4], const float* b1n,
-                                           const unsigned char* ring_lane, const WStream<NW>& ws, long fill_slot) {
-    constexpr int FPW = WStream<NW>::FPW, DPB = FPW / 2, STRIDE = 12 / DPB;
+                                           const unsigned char* ring_lane, const WS& ws, long fill_slot) {
+    constexpr int FPW = WS::FPW, DPB = FPW / 2, STRIDE = 12 / DPB;
     if (BARVM >= 0) ring_barrier<BARVM>();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
         const int I = I0 + q;
-        if (FILL && q % STRIDE == 0) issue_q<NW, ((I0 / 12) & 1) * DPB, STRIDE>(ws, fill_slot, q);
+        if (FILL && q % STRIDE == 0) issue_q<WS, ((I0 / 12) & 1) * DPB, STRIDE>(ws, fill_slot, q);
         if (q < NLOOK) m.wr[(I + kWPF) % kWRing] = *reinterpret_cast<const bf16x8*>(ring_lane + ((I + kWPF) % kRingFrags) * 1024);
         if (GG >= 0 && REARM && q == 0) m.bias = *reinterpret_cast<const f32x4*>(b1n + 32 * (GG >> 2) + 8 * (GG & 3));
         if (KIND == 0) {
             const int ks = 6 * KI + (q >> 1), tile = q & 1;
             a1w[tile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], xf[ks], a1w[tile], 0, 0, 0);
-        } else {
+        } else if (KIND == 1) {
             m.y[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], hfr[KI], m.y[q], 0, 0, 0);
+        } else {   // KIND 2: out-projection, k-step KI of the attention output rows (xf), 12 feature tiles
+            m.y[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], xf[KI], m.y[q], 0, 0, 0);
         }
 #ifndef MDGEN_DEV_ROWS_NOGELU   // (experiment build, timing only: the main loop without its VALU work)
         if (GG >= 0) gelu_stage_q<REARM>(m, a1r, GG, q, hfw);
@@ -209,14 +212,31 @@ __device__ __forceinline__ void gelu_group_plain(MlpPipe& m, f32x16 (&a1r)[2], c
     st[i] = __builtin_amdgcn_s_memtime();              \
     __builtin_amdgcn_sched_barrier(0)
 
-template <int NW>
+// out-projection blocks KS .. 23 of the fused form (one block = one k-step of the attention output rows x 12 feature tiles;
+// two blocks per ring slot, slot s = global slot: barrier + refill of slot s + 3)
+template <int NW, int KS, class WS>
+__device__ __forceinline__ void proj_blocks(MlpPipe& m, const bf16x8 (&xf)[24], const unsigned char* ring_lane, const WS& ws) {
+    constexpr int FPW = WS::FPW;
+    pipe_block<NW, (12 * KS) % kRingFrags, 2, KS, -1, false, (KS & 1) == 0 ? FPW : -1, true>(
+        m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], nullptr, ring_lane, ws, KS / 2 + 3);
+    if constexpr (KS + 1 < 24) proj_blocks<NW, KS + 1>(m, xf, ring_lane, ws);
+}
+
+// PROJ: the temporal attention's out-projection + gated residual (mha.py:397, latent_model.py:476) runs in the same kernel,
+// ahead of the MLP, on the same 32 rows per wave: the attention output rows are loaded straight into B-operand fragments,
+// the 288 fragments of W_o lead the weight stream (12 ring slots = three ring revolutions), the updated residual rows are
+// written once and KEPT in registers for the MLP's LayerNorm -- one kernel, one read of the rows less (98 MB at cfg-2), no
+// launch boundary (k_proj<0> was an HBM-bound 58 us kernel of its own).
+template <int NW, bool PROJ>
 __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kRingBytes + kF * 4 + 512];   // ring | fc1 bias | slack: the last re-arm reads the (non-existent) chunk 24
-    constexpr int FPW = WStream<NW>::FPW;
+    constexpr int NPRE = PROJ ? 12 : 0;   // ring slots of the out-projection ahead of the MLP stream
+    using WS = WStream<NW, NPRE>;
+    constexpr int FPW = WS::FPW;
     const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id(), hh = lane >> 5, n = lane & 31;
     unsigned long long st[6];
     ROWS_STAMP(0);
-    WStream<NW> ws{p.wstream, lds_addr(smem), (unsigned)lane * 16u, w};
+    WS ws{p.wstream, p.wo_stream, lds_addr(smem), (unsigned)lane * 16u, w};
     // fc1 bias -> LDS, six 1 KiB DMAs (wave w: pieces w, w + NW, ...), BEFORE the stream's: barrier 0 then certifies them too.
     // (A load + ds_write loop here cost two serialised memory round trips ahead of the row loads.)
 #pragma unroll
@@ -231,14 +251,31 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
     const long t = ((long)blockIdx.x * NW + w) * 32 + n;
     const int tok = t < p.nrows ? (int)t : -1;
     bf16x8 xf[24];
-    rows_ln(p.h, tok, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, xf);
-    ROWS_STAMP(1);
     MlpPipe m;
+    const unsigned char* ring_lane = smem + lane * 16;
+    if (PROJ) {
+        rows_load_bf16(p.o, tok, xf);
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m.y[i][r] = acc_zero();
+        ring_barrier<FPW>();   // barrier 0: slots 0 and 1 of the out-projection (and the fc1 bias table) have landed
+#pragma unroll
+        for (int i = 0; i < kWPF; ++i) m.wr[i] = *reinterpret_cast<const bf16x8*>(ring_lane + i * 1024);
+        // the first block's barrier is the one just passed: blocks 0 .. 23 open slots 0 .. 11 at their even members
+        pipe_block<NW, 0, 2, 0, -1, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], nullptr, ring_lane, ws, 3);
+        proj_blocks<NW, 1>(m, xf, ring_lane, ws);
+        f32x4 v[48];
+        rows_gate_residual_keep(m.y, tok, p.bo, p.mm, p.gate_chunk_o, p.h, v);
+        rows_norm(v, tok, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, xf);
+    } else {
+        rows_ln(p.h, tok, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, xf);
+    }
+    ROWS_STAMP(1);
 #pragma unroll
     for (int i = 0; i < 12; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) m.y[i][r] = acc_zero();
-    const unsigned char* ring_lane = smem + lane * 16;
     const float* b1l = b1s + 4 * hh;   // LDS bias row of chunk c: + 64 c (this lane half's four units of every group of 8)
     // ---- P0: X(0).  Barrier 0 certifies slots 0 and 1 (only the FPW DMAs of slot 2 may be in flight) and the LDS copy of b1.
     ring_barrier<FPW>();
@@ -246,19 +283,19 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
     for (int i = 0; i < kWPF; ++i) m.wr[i] = *reinterpret_cast<const bf16x8*>(ring_lane + i * 1024);
     arm_chunk(m.a1[0], b1l);
     arm_chunk(m.a1[1], b1l + 64);
-    pipe_block<NW, 0, 0, 0, -1, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 3);
-    pipe_block<NW, 12, 0, 1, -1, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 3);
-    pipe_block<NW, 24, 0, 2, -1, false, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 4);
-    pipe_block<NW, 36, 0, 3, -1, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 4);
+    pipe_block<NW, 0, 0, 0, -1, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, NPRE + 3);
+    pipe_block<NW, 12, 0, 1, -1, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, NPRE + 3);
+    pipe_block<NW, 24, 0, 2, -1, false, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, NPRE + 4);
+    pipe_block<NW, 36, 0, 3, -1, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, NPRE + 4);
     // ---- P1: X(1) -> a1[1] with GELU(0): a1[0] -> hf[0] (even groups ride in the blocks, odd ones run between them);
     //          a1[0] is re-armed with the bias of chunk 2
-    pipe_block<NW, 48, 0, 0, 0, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], b1l + 128, ring_lane, ws, 5);
+    pipe_block<NW, 48, 0, 0, 0, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], b1l + 128, ring_lane, ws, NPRE + 5);
     gelu_group_plain<true>(m, m.a1[0], b1l + 128, 1, m.hf[0]);
-    pipe_block<NW, 60, 0, 1, 2, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], b1l + 128, ring_lane, ws, 5);
+    pipe_block<NW, 60, 0, 1, 2, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], b1l + 128, ring_lane, ws, NPRE + 5);
     gelu_group_plain<true>(m, m.a1[0], b1l + 128, 3, m.hf[0]);
-    pipe_block<NW, 72, 0, 2, 4, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], b1l + 128, ring_lane, ws, 6);
+    pipe_block<NW, 72, 0, 2, 4, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], b1l + 128, ring_lane, ws, NPRE + 6);
     gelu_group_plain<true>(m, m.a1[0], b1l + 128, 5, m.hf[0]);
-    pipe_block<NW, 84, 0, 3, 6, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], b1l + 128, ring_lane, ws, 6);
+    pipe_block<NW, 84, 0, 3, 6, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], b1l + 128, ring_lane, ws, NPRE + 6);
     gelu_group_plain<true>(m, m.a1[0], b1l + 128, 7, m.hf[0]);
     ROWS_STAMP(2);
     // ---- iterations c = 1 .. 22 (two per trip: the register double buffers a1 / hf alternate)
@@ -267,43 +304,43 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
         {   // odd c: X(c + 1) -> a1[0], GELU(c): a1[1] -> hf[1] (a1[1] re-armed for chunk c + 2), Y(c - 1) <- hf[0]
             const long s0 = 4 * c;
             const float* bn = b1l + 64 * (c + 2);
-            pipe_block<NW, 0, 0, 0, 0, true, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 3);
-            pipe_block<NW, 12, 1, 0, 1, true, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 3);
-            pipe_block<NW, 24, 0, 1, 2, true, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 4);
-            pipe_block<NW, 36, 1, 1, 3, true, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 4);
-            pipe_block<NW, 48, 0, 2, 4, true, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 5);
-            pipe_block<NW, 60, 1, 2, 5, true, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 5);
-            pipe_block<NW, 72, 0, 3, 6, true, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 6);
-            pipe_block<NW, 84, 1, 3, 7, true, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, s0 + 6);
+            pipe_block<NW, 0, 0, 0, 0, true, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, NPRE + s0 + 3);
+            pipe_block<NW, 12, 1, 0, 1, true, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, NPRE + s0 + 3);
+            pipe_block<NW, 24, 0, 1, 2, true, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, NPRE + s0 + 4);
+            pipe_block<NW, 36, 1, 1, 3, true, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, NPRE + s0 + 4);
+            pipe_block<NW, 48, 0, 2, 4, true, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, NPRE + s0 + 5);
+            pipe_block<NW, 60, 1, 2, 5, true, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, NPRE + s0 + 5);
+            pipe_block<NW, 72, 0, 3, 6, true, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, NPRE + s0 + 6);
+            pipe_block<NW, 84, 1, 3, 7, true, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], bn, ring_lane, ws, NPRE + s0 + 6);
         }
         {   // even c + 1: X(c + 2) -> a1[1], GELU(c + 1): a1[0] -> hf[0] (a1[0] re-armed for chunk c + 3), Y(c) <- hf[1]
             const long s0 = 4 * (c + 1);
             const float* bn = b1l + 64 * (c + 3);   // c + 3 = 24 on the last trip: slack behind the table, never consumed
-            pipe_block<NW, 0, 0, 0, 0, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 3);
-            pipe_block<NW, 12, 1, 0, 1, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 3);
-            pipe_block<NW, 24, 0, 1, 2, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 4);
-            pipe_block<NW, 36, 1, 1, 3, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 4);
-            pipe_block<NW, 48, 0, 2, 4, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 5);
-            pipe_block<NW, 60, 1, 2, 5, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 5);
-            pipe_block<NW, 72, 0, 3, 6, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 6);
-            pipe_block<NW, 84, 1, 3, 7, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, s0 + 6);
+            pipe_block<NW, 0, 0, 0, 0, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, NPRE + s0 + 3);
+            pipe_block<NW, 12, 1, 0, 1, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, NPRE + s0 + 3);
+            pipe_block<NW, 24, 0, 1, 2, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, NPRE + s0 + 4);
+            pipe_block<NW, 36, 1, 1, 3, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, NPRE + s0 + 4);
+            pipe_block<NW, 48, 0, 2, 4, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, NPRE + s0 + 5);
+            pipe_block<NW, 60, 1, 2, 5, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, NPRE + s0 + 5);
+            pipe_block<NW, 72, 0, 3, 6, true, FPW, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, NPRE + s0 + 6);
+            pipe_block<NW, 84, 1, 3, 7, true, -1, true>(m, xf, m.a1[1], m.a1[0], m.hf[0], m.hf[1], bn, ring_lane, ws, NPRE + s0 + 6);
         }
     }
     ROWS_STAMP(3);
     // ---- E0: Y(22) <- hf[0] with GELU(23): a1[1] -> hf[1] (slots 92, 93; slot 95 is the last one to fetch)
-    pipe_block<NW, 0, 1, 0, 0, false, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], b1l, ring_lane, ws, 95);
+    pipe_block<NW, 0, 1, 0, 0, false, FPW, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], b1l, ring_lane, ws, NPRE + 95);
     gelu_group_plain<false>(m, m.a1[1], b1l, 1, m.hf[1]);
-    pipe_block<NW, 12, 1, 1, 2, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], b1l, ring_lane, ws, 95);
+    pipe_block<NW, 12, 1, 1, 2, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], b1l, ring_lane, ws, NPRE + 95);
     gelu_group_plain<false>(m, m.a1[1], b1l, 3, m.hf[1]);
-    pipe_block<NW, 24, 1, 2, 4, false, FPW, false>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], b1l, ring_lane, ws, 0);
+    pipe_block<NW, 24, 1, 2, 4, false, FPW, false>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], b1l, ring_lane, ws, NPRE + 0);
     gelu_group_plain<false>(m, m.a1[1], b1l, 5, m.hf[1]);
-    pipe_block<NW, 36, 1, 3, 6, false, -1, false>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], b1l, ring_lane, ws, 0);
+    pipe_block<NW, 36, 1, 3, 6, false, -1, false>(m, xf, m.a1[0], m.a1[1], m.hf[1], m.hf[0], b1l, ring_lane, ws, NPRE + 0);
     gelu_group_plain<false>(m, m.a1[1], b1l, 7, m.hf[1]);
     // ---- E1: Y(23) <- hf[1] (slots 94, 95: everything has been requested; barrier 94 waits for all of it)
-    pipe_block<NW, 48, 1, 0, -1, false, 0, false>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 0);
-    pipe_block<NW, 60, 1, 1, -1, false, -1, false>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 0);
-    pipe_block<NW, 72, 1, 2, -1, false, 0, false>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 0);
-    pipe_block<NW, 84, 1, 3, -1, false, -1, false, 12 - kWPF>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, 0);
+    pipe_block<NW, 48, 1, 0, -1, false, 0, false>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, NPRE + 0);
+    pipe_block<NW, 60, 1, 1, -1, false, -1, false>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, NPRE + 0);
+    pipe_block<NW, 72, 1, 2, -1, false, 0, false>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, NPRE + 0);
+    pipe_block<NW, 84, 1, 3, -1, false, -1, false, 12 - kWPF>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, NPRE + 0);
     ROWS_STAMP(4);
     // ---- gated residual
     rows_gate_residual<0, 6>(m.y, tok, p.b2, p.mm, p.gate_chunk, p.h);
@@ -321,8 +358,9 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
 // ---- weight-stream packing ------------------------------------------------------------------------------------------
 // dst fragment f (1 KiB = 64 lanes x 8 bf16) <- rows 32 tile .. + 31 of the matrix tab[f] names, K slice of k-step ks in
 // kappa order (rows.h).  tab[f] = mat << 16 | tile << 8 | ks; only entries with mat == which are written.
+// `kappa` = 0: natural K order k = 16 ks + 8 hh + j instead (operands whose B fragments are loaded from memory: the out-projection).
 __global__ void k_pack_stream(const float* __restrict__ wsrc, int ld, int which, const int* __restrict__ tab, int nfrag,
-                              float scale, bf16x8* __restrict__ dst) {
+                              float scale, int kappa, bf16x8* __restrict__ dst) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)nfrag * 64) return;
     const int lane = (int)(i & 63), f = (int)(i >> 6);
@@ -332,20 +370,33 @@ __global__ void k_pack_stream(const float* __restrict__ wsrc, int ld, int which,
     const int row = tile * 32 + (lane & 31), hh = lane >> 5;
     bf16x8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (__bf16)(wsrc[(long)row * ld + 16 * ks + 8 * (j >> 2) + 4 * hh + (j & 3)] * scale);
+    for (int j = 0; j < 8; ++j)
+        v[j] = (__bf16)(wsrc[(long)row * ld + 16 * ks + (kappa ? 8 * (j >> 2) + 4 * hh + (j & 3) : 8 * hh + j)] * scale);
     dst[i] = v;
 }
 
-void launch_pack_stream(const float* w, int ld, int which, const int* tab, int nfrag, float scale, bf16x8* dst, hipStream_t s) {
+void launch_pack_stream(const float* w, int ld, int which, const int* tab, int nfrag, float scale, int kappa, bf16x8* dst,
+                        hipStream_t s) {
     const long total = (long)nfrag * 64;
-    hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, ld, which, tab, nfrag, scale, dst);
+    hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, ld, which, tab, nfrag, scale, kappa, dst);
 }
 
 void launch_mlp_rows(const MlpRowsParams& p, int nw, hipStream_t s) {
     const long tiles = (p.nrows + 31) / 32;
-    if (nw == 4) hipLaunchKernelGGL((k_mlp_rows<4>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, p);
-    else if (nw == 2) hipLaunchKernelGGL((k_mlp_rows<2>), dim3((unsigned)((tiles + 1) / 2)), dim3(128), 0, s, p);
-    else hipLaunchKernelGGL((k_mlp_rows<1>), dim3((unsigned)tiles), dim3(64), 0, s, p);
+    const bool proj = p.o != nullptr;
+    if (nw == 4) {
+        const dim3 g((unsigned)((tiles + 3) / 4)), b(256);
+        if (proj) hipLaunchKernelGGL((k_mlp_rows<4, true>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((k_mlp_rows<4, false>), g, b, 0, s, p);
+    } else if (nw == 2) {
+        const dim3 g((unsigned)((tiles + 1) / 2)), b(128);
+        if (proj) hipLaunchKernelGGL((k_mlp_rows<2, true>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((k_mlp_rows<2, false>), g, b, 0, s, p);
+    } else {
+        const dim3 g((unsigned)tiles), b(64);
+        if (proj) hipLaunchKernelGGL((k_mlp_rows<1, true>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((k_mlp_rows<1, false>), g, b, 0, s, p);
+    }
 }
 
 }  // namespace mdg

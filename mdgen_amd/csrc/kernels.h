@@ -66,6 +66,12 @@ struct MlpRowsParams {
     int shift_chunk, scale_chunk, gate_chunk;
     const unsigned char* wstream;   // 2304 fragments of 1 KiB
     const float *b1, *b2;
+    // fused out-projection of the preceding attention sub-layer (o != null): attention output rows, W_o as 288 fragments in
+    // consumption order (k-step major, natural k), its bias and gate chunk
+    const __bf16* o;
+    const unsigned char* wo_stream;
+    const float* bo;
+    int gate_chunk_o;
     unsigned long long* trace;      // measurement only: [wave][8] s_memtime stamps, or null
     long trace_cap;
 };
@@ -150,7 +156,8 @@ void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
 void launch_mlp(const MlpParams& p, hipStream_t s);
 void launch_mlp_rows(const MlpRowsParams& p, int nw, hipStream_t s);
-void launch_pack_stream(const float* w, int ld, int which, const int* tab, int nfrag, float scale, bf16x8* dst, hipStream_t s);
+void launch_pack_stream(const float* w, int ld, int which, const int* tab, int nfrag, float scale, int kappa, bf16x8* dst,
+                        hipStream_t s);
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s);
 void launch_final(const FinalParams& p, hipStream_t s);
 void launch_flash(const FlashParams& p, hipStream_t s);

@@ -71,10 +71,15 @@ __device__ __forceinline__ void ring_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
 }
 
-template <int NW>
+// NW waves share the stream; the first NPRE slots come from `pre` (a second matrix in front of the main stream: the
+// out-projection ahead of the MLP), the rest from `src`.  Slot numbers are GLOBAL (prefix included); NPRE is a multiple of
+// the ring size, so a slot's ring position does not depend on it.
+template <int NW, int NPRE = 0>
 struct WStream {
+    static_assert(NPRE % kRingSlots == 0, "the prefix must cover whole ring revolutions");
     static constexpr int FPW = kSlotFrags / NW;   // DMAs per wave per slot
-    const unsigned char* src;   // stream base (uniform)
+    const unsigned char* src;   // main stream (uniform)
+    const unsigned char* pre;   // prefix stream (uniform; unused when NPRE == 0)
     unsigned ring;              // LDS byte address of the ring
     unsigned voff;              // lane * 16
     int w;                      // wave index (uniform)
@@ -83,8 +88,8 @@ struct WStream {
     template <int D>
     __device__ __forceinline__ void issue(long slot) const {
         const int f = w * FPW + (D & ~3);
-        dma_frag<(D & 3) * 1024, (D & 3) == 0>(src + slot * kSlotBytes + f * 1024, voff,
-                                               ring + ((unsigned)slot & 3u) * kSlotBytes + f * 1024);
+        const unsigned char* base = (NPRE > 0 && slot < NPRE) ? pre + slot * kSlotBytes : src + (slot - NPRE) * kSlotBytes;
+        dma_frag<(D & 3) * 1024, (D & 3) == 0>(base + f * 1024, voff, ring + ((unsigned)slot & 3u) * kSlotBytes + f * 1024);
     }
     template <int D0 = 0>
     __device__ __forceinline__ void issue_slot(long slot) const {
@@ -105,13 +110,13 @@ __device__ __forceinline__ bf16x8 ring_frag(const unsigned char* ring_lane) {
 // together: 48 KiB per wave), reduces them locally and with its partner lane n + 32 (one permlane32 swap per
 // statistic), and packs xf[ks] = the B operand of k-step ks.  The modulation vectors are read through per-lane row
 // offsets, so a tile may straddle samples.
-__device__ __forceinline__ void rows_ln(const float* __restrict__ x, int tok, const ModMap mm, int shift_chunk,
-                                        int scale_chunk, float eps, bf16x8 (&xf)[24]) {
+// rows_load: v[2 ks + q][0..3] = features 16 ks + 8 q + 4 hh + (0..3) of the lane's row (the register image the epilogues
+// produce as well: accumulator register 4 a + i of tile ft is v[4 ft + a][i]).  rows_norm: statistics + modulate + pack.
+__device__ __forceinline__ void rows_load(const float* __restrict__ x, int tok, f32x4 (&v)[48]) {
     const int hh = lane_id() >> 5;
     const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
     const unsigned off = tokc * (unsigned)(kC * 4) + (unsigned)hh * 16u;
-    f32x4 v[48];
 #ifdef MDGEN_DEV_ROWS_COALESCED   // (experiment build: the same 48 KiB per wave read as 48 fully coalesced 1 KiB requests -- WRONG values,
                                   // timing only: does the 32-byte-per-row request pattern cost HBM efficiency?)
     const unsigned offc = (tokc & ~31u) * (unsigned)(kC * 4) + (unsigned)lane_id() * 16u;
@@ -121,6 +126,11 @@ __device__ __forceinline__ void rows_ln(const float* __restrict__ x, int tok, co
 #pragma unroll
     for (int i = 0; i < 48; ++i) v[i] = *reinterpret_cast<const f32x4*>(xb + off + 32u * i);
 #endif
+}
+__device__ __forceinline__ void rows_norm(const f32x4 (&v)[48], int tok, const ModMap mm, int shift_chunk, int scale_chunk,
+                                          float eps, bf16x8 (&xf)[24]) {
+    const int hh = lane_id() >> 5;
+    const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
     const unsigned mo = tok < 0 ? 0u : (unsigned)mm.row_off(tokc);
     const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
     const unsigned osc = (mo + (unsigned)(scale_chunk * kC)) * 4u + (unsigned)hh * 16u;
@@ -182,6 +192,13 @@ __device__ __forceinline__ void rows_ln(const float* __restrict__ x, int tok, co
     }
 }
 
+__device__ __forceinline__ void rows_ln(const float* __restrict__ x, int tok, const ModMap mm, int shift_chunk,
+                                        int scale_chunk, float eps, bf16x8 (&xf)[24]) {
+    f32x4 v[48];
+    rows_load(x, tok, v);
+    rows_norm(v, tok, mm, shift_chunk, scale_chunk, eps, xf);
+}
+
 // ---- gated residual epilogue of the wave's 32 rows ----------------------------------------------------------------
 // h[tok][32 ft + 8 a + 4 hh + i] += gate * (y[ft][4 a + i] + bias)   (latent_model.py:462,476,481): 16-byte accesses,
 // the same address pattern as rows_ln; loads unconditional, stores predicated on the row being real.
@@ -212,6 +229,58 @@ __device__ __forceinline__ void rows_gate_residual(const f32x16 (&y)[12], int to
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] += g[i][j] * (y[ft][4 * a + j] + b[i][j]);
         if (tok >= 0) *reinterpret_cast<f32x4*>(hb + off + 32u * (unsigned)(FT0 * 4 + i)) = o;
+    }
+}
+
+// The same update, keeping the updated rows in registers (rows_load's image) for the LayerNorm of the NEXT sub-layer: the
+// residual stream is written (the next epilogue needs it back) but not read again by the next prologue.
+__device__ __forceinline__ void rows_gate_residual_keep(const f32x16 (&y)[12], int tok, const float* __restrict__ bias,
+                                                        const ModMap mm, int gate_chunk, float* __restrict__ h,
+                                                        f32x4 (&v)[48]) {
+    const int hh = lane_id() >> 5;
+    const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
+    unsigned char* hb = reinterpret_cast<unsigned char*>(h);
+    const unsigned off = tokc * (unsigned)(kC * 4) + (unsigned)hh * 16u;
+    const unsigned mo = tok < 0 ? 0u : (unsigned)mm.row_off(tokc);
+    const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
+    const unsigned og = (mo + (unsigned)(gate_chunk * kC)) * 4u + (unsigned)hh * 16u;
+    const unsigned char* bb = reinterpret_cast<const unsigned char*>(bias);
+    // the 48 row loads first (all in flight together, as in rows_load), then gate / bias a tile at a time
+#pragma unroll
+    for (int i = 0; i < 48; ++i) v[i] = *reinterpret_cast<const f32x4*>(hb + off + 32u * i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ft = 0; ft < 12; ++ft) {
+        f32x4 g[4], b[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            g[a] = *reinterpret_cast<const f32x4*>(mb + og + 32u * (4 * ft + a));
+            b[a] = *reinterpret_cast<const f32x4*>(bb + (unsigned)hh * 16u + 32u * (4 * ft + a));
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            f32x4 o = v[4 * ft + a];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += g[a][j] * (y[ft][4 * a + j] + b[a][j]);
+            v[4 * ft + a] = o;
+            if (tok >= 0) *reinterpret_cast<f32x4*>(hb + off + 32u * (4 * ft + a)) = o;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// bf16 rows [token][384] (the attention kernel's output) -> B-operand fragments in NATURAL k order: lane (n, hh), k-step ks
+// = the 16 bytes at feature 16 ks + 8 hh of its row.  24 unconditional 16-byte loads.
+__device__ __forceinline__ void rows_load_bf16(const __bf16* __restrict__ o, int tok, bf16x8 (&xf)[24]) {
+    const int hh = lane_id() >> 5;
+    const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
+    const unsigned char* ob = reinterpret_cast<const unsigned char*>(o);
+    const unsigned off = tokc * (unsigned)(kC * 2) + (unsigned)hh * 16u;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(ob + off + 32u * ks);
+        xf[ks] = __builtin_bit_cast(bf16x8, tok >= 0 ? t : z);
     }
 }
 

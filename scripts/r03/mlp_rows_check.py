@@ -57,7 +57,7 @@ def timing(wl, S, path, streams=1, trace=False):
         torch.cuda.synchronize()
         t = buf.cpu().numpy().reshape(nw, 8).astype(np.int64)
         t = t[t[:, 0] != 0]
-        names = ["ln prologue", "P0+P1", "22 iterations", "E0+E1", "epilogue"]
+        names = ["(proj +) LN", "P0+P1", "22 iterations", "E0+E1", "epilogue"]
         t0 = t[:, 0].min()
         print(f"  k_mlp_rows stamps over {len(t)} waves; kernel span {t[:, 5].max() - t0} ticks (100 MHz s_memtime)")
         for i, nm in enumerate(names):
@@ -72,7 +72,5 @@ a0 = timing("tetrapeptide_fwdsim_crop4_T1000_B16", 3, 0)
 a1 = timing("tetrapeptide_fwdsim_crop4_T1000_B16", 3, 1, trace=True)
 d = (a1 - a0).float()
 print(f"cfg-2 S=3 atom14 rows vs panel: rms {d.pow(2).mean().sqrt():.4f} A  max {d.abs().max():.4f} A")
-timing("tetrapeptide_fwdsim_crop4_T1000_B16", 3, 1, streams=2)
-timing("tetrapeptide_fwdsim_crop4_T1000_B16", 3, 0, streams=2)
 timing("atlas_crop256_T250_B1", 3, 0)
 timing("atlas_crop256_T250_B1", 3, 1)
