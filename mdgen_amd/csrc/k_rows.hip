@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
     using WS = WStream<NW, NPRE>;
     constexpr int FPW = WS::FPW;
     const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id(), hh = lane >> 5, n = lane & 31;
-    unsigned long long st[6];
+    unsigned long long st[8] = {};
     ROWS_STAMP(0);
     WS ws{p.wstream, p.wo_stream, lds_addr(smem), (unsigned)lane * 16u, w};
     // fc1 bias -> LDS, six 1 KiB DMAs (wave w: pieces w, w + NW, ...), BEFORE the stream's: barrier 0 then certifies them too.
@@ -255,27 +255,23 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
     const unsigned char* ring_lane = smem + lane * 16;
     if (PROJ) {
         rows_load_bf16(p.o, tok, xf);
-#pragma unroll
-        for (int i = 0; i < 12; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m.y[i][r] = acc_zero();
+        rows_acc_init(m.y, p.bo);
         ring_barrier<FPW>();   // barrier 0: slots 0 and 1 of the out-projection (and the fc1 bias table) have landed
 #pragma unroll
         for (int i = 0; i < kWPF; ++i) m.wr[i] = *reinterpret_cast<const bf16x8*>(ring_lane + i * 1024);
         // the first block's barrier is the one just passed: blocks 0 .. 23 open slots 0 .. 11 at their even members
         pipe_block<NW, 0, 2, 0, -1, false, -1, true>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], nullptr, ring_lane, ws, 3);
         proj_blocks<NW, 1>(m, xf, ring_lane, ws);
+        ROWS_STAMP(6);
         f32x4 v[48];
-        rows_gate_residual_keep(m.y, tok, p.bo, p.mm, p.gate_chunk_o, p.h, v);
+        rows_gate_residual_keep(m.y, tok, p.mm, p.gate_chunk_o, p.h, v);
+        ROWS_STAMP(7);
         rows_norm(v, tok, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, xf);
     } else {
         rows_ln(p.h, tok, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, xf);
     }
     ROWS_STAMP(1);
-#pragma unroll
-    for (int i = 0; i < 12; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m.y[i][r] = acc_zero();
+    rows_acc_init(m.y, p.b2);
     const float* b1l = b1s + 4 * hh;   // LDS bias row of chunk c: + 64 c (this lane half's four units of every group of 8)
     // ---- P0: X(0).  Barrier 0 certifies slots 0 and 1 (only the FPW DMAs of slot 2 may be in flight) and the LDS copy of b1.
     ring_barrier<FPW>();
@@ -343,14 +339,14 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
     pipe_block<NW, 84, 1, 3, -1, false, -1, false, 12 - kWPF>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, NPRE + 0);
     ROWS_STAMP(4);
     // ---- gated residual
-    rows_gate_residual<0, 6>(m.y, tok, p.b2, p.mm, p.gate_chunk, p.h);
-    rows_gate_residual<6, 12>(m.y, tok, p.b2, p.mm, p.gate_chunk, p.h);
+    rows_gate_residual<0, 6>(m.y, tok, p.mm, p.gate_chunk, p.h);
+    rows_gate_residual<6, 12>(m.y, tok, p.mm, p.gate_chunk, p.h);
     ROWS_STAMP(5);
     if (p.trace && lane == 0) {
         const long i = ((long)blockIdx.x * NW + w) * 8;
         if (i + 8 <= p.trace_cap) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) p.trace[i + k] = st[k];
+            for (int k = 0; k < 8; ++k) p.trace[i + k] = st[k];
         }
     }
 }

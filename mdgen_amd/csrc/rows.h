@@ -156,7 +156,7 @@ __device__ __forceinline__ void rows_norm(const f32x4 (&v)[48], int tok, const M
     asm volatile("" : "+v"(mean2));   // opaque copy: keeps hipcc from holding on to the 192 centred values of the variance pass
     // modulate + pack, k-step by k-step; the (L2-resident) modulation vectors are requested kModPF k-steps ahead and the
     // loop is fenced so that hipcc neither sinks those loads to their use nor hoists all 96 of them (384 registers)
-    constexpr int kModPF = 1;
+    constexpr int kModPF = 2;
     f32x4 sc[kModPF + 1][2], sh[kModPF + 1][2];
 #pragma unroll
     for (int ks = 0; ks < kModPF; ++ks)
@@ -199,12 +199,26 @@ __device__ __forceinline__ void rows_ln(const float* __restrict__ x, int tok, co
     rows_norm(v, tok, mm, shift_chunk, scale_chunk, eps, xf);
 }
 
+// ---- accumulators that START from the bias: y[ft][4 a + j] = bias[32 ft + 8 a + 4 hh + j] -----------------------------------
+// (48 16-byte loads of an L2-resident vector, once per GEMM: the epilogue then needs neither the bias loads nor the adds)
+__device__ __forceinline__ void rows_acc_init(f32x16 (&y)[12], const float* __restrict__ bias) {
+    const unsigned char* bb = reinterpret_cast<const unsigned char*>(bias) + (lane_id() >> 5) * 16;
+#pragma unroll
+    for (int ft = 0; ft < 12; ++ft)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bb + 32u * (4 * ft + a));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[ft][4 * a + j] = b[j];
+        }
+}
+
 // ---- gated residual epilogue of the wave's 32 rows ----------------------------------------------------------------
-// h[tok][32 ft + 8 a + 4 hh + i] += gate * (y[ft][4 a + i] + bias)   (latent_model.py:462,476,481): 16-byte accesses,
-// the same address pattern as rows_ln; loads unconditional, stores predicated on the row being real.
+// h[tok][32 ft + 8 a + 4 hh + i] += gate * y[ft][4 a + i]   (latent_model.py:462,476,481; y already holds the bias): 16-byte
+// accesses, the same address pattern as rows_load; loads unconditional, stores predicated on the row being real.
 template <int FT0, int FT1>
-__device__ __forceinline__ void rows_gate_residual(const f32x16 (&y)[12], int tok, const float* __restrict__ bias,
-                                                   const ModMap mm, int gate_chunk, float* __restrict__ h) {
+__device__ __forceinline__ void rows_gate_residual(const f32x16 (&y)[12], int tok, const ModMap mm, int gate_chunk,
+                                                   float* __restrict__ h) {
     const int hh = lane_id() >> 5;
     const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
     unsigned char* hb = reinterpret_cast<unsigned char*>(h);
@@ -212,31 +226,29 @@ __device__ __forceinline__ void rows_gate_residual(const f32x16 (&y)[12], int to
     const unsigned mo = tok < 0 ? 0u : (unsigned)mm.row_off(tokc);
     const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
     const unsigned og = (mo + (unsigned)(gate_chunk * kC)) * 4u + (unsigned)hh * 16u;
-    const unsigned char* bb = reinterpret_cast<const unsigned char*>(bias);
     constexpr int NV = (FT1 - FT0) * 4;
-    f32x4 hv[NV], g[NV], b[NV];
+    f32x4 hv[NV], g[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const unsigned fo = 32u * (unsigned)(FT0 * 4 + i);   // byte offset of feature 32 ft + 8 a (+ 4 hh via off / og)
         hv[i] = *reinterpret_cast<const f32x4*>(hb + off + fo);
         g[i] = *reinterpret_cast<const f32x4*>(mb + og + fo);
-        b[i] = *reinterpret_cast<const f32x4*>(bb + (unsigned)hh * 16u + fo);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int ft = FT0 + (i >> 2), a = i & 3;
         f32x4 o = hv[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] += g[i][j] * (y[ft][4 * a + j] + b[i][j]);
+        for (int j = 0; j < 4; ++j) o[j] += g[i][j] * y[ft][4 * a + j];
         if (tok >= 0) *reinterpret_cast<f32x4*>(hb + off + 32u * (unsigned)(FT0 * 4 + i)) = o;
     }
 }
 
 // The same update, keeping the updated rows in registers (rows_load's image) for the LayerNorm of the NEXT sub-layer: the
-// residual stream is written (the next epilogue needs it back) but not read again by the next prologue.
-__device__ __forceinline__ void rows_gate_residual_keep(const f32x16 (&y)[12], int tok, const float* __restrict__ bias,
-                                                        const ModMap mm, int gate_chunk, float* __restrict__ h,
-                                                        f32x4 (&v)[48]) {
+// residual stream is written (the next epilogue needs it back) but not read again by the next prologue.  The gate vectors
+// are requested one feature tile ahead (fenced: left alone hipcc either serialises a round trip per tile or hoists all 48).
+__device__ __forceinline__ void rows_gate_residual_keep(const f32x16 (&y)[12], int tok, const ModMap mm, int gate_chunk,
+                                                        float* __restrict__ h, f32x4 (&v)[48]) {
     const int hh = lane_id() >> 5;
     const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
     unsigned char* hb = reinterpret_cast<unsigned char*>(h);
@@ -244,24 +256,23 @@ __device__ __forceinline__ void rows_gate_residual_keep(const f32x16 (&y)[12], i
     const unsigned mo = tok < 0 ? 0u : (unsigned)mm.row_off(tokc);
     const unsigned char* mb = reinterpret_cast<const unsigned char*>(mm.mod);
     const unsigned og = (mo + (unsigned)(gate_chunk * kC)) * 4u + (unsigned)hh * 16u;
-    const unsigned char* bb = reinterpret_cast<const unsigned char*>(bias);
-    // the 48 row loads first (all in flight together, as in rows_load), then gate / bias a tile at a time
+    f32x4 g[2][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) g[0][a] = *reinterpret_cast<const f32x4*>(mb + og + 32u * a);
 #pragma unroll
     for (int i = 0; i < 48; ++i) v[i] = *reinterpret_cast<const f32x4*>(hb + off + 32u * i);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ft = 0; ft < 12; ++ft) {
-        f32x4 g[4], b[4];
+        if (ft + 1 < 12) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            g[a] = *reinterpret_cast<const f32x4*>(mb + og + 32u * (4 * ft + a));
-            b[a] = *reinterpret_cast<const f32x4*>(bb + (unsigned)hh * 16u + 32u * (4 * ft + a));
+            for (int a = 0; a < 4; ++a) g[(ft + 1) & 1][a] = *reinterpret_cast<const f32x4*>(mb + og + 32u * (4 * (ft + 1) + a));
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             f32x4 o = v[4 * ft + a];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += g[a][j] * (y[ft][4 * a + j] + b[a][j]);
+            for (int j = 0; j < 4; ++j) o[j] += g[ft & 1][a][j] * y[ft][4 * a + j];
             v[4 * ft + a] = o;
             if (tok >= 0) *reinterpret_cast<f32x4*>(hb + off + 32u * (4 * ft + a)) = o;
         }

@@ -63,6 +63,8 @@ def timing(wl, S, path, streams=1, trace=False):
         for i, nm in enumerate(names):
             d = t[:, i + 1] - t[:, i]
             print(f"    {nm:14s} mean {d.mean():8.0f}  p10 {np.percentile(d, 10):8.0f}  p90 {np.percentile(d, 90):8.0f} ticks")
+        if t[:, 6].any():
+            print(f"    fused out-projection: rows + 24 blocks {np.mean(t[:, 6] - t[:, 0]):8.0f}  residual epilogue (keep) {np.mean(t[:, 7] - t[:, 6]):8.0f}  LayerNorm from registers {np.mean(t[:, 1] - t[:, 7]):8.0f} ticks")
         start = t[:, 0] - t0
         print(f"    wave start: first round <= {np.percentile(start, 45):.0f}, later median {np.percentile(start, 80):.0f}; lifetime mean {(t[:, 5] - t[:, 0]).mean():.0f}")
         np.save(os.path.join(ROOT, "gpurun_out", "mlp_rows_trace.npy"), t)
