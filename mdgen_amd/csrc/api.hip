@@ -126,7 +126,7 @@ struct mdgen_ctx {
     int opt_attn_path = 0;      // tiled attention: 0 fixed-anchor fast loop with overflow check + fallback, 1 robust loop always
     int opt_mlp_path = 1;       // MLP block: 0 resident-panel kernel (k_mlp), 1 row-owner kernel (k_mlp_rows) when the launch
                                 // fills the chip, 2 row-owner kernel always
-    int opt_fuse_proj = 1;      // with the row-owner MLP kernel: run the temporal attention's out-projection inside it
+    int opt_fuse_proj = 0;      // with the row-owner MLP kernel: run the temporal attention's out-projection inside it (same wall time)
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
     std::vector<void*> milestone_events;          // mdgen_train_set_milestone_events (hipEvent_t handles, caller-owned)

@@ -1579,3 +1579,33 @@ def test_training_gradients_bf16_operands_vs_reference_fixture():
             continue
         assert e < 5e-2 and cos > 0.999, (k, e, cos)
     tm.model.set_option("train_precision", 32)
+
+
+def test_row_owner_mlp_paths_agree():
+    """The MLP block has three forms: the 64-row resident-panel kernel (`mlp_path` 0), the row-owner kernel (`mlp_path` 2:
+    activations in registers, LDS-DMA weight stream) and the row-owner kernel with the temporal out-projection fused in front
+    of it (`fuse_proj` 1).  All three against the reference golden at the bf16 gate, and against each other (different
+    summation orders / GELU polynomial: a few 1e-3); the IPA stack (S*B*L rows: partial tiles, idle waves) takes the
+    row-owner kernel too under `mlp_path` 2."""
+    from mdgen_amd.model import LatentMDGenModel
+    dev = _cuda()
+    for name in ("fwd_full_pep", "fwd_full_atlas"):
+        g = load_golden(name)
+        cfg, sd = weights_for(g)
+        outs = {}
+        for key, opts in (("panel", {"mlp_path": 0}), ("rows", {"mlp_path": 2, "fuse_proj": 0}), ("rows+proj", {"mlp_path": 2, "fuse_proj": 1})):
+            m = LatentMDGenModel(cfg)
+            m.load_state_dict(sd)
+            for k, v in opts.items():
+                m.set_option(k, v)
+            kw = _kw(g, dev)
+            kw.pop("end_frames")
+            out = m.forward(**kw)
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all()
+            outs[key] = out.cpu()
+            e = rel_l2(outs[key], g["out"])
+            print(f"{name} {key}: rel-L2 vs reference {e:.2e}")
+            assert e < TOL_FWD
+            del m
+        assert rel_l2(outs["rows"], outs["panel"]) < 6e-3 and rel_l2(outs["rows+proj"], outs["rows"]) < 6e-3
