@@ -64,7 +64,47 @@ struct LinearParams {
     float* c2;                              // mode 6: GELU output
 };
 
-// Operand precision of k32_linear / k32_dw: 0 = fp32 products (v_mfma_f32_32x32x2_f32, the exact mode), 1 = operands rounded
+// epilogue shared by k32_linear and k16_linear: bias, then store / GELU / gated residual / Euler / scale / accumulate (LinearParams::mode)
+__device__ __forceinline__ void linear_epilogue(const LinearParams& p, const f32x16 (&acc)[2][2], long row0, int colt, int wr, int wc) {
+    const int lane = lane_id();
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int col = colt + wc * 64 + u * 32 + (lane & 31);
+        if (col >= p.m) continue;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + wr * 64 + t * 32 + mfma_row(r, hh);
+                if (row >= p.n) continue;
+                float v = acc[t][u][r] + bias;
+                float* dst = p.c + row * p.ldc + p.col0 + col;
+                if (p.mode == 0) {
+                    *dst = v;
+                } else if (p.mode == 1) {
+                    *dst = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                } else if (p.mode == 2) {
+                    const float g = p.gated ? p.mm.mod[p.mm.row_off(row) + p.gate_chunk * kC + col] : 1.0f;
+                    *dst = *dst + g * v;
+                } else if (p.mode == 3) {
+                    *dst = *dst + p.scalar * v;
+                } else if (p.mode == 4) {
+                    *dst = v * p.scalar;
+                } else if (p.mode == 5) {
+                    *dst = *dst + v;
+                } else {
+                    *dst = v;
+                    p.c2[row * p.ldc + p.col0 + col] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                }
+            }
+        }
+    }
+}
+
+// Operand precision of the training step's linear layers / weight gradients: 0 = fp32 products (k32_linear / k32_dw on
+// v_mfma_f32_32x32x2_f32, the exact mode), 1 = k16_linear / k16_dw: operands rounded
 // to bf16 on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- what the reference
 // trains with (train.py:13 `torch.set_float32_matmul_precision('medium')` = bf16-class products, fp32 accumulate, fp32
 // master weights).  Set by mdgen_train_forward_backward from the context option "train_precision" for the duration of the
@@ -72,20 +112,14 @@ struct LinearParams {
 int g_k32_bf16_operands = 0;
 
 // Workgroup tile 128 rows x 128 columns, wave tile 64 x 64 (2 x 2 MFMA tiles: every LDS operand read feeds two MFMAs),
-// k in steps of BK (16 fp32 / 32 bf16); the next k-step's global loads are issued before the current one's MFMAs (register
-// prefetch), so a k-step costs max(MFMA, memory) instead of their sum.  Loads are unconditional with clamped indices.
-// BF: LDS tiles hold bf16 [128][32] with 80-byte rows (the 16-byte fragment reads of 16 consecutive rows then fall on 16
-// distinct slots of the 256-byte bank row); a fragment read IS the MFMA operand (row = lane & 31, k = 8 (lane >> 5) .. + 7).
-template <bool BF>
+// k in steps of 16; the next k-step's global loads are issued before the current one's MFMAs (register prefetch), so a
+// k-step costs max(MFMA, memory) instead of their sum.  Loads are unconditional with clamped indices.
 __global__ __launch_bounds__(256) void k32_linear(const LinearParams p) {
-    constexpr int BK = BF ? 32 : 16, LD = BK + 1, TM = 128, KPT = BK / 4;   // KPT: consecutive k per thread and row
-    constexpr int ROWB = 80;                                                // BF: bytes per LDS row
-    __shared__ __attribute__((aligned(16))) float As[BF ? TM * ROWB / 4 : TM * LD];
-    __shared__ __attribute__((aligned(16))) float Ws[BF ? TM * ROWB / 4 : TM * LD];
+    constexpr int BK = 16, LD = BK + 1, TM = 128;
+    __shared__ float As[TM * LD];
+    __shared__ float Ws[TM * LD];
     const int lane = lane_id(), w = wave_id();
-    // grid = (column tiles, row tiles): the workgroups that share a 128-row slice of A are dispatched back to back, so that
-    // slice leaves HBM once and the other column tiles find it in the Infinity Cache (with row tiles fastest A was re-read
-    // m / 128 = 3 .. 12 times from HBM: 1.2 GB per fc1 / fc2 launch at cfg-5's size)
+    // grid = (column tiles, row tiles): the workgroups that share a 128-row slice of A are dispatched back to back
     const long row0 = (long)blockIdx.y * TM;
     const int colt = blockIdx.x * TM;
     const int wr = w >> 1, wc = w & 1;   // wave -> 64 x 64 sub-tile
@@ -96,12 +130,11 @@ __global__ __launch_bounds__(256) void k32_linear(const LinearParams p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = opaque_zero();   // a real zero tuple, not the inline constant (common.h)
-    // staging: thread -> rows lr, lr + 64 and KPT consecutive k of the BK (16-byte loads when the operand allows it); a
-    // transposed weight operand ([k][m], the dX = dY W products) is staged k-major instead: thread -> k index tid / 16
-    // (+ 16 for BF) and eight consecutive columns, so that its loads are contiguous too
-    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * KPT;
+    // staging: thread -> rows lr, lr + 64 and four consecutive k of the 16 (one 16-byte load each when the operand
+    // allows it); a transposed weight operand ([k][m], the dX = dY W products) is staged k-major instead: thread ->
+    // k index tid / 16 and eight consecutive columns, so that its loads are contiguous too
+    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 4;
     const int tk = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 8;
-    constexpr int NTK = BK / 16;   // k rows per thread in the k-major staging
     long ar[2];
     int wrow[2];
 #pragma unroll
@@ -112,7 +145,121 @@ __global__ __launch_bounds__(256) void k32_linear(const LinearParams p) {
     const bool veca = ((p.lda | p.k) & 3) == 0 && ((unsigned long long)p.a & 15) == 0;
     const bool vecw = p.wtrans ? ((p.ldw | p.m) & 7) == 0 && ((unsigned long long)p.w & 15) == 0
                                : ((p.ldw | p.k) & 3) == 0 && ((unsigned long long)p.w & 15) == 0;
-    float av[2][KPT], wv[2 * NTK][BF ? 8 : 4];   // wv: row-major staging uses [2][KPT] of it, k-major [NTK * 2][4]
+    float av[2][4], wv[2][4];
+    auto fetch = [&](int k0) {
+        if (veca) {
+            const int kc = k0 + lk < p.k ? k0 + lk : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p.a + ar[h] * p.lda + kc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[h][j] = k0 + lk < p.k ? v[j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = k0 + lk + j, kc = kk < p.k ? kk : p.k - 1;
+                    const float a = p.a[ar[h] * p.lda + kc];
+                    av[h][j] = kk < p.k ? a : 0.f;
+                }
+        }
+        if (vecw && p.wtrans) {          // wv[h][j] = W^T[k0 + tk][colt + tc + 4 h + j]
+            const int kc = k0 + tk < p.k ? k0 + tk : 0;
+            const int cc = colt + tc < p.m ? colt + tc : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + (long)kc * p.ldw + cc + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wv[h][j] = (k0 + tk < p.k && colt + tc < p.m) ? v[j] : 0.f;
+            }
+        } else if (vecw) {
+            const int kc = k0 + lk < p.k ? k0 + lk : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + (long)wrow[h] * p.ldw + kc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wv[h][j] = k0 + lk < p.k ? v[j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = k0 + lk + j, kc = kk < p.k ? kk : p.k - 1;
+                    const float b = p.wtrans ? p.w[(long)kc * p.ldw + wrow[h]] : p.w[(long)wrow[h] * p.ldw + kc];
+                    wv[h][j] = kk < p.k ? b : 0.f;
+                }
+        }
+    };
+    const bool wkmajor = vecw && p.wtrans;
+    fetch(0);
+    const int i = lane & 31, kh = lane >> 5;
+    for (int k0 = 0; k0 < p.k; k0 += BK) {
+        __syncthreads();   // previous tile consumed
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                As[(lr + 64 * h) * LD + lk + j] = av[h][j];
+                if (wkmajor) Ws[(tc + 4 * h + j) * LD + tk] = wv[h][j];
+                else Ws[(lr + 64 * h) * LD + lk + j] = wv[h][j];
+            }
+        __syncthreads();
+        if (k0 + BK < p.k) fetch(k0 + BK);   // in flight under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = As[(wr * 64 + t * 32 + i) * LD + kk + kh];
+                b[t] = Ws[(wc * 64 + t * 32 + i) * LD + kk + kh];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
+        }
+    }
+    linear_epilogue(p, acc, row0, colt, wr, wc);
+}
+
+// The bf16-operand linear layer of the training step (option train_precision = 16), as a kernel of its own: same operands,
+// modes and epilogue as k32_linear, but built for the bf16 MFMA's 16x arithmetic rate, i.e. around memory and barriers:
+// k in steps of 64 (four MFMA k-steps per LDS tile: 16 MFMAs per wave between barriers), two LDS buffers and ONE barrier per
+// step (the step's MFMAs read buffer i while the registers that were prefetched during the previous step's MFMAs go to
+// buffer i ^ 1), operands rounded to bf16 on their way into LDS, 144-byte LDS rows (16 consecutive rows fall on 16 distinct
+// 16-byte slots of the 256-byte bank row), fragment reads that ARE the MFMA operands.
+__global__ __launch_bounds__(256, 2) void k16_linear(const LinearParams p) {
+    constexpr int BK = 64, TM = 128, ROWB = 144, KPT = 16, NTK = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char Ab[2][TM * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Wb[2][TM * ROWB];
+    const int lane = lane_id(), w = wave_id();
+    const long row0 = (long)blockIdx.y * TM;
+    const int colt = blockIdx.x * TM;
+    const int wr = w >> 1, wc = w & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = opaque_zero();
+    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * KPT;      // row-major staging: rows lr, lr + 64; 16 consecutive k
+    const int tk = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 8;       // k-major staging (wtrans): k rows tk + 16 z, 8 columns
+    long ar[2];
+    int wrow[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        ar[h] = row0 + lr + 64 * h < p.n ? row0 + lr + 64 * h : p.n - 1;
+        wrow[h] = colt + lr + 64 * h < p.m ? colt + lr + 64 * h : p.m - 1;
+    }
+    const bool veca = ((p.lda | p.k) & 3) == 0 && ((unsigned long long)p.a & 15) == 0;
+    const bool vecw = p.wtrans ? ((p.ldw | p.m) & 7) == 0 && ((unsigned long long)p.w & 15) == 0
+                               : ((p.ldw | p.k) & 3) == 0 && ((unsigned long long)p.w & 15) == 0;
+    const bool wkmajor = vecw && p.wtrans;
+    float av[2][KPT], wv[2 * NTK][KPT];   // wv: row-major staging uses [2][16] of it, k-major [2 z + h][4]
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < KPT / 4; ++q) {
@@ -136,7 +283,7 @@ __global__ __launch_bounds__(256) void k32_linear(const LinearParams p) {
                     }
             }
         }
-        if (vecw && p.wtrans) {          // wv[2 z + h][j] = W^T[k0 + tk + 16 z][colt + tc + 4 h + j]
+        if (wkmajor) {          // wv[2 z + h][j] = W^T[k0 + tk + 16 z][colt + tc + 4 h + j]
 #pragma unroll
             for (int z = 0; z < NTK; ++z) {
                 const int kr = k0 + tk + 16 * z;
@@ -174,107 +321,54 @@ __global__ __launch_bounds__(256) void k32_linear(const LinearParams p) {
             }
         }
     };
-    const bool wkmajor = vecw && p.wtrans;
-    fetch(0);
-    const int i = lane & 31, kh = lane >> 5;
-    unsigned char* Ab = reinterpret_cast<unsigned char*>(As);
-    unsigned char* Wb = reinterpret_cast<unsigned char*>(Ws);
-    for (int k0 = 0; k0 < p.k; k0 += BK) {
-        __syncthreads();   // previous tile consumed
-        if (BF) {
+    auto stage = [&](int buf) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                *reinterpret_cast<u32x4*>(Ab + (lr + 64 * h) * ROWB + lk * 2) =
-                    u32x4{pack_bf16(av[h][0], av[h][1]), pack_bf16(av[h][2], av[h][3]), pack_bf16(av[h][4], av[h][5]), pack_bf16(av[h][6], av[h][7])};
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                *reinterpret_cast<u32x4*>(&Ab[buf][(lr + 64 * h) * ROWB + lk * 2 + 16 * q]) =
+                    u32x4{pack_bf16(av[h][8 * q], av[h][8 * q + 1]), pack_bf16(av[h][8 * q + 2], av[h][8 * q + 3]),
+                          pack_bf16(av[h][8 * q + 4], av[h][8 * q + 5]), pack_bf16(av[h][8 * q + 6], av[h][8 * q + 7])};
                 if (!wkmajor)
-                    *reinterpret_cast<u32x4*>(Wb + (lr + 64 * h) * ROWB + lk * 2) =
-                        u32x4{pack_bf16(wv[h][0], wv[h][1]), pack_bf16(wv[h][2], wv[h][3]), pack_bf16(wv[h][4], wv[h][5]), pack_bf16(wv[h][6], wv[h][7])};
+                    *reinterpret_cast<u32x4*>(&Wb[buf][(lr + 64 * h) * ROWB + lk * 2 + 16 * q]) =
+                        u32x4{pack_bf16(wv[h][8 * q], wv[h][8 * q + 1]), pack_bf16(wv[h][8 * q + 2], wv[h][8 * q + 3]),
+                              pack_bf16(wv[h][8 * q + 4], wv[h][8 * q + 5]), pack_bf16(wv[h][8 * q + 6], wv[h][8 * q + 7])};
             }
-            if (wkmajor) {
+        if (wkmajor) {
 #pragma unroll
-                for (int z = 0; z < NTK; ++z)
+            for (int z = 0; z < NTK; ++z)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            *reinterpret_cast<uint16_t*>(Wb + (tc + 4 * h + j) * ROWB + (tk + 16 * z) * 2) = (uint16_t)pack_bf16(wv[2 * z + h][j], 0.f);
-            }
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    As[(lr + 64 * h) * LD + lk + j] = av[h][j];
-                    if (wkmajor) Ws[(tc + 4 * h + j) * LD + tk] = wv[h][j];
-                    else Ws[(lr + 64 * h) * LD + lk + j] = wv[h][j];
-                }
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<uint16_t*>(&Wb[buf][(tc + 4 * h + j) * ROWB + (tk + 16 * z) * 2]) = (uint16_t)pack_bf16(wv[2 * z + h][j], 0.f);
         }
+    };
+    const int i = lane & 31, kh = lane >> 5;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < p.k; k0 += BK, buf ^= 1) {
+        const bool more = k0 + BK < p.k;
+        if (more) fetch(k0 + BK);   // in flight under the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const bf16x8*>(&Ab[buf][(wr * 64 + t * 32 + i) * ROWB + ks * 32 + kh * 16]);
+                b[t] = *reinterpret_cast<const bf16x8*>(&Wb[buf][(wc * 64 + t * 32 + i) * ROWB + ks * 32 + kh * 16]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b[u], acc[t][u], 0, 0, 0);
+        }
+        if (more) stage(buf ^ 1);   // buffer buf ^ 1 was consumed before the barrier that closed the previous step
         __syncthreads();
-        if (k0 + BK < p.k) fetch(k0 + BK);   // in flight under the MFMAs below
-        if (BF) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 a[2], b[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    a[t] = *reinterpret_cast<const bf16x8*>(Ab + (wr * 64 + t * 32 + i) * ROWB + ks * 32 + kh * 16);
-                    b[t] = *reinterpret_cast<const bf16x8*>(Wb + (wc * 64 + t * 32 + i) * ROWB + ks * 32 + kh * 16);
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b[u], acc[t][u], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                float a[2], b[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    a[t] = As[(wr * 64 + t * 32 + i) * LD + kk + kh];
-                    b[t] = Ws[(wc * 64 + t * 32 + i) * LD + kk + kh];
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
-            }
-        }
     }
-    const int hh = lane >> 5;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int col = colt + wc * 64 + u * 32 + (lane & 31);
-        if (col >= p.m) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long row = row0 + wr * 64 + t * 32 + mfma_row(r, hh);
-                if (row >= p.n) continue;
-                float v = acc[t][u][r] + bias;
-                float* dst = p.c + row * p.ldc + p.col0 + col;
-                if (p.mode == 0) {
-                    *dst = v;
-                } else if (p.mode == 1) {
-                    *dst = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                } else if (p.mode == 2) {
-                    const float g = p.gated ? p.mm.mod[p.mm.row_off(row) + p.gate_chunk * kC + col] : 1.0f;
-                    *dst = *dst + g * v;
-                } else if (p.mode == 3) {
-                    *dst = *dst + p.scalar * v;
-                } else if (p.mode == 4) {
-                    *dst = v * p.scalar;
-                } else if (p.mode == 5) {
-                    *dst = *dst + v;
-                } else {
-                    *dst = v;
-                    p.c2[row * p.ldc + p.col0 + col] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                }
-            }
-        }
-    }
+    linear_epilogue(p, acc, row0, colt, wr, wc);
 }
 
 // q (pre-scaled by the caller's linear, mode 4) and k: rotate-half RoPE in place.  buf[token][ld]: q at col 0, k at col
@@ -400,8 +494,8 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
                      int wtrans, float* c2) {
     LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, wtrans, c, ldc, col0, mm, gate_chunk, gated, scalar, c2};
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128));
-    if (g_k32_bf16_operands) hipLaunchKernelGGL(k32_linear<true>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k32_linear<false>, grid, dim3(256), 0, s, p);
+    if (g_k32_bf16_operands) hipLaunchKernelGGL(k16_linear, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k32_linear, grid, dim3(256), 0, s, p);
 }
 void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, hipStream_t s) {
     const long total = ntok * kH * 12 * 2;

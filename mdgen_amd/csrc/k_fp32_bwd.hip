@@ -20,14 +20,11 @@ namespace mdg {
 // Workgroup tile 128 x 128, wave tile 64 x 64 (2 x 2 MFMA tiles), sixteen token rows per step, the next step's rows
 // requested before the current step's MFMAs.  Both operands are read along their contiguous dimension (thread -> token
 // row tid / 16, eight consecutive columns: two 16-byte loads each) and transposed on their way into LDS.
-// BF (g_k32_bf16_operands, k_fp32.hip): both operands are rounded to bf16 on their way into LDS ([row][32 tokens], 80-byte
-// rows) and multiplied on v_mfma_f32_32x32x16_bf16; 32 token rows per step instead of 16.
-template <bool BF>
 __global__ __launch_bounds__(256) void k32_dw(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
                                               long n, int m, int k, float* __restrict__ part) {
-    constexpr int BN = BF ? 32 : 16, LD = BN + 1, TM = 128, NR = BN / 16, ROWB = 80;
-    __shared__ __attribute__((aligned(16))) float As[BF ? TM * ROWB / 4 : TM * LD];   // dY^T tile: [m][n]
-    __shared__ __attribute__((aligned(16))) float Bs[BF ? TM * ROWB / 4 : TM * LD];   // X^T  tile: [k][n]
+    constexpr int BN = 16, LD = BN + 1, TM = 128;
+    __shared__ float As[TM * LD];   // dY^T tile: [m][n]
+    __shared__ float Bs[TM * LD];   // X^T  tile: [k][n]
     const int lane = lane_id(), w = wave_id();
     const int m0 = blockIdx.x * TM, k0 = blockIdx.y * TM;
     const long per = ((n + gridDim.z - 1) / gridDim.z + BN - 1) / BN * BN;
@@ -40,14 +37,116 @@ __global__ __launch_bounds__(256) void k32_dw(const float* __restrict__ dy, int 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = opaque_zero();
-    const int ln = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 8;   // staging: 16 token rows (x NR) x 128 columns (8 per thread)
+    const int ln = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 8;   // staging: 16 token rows x 128 columns (8 per thread)
     const bool veca = ((ldy | m) & 7) == 0 && ((unsigned long long)dy & 15) == 0;
     const bool vecb = ((ldx | k) & 7) == 0 && ((unsigned long long)x & 15) == 0;
-    float av[NR][8], bv[NR][8];
+    float av[8], bv[8];
+    auto fetch = [&](long n0) {
+        const long row = n0 + ln < nhi ? n0 + ln : (nhi > 0 ? nhi - 1 : 0);
+        const bool rok = n0 + ln < nhi;
+        if (veca) {
+            const int mc = m0 + lc < m ? m0 + lc : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(dy + row * ldy + mc + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[4 * h + j] = (rok && m0 + lc < m) ? v[j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int mc = m0 + lc + j;
+                const float v = dy[row * ldy + (mc < m ? mc : m - 1)];
+                av[j] = (rok && mc < m) ? v : 0.f;
+            }
+        }
+        if (vecb) {
+            const int kc = k0 + lc < k ? k0 + lc : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ldx + kc + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[4 * h + j] = (rok && k0 + lc < k) ? v[j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kc = k0 + lc + j;
+                const float v = x[row * ldx + (kc < k ? kc : k - 1)];
+                bv[j] = (rok && kc < k) ? v : 0.f;
+            }
+        }
+    };
+    if (nlo < nhi) fetch(nlo);
+    const int i = lane & 31, kh = lane >> 5;
+    for (long n0 = nlo; n0 < nhi; n0 += BN) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            As[(lc + j) * LD + ln] = av[j];
+            Bs[(lc + j) * LD + ln] = bv[j];
+        }
+        __syncthreads();
+        if (n0 + BN < nhi) fetch(n0 + BN);
+#pragma unroll
+        for (int kk = 0; kk < BN; kk += 2) {
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = As[(wr * 64 + t * 32 + i) * LD + kk + kh];
+                b[t] = Bs[(wc * 64 + t * 32 + i) * LD + kk + kh];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
+        }
+    }
+    const int hh = lane >> 5;
+    float* dst = part + (long)blockIdx.z * m * k;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int col = k0 + wc * 64 + u * 32 + (lane & 31);
+        if (col >= k) continue;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + t * 32 + mfma_row(r, hh);
+                if (row < m) dst[(long)row * k + col] = acc[t][u][r];
+            }
+    }
+}
+// The bf16-operand weight gradient (option train_precision = 16) as a kernel of its own, built like k16_linear (k_fp32.hip):
+// 64 token rows per step (four MFMA k-steps), two LDS buffers and one barrier per step, operands rounded to bf16 on their
+// way into LDS.  Both operands are read along their contiguous dimension (thread -> FOUR ADJACENT token rows 4 r .. 4 r + 3,
+// eight consecutive columns) and transposed on the way in: the four token values of a column are one 8-byte LDS store.
+// part[z][m][k] = sum_{n in slice z} dY[n][m] * X[n][k].
+__global__ __launch_bounds__(256, 2) void k16_dw(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                                                 long n, int m, int k, float* __restrict__ part) {
+    constexpr int BN = 64, TM = 128, ROWB = 144;
+    __shared__ __attribute__((aligned(16))) unsigned char Ab[2][TM * ROWB];   // dY^T tile: [m][n]
+    __shared__ __attribute__((aligned(16))) unsigned char Bb[2][TM * ROWB];   // X^T  tile: [k][n]
+    const int lane = lane_id(), w = wave_id();
+    const int m0 = blockIdx.x * TM, k0 = blockIdx.y * TM;
+    const long per = ((n + gridDim.z - 1) / gridDim.z + BN - 1) / BN * BN;
+    const long nlo = (long)blockIdx.z * per, nhi = nlo + per < n ? nlo + per : n;
+    const int wr = w >> 1, wc = w & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = opaque_zero();
+    const int rg = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 8;   // token rows 4 rg .. 4 rg + 3, columns lc .. lc + 7
+    const bool veca = ((ldy | m) & 7) == 0 && ((unsigned long long)dy & 15) == 0;
+    const bool vecb = ((ldx | k) & 7) == 0 && ((unsigned long long)x & 15) == 0;
+    float av[4][8], bv[4][8];
     auto fetch = [&](long n0) {
 #pragma unroll
-        for (int z = 0; z < NR; ++z) {
-            const long rw = n0 + ln + 16 * z;
+        for (int z = 0; z < 4; ++z) {
+            const long rw = n0 + 4 * rg + z;
             const long row = rw < nhi ? rw : (nhi > 0 ? nhi - 1 : 0);
             const bool rok = rw < nhi;
             if (veca) {
@@ -84,58 +183,38 @@ __global__ __launch_bounds__(256) void k32_dw(const float* __restrict__ dy, int 
             }
         }
     };
-    if (nlo < nhi) fetch(nlo);
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            *reinterpret_cast<u32x2*>(&Ab[buf][(lc + j) * ROWB + 8 * rg]) = u32x2{pack_bf16(av[0][j], av[1][j]), pack_bf16(av[2][j], av[3][j])};
+            *reinterpret_cast<u32x2*>(&Bb[buf][(lc + j) * ROWB + 8 * rg]) = u32x2{pack_bf16(bv[0][j], bv[1][j]), pack_bf16(bv[2][j], bv[3][j])};
+        }
+    };
     const int i = lane & 31, kh = lane >> 5;
-    unsigned char* Ab = reinterpret_cast<unsigned char*>(As);
-    unsigned char* Bb = reinterpret_cast<unsigned char*>(Bs);
-    for (long n0 = nlo; n0 < nhi; n0 += BN) {
-        __syncthreads();
-        if (BF) {
+    if (nlo < nhi) {
+        fetch(nlo);
+        stage(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (long n0 = nlo; n0 < nhi; n0 += BN, buf ^= 1) {
+        const bool more = n0 + BN < nhi;
+        if (more) fetch(n0 + BN);
 #pragma unroll
-            for (int z = 0; z < NR; ++z)
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[2], b[2];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    *reinterpret_cast<uint16_t*>(Ab + (lc + j) * ROWB + (ln + 16 * z) * 2) = (uint16_t)pack_bf16(av[z][j], 0.f);
-                    *reinterpret_cast<uint16_t*>(Bb + (lc + j) * ROWB + (ln + 16 * z) * 2) = (uint16_t)pack_bf16(bv[z][j], 0.f);
-                }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                As[(lc + j) * LD + ln] = av[0][j];
-                Bs[(lc + j) * LD + ln] = bv[0][j];
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const bf16x8*>(&Ab[buf][(wr * 64 + t * 32 + i) * ROWB + ks * 32 + kh * 16]);
+                b[t] = *reinterpret_cast<const bf16x8*>(&Bb[buf][(wc * 64 + t * 32 + i) * ROWB + ks * 32 + kh * 16]);
             }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b[u], acc[t][u], 0, 0, 0);
         }
+        if (more) stage(buf ^ 1);
         __syncthreads();
-        if (n0 + BN < nhi) fetch(n0 + BN);
-        if (BF) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 a[2], b[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    a[t] = *reinterpret_cast<const bf16x8*>(Ab + (wr * 64 + t * 32 + i) * ROWB + ks * 32 + kh * 16);
-                    b[t] = *reinterpret_cast<const bf16x8*>(Bb + (wc * 64 + t * 32 + i) * ROWB + ks * 32 + kh * 16);
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b[u], acc[t][u], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < BN; kk += 2) {
-                float a[2], b[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    a[t] = As[(wr * 64 + t * 32 + i) * LD + kk + kh];
-                    b[t] = Bs[(wc * 64 + t * 32 + i) * LD + kk + kh];
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
-            }
-        }
     }
     const int hh = lane >> 5;
     float* dst = part + (long)blockIdx.z * m * k;
@@ -152,6 +231,7 @@ __global__ __launch_bounds__(256) void k32_dw(const float* __restrict__ dy, int 
             }
     }
 }
+
 __global__ void k32_reduce_add(const float* __restrict__ part, int nsplit, long count, float* __restrict__ dst) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -622,8 +702,8 @@ void launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int 
     if (nsplit < 1) nsplit = 1;
     while (nsplit > 1 && (size_t)nsplit * m * k > part_floats) --nsplit;
     const dim3 grid((m + 127) / 128, (k + 127) / 128, nsplit);
-    if (g_k32_bf16_operands) hipLaunchKernelGGL(k32_dw<true>, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
-    else hipLaunchKernelGGL(k32_dw<false>, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
+    if (g_k32_bf16_operands) hipLaunchKernelGGL(k16_dw, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
+    else hipLaunchKernelGGL(k32_dw, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
     const long count = (long)m * k;
     hipLaunchKernelGGL(k32_reduce_add, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part, nsplit, count, dw);
 }
