@@ -167,9 +167,12 @@ def pmc_traffic(kernel_class, workload):
         kern = m.get("kernels")
     if not kern or not sub:
         return None, None
-    for name, v in kern.items():
-        if sub in name:
-            return v["hbm_bytes_per_launch"], "profiles/pmc_traffic.json (" + m.get("method", "") + ")"
+    # the MLP class has two kernels (row-owner k_mlp_rows for launches that fill the chip, panel k_mlp<3> otherwise): take the
+    # one with the larger grid, i.e. the trunk's
+    hits = [(v.get("grid_threads", 0), v) for name, v in kern.items() if sub in name]
+    if hits:
+        v = max(hits, key=lambda t: t[0])[1]
+        return v["hbm_bytes_per_launch"], "profiles/pmc_traffic.json (" + m.get("method", "") + ")"
     return None, None
 
 
