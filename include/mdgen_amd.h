@@ -109,6 +109,15 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      automatic re-run of the affected (head, 64 queries) on the robust loop; 1 the robust loop
  *                      (running row max, shift re-anchored as it grows) for everything.  Same results to fp32
  *                      rounding; 1 is ~1.5x slower.
+ *   "mlp_path"         the MLP block (latent_model.py:478-481, layers.py:77-84): 0 the 64-row resident-panel kernel
+ *                      (csrc/k_gemm.hip k_mlp); 1 (default) the row-owner kernel (csrc/k_rows.hip k_mlp_rows: a wave owns 32
+ *                      rows, activations in registers, weights as one LDS-DMA stream) for launches of >= 768 row tiles,
+ *                      which fill the chip, and the panel kernel below that; 2 the row-owner kernel always.
+ *   "fuse_proj"        0 (default) / 1: with the row-owner MLP kernel, run the temporal attention's out-projection +
+ *                      gated residual (mha.py:397, latent_model.py:476) inside it, ahead of the MLP.
+ *   "train_precision"  operands of the linear layers and weight gradients of mdgen_train_forward_backward: 32 (default)
+ *                      fp32, the exact mode; 16 rounded to bf16, fp32 accumulation, fp32 master weights (train.py:13
+ *                      set_float32_matmul_precision('medium')); everything else stays fp32.
  * Returns -4 for an unknown name, -2 for a value out of range. */
 int32_t mdgen_ctx_set_option(mdgen_ctx* ctx, const char* name, int32_t value);
 /* number of state_dict keys the model needs; name of the i-th (for loaders / tests) */
