@@ -318,10 +318,14 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=137)
     ap.add_argument("--synthetic", type=int, default=0, metavar="N", help="N synthetic steps per epoch instead of a dataset")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--single_device", action="store_true",
+                    help="every rank on cuda:0 (with --backend gloo: lets a one-GPU box run the multi-rank path; RCCL refuses it)")
     a = ap.parse_args(argv)
     if not a.prepend_ipa or a.sim_condition == a.tps_condition:
         raise SystemExit("the accelerated path trains the prepend_ipa models with exactly one of --sim_condition / --tps_condition")
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    if a.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
