@@ -122,6 +122,7 @@ struct mdgen_ctx {
     int opt_precision = 16;     // GEMM / attention operand precision: 16 = bf16 MFMA path, 32 = fp32 path (k_fp32.hip)
     int opt_keep_fp32 = 0;      // keep an fp32 copy of every weight handed over (required by precision 32)
     std::map<std::string, float*> w32;   // fp32 copies, natural layout, keyed by the reference's state_dict key
+    std::map<std::string, bool> w32_bound;   // keys whose w32 entry points into the caller's flat parameter buffer (mdgen_train_bind_params)
     int opt_streams = 2;        // concurrent sub-batch streams of the Euler rollout (1 = caller's stream only)
     int opt_attn_path = 0;      // tiled attention: 0 fixed-anchor fast loop with overflow check + fallback, 1 robust loop always
     int opt_mlp_path = 1;       // MLP block: 0 resident-panel kernel (k_mlp), 1 row-owner kernel (k_mlp_rows) when the launch
@@ -556,7 +557,9 @@ extern "C" int32_t mdgen_ctx_set_weight(mdgen_ctx* c, const char* key, const flo
         float*& dst = c->w32[key];
         if (!dst)
             if (int e = c->dalloc(&dst, n)) return e;
-        if (dst != data)   // (bound parameters, mdgen_train_bind_params: the refresh hands the flat buffer's own views over)
+        // a BOUND entry (mdgen_train_bind_params) is the caller's master copy of the parameter: never written from here -- a
+        // set_weight with other values (EMA weights swapped in for validation) only re-packs the sampler's operands
+        if (dst != data && !c->w32_bound.count(key))
             HIPCHK(hipMemcpyAsync(dst, data, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     c->provided[key] = true;

@@ -253,6 +253,23 @@ class Trainer:
         self.global_step += 1
         return loss.mean()
 
+    @torch.no_grad()
+    def validation_loss(self, batches) -> float:
+        """`validation_step` of the reference (wrapper.py:88-97, 107-110): the flow-matching loss of `general_step` over
+        `batches` with the EMA weights swapped in when an EMA is kept (restored afterwards); forward only."""
+        if self.ema is not None:
+            sd = self.ema.state_dict()["params"]
+            self.tm.model.load_state_dict({k: v for k, v in sd.items()})   # (bound fp32 master parameters are not touched)
+            self.tm._stale = False                # the packs now hold the EMA: no lazy re-pack in front of the forward passes
+        tot, n = 0.0, 0
+        for batch in batches:
+            loss, _ = self.wrapper.general_step(batch, stage="val")
+            tot += float(loss.mean())
+            n += 1
+        if self.ema is not None:
+            self.tm.mark_updated()                # the packed sampler weights hold the EMA now: re-pack before the next use
+        return tot / max(n, 1)
+
     # ---- checkpoint / resume (the Lightning layout `NewMDGenWrapper.load_from_checkpoint` reads; SURVEY section 5) ----
     def save_checkpoint(self, path):
         sd = self.tm.state_dict()
@@ -317,6 +334,9 @@ def main(argv=None):
     ap.add_argument("--print_freq", type=int, default=100)
     ap.add_argument("--seed", type=int, default=137)
     ap.add_argument("--synthetic", type=int, default=0, metavar="N", help="N synthetic steps per epoch instead of a dataset")
+    ap.add_argument("--val_split", default=None)
+    ap.add_argument("--val_batches", type=int, default=None)
+    ap.add_argument("--no_validate", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--single_device", action="store_true",
                     help="every rank on cuda:0 (with --backend gloo: lets a one-GPU box run the multi-rank path; RCCL refuses it)")
@@ -366,6 +386,25 @@ def main(argv=None):
             for i in range(n):
                 items = [ds[j] for j in order[i * a.batch_size:(i + 1) * a.batch_size]]
                 yield {k: torch.stack([it[k] for it in items]) for k in ("torsions", "torsion_mask", "trans", "rots", "seqres", "mask")}
+    val_ds = None
+    if not a.no_validate and not a.synthetic and a.val_split:
+        from .dataset import MDGenDataset as _DS
+        val_ds = _DS(a, split=a.val_split, device=dev)
+
+    def val_batches(epoch):
+        if a.synthetic:
+            for i in range(min(a.synthetic, a.val_batches or 2)):
+                yield _bench.synth_batch(a.batch_size, a.num_frames, a.crop, 16 if a.crop >= 64 else 0, dev,
+                                         seed=900000 + 10 * i + rank, tps=a.tps_condition)
+        elif val_ds is not None:
+            idx = list(range(len(val_ds)))[rank::world]
+            n = len(idx) // a.batch_size
+            if a.val_batches:
+                n = min(n, a.val_batches)
+            for i in range(n):
+                items = [val_ds[j] for j in idx[i * a.batch_size:(i + 1) * a.batch_size]]
+                yield {k: torch.stack([it[k] for it in items]) for k in ("torsions", "torsion_mask", "trans", "rots", "seqres", "mask")}
+
     for epoch in range(a.epochs):
         t0, n, comm = time.perf_counter(), 0, 0.0
         for batch in batches(epoch):
@@ -376,9 +415,15 @@ def main(argv=None):
                 print(f"epoch {epoch} step {n}: loss {float(loss):.4f}", flush=True)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        vloss = None
+        if not a.no_validate and (a.synthetic or val_ds is not None):
+            vloss = tr.validation_loss(val_batches(epoch))
+            if dist:
+                from .sharding import sum_over_ranks
+                vloss = sum_over_ranks(vloss, dist, dev if a.backend == "nccl" else None) / world
         if rank == 0:
             print(f"epoch {epoch}: {n} steps, {dt / max(n, 1) * 1e3:.1f} ms/step, exposed all-reduce wait {comm / max(n, 1):.2f} ms/step, "
-                  f"world {world}", flush=True)
+                  f"world {world}" + (f", validation loss {vloss:.4f}" if vloss is not None else ""), flush=True)
             if (epoch + 1) % a.ckpt_freq == 0:
                 os.makedirs(a.out_dir, exist_ok=True)
                 tr.save_checkpoint(os.path.join(a.out_dir, f"epoch={epoch}.ckpt"))

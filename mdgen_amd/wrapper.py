@@ -67,7 +67,27 @@ class NewMDGenWrapper:
         w = cls(args, device=device, precision=precision)
         sd = {k[len("model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("model.")}
         w.load_model_state_dict(sd)
+        w.ema_state = ckpt.get("ema")            # wrapper.py:120-124 `on_load_checkpoint`
         return w
+
+    # wrapper.py:64-76: validation runs on the EMA weights and restores the raw ones afterwards
+    def load_ema_weights(self, ema_params=None):
+        """Swap the EMA parameters in (`ema_params`: a full state dict; default: the checkpoint's `ema['params']`)."""
+        if ema_params is None:
+            if not getattr(self, "ema_state", None):
+                raise L.MdgenError("no EMA state: the checkpoint has no 'ema' entry (trained without --ema)")
+            ema_params = self.ema_state["params"]
+        if not hasattr(self, "model_state_dict"):
+            raise L.MdgenError("load_ema_weights needs the raw weights to restore later: use load_model_state_dict()")
+        self.cached_weights = self.model_state_dict
+        self.model.load_state_dict({k: v for k, v in ema_params.items()})
+        return self
+
+    def restore_cached_weights(self):
+        if getattr(self, "cached_weights", None) is not None:
+            self.model.load_state_dict(self.cached_weights)
+            self.cached_weights = None
+        return self
 
     def load_model_state_dict(self, sd):
         """Hand the `model.*` tensors to the library and remember them (the training step starts from them)."""

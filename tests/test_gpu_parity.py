@@ -1609,3 +1609,51 @@ def test_row_owner_mlp_paths_agree():
             assert e < TOL_FWD
             del m
         assert rel_l2(outs["rows"], outs["panel"]) < 6e-3 and rel_l2(outs["rows+proj"], outs["rows"]) < 6e-3
+
+
+def test_validation_on_ema_weights_leaves_the_master_parameters_alone(tmp_path):
+    """wrapper.py:64-76, 88-97: validation runs on the EMA weights.  `Trainer.validation_loss` swaps them into the library (the
+    training kernels' fp32 weights are BOUND to the flat parameter buffer: the swap must not write there), evaluates
+    `general_step`, and the next training step continues from the raw parameters: two steps with a validation pass in
+    between equal two steps without one, bit for bit.  Also: checkpoint -> `load_from_checkpoint` -> `load_ema_weights` /
+    `restore_cached_weights` on the inference wrapper."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict
+    from mdgen_amd.train import Trainer
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    dev = _cuda()
+    B, T, L = 2, 6, 5
+    cfg = ModelConfig(crop=L, num_frames=T, num_layers=1, abs_pos_emb=True, sim_condition=True)
+    sd = synth_state_dict(cfg, 23)
+    g0 = load_golden("prep_sim")
+    batch = {k[3:]: v.to(dev) for k, v in g0.items() if k.startswith("in_")}
+    res = []
+    for validate in (False, True):
+        w = NewMDGenWrapper(cfg)
+        w.load_model_state_dict(sd)
+        tr = Trainer(w, lr=1e-3, grad_clip=1.0, ema_decay=0.5)
+        gen = torch.Generator().manual_seed(3)
+        for step in range(2):
+            t = torch.rand(B, generator=gen).to(dev)
+            x0 = torch.randn(B, T, L, cfg.latent_dim, generator=gen).to(dev)
+            tr.training_step(batch, t=t, x0=x0)
+            if validate and step == 0:
+                v_ema = tr.validation_loss([batch])
+                assert v_ema == v_ema and v_ema > 0
+        torch.cuda.synchronize()
+        res.append((tr.tm.params.data.clone(), tr.ema.data.clone()))
+        if validate:
+            path = str(tmp_path / "t.ckpt")
+            tr.save_checkpoint(path)
+        tr.close()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    wi = NewMDGenWrapper.load_from_checkpoint(path)
+    kw = dict(x=torch.zeros(B, T, L, cfg.latent_dim, device=dev), t=torch.zeros(B, device=dev))
+    prep = wi.prep_batch(batch)
+    mk = dict(prep["model_kwargs"]); mk["mask"] = mk["mask"].contiguous(); mk.pop("end_frames")
+    raw = wi.model.forward(**kw, **mk)
+    wi.load_ema_weights()
+    ema = wi.model.forward(**kw, **mk)
+    wi.restore_cached_weights()
+    raw2 = wi.model.forward(**kw, **mk)
+    assert torch.equal(raw, raw2) and not torch.equal(raw, ema) and torch.isfinite(ema).all()
