@@ -212,11 +212,8 @@ extern "C" int mdgen_dev_qkv_stamps(void* host, size_t bytes) {
 #define QKV_STAMP(slot)
 #endif
 
-// DEEP (launches of <= 256 workgroups: one per CU at most): weight fragments eight k-steps ahead instead of four, 512 registers
-// per wave -- a lone workgroup has nothing else on its CU to hide the L2 round trips of its weight stream behind.
-template <bool SMALL, bool DEEP>
-__global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_ln_qkv(const QkvParams p) {
-    constexpr int PFW = DEEP ? 8 : 4;
+template <bool SMALL>
+__global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
     PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
     unsigned char* panel = smem + sizeof(PanelRows);
@@ -256,14 +253,14 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_ln_qkv(const QkvParams p)
     f32x16 acc[6];
     // ---- Q (heads 4w..4w+3), transposed
     zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, true, PFW>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     QKV_STAMP(2);
     epilogue_heads_T<true>(acc, pr, w, p.bq, p.rope, SMALL, pos0, len, seq, ntile, tile0, p.qf, p.qkv_small, 0);
     __builtin_amdgcn_sched_barrier(0);
     QKV_STAMP(3);
     // ---- K
     zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, true, PFW>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     QKV_STAMP(4);
     epilogue_heads_T<true>(acc, pr, w, p.bk, p.rope, SMALL, pos0, len, seq, ntile, tile0, p.kf, p.qkv_small, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -271,10 +268,10 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_ln_qkv(const QkvParams p)
     // ---- V
     zero_acc<6>(acc);
     if (SMALL) {
-        wave_gemm<2, 3, 24, true, PFW>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
         epilogue_heads_T<false>(acc, pr, w, p.bv, nullptr, true, pos0, len, seq, ntile, tile0, nullptr, p.qkv_small, 2);
     } else {
-        wave_gemm<2, 3, 24, false, PFW>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
         QKV_STAMP(6);
         epilogue_v_flash(acc, w, p.bv, seq, ntile, tile0, p.vf);
         if ((int)blockIdx.x - seq * p.panels_per_seq == p.panels_per_seq - 1) {   // the sequence's last panel
@@ -324,8 +321,8 @@ __device__ __forceinline__ void load_head_bias(const float* bias_perm, int w, in
 
 // PROJ: also run the sub-layer's out-projection and gated residual update here (mha.py:397, latent_model.py:462):
 // the attention output goes straight into the LDS panel as the A operand instead of through HBM.
-template <bool PROJ, bool DEEP>
-__global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_ln_qkv_attn4(const QkvParams p) {
+template <bool PROJ>
+__global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
     // q of the second 32-token tile waits in LDS while the K GEMM runs ([wave][value][lane]: conflict-free): with
     // all 48 packed q registers live across that GEMM hipcc spilled ~90 registers per lane -- 180 MB of scratch
@@ -362,7 +359,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_ln_qkv_attn4(const QkvPar
     f32x4 rq[2][4];
     // ---- Q (heads 4w..4w+3): RoPE, keep as bf16 pairs (48 registers)
     zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, true, DEEP ? 8 : 4>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     load_head_bias(p.bq, w, hh, bb);
     load_rope(rq);
     uint32_t qp[2][4][6];
@@ -386,7 +383,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_ln_qkv_attn4(const QkvPar
     __builtin_amdgcn_sched_barrier(0);
     // ---- K: RoPE in place, then the scores of the 4 keys of the quad + the bias key; softmax -> P (40 registers)
     zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, true, DEEP ? 6 : 2>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);   // shallow ring: q is live
+    wave_gemm<2, 3, 24, true, 2>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);   // shallow ring: q is live
     load_head_bias(p.bk, w, hh, bb);
     load_rope(rq);
     // pass 1: bias + RoPE IN PLACE in the accumulators (frees the bias / rotary registers before the scores)
@@ -482,7 +479,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_ln_qkv_attn4(const QkvPar
     __builtin_amdgcn_sched_barrier(0);
     // ---- V (transposed as well: a lane holds features 12 hh .. 12 hh + 11 of each head of its token)
     zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, true, DEEP ? 6 : 3>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    wave_gemm<2, 3, 24, true, 3>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     load_head_bias(p.bv, w, hh, bb);
     {
         float* Pf = &P[0][0][0];
@@ -529,7 +526,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_ln_qkv_attn4(const QkvPar
     // ---- out-projection + gated residual, as k_proj<0>
     __syncthreads();   // the whole attention output is in the panel
     zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, false, DEEP ? 8 : 4>(panel, kRowB, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
     epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk,
                                   true, p.h_rw);
@@ -656,8 +653,8 @@ __device__ __forceinline__ void prologue_micro_attn(unsigned char* panel, const 
     }
 }
 
-template <int MODE, bool DEEP>
-__global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_proj(const ProjParams p) {
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_proj(const ProjParams p) {
     constexpr int K = (MODE == 1) ? kIpaFeat : kC;
     constexpr int ROWB = K * 2;
     constexpr int KS = K / 16;
@@ -676,7 +673,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_proj(const ProjParams p) 
     const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id();
     f32x16 acc[6];
     zero_acc<6>(acc);
-    wave_gemm<2, 3, KS, false, DEEP ? 8 : 4>(panel, ROWB, 0, 0, p.w + (size_t)(3 * w) * KS * 64 + lane, KS * 64, acc);
+    wave_gemm<2, 3, KS, false>(panel, ROWB, 0, 0, p.w + (size_t)(3 * w) * KS * 64 + lane, KS * 64, acc);
     if (MODE == 1) {
         epilogue_gate_residual<2, 3>(acc, pr, 96 * w, p.bias, p.mm, p.gate_chunk, p.gated != 0, p.h);
     } else {
@@ -733,19 +730,13 @@ __device__ __forceinline__ void gelu_group(const f32x16* a1, const f32x4& ba, un
 // are L2-resident but an L2 round trip is several hundred cycles, and both waves of a SIMD start their stages
 // together: with the first loads issued at the stage's own start every stage -- 24 per panel -- began with that
 // bubble; phase stamps showed both stage kinds at ~55 % of their MFMA / VALU bound).
-// Prefetch depths.  DEEP = false: two workgroups per CU, 256 registers per wave: kPFX = 5 W1 fragments in flight in the fc1
-// stage (six spill), two k-steps of W2 ahead in the fc2 stage.  DEEP = true (launches of <= 256 workgroups, e.g. B = 1
-// tetrapeptides: one workgroup per CU anyway, 512 registers per wave, and nothing else on the CU to hide an L2 round trip
-// behind): eight / four.  A wave's chain of k-steps is paced by latency x fragments in flight (section 3.1).
-template <bool DEEP> struct MlpDepth { static constexpr int PFX = DEEP ? 8 : 5, PFY = DEEP ? 4 : 2; };
-template <int PFX>
+constexpr int kPFX = 5;  // W1 fragments in flight per wave in the fc1 stage (see stage_x)
 struct XPre {            // fc1 stage
-    bf16x8 w[PFX];       // W1 fragments of k-steps 0..PFX-1
+    bf16x8 w[kPFX];      // W1 fragments of k-steps 0..kPFX-1
     bf16x8 a[2];         // panel fragments (two 32-token tiles) of k-step 0
 };
-template <int PFY>
 struct YPre {            // fc2 stage
-    bf16x8 w[PFY][3];    // W2 fragments of k-steps 0 .. PFY-1 (three feature tiles each)
+    bf16x8 w[2][3];      // W2 fragments of k-steps 0, 1 (three feature tiles each)
     bf16x8 a[2];         // hbuf fragments of k-step 0
 };
 constexpr int kW2S = 96 * 64;   // bf16x8 elements between two feature tiles of the packed W2
@@ -753,14 +744,14 @@ constexpr int kW2S = 96 * 64;   // bf16x8 elements between two feature tiles of 
 // X(c): a1 = fc1 of this wave's 32 hidden units of chunk c (transposed: D[hidden][token]), 24 k-steps.  Its last
 // k-steps request what the following Y stage starts with.
 // It also requests the fc1 bias of its own 32 hidden units (b1c), consumed by the GELU of that Y stage.
-template <bool NEXT, int PFX, int PFY>
-__device__ __forceinline__ void stage_x(const unsigned char* panel, const bf16x8* __restrict__ w1c, const XPre<PFX>& pre, f32x16* a1,
+template <bool NEXT>
+__device__ __forceinline__ void stage_x(const unsigned char* panel, const bf16x8* __restrict__ w1c, const XPre& pre, f32x16* a1,
                                         const float* b1c, f32x4& b0, const bf16x8* __restrict__ w2n,
-                                        const unsigned char* hrn, YPre<PFY>& nxt, unsigned long long* midstamp = nullptr) {
+                                        const unsigned char* hrn, YPre& nxt, unsigned long long* midstamp = nullptr) {
     // Weight fragments come from L2 with ~600 cycles of latency under load (in-kernel stamps: a k-step took 210 cycles
     // with three fragments in flight, 64 of them matrix-pipe time; with five 170), so the number in flight sets the
     // pace: kPFX, as many as the register file allows (six spill).
-    constexpr int KS = 24, PF = PFX;
+    constexpr int KS = 24, PF = kPFX;
     bf16x8 wring[PF + 1];
     bf16x8 aring[2][2];
 #pragma unroll
@@ -774,9 +765,9 @@ __device__ __forceinline__ void stage_x(const unsigned char* panel, const bf16x8
 #pragma unroll
             for (int t = 0; t < 2; ++t) aring[(ks + 1) & 1][t] = panel_frag(panel, kRowB, t, ks + 1);
         }
-        if (NEXT && ks >= KS - 1 - PFY && ks < KS - 1) {   // the fc2 stage's first PFY k-steps of W2, one per k-step here
+        if (NEXT && (ks == KS - 3 || ks == KS - 2)) {
 #pragma unroll
-            for (int f = 0; f < 3; ++f) nxt.w[ks - (KS - 1 - PFY)][f] = w2n[(size_t)f * kW2S + (ks - (KS - 1 - PFY)) * 64];
+            for (int f = 0; f < 3; ++f) nxt.w[ks - (KS - 3)][f] = w2n[(size_t)f * kW2S + (ks - (KS - 3)) * 64];
         }
         if (NEXT && ks == KS - 1) {
 #pragma unroll
@@ -796,12 +787,11 @@ __device__ __forceinline__ void stage_x(const unsigned char* panel, const bf16x8
 
 // Y(c): y += hbuf[(c-1)&1] (64 x 128) . W2 slab^T, eight k-steps, each carrying one GELU group of chunk c (written to
 // hbuf[c&1]); its last k-steps request what the following X stage starts with.
-template <bool NEXT, int PFX, int PFY>
-__device__ __forceinline__ void stage_y(const unsigned char* hr, const bf16x8* __restrict__ w2c, const YPre<PFY>& pre, f32x16* y,
+template <bool NEXT>
+__device__ __forceinline__ void stage_y(const unsigned char* hr, const bf16x8* __restrict__ w2c, const YPre& pre, f32x16* y,
                                         const f32x16* a1, const f32x4& b0, const float* b1c, unsigned char* hw, int w, int hh,
-                                        int tk, const unsigned char* panel, const bf16x8* __restrict__ w1n, XPre<PFX>& nxt) {
-    constexpr int KS = 8, PF = PFY;
-    constexpr int kPFX = PFX;
+                                        int tk, const unsigned char* panel, const bf16x8* __restrict__ w1n, XPre& nxt) {
+    constexpr int KS = 8, PF = 2;
     bf16x8 wring[PF + 1][3];
     bf16x8 aring[2][2];
 #pragma unroll
@@ -846,9 +836,8 @@ __device__ __forceinline__ void stage_y(const unsigned char* hr, const bf16x8* _
     }
 }
 
-template <bool DEEP>
-__global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_mlp(const MlpParams p) {
-    constexpr int kPFX = MlpDepth<DEEP>::PFX, kPFY = MlpDepth<DEEP>::PFY;
+template <int PF1>
+__global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kPanelBytes + 2 * kPanel * kHRowB];
     unsigned char* panel = smem;
     unsigned char* hb0 = smem + kPanelBytes;
@@ -874,8 +863,8 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_mlp(const MlpParams p) {
     f32x16 y[6];
     zero_acc<6>(y);
     f32x16 a1[2];
-    XPre<kPFX> xp;
-    YPre<kPFY> yp;
+    XPre xp;
+    YPre yp;
     {   // what X(0) starts with: nothing ran before it that could have prefetched
 #pragma unroll
         for (int i = 0; i < kPFX; ++i) xp.w[i] = w1l[i * 64];
@@ -884,7 +873,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_mlp(const MlpParams p) {
     }
     f32x4 b0;
     zero_acc<2>(a1);
-    stage_x<false, kPFX, kPFY>(panel, w1l, xp, a1, b1l, b0, nullptr, nullptr, yp);
+    stage_x<false>(panel, w1l, xp, a1, b1l, b0, nullptr, nullptr, yp);
     {   // chunk 0: nothing to overlap its GELU with yet; request X(1)'s first operands under it
 #pragma unroll
         for (int i = 0; i < kPFX; ++i) xp.w[i] = w1l[W1C + i * 64];
@@ -908,16 +897,16 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void k_mlp(const MlpParams p) {
 #ifdef MDGEN_DEV_MLP_STAMPX
         unsigned long long mid = 0;
         if (c == 5) stamp(p, 25);   // after the barrier, before fc1(5)
-        stage_x<true, kPFX, kPFY>(panel, w1l + (size_t)c * W1C, xp, a1, b1l + c * kHC, b0, w2l + (size_t)8 * (c - 1) * 64, hr, yp,
+        stage_x<true>(panel, w1l + (size_t)c * W1C, xp, a1, b1l + c * kHC, b0, w2l + (size_t)8 * (c - 1) * 64, hr, yp,
                       c == 5 ? &mid : nullptr);
         if (c == 5) stamp(p, 30, mid);
 #else
-        stage_x<true, kPFX, kPFY>(panel, w1l + (size_t)c * W1C, xp, a1, b1l + c * kHC, b0, w2l + (size_t)8 * (c - 1) * 64, hr, yp);
+        stage_x<true>(panel, w1l + (size_t)c * W1C, xp, a1, b1l + c * kHC, b0, w2l + (size_t)8 * (c - 1) * 64, hr, yp);
 #endif
         stamp(p, 1 + 2 * c);
         // Y(c): GELU(c) -> hw  ||  fc2(c - 1) from hr; requests the first operands of X(c + 1) (clamped at the end)
         const int cn = c + 1 < kNChunk ? c + 1 : c;
-        stage_y<true, kPFX, kPFY>(hr, w2l + (size_t)8 * (c - 1) * 64, yp, y, a1, b0, b1l + c * kHC, hw, w, hh, tk, panel, w1l + (size_t)cn * W1C, xp);
+        stage_y<true>(hr, w2l + (size_t)8 * (c - 1) * 64, yp, y, a1, b0, b1l + c * kHC, hw, w, hh, tk, panel, w1l + (size_t)cn * W1C, xp);
         stamp(p, 2 + 2 * c);
         lds_barrier();   // hbuf[c & 1] is complete; every wave has left hbuf[(c - 1) & 1]
     }
@@ -1011,40 +1000,27 @@ __global__ __launch_bounds__(256, 2) void k_final(const FinalParams p) {
 
 // ---- launchers ----------------------------------------------------------------------------------
 void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s) {
-    // grids of <= 256 workgroups (one per CU at most) take the deep-prefetch builds
     if (small) {
         const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-        if (grid <= 256) hipLaunchKernelGGL((k_ln_qkv<true, true>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((k_ln_qkv<true, false>), dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_ln_qkv<true>, dim3(grid), dim3(256), 0, s, p);
     } else {
-        const int grid = p.ax.nseq * p.panels_per_seq;
-        if (grid <= 256) hipLaunchKernelGGL((k_ln_qkv<false, true>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((k_ln_qkv<false, false>), dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_ln_qkv<false>, dim3(p.ax.nseq * p.panels_per_seq), dim3(256), 0, s, p);
     }
 }
 void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-    const bool deep = grid <= 256;
-    if (fuse_proj && deep) hipLaunchKernelGGL((k_ln_qkv_attn4<true, true>), dim3(grid), dim3(256), 0, s, p);
-    else if (fuse_proj) hipLaunchKernelGGL((k_ln_qkv_attn4<true, false>), dim3(grid), dim3(256), 0, s, p);
-    else if (deep) hipLaunchKernelGGL((k_ln_qkv_attn4<false, true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_ln_qkv_attn4<false, false>), dim3(grid), dim3(256), 0, s, p);
+    if (fuse_proj) hipLaunchKernelGGL(k_ln_qkv_attn4<true>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_ln_qkv_attn4<false>, dim3(grid), dim3(256), 0, s, p);
 }
 void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-    const bool deep = grid <= 256;
-    if (mode == 0 && deep) hipLaunchKernelGGL((k_proj<0, true>), dim3(grid), dim3(256), 0, s, p);
-    else if (mode == 0) hipLaunchKernelGGL((k_proj<0, false>), dim3(grid), dim3(256), 0, s, p);
-    else if (mode == 1 && deep) hipLaunchKernelGGL((k_proj<1, true>), dim3(grid), dim3(256), 0, s, p);
-    else if (mode == 1) hipLaunchKernelGGL((k_proj<1, false>), dim3(grid), dim3(256), 0, s, p);
-    else if (deep) hipLaunchKernelGGL((k_proj<2, true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_proj<2, false>), dim3(grid), dim3(256), 0, s, p);
+    if (mode == 0) hipLaunchKernelGGL(k_proj<0>, dim3(grid), dim3(256), 0, s, p);
+    else if (mode == 1) hipLaunchKernelGGL(k_proj<1>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_proj<2>, dim3(grid), dim3(256), 0, s, p);
 }
 void launch_mlp(const MlpParams& p, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-    // <= 256 workgroups: one per CU at most -- the deep-prefetch build (512 registers per wave)
-    if (grid <= 256) hipLaunchKernelGGL((k_mlp<true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_mlp<false>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((k_mlp<3>), dim3(grid), dim3(256), 0, s, p);
 }
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
