@@ -1,0 +1,500 @@
+// Attention of the training step with bf16 matrix operands (option train_precision = 16): forward with the
+// log-sum-exp tape, and the two backward passes that start from that tape.  Same contract, same buffers and the same
+// fp32 inputs / outputs as k32_attn / k32_attn_bwd_q / k32_attn_bwd_kv (k_fp32.hip, k_fp32_bwd.hip), which remain the
+// exact-fp32 path; these kernels put the four products of the attention and the five of its backward on the matrix
+// cores (reference: mha.py:265-268, 359-396 forward; the backward is what autograd derives from it).
+//
+// Shape of all three: a workgroup of four waves OWNS 128 rows of one (sequence, head) -- queries in the forward and in
+// the query pass, keys in the key pass -- one 32-row tile per wave, held in registers as MFMA B operands (lane =
+// row).  The OTHER side streams through LDS in chunks of 64 rows, converted to bf16 on the way in, the next chunk's
+// global loads in flight while the current one is multiplied.  Every product is computed transposed, D[other][own],
+// so that everything that is per own row (running max, log-sum-exp, delta = dO . O, key validity) is per LANE, and so
+// that the accumulator registers of one product, packed to bf16 pairs, ARE the B operand of the next one (its
+// contraction runs over the `other` rows in accumulator order; the LDS copy that supplies the matching A operand is
+// written transposed in that order, perm_pos()).
+//
+//   forward      S^T = K Q^T            P^T = exp(S^T - m)        O^T += V^T P^T                 (online softmax over chunks)
+//   query pass   S^T = K Q^T            dP^T = V dO^T - delta     dS^T = P^T o dP^T              dQ^T += K^T dS^T
+//   key pass     S = Q K^T - lse        dP = dO V^T - delta       dV^T += dO^T P    dK^T += Q^T dS
+//
+// The learned bias key / value (rotated at position len, mha.py:359-366) is row `len` of the key side; key padding is
+// an additive -3e38 that the score accumulators start from (forward, query pass) or a per-lane flag (key pass).
+#include "common.h"
+#include "kernels.h"
+
+namespace mdg {
+namespace {
+
+constexpr int kRowB = 80;      // bytes of one row of a row-major tile: 32 bf16 features (24 + 8 zeros) + 16 of padding
+constexpr int kTrB = 144;      // bytes of one feature row of a transposed tile: 64 bf16 rows + 16 of padding
+constexpr int kChunk = 64;     // streamed rows per LDS fill
+constexpr float kMasked = -3.0e38f;
+
+// Position, in the contraction order of a chained B operand, of row rho (0..31) of a tile: accumulator register
+// 8 s + j of lane-half hh holds row mfma_row(8 s + j, hh) and becomes element (k-step s, 8 hh + j).
+__device__ __forceinline__ int perm_pos(int rho) {
+    return 16 * (rho >> 4) + 8 * ((rho >> 2) & 1) + 4 * ((rho >> 3) & 1) + (rho & 3);
+}
+
+__device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float half_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// rotated bias key (24) | bias value (24) of one head, computed once per workgroup
+__device__ __forceinline__ void fill_bias(float* sb, const float* bias_k, const float* bias_v, const float* inv_freq, int hd,
+                                          int len) {
+    const int d = threadIdx.x;
+    if (d < kDH) {
+        const int i = d % 12;
+        const float ang = (float)len * inv_freq[i];
+        const float c = cosf(ang), s = sinf(ang);
+        const float x1 = bias_k[hd * kDH + i], x2 = bias_k[hd * kDH + i + 12];
+        sb[d] = d < 12 ? x1 * c - x2 * s : x2 * c + x1 * s;
+        sb[kDH + d] = bias_v[hd * kDH + d];
+    }
+}
+
+struct Own {   // one owned row as an MFMA B operand: features 8 hh .. 8 hh + 7 | 16 + 8 hh .. (zeros past feature 23)
+    bf16x8 f0, f1;
+};
+// `row` points at the row's 24 floats (global or LDS); null: a zero row
+template <typename P>
+__device__ __forceinline__ Own own_row(P row, int hh, float* part_dot = nullptr, const float* other = nullptr) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a, c = a, d = a;
+    if (row) {
+        a = *reinterpret_cast<const f32x4*>(row + 8 * hh);
+        b = *reinterpret_cast<const f32x4*>(row + 8 * hh + 4);
+        if (hh == 0) {
+            c = *reinterpret_cast<const f32x4*>(row + 16);
+            d = *reinterpret_cast<const f32x4*>(row + 20);
+        }
+    }
+    if (part_dot) {   // this lane's share of row . other (the partner lane holds the rest)
+        const f32x4 oa = *reinterpret_cast<const f32x4*>(other + 8 * hh), ob = *reinterpret_cast<const f32x4*>(other + 8 * hh + 4);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += a[i] * oa[i] + b[i] * ob[i];
+        if (hh == 0) {
+            const f32x4 oc = *reinterpret_cast<const f32x4*>(other + 16), od = *reinterpret_cast<const f32x4*>(other + 20);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += c[i] * oc[i] + d[i] * od[i];
+        }
+        *part_dot = s;
+    }
+    Own o;
+    o.f0 = __builtin_bit_cast(bf16x8, u32x4{pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(b[0], b[1]), pack_bf16(b[2], b[3])});
+    o.f1 = __builtin_bit_cast(bf16x8, u32x4{pack_bf16(c[0], c[1]), pack_bf16(c[2], c[3]), pack_bf16(d[0], d[1]), pack_bf16(d[2], d[3])});
+    return o;
+}
+
+// Accumulator registers 0..7 / 8..15 packed to the two B operands of the next product.
+__device__ __forceinline__ void chain(const f32x16& v, bf16x8& b0, bf16x8& b1) {
+    b0 = __builtin_bit_cast(bf16x8, u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])});
+    b1 = __builtin_bit_cast(bf16x8, u32x4{pack_bf16(v[8], v[9]), pack_bf16(v[10], v[11]), pack_bf16(v[12], v[13]), pack_bf16(v[14], v[15])});
+}
+
+// One value per accumulator register, taken from a per-row LDS table of the tile (row of register r = mfma_row(r, hh)).
+__device__ __forceinline__ f32x16 rows_from(const float* tab, int hh, float sign) {
+    f32x16 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tab + 8 * g + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[4 * g + i] = sign * t[i];
+    }
+    return v;
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// The streamed side: thread `tid` < 192 carries rows (2 pair, 2 pair + 1) x features (4 quad .. 4 quad + 3) of the chunk for
+// up to two source matrices; threads 192..255 carry one per-row scalar (or two) each.
+struct Item {
+    int pair, quad;
+    bool on;
+};
+__device__ __forceinline__ Item item_of(int tid) { return Item{tid / 6, tid % 6, tid < 192}; }
+
+__device__ __forceinline__ void put_rowmajor(unsigned char* tile, const Item& it, const f32x4 (&v)[2]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        *reinterpret_cast<u32x2*>(tile + (2 * it.pair + e) * kRowB + it.quad * 8) =
+            u32x2{pack_bf16(v[e][0], v[e][1]), pack_bf16(v[e][2], v[e][3])};
+}
+__device__ __forceinline__ void put_transposed(unsigned char* tile, const Item& it, const f32x4 (&v)[2]) {
+    const int rho = 2 * it.pair;
+    const int col = (rho >> 5) * 64 + perm_pos(rho & 31) * 2;   // rows rho, rho + 1 are neighbours in the permuted order
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<uint32_t*>(tile + (4 * it.quad + i) * kTrB + col) = pack_bf16(v[0][i], v[1][i]);
+}
+// zero what the fills never write: features 24..31 of the row-major tiles, feature rows 24..31 of the transposed ones
+__device__ __forceinline__ void clear_rowmajor(unsigned char* tile) {
+    for (int e = threadIdx.x; e < kChunk; e += 256) *reinterpret_cast<u32x4*>(tile + e * kRowB + 48) = u32x4{0, 0, 0, 0};
+}
+__device__ __forceinline__ void clear_transposed(unsigned char* tile) {
+    for (int e = threadIdx.x; e < 8 * (kTrB / 16); e += 256) *reinterpret_cast<u32x4*>(tile + 24 * kTrB + e * 16) = u32x4{0, 0, 0, 0};
+}
+
+struct Wg {   // which rows this workgroup / wave owns
+    int seq, hd, blk;
+};
+__device__ __forceinline__ Wg wg_of(int nblk) {
+    return Wg{(int)(blockIdx.x / (nblk * kH)), (int)((blockIdx.x / nblk) % kH), (int)(blockIdx.x % nblk)};
+}
+
+}  // namespace
+
+// ---- forward -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k16_attn(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
+                                                   const float* __restrict__ bias_k, const float* __restrict__ bias_v,
+                                                   const float* __restrict__ inv_freq, float* __restrict__ out,
+                                                   float* __restrict__ lse_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK[kChunk * kRowB];
+    __shared__ __attribute__((aligned(16))) unsigned char sVt[32 * kTrB];
+    __shared__ __attribute__((aligned(16))) float sM[kChunk];
+    __shared__ __attribute__((aligned(16))) float sB[2 * kDH];
+    const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5;
+    const Wg g = wg_of((len + 127) / 128);
+    fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
+    clear_rowmajor(sK);
+    clear_transposed(sVt);
+    const int qi = g.blk * 128 + wave_id() * 32 + l31;
+    const long qtok = ax.token(g.seq, qi < len ? qi : len - 1);
+    const Own q = own_row(qkv + qtok * ld + g.hd * kDH, hh);
+    const Item it = item_of(tid);
+    f32x4 kf[2], vf[2];
+    float mval = 0.f;
+    auto fetch = [&](int c0) {
+        if (it.on) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = c0 + 2 * it.pair + e;
+                kf[e] = vf[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j < len) {
+                    const float* row = qkv + ax.token(g.seq, j) * ld + g.hd * kDH + 4 * it.quad;
+                    kf[e] = *reinterpret_cast<const f32x4*>(row + kC);
+                    vf[e] = *reinterpret_cast<const f32x4*>(row + 2 * kC);
+                }
+            }
+        } else {
+            const int j = c0 + tid - 192;
+            mval = j < len ? (mk.at(ax.token(g.seq, j)) != 0.f ? 0.f : kMasked) : (j == len ? 0.f : kMasked);
+        }
+    };
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = opaque_zero();
+    float mrun = kMasked, den = 0.f;
+    fetch(0);
+    for (int c0 = 0; c0 < len + 1; c0 += kChunk) {
+        __syncthreads();
+        if (it.on) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (c0 + 2 * it.pair + e == len) {   // the bias key / value (LDS table, ready after the first barrier)
+                    kf[e] = *reinterpret_cast<const f32x4*>(sB + 4 * it.quad);
+                    vf[e] = *reinterpret_cast<const f32x4*>(sB + kDH + 4 * it.quad);
+                }
+            put_rowmajor(sK, it, kf);
+            put_transposed(sVt, it, vf);
+        } else {
+            sM[tid - 192] = mval;
+        }
+        __syncthreads();
+        if (c0 + kChunk < len + 1) fetch(c0 + kChunk);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (c0 + 32 * t > len) break;
+            f32x16 s = rows_from(sM + 32 * t, hh, 1.0f);
+            const unsigned char* kr = sK + (32 * t + l31) * kRowB + hh * 16;
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(kr), q.f0, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(kr + 32), q.f1, s, 0, 0, 0);
+            float tmax = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+            const float mnew = fmaxf(mrun, half_max(tmax));
+            const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * kLog2e);
+            mrun = mnew;
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = __builtin_amdgcn_exp2f((s[r] - mnew) * kLog2e);
+                sum += s[r];
+                o[r] *= alpha;
+            }
+            den = den * alpha + sum;
+            bf16x8 p0, p1;
+            chain(s, p0, p1);
+            const unsigned char* vr = sVt + l31 * kTrB + 64 * t + hh * 16;
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(vr), p0, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(vr + 32), p1, o, 0, 0, 0);
+        }
+    }
+    den = half_sum(den);
+    if (qi >= len) return;
+    const float inv = 1.0f / den;
+    float* dst = out + qtok * kC + g.hd * kDH + 4 * hh;
+#pragma unroll
+    for (int gq = 0; gq < 3; ++gq)
+        *reinterpret_cast<f32x4*>(dst + 8 * gq) = f32x4{o[4 * gq] * inv, o[4 * gq + 1] * inv, o[4 * gq + 2] * inv, o[4 * gq + 3] * inv};
+    if (lse_out && hh == 0) lse_out[qtok * kH + g.hd] = mrun + logf(den);
+}
+
+// ---- backward, query pass ------------------------------------------------------------------------------------------
+// dq into dqkv[:, 0:384]; (lse, delta) into stats[token][head][2] for the key pass.
+__global__ __launch_bounds__(256, 2) void k16_attn_bwd_q(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
+                                                         const float* __restrict__ bias_k, const float* __restrict__ bias_v,
+                                                         const float* __restrict__ inv_freq, const float* __restrict__ o,
+                                                         const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                         float* __restrict__ stats, const float* __restrict__ lse_in) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK[kChunk * kRowB];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[kChunk * kRowB];
+    __shared__ __attribute__((aligned(16))) unsigned char sKt[32 * kTrB];
+    __shared__ __attribute__((aligned(16))) float sM[kChunk];
+    __shared__ __attribute__((aligned(16))) float sB[2 * kDH];
+    const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5;
+    const Wg g = wg_of((len + 127) / 128);
+    fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
+    clear_rowmajor(sK);
+    clear_rowmajor(sV);
+    clear_transposed(sKt);
+    const int qi = g.blk * 128 + wave_id() * 32 + l31;
+    const long qtok = ax.token(g.seq, qi < len ? qi : len - 1);
+    const Own q = own_row(qkv + qtok * ld + g.hd * kDH, hh);
+    float delta;
+    const Own dO = own_row(dout + qtok * kC + g.hd * kDH, hh, &delta, o + qtok * kC + g.hd * kDH);
+    delta = half_sum(delta);
+    const float lse = lse_in[qtok * kH + g.hd];
+    const Item it = item_of(tid);
+    f32x4 kf[2], vf[2];
+    float mval = 0.f;
+    auto fetch = [&](int c0) {
+        if (it.on) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = c0 + 2 * it.pair + e;
+                kf[e] = vf[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j < len) {
+                    const float* row = qkv + ax.token(g.seq, j) * ld + g.hd * kDH + 4 * it.quad;
+                    kf[e] = *reinterpret_cast<const f32x4*>(row + kC);
+                    vf[e] = *reinterpret_cast<const f32x4*>(row + 2 * kC);
+                }
+            }
+        } else {
+            const int j = c0 + tid - 192;
+            mval = j < len ? (mk.at(ax.token(g.seq, j)) != 0.f ? 0.f : kMasked) : (j == len ? 0.f : kMasked);
+        }
+    };
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = opaque_zero();
+    fetch(0);
+    for (int c0 = 0; c0 < len + 1; c0 += kChunk) {
+        __syncthreads();
+        if (it.on) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (c0 + 2 * it.pair + e == len) {
+                    kf[e] = *reinterpret_cast<const f32x4*>(sB + 4 * it.quad);
+                    vf[e] = *reinterpret_cast<const f32x4*>(sB + kDH + 4 * it.quad);
+                }
+            put_rowmajor(sK, it, kf);
+            put_rowmajor(sV, it, vf);
+            put_transposed(sKt, it, kf);
+        } else {
+            sM[tid - 192] = mval;
+        }
+        __syncthreads();
+        if (c0 + kChunk < len + 1) fetch(c0 + kChunk);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (c0 + 32 * t > len) break;
+            f32x16 s = rows_from(sM + 32 * t, hh, 1.0f);
+            f32x16 dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] = -delta;
+            const unsigned char* kr = sK + (32 * t + l31) * kRowB + hh * 16;
+            const unsigned char* vr = sV + (32 * t + l31) * kRowB + hh * 16;
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(kr), q.f0, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(kr + 32), q.f1, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(vr), dO.f0, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(vr + 32), dO.f1, dp, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f((s[r] - lse) * kLog2e) * dp[r];
+            bf16x8 d0, d1;
+            chain(s, d0, d1);
+            const unsigned char* tr = sKt + l31 * kTrB + 64 * t + hh * 16;
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(tr), d0, dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(tr + 32), d1, dq, 0, 0, 0);
+        }
+    }
+    if (qi >= len) return;
+    float* dst = dqkv + qtok * ld + g.hd * kDH + 4 * hh;
+#pragma unroll
+    for (int gq = 0; gq < 3; ++gq)
+        *reinterpret_cast<f32x4*>(dst + 8 * gq) = f32x4{dq[4 * gq], dq[4 * gq + 1], dq[4 * gq + 2], dq[4 * gq + 3]};
+    if (hh == 0) {
+        stats[(qtok * kH + g.hd) * 2] = lse;
+        stats[(qtok * kH + g.hd) * 2 + 1] = delta;
+    }
+}
+
+// ---- backward, key pass --------------------------------------------------------------------------------------------
+// Real keys write dqkv[:, 384:1152]; the bias key writes dbias[seq][head][48] (dk rotated back | dv).
+__global__ __launch_bounds__(256, 2) void k16_attn_bwd_kv(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
+                                                          const float* __restrict__ bias_k, const float* __restrict__ bias_v,
+                                                          const float* __restrict__ inv_freq, const float* __restrict__ dout,
+                                                          const float* __restrict__ stats, float* __restrict__ dqkv,
+                                                          float* __restrict__ dbias) {
+    __shared__ __attribute__((aligned(16))) unsigned char sQ[kChunk * kRowB];
+    __shared__ __attribute__((aligned(16))) unsigned char sdO[kChunk * kRowB];
+    __shared__ __attribute__((aligned(16))) unsigned char sQt[32 * kTrB];
+    __shared__ __attribute__((aligned(16))) unsigned char sdOt[32 * kTrB];
+    __shared__ __attribute__((aligned(16))) float sLse[kChunk];
+    __shared__ __attribute__((aligned(16))) float sDel[kChunk];
+    __shared__ __attribute__((aligned(16))) float sB[2 * kDH];
+    const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5;
+    const Wg g = wg_of((len + 1 + 127) / 128);
+    fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
+    clear_rowmajor(sQ);
+    clear_rowmajor(sdO);
+    clear_transposed(sQt);
+    clear_transposed(sdOt);
+    const int j = g.blk * 128 + wave_id() * 32 + l31;
+    const long ktok = ax.token(g.seq, j < len ? j : len - 1);
+    const bool valid = j < len ? mk.at(ktok) != 0.f : j == len;
+    const bool has_bias = g.blk * 128 <= len && len < g.blk * 128 + 128;   // workgroup-uniform
+    const Item it = item_of(tid);
+    f32x4 qf[2], df[2];
+    float lval = 0.f, dval = 0.f;
+    auto fetch = [&](int c0) {
+        if (it.on) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = c0 + 2 * it.pair + e;
+                qf[e] = df[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i < len) {
+                    const long t = ax.token(g.seq, i);
+                    qf[e] = *reinterpret_cast<const f32x4*>(qkv + t * ld + g.hd * kDH + 4 * it.quad);
+                    df[e] = *reinterpret_cast<const f32x4*>(dout + t * kC + g.hd * kDH + 4 * it.quad);
+                }
+            }
+        } else {
+            const int i = c0 + tid - 192;
+            const long t = ax.token(g.seq, i < len ? i : len - 1);
+            lval = i < len ? stats[(t * kH + g.hd) * 2] : 3.0e38f;     // beyond len: p = exp(-inf) = 0
+            dval = stats[(t * kH + g.hd) * 2 + 1];
+        }
+    };
+    fetch(0);
+    __syncthreads();   // sB
+    Own k, v;
+    if (j < len) {
+        k = own_row(qkv + ktok * ld + kC + g.hd * kDH, hh);
+        v = own_row(qkv + ktok * ld + 2 * kC + g.hd * kDH, hh);
+    } else if (j == len) {
+        k = own_row((const float*)sB, hh);
+        v = own_row((const float*)(sB + kDH), hh);
+    } else {
+        k = own_row((const float*)nullptr, hh);
+        v = k;
+    }
+    f32x16 dk, dv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[r] = dv[r] = opaque_zero();
+    for (int c0 = 0; c0 < len; c0 += kChunk) {
+        __syncthreads();
+        if (it.on) {
+            put_rowmajor(sQ, it, qf);
+            put_rowmajor(sdO, it, df);
+            put_transposed(sQt, it, qf);
+            put_transposed(sdOt, it, df);
+        } else {
+            sLse[tid - 192] = lval;
+            sDel[tid - 192] = dval;
+        }
+        __syncthreads();
+        if (c0 + kChunk < len) fetch(c0 + kChunk);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (c0 + 32 * t >= len) break;
+            f32x16 s = rows_from(sLse + 32 * t, hh, -1.0f);
+            f32x16 dp = rows_from(sDel + 32 * t, hh, -1.0f);
+            const unsigned char* qr = sQ + (32 * t + l31) * kRowB + hh * 16;
+            const unsigned char* dr = sdO + (32 * t + l31) * kRowB + hh * 16;
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(qr), k.f0, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(qr + 32), k.f1, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(dr), v.f0, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(dr + 32), v.f1, dp, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = valid ? __builtin_amdgcn_exp2f(s[r] * kLog2e) : 0.f;
+                dp[r] *= s[r];
+            }
+            bf16x8 p0, p1, d0, d1;
+            chain(s, p0, p1);
+            chain(dp, d0, d1);
+            const unsigned char* dt = sdOt + l31 * kTrB + 64 * t + hh * 16;
+            const unsigned char* qt = sQt + l31 * kTrB + 64 * t + hh * 16;
+            dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(dt), p0, dv, 0, 0, 0);
+            dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(dt + 32), p1, dv, 0, 0, 0);
+            dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(qt), d0, dk, 0, 0, 0);
+            dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(qt + 32), d1, dk, 0, 0, 0);
+        }
+    }
+    if (j < len) {
+        float* dst = dqkv + ktok * ld + kC + g.hd * kDH + 4 * hh;
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq) {
+            *reinterpret_cast<f32x4*>(dst + 8 * gq) = f32x4{dk[4 * gq], dk[4 * gq + 1], dk[4 * gq + 2], dk[4 * gq + 3]};
+            *reinterpret_cast<f32x4*>(dst + kC + 8 * gq) = f32x4{dv[4 * gq], dv[4 * gq + 1], dv[4 * gq + 2], dv[4 * gq + 3]};
+        }
+    }
+    if (!has_bias) return;
+    // bias key: its two lanes drop (dk | dv) into the table, 24 threads undo the rotation (position len) and write the
+    // per-sequence row that is summed over sequences afterwards
+    __syncthreads();
+    if (j == len) {
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sB[8 * gq + 4 * hh + i] = dk[4 * gq + i];
+                sB[kDH + 8 * gq + 4 * hh + i] = dv[4 * gq + i];
+            }
+    }
+    __syncthreads();
+    float* dst = dbias + ((long)g.seq * kH + g.hd) * 2 * kDH;
+    if (tid < 12) {
+        const float ang = (float)len * inv_freq[tid];
+        const float c = cosf(ang), s = sinf(ang);
+        dst[tid] = sB[tid] * c + sB[tid + 12] * s;            // R(-theta): d x1 = d y1 c + d y2 s
+        dst[tid + 12] = sB[tid + 12] * c - sB[tid] * s;       //            d x2 = d y2 c - d y1 s
+    } else if (tid >= 32 && tid < 32 + kDH) {
+        dst[kDH + tid - 32] = sB[kDH + tid - 32];
+    }
+}
+
+void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
+                   const float* inv_freq, float* out, hipStream_t s, float* lse_out) {
+    const int nqb = (ax.len + 127) / 128;
+    hipLaunchKernelGGL(k16_attn, dim3((unsigned)((long)ax.nseq * kH * nqb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
+                       inv_freq, out, lse_out);
+}
+void launch16_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
+                       const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
+                       float* stats, float* dbias, hipStream_t s, const float* lse_in) {
+    const int nqb = (ax.len + 127) / 128, nkb = (ax.len + 1 + 127) / 128;
+    hipLaunchKernelGGL(k16_attn_bwd_q, dim3((unsigned)((long)ax.nseq * kH * nqb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k,
+                       bias_v, inv_freq, o, dout, dqkv, stats, lse_in);
+    hipLaunchKernelGGL(k16_attn_bwd_kv, dim3((unsigned)((long)ax.nseq * kH * nkb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k,
+                       bias_v, inv_freq, dout, stats, dqkv, dbias);
+}
+
+}  // namespace mdg
