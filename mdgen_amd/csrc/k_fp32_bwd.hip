@@ -122,6 +122,9 @@ __global__ __launch_bounds__(256) void k32_dw(const float* __restrict__ dy, int 
 // way into LDS.  Both operands are read along their contiguous dimension (thread -> FOUR ADJACENT token rows 4 r .. 4 r + 3,
 // eight consecutive columns) and transposed on the way in: the four token values of a column are one 8-byte LDS store.
 // part[z][m][k] = sum_{n in slice z} dY[n][m] * X[n][k].
+// FAST: both operands 16-byte aligned with row strides and widths that are multiples of 8 (every trunk layer), decided by
+// the launcher, so that the sixteen loads of a step are issued back to back instead of one per run-time-tested block.
+template <bool FAST>
 __global__ __launch_bounds__(256, 2) void k16_dw(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
                                                  long n, int m, int k, float* __restrict__ part) {
     constexpr int BN = 64, TM = 128, ROWB = 144;
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(256, 2) void k16_dw(const float* __restrict__ dy, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = opaque_zero();
     const int rg = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 8;   // token rows 4 rg .. 4 rg + 3, columns lc .. lc + 7
-    const bool veca = ((ldy | m) & 7) == 0 && ((unsigned long long)dy & 15) == 0;
-    const bool vecb = ((ldx | k) & 7) == 0 && ((unsigned long long)x & 15) == 0;
+    const bool veca = FAST || (((ldy | m) & 7) == 0 && ((unsigned long long)dy & 15) == 0);
+    const bool vecb = FAST || (((ldx | k) & 7) == 0 && ((unsigned long long)x & 15) == 0);
     float av[4][8], bv[4][8];
     auto fetch = [&](long n0) {
 #pragma unroll
@@ -702,7 +705,9 @@ void launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int 
     if (nsplit < 1) nsplit = 1;
     while (nsplit > 1 && (size_t)nsplit * m * k > part_floats) --nsplit;
     const dim3 grid((m + 127) / 128, (k + 127) / 128, nsplit);
-    if (g_k32_bf16_operands) hipLaunchKernelGGL(k16_dw, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
+    const bool fast = ((ldy | m | ldx | k) & 7) == 0 && (((unsigned long long)dy | (unsigned long long)x) & 15) == 0;
+    if (g_k32_bf16_operands && fast) hipLaunchKernelGGL(k16_dw<true>, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
+    else if (g_k32_bf16_operands) hipLaunchKernelGGL(k16_dw<false>, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
     else hipLaunchKernelGGL(k32_dw, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
     const long count = (long)m * k;
     hipLaunchKernelGGL(k32_reduce_add, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part, nsplit, count, dw);
