@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void k16_attn_bwd_q(const float* __restrict
 }
 
 // ---- backward, key pass --------------------------------------------------------------------------------------------
-// Real keys write dqkv[:, 384:1152]; the bias key writes dbias[seq][head][48] (dk rotated back | dv).
+// Real keys write dqkv[:, 384:1152]; the bias key writes dbias[seq][dk rotated back: head x 24 | dv: head x 24].
 __global__ __launch_bounds__(256, 2) void k16_attn_bwd_kv(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
                                                           const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                           const float* __restrict__ inv_freq, const float* __restrict__ dout,
@@ -470,14 +470,14 @@ __global__ __launch_bounds__(256, 2) void k16_attn_bwd_kv(const float* __restric
             }
     }
     __syncthreads();
-    float* dst = dbias + ((long)g.seq * kH + g.hd) * 2 * kDH;
+    float* dst = dbias + (long)g.seq * 2 * kC + g.hd * kDH;
     if (tid < 12) {
         const float ang = (float)len * inv_freq[tid];
         const float c = cosf(ang), s = sinf(ang);
         dst[tid] = sB[tid] * c + sB[tid + 12] * s;            // R(-theta): d x1 = d y1 c + d y2 s
         dst[tid + 12] = sB[tid + 12] * c - sB[tid] * s;       //            d x2 = d y2 c - d y1 s
     } else if (tid >= 32 && tid < 32 + kDH) {
-        dst[kDH + tid - 32] = sB[kDH + tid - 32];
+        dst[kC + tid - 32] = sB[kDH + tid - 32];
     }
 }
 

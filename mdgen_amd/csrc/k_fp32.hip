@@ -396,15 +396,14 @@ __global__ __launch_bounds__(256, 2) void k16_linear(const LinearParams p) {
     linear_epilogue(p, acc, row0, colt, wr, wc);
 }
 
-// k16_linear for the shapes the trunk actually has (k a multiple of 64, 16-byte aligned rows): no bounds checks or
-// alignment branches in the loop, so that a k-step is sixteen 16-byte loads issued together, the sixteen MFMAs of the
-// previous step's tile, and the conversion of the loaded registers into the other LDS buffer.  (In the general kernel
-// every one of those loads sits in its own basic block behind a run-time `vectorisable?` test and is waited for on the
-// spot: measured 185 us for a 64 000 x 384 x 384 layer, 1 TB/s of activation traffic.)  WT: the weight is read k-major
-// (dX = dY W: the contraction runs over the weight's rows); a thread then carries two adjacent k rows of eight columns,
-// so that each LDS store is a packed pair.  Tile order: the column tiles of one 128-row slice run back to back on ONE
-// XCD (workgroup i goes to XCD i % 8), whose L2 then serves the slice's re-reads.
-template <bool WT>
+// k16_linear for the shapes the trunk actually has (k a multiple of 64, 16-byte aligned rows, weight stored [m][k]): no
+// bounds checks or alignment branches in the loop, so that a k-step is sixteen 16-byte loads issued together, the sixteen
+// MFMAs of the previous step's tile, and the conversion of the loaded registers into the other LDS buffer.  (In the
+// general kernel every one of those loads sits in its own basic block behind a run-time `vectorisable?` test and is waited
+// for on the spot: measured 185 us for a 64 000 x 384 x 384 layer, 1 TB/s of activation traffic.)  Each load instruction
+// of a wave covers FOUR WHOLE 256-byte row segments (lane -> 16-byte piece tid & 15 of row tid >> 4), i.e. eight full
+// cache lines, instead of a quarter of each of 32 lines.  Tile order: the column tiles of one 128-row slice run back to
+// back on ONE XCD (workgroup i goes to XCD i % 8), whose L2 then serves the slice's re-reads.
 __global__ __launch_bounds__(256, 2) void k16_linear_fast(const LinearParams p, int nrt, int nct) {
     constexpr int BK = 64, TM = 128, ROWB = 144;
     __shared__ __attribute__((aligned(16))) unsigned char Ab[2][TM * ROWB];
@@ -423,59 +422,28 @@ __global__ __launch_bounds__(256, 2) void k16_linear_fast(const LinearParams p, 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = opaque_zero();
-    const int lr = tid >> 2, lk = (tid & 3) * 16;     // row-major operands: rows lr, lr + 64; 16 consecutive k
-    const int tk = tid >> 4, tc = (tid & 15) * 8;     // k-major weight: k rows 2 tk, 2 tk + 1 (+ 32); 8 columns
-    const float* ap[2];
-    const float* wp[2];
+    const int r0 = tid >> 4, piece = tid & 15;        // rows r0 + 16 q, k0 + 4 piece .. + 3
+    const float* ap[8];
+    const float* wp[8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const long r = row0 + lr + 64 * h < p.n ? row0 + lr + 64 * h : p.n - 1;   // rows / columns past the end: clamped
-        ap[h] = p.a + r * p.lda + lk;                                             // loads, results never stored
-        const int c = colt + lr + 64 * h < p.m ? colt + lr + 64 * h : p.m - 1;
-        wp[h] = p.w + (long)c * p.ldw + lk;
+    for (int q = 0; q < 8; ++q) {
+        const long r = row0 + r0 + 16 * q < p.n ? row0 + r0 + 16 * q : p.n - 1;   // rows / columns past the end: clamped
+        ap[q] = p.a + r * p.lda + 4 * piece;                                      // loads, results never stored
+        const int c = colt + r0 + 16 * q < p.m ? colt + r0 + 16 * q : p.m - 1;
+        wp[q] = p.w + (long)c * p.ldw + 4 * piece;
     }
-    const float* wt = p.w + (long)(2 * tk) * p.ldw + (colt + tc + 8 <= p.m ? colt + tc : 0);
-    f32x4 av[2][4], wv[2][4];
+    f32x4 av[8], wv[8];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int q = 0; q < 8; ++q) av[q] = *reinterpret_cast<const f32x4*>(ap[q] + k0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) av[h][q] = *reinterpret_cast<const f32x4*>(ap[h] + k0 + 4 * q);
-        if (WT) {   // wv[z][2 kk + half]: k row k0 + 2 tk + 32 z + kk, columns tc + 4 half ..
-#pragma unroll
-            for (int z = 0; z < 2; ++z)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf)
-                        wv[z][2 * kk + hf] = *reinterpret_cast<const f32x4*>(wt + (long)(k0 + 32 * z + kk) * p.ldw + 4 * hf);
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) wv[h][q] = *reinterpret_cast<const f32x4*>(wp[h] + k0 + 4 * q);
-        }
-    };
-    auto pack8 = [](const f32x4& x, const f32x4& y) {
-        return u32x4{pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3])};
+        for (int q = 0; q < 8; ++q) wv[q] = *reinterpret_cast<const f32x4*>(wp[q] + k0);
     };
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                *reinterpret_cast<u32x4*>(&Ab[buf][(lr + 64 * h) * ROWB + lk * 2 + 16 * q]) = pack8(av[h][2 * q], av[h][2 * q + 1]);
-                if (!WT) *reinterpret_cast<u32x4*>(&Wb[buf][(lr + 64 * h) * ROWB + lk * 2 + 16 * q]) = pack8(wv[h][2 * q], wv[h][2 * q + 1]);
-            }
-        if (WT) {
-#pragma unroll
-            for (int z = 0; z < 2; ++z)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        *reinterpret_cast<uint32_t*>(&Wb[buf][(tc + 4 * hf + j) * ROWB + (2 * tk + 32 * z) * 2]) =
-                            pack_bf16(wv[z][hf][j], wv[z][2 + hf][j]);
+        for (int q = 0; q < 8; ++q) {
+            *reinterpret_cast<u32x2*>(&Ab[buf][(r0 + 16 * q) * ROWB + piece * 8]) = u32x2{pack_bf16(av[q][0], av[q][1]), pack_bf16(av[q][2], av[q][3])};
+            *reinterpret_cast<u32x2*>(&Wb[buf][(r0 + 16 * q) * ROWB + piece * 8]) = u32x2{pack_bf16(wv[q][0], wv[q][1]), pack_bf16(wv[q][2], wv[q][3])};
         }
     };
     const int i = lane & 31, kh = lane >> 5;
@@ -503,6 +471,28 @@ __global__ __launch_bounds__(256, 2) void k16_linear_fast(const LinearParams p, 
         __syncthreads();
     }
     linear_epilogue(p, acc, row0, colt, wr, wc);
+}
+
+// dst[c][r] = src[r][c]: the weight of a dX = dY W product, turned once per use so that the product runs through the same
+// [m][k] kernel as the forward layer (64 x 64 tiles through LDS; a 384 x 384 weight is 36 workgroups, ~3 us).
+__global__ __launch_bounds__(256) void k32_transpose(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        tile[ty + 4 * i][tx] = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(long)c * rows + r] = tile[tx][ty + 4 * i];
+    }
+}
+void launch32_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(k32_transpose, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, src, rows, cols, dst);
 }
 
 // q (pre-scaled by the caller's linear, mode 4) and k: rotate-half RoPE in place.  buf[token][ld]: q at col 0, k at col
@@ -633,15 +623,13 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
         return;
     }
     const auto al = [](const void* q) { return ((unsigned long long)q & 15) == 0; };
-    const bool fast = k % 64 == 0 && (lda & 3) == 0 && (ldw & 3) == 0 && al(a) && al(w) && (!wtrans || (m & 7) == 0);
+    const bool fast = !wtrans && k % 64 == 0 && (lda & 3) == 0 && (ldw & 3) == 0 && al(a) && al(w);
     if (!fast) {
         hipLaunchKernelGGL(k16_linear, grid, dim3(256), 0, s, p);
         return;
     }
     const int nrt = (int)((n + 127) / 128), nct = (m + 127) / 128;
-    const dim3 g1((unsigned)(8 * ((nrt + 7) / 8) * nct));
-    if (wtrans) hipLaunchKernelGGL(k16_linear_fast<true>, g1, dim3(256), 0, s, p, nrt, nct);
-    else hipLaunchKernelGGL(k16_linear_fast<false>, g1, dim3(256), 0, s, p, nrt, nct);
+    hipLaunchKernelGGL(k16_linear_fast, dim3((unsigned)(8 * ((nrt + 7) / 8) * nct)), dim3(256), 0, s, p, nrt, nct);
 }
 void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, hipStream_t s) {
     const long total = ntok * kH * 12 * 2;

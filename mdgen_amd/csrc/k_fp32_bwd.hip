@@ -119,11 +119,12 @@ __global__ __launch_bounds__(256) void k32_dw(const float* __restrict__ dy, int 
 }
 // The bf16-operand weight gradient (option train_precision = 16) as a kernel of its own, built like k16_linear (k_fp32.hip):
 // 64 token rows per step (four MFMA k-steps), two LDS buffers and one barrier per step, operands rounded to bf16 on their
-// way into LDS.  Both operands are read along their contiguous dimension (thread -> FOUR ADJACENT token rows 4 r .. 4 r + 3,
-// eight consecutive columns) and transposed on the way in: the four token values of a column are one 8-byte LDS store.
+// way into LDS.  Both operands are read along their contiguous dimension and transposed on the way in: a thread carries FOUR
+// ADJACENT token rows of a few columns, so that the four token values of a column are one 8-byte LDS store.
 // part[z][m][k] = sum_{n in slice z} dY[n][m] * X[n][k].
 // FAST: both operands 16-byte aligned with row strides and widths that are multiples of 8 (every trunk layer), decided by
-// the launcher, so that the sixteen loads of a step are issued back to back instead of one per run-time-tested block.
+// the launcher: no run-time-tested blocks around the loads, and each load instruction of a wave covers two whole 512-byte
+// row segments (lane -> 16-byte piece tid & 31 of token row 4 (tid >> 5) + z).
 template <bool FAST>
 __global__ __launch_bounds__(256, 2) void k16_dw(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
                                                  long n, int m, int k, float* __restrict__ part) {
@@ -142,11 +143,31 @@ __global__ __launch_bounds__(256, 2) void k16_dw(const float* __restrict__ dy, i
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = opaque_zero();
-    const int rg = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 8;   // token rows 4 rg .. 4 rg + 3, columns lc .. lc + 7
-    const bool veca = FAST || (((ldy | m) & 7) == 0 && ((unsigned long long)dy & 15) == 0);
-    const bool vecb = FAST || (((ldx | k) & 7) == 0 && ((unsigned long long)x & 15) == 0);
-    float av[4][8], bv[4][8];
+    // general: token rows 4 rg .. 4 rg + 3, columns lc .. lc + 7;  FAST: token rows 4 (rq + 8 zz) .. + 3, columns lp .. lp + 3
+    const int rg = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 8;
+    const int rq = threadIdx.x >> 5, lp = (threadIdx.x & 31) * 4;
+    const bool veca = !FAST && ((ldy | m) & 7) == 0 && ((unsigned long long)dy & 15) == 0;
+    const bool vecb = !FAST && ((ldx | k) & 7) == 0 && ((unsigned long long)x & 15) == 0;
+    float av[4][8], bv[4][8];    // FAST: [z][4 zz + j]
     auto fetch = [&](long n0) {
+        if (FAST) {
+            const int mc = m0 + lp < m ? m0 + lp : 0, kc = k0 + lp < k ? k0 + lp : 0;
+#pragma unroll
+            for (int zz = 0; zz < 2; ++zz)
+#pragma unroll
+                for (int z = 0; z < 4; ++z) {
+                    const long rw = n0 + 4 * (rq + 8 * zz) + z;
+                    const long row = rw < nhi ? rw : nhi - 1;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(dy + row * ldy + mc);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(x + row * ldx + kc);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        av[z][4 * zz + j] = rw < nhi ? a[j] : 0.f;     // columns past m / k: clamped loads, results never stored
+                        bv[z][4 * zz + j] = rw < nhi ? b[j] : 0.f;
+                    }
+                }
+            return;
+        }
 #pragma unroll
         for (int z = 0; z < 4; ++z) {
             const long rw = n0 + 4 * rg + z;
@@ -187,6 +208,17 @@ __global__ __launch_bounds__(256, 2) void k16_dw(const float* __restrict__ dy, i
         }
     };
     auto stage = [&](int buf) {
+        if (FAST) {
+#pragma unroll
+            for (int zz = 0; zz < 2; ++zz)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * zz + j;
+                    *reinterpret_cast<u32x2*>(&Ab[buf][(lp + j) * ROWB + 8 * (rq + 8 * zz)]) = u32x2{pack_bf16(av[0][c], av[1][c]), pack_bf16(av[2][c], av[3][c])};
+                    *reinterpret_cast<u32x2*>(&Bb[buf][(lp + j) * ROWB + 8 * (rq + 8 * zz)]) = u32x2{pack_bf16(bv[0][c], bv[1][c]), pack_bf16(bv[2][c], bv[3][c])};
+                }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             *reinterpret_cast<u32x2*>(&Ab[buf][(lc + j) * ROWB + 8 * rg]) = u32x2{pack_bf16(av[0][j], av[1][j]), pack_bf16(av[2][j], av[3][j])};
@@ -534,7 +566,8 @@ __global__ __launch_bounds__(256) void k32_attn_bwd_q(const float* __restrict__ 
 }
 
 // Key pass: thread = key (the bias key is key `len`), queries staged through LDS.  dk = sum_i ds_ij q_i, dv = sum_i p_ij dO_i.
-// Real keys write dqkv[:, 384:1152]; the bias key writes dbias[seq][head][48] (dk rotated | dv), reduced over sequences later.
+// Real keys write dqkv[:, 384:1152]; the bias key writes dbias[seq][dk rotated back: head x 24 | dv: head x 24],
+// reduced over sequences later (two column sums: the rows ARE the (1, 1, C) bias tensors' layout).
 __global__ __launch_bounds__(256) void k32_attn_bwd_kv(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
                                                        const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                        const float* __restrict__ inv_freq, const float* __restrict__ dout,
@@ -618,7 +651,7 @@ __global__ __launch_bounds__(256) void k32_attn_bwd_kv(const float* __restrict__
             dqkv[ktok * ld + 2 * kC + hd * kDH + d] = dv[d];
         }
     } else {   // bias key: undo its rotation (position len) here, so that the per-sequence rows just add up
-        float* dst = dbias + ((long)seq * kH + hd) * 2 * kDH;
+        float* dst = dbias + (long)seq * 2 * kC + hd * kDH;
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             const float ang = (float)len * inv_freq[i];
@@ -627,7 +660,7 @@ __global__ __launch_bounds__(256) void k32_attn_bwd_kv(const float* __restrict__
             dst[i + 12] = dk[i + 12] * c - dk[i] * s;       //            d x2 = d y2 c - d y1 s
         }
 #pragma unroll
-        for (int d = 0; d < kDH; ++d) dst[kDH + d] = dv[d];
+        for (int d = 0; d < kDH; ++d) dst[kC + d] = dv[d];
     }
 }
 

@@ -201,6 +201,7 @@ void launch32_embed_rows_bwd(const float* dx0, const int64_t* aatype, int ngroup
 void launch32_temb_bwd(const float* t_rows, int nrows, float tmul, const float* w0, const float* b0, const float* w2,
                        const float* b2, const float* dst, float* emb, float* h1, float* dpre1, float* dpre2, hipStream_t s);
 void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, hipStream_t s);
+void launch32_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s);   // dst[c][r] = src[r][c]
 // bf16-operand (MFMA) attention of the training step, k_attn16.hip: same arguments as launch32_attn / launch32_attn_bwd; the
 // backward needs the forward's log-sum-exp tape (lse_in != nullptr).
 void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
