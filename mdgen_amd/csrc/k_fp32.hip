@@ -56,12 +56,19 @@ struct LinearParams {
     const float* bias;
     long n; int m, k;
     int mode;             // 0 store, 1 GELU store, 2 gated residual into c, 3 Euler: c += dt * val, 4 store * scale,
-                          // 5 accumulate (c += val), 6 store val AND GELU(val) (second copy at c2: training tape)
+                          // 5 accumulate (c += val), 6 store val AND GELU(val) (second copy at c2: training tape),
+                          // 7 store val * gelu'(c2[..]) (c2 = the taped pre-activation, read only: backward of the GELU)
     int wtrans;           // 1: the weight operand is stored [k][m] (ldw = row stride): y = x W, used for dX = dY W
     float* c; int ldc; int col0;
     ModMap mm; int gate_chunk; int gated;   // mode 2
     float scalar;                           // mode 3: dt; mode 4: scale
     float* c2;                              // mode 6: GELU output
+    // column segments (k16_linear_fast only; 0 = off): output columns [j seg_cols, (j + 1) seg_cols) are the layer
+    // (w_seg[j], bias_seg[j]) times scale_seg[j] -- q, k and v projections of one LayerNorm output as ONE pass over it
+    int seg_cols;
+    const float* w_seg[3];
+    const float* bias_seg[3];
+    float scale_seg[3];
 };
 
 // epilogue shared by k32_linear and k16_linear: bias, then store / GELU / gated residual / Euler / scale / accumulate (LinearParams::mode)
@@ -76,7 +83,10 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
     for (int u = 0; u < 2; ++u) {
         const int col = colt + wc * 64 + u * 32 + (lane & 31);
         if (col >= p.m) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
+        const int sg = p.seg_cols ? col / p.seg_cols : 0;
+        const float* bp = p.seg_cols ? p.bias_seg[sg] : p.bias;
+        const float bias = bp ? bp[col - sg * p.seg_cols] : 0.f;
+        const float sscale = p.seg_cols ? p.scale_seg[sg] : 1.0f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const long rbase = row0 + wr * 64 + t * 32;
@@ -97,7 +107,7 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
                 const float v = acc[t][u][r] + bias;
                 float* dst = p.c + row * p.ldc + p.col0 + col;
                 if (MODE == 0) {
-                    *dst = v;
+                    *dst = p.seg_cols ? v * sscale : v;
                 } else if (MODE == 1) {
                     *dst = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
                 } else if (MODE == 2) {
@@ -108,6 +118,11 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
                     *dst = v * p.scalar;
                 } else if (MODE == 5) {
                     *dst = old[r] + v;
+                } else if (MODE == 7) {   // d pre = d hid * gelu'(pre), gelu'(x) = Phi(x) + x phi(x)   (layers.py:77-84 exact-erf GELU)
+                    const float x = p.c2[row * p.ldc + p.col0 + col];
+                    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+                    const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+                    *dst = v * (cdf + x * pdf);
                 } else {
                     *dst = v;
                     p.c2[row * p.ldc + p.col0 + col] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
@@ -124,6 +139,7 @@ __device__ __forceinline__ void linear_epilogue(const LinearParams& p, const f32
         case 3: linear_epilogue_mode<3>(p, acc, row0, colt, wr, wc); break;
         case 4: linear_epilogue_mode<4>(p, acc, row0, colt, wr, wc); break;
         case 5: linear_epilogue_mode<5>(p, acc, row0, colt, wr, wc); break;
+        case 7: linear_epilogue_mode<7>(p, acc, row0, colt, wr, wc); break;
         default: linear_epilogue_mode<6>(p, acc, row0, colt, wr, wc); break;
     }
 }
@@ -423,14 +439,17 @@ __global__ __launch_bounds__(256, 2) void k16_linear_fast(const LinearParams p, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = opaque_zero();
     const int r0 = tid >> 4, piece = tid & 15;        // rows r0 + 16 q, k0 + 4 piece .. + 3
+    const int sg = p.seg_cols ? colt / p.seg_cols : 0;          // segments are whole numbers of column tiles (launcher)
+    const float* wbase = p.seg_cols ? p.w_seg[sg] : p.w;
+    const int ccol = colt - sg * p.seg_cols, mseg = p.seg_cols ? p.seg_cols : p.m;
     const float* ap[8];
     const float* wp[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const long r = row0 + r0 + 16 * q < p.n ? row0 + r0 + 16 * q : p.n - 1;   // rows / columns past the end: clamped
         ap[q] = p.a + r * p.lda + 4 * piece;                                      // loads, results never stored
-        const int c = colt + r0 + 16 * q < p.m ? colt + r0 + 16 * q : p.m - 1;
-        wp[q] = p.w + (long)c * p.ldw + 4 * piece;
+        const int c = ccol + r0 + 16 * q < mseg ? ccol + r0 + 16 * q : mseg - 1;
+        wp[q] = wbase + (long)c * p.ldw + 4 * piece;
     }
     f32x4 av[8], wv[8];
     auto fetch = [&](int k0) {
@@ -473,9 +492,10 @@ __global__ __launch_bounds__(256, 2) void k16_linear_fast(const LinearParams p, 
     linear_epilogue(p, acc, row0, colt, wr, wc);
 }
 
-// dst[c][r] = src[r][c]: the weight of a dX = dY W product, turned once per use so that the product runs through the same
+// dst[c][r] (row stride ldd) = src[r][c]: the weight of a dX = dY W product, turned once per use so that the product runs through the same
 // [m][k] kernel as the forward layer (64 x 64 tiles through LDS; a 384 x 384 weight is 36 workgroups, ~3 us).
-__global__ __launch_bounds__(256) void k32_transpose(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
+__global__ __launch_bounds__(256) void k32_transpose(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst,
+                                                     int ldd) {
     __shared__ float tile[64][65];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -488,11 +508,12 @@ __global__ __launch_bounds__(256) void k32_transpose(const float* __restrict__ s
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = c0 + ty + 4 * i, r = r0 + tx;
-        if (c < cols && r < rows) dst[(long)c * rows + r] = tile[tx][ty + 4 * i];
+        if (c < cols && r < rows) dst[(long)c * ldd + r] = tile[tx][ty + 4 * i];
     }
 }
-void launch32_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(k32_transpose, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, src, rows, cols, dst);
+void launch32_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s, int ldd) {
+    hipLaunchKernelGGL(k32_transpose, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0, s, src, rows, cols,
+                       dst, ldd ? ldd : rows);
 }
 
 // q (pre-scaled by the caller's linear, mode 4) and k: rotate-half RoPE in place.  buf[token][ld]: q at col 0, k at col
@@ -616,7 +637,7 @@ void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chu
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
                      int wtrans, float* c2) {
-    LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, wtrans, c, ldc, col0, mm, gate_chunk, gated, scalar, c2};
+    LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, wtrans, c, ldc, col0, mm, gate_chunk, gated, scalar, c2, 0, {}, {}, {}};
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128));
     if (!g_k32_bf16_operands) {
         hipLaunchKernelGGL(k32_linear, grid, dim3(256), 0, s, p);
@@ -630,6 +651,19 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
     }
     const int nrt = (int)((n + 127) / 128), nct = (m + 127) / 128;
     hipLaunchKernelGGL(k16_linear_fast, dim3((unsigned)(8 * ((nrt + 7) / 8) * nct)), dim3(256), 0, s, p, nrt, nct);
+}
+// q | k | v (three [mseg][k] layers of the same input) in one pass of k16_linear_fast: c[n][col0 + j mseg + i] =
+// (a . w[j][i] + bias[j][i]) * scale[j].  false: shape not eligible (or exact-fp32 mode), nothing launched.
+bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ldw, const float* const* bias, const float* scale,
+                          long n, int mseg, int k, float* c, int ldc, int col0, hipStream_t s) {
+    const auto al = [](const void* q) { return ((unsigned long long)q & 15) == 0; };
+    if (!g_k32_bf16_operands || mseg % 128 || k % 64 || (lda & 3) || (ldw & 3) || !al(a) || !al(w[0]) || !al(w[1]) || !al(w[2]))
+        return false;
+    LinearParams p{a, lda, w[0], ldw, nullptr, n, 3 * mseg, k, 0, 0, c, ldc, col0, ModMap{nullptr, 1, 1, 0, 0}, 0, 0, 0.f, nullptr,
+                   mseg, {w[0], w[1], w[2]}, {bias[0], bias[1], bias[2]}, {scale[0], scale[1], scale[2]}};
+    const int nrt = (int)((n + 127) / 128), nct = 3 * mseg / 128;
+    hipLaunchKernelGGL(k16_linear_fast, dim3((unsigned)(8 * ((nrt + 7) / 8) * nct)), dim3(256), 0, s, p, nrt, nct);
+    return true;
 }
 void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, hipStream_t s) {
     const long total = ntok * kH * 12 * 2;

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k32_dw(const float* __restrict__ dy, int 
 // row segments (lane -> 16-byte piece tid & 31 of token row 4 (tid >> 5) + z).
 template <bool FAST>
 __global__ __launch_bounds__(256, 2) void k16_dw(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
-                                                 long n, int m, int k, float* __restrict__ part) {
+                                                 long n, int m, int k, float* __restrict__ part, float* __restrict__ bpart) {
     constexpr int BN = 64, TM = 128, ROWB = 144;
     __shared__ __attribute__((aligned(16))) unsigned char Ab[2][TM * ROWB];   // dY^T tile: [m][n]
     __shared__ __attribute__((aligned(16))) unsigned char Bb[2][TM * ROWB];   // X^T  tile: [k][n]
@@ -207,8 +207,15 @@ __global__ __launch_bounds__(256, 2) void k16_dw(const float* __restrict__ dy, i
             }
         }
     };
+    // FAST, bpart != nullptr: the workgroups of the first k tile also sum their dY columns (the bias gradient, in fp32
+    // from the registers the operand passes through): bpart[z][m]
+    const bool colsum = FAST && bpart && blockIdx.y == 0;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
     auto stage = [&](int buf) {
         if (FAST) {
+            if (colsum)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) cs[c & 3] += (av[0][c] + av[1][c]) + (av[2][c] + av[3][c]);
 #pragma unroll
             for (int zz = 0; zz < 2; ++zz)
 #pragma unroll
@@ -265,14 +272,67 @@ __global__ __launch_bounds__(256, 2) void k16_dw(const float* __restrict__ dy, i
                 if (row < m) dst[(long)row * k + col] = acc[t][u][r];
             }
     }
+    if (colsum) {   // eight row groups per column -> one value (the operand tiles are dead: the loop ended on a barrier)
+        float* red = reinterpret_cast<float*>(&Ab[0][0]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[rq * TM + lp + j] = cs[j];
+        __syncthreads();
+        if (threadIdx.x < TM && m0 + threadIdx.x < m) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v += red[g * TM + threadIdx.x];
+            bpart[(long)blockIdx.z * m + m0 + threadIdx.x] = v;
+        }
+    }
 }
 
-__global__ void k32_reduce_add(const float* __restrict__ part, int nsplit, long count, float* __restrict__ dst) {
+__global__ void k32_reduce_add(const float* __restrict__ part, int nsplit, long stride, long count, float* __restrict__ dst) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += part[(long)z * count + i];
+    for (int z = 0; z < nsplit; ++z) s += part[(long)z * stride + i];
     dst[i] += s;
+}
+
+// out[b][c] = sum_r x[b][r] W[r][c] for a handful of rows b and a LONG contraction (the time embedder behind all adaLN
+// heads: B rows, K = every modulation output of the network).  As a GEMM tile that is three workgroups walking the
+// whole weight one after the other (1.7 ms at cfg-5); here it is a matrix-vector product split over slices of 64
+// weight rows, thread = output column, partials summed in a fixed order by the second kernel.
+__global__ __launch_bounds__(128) void k32_skinny_wt(const float* __restrict__ x, int ldx, const float* __restrict__ W, int ldw,
+                                                     int nb, int m, long K, float* __restrict__ part) {
+    const int c = blockIdx.y * 128 + threadIdx.x;
+    const long r0 = (long)blockIdx.x * 64, r1 = r0 + 64 < K ? r0 + 64 : K;
+    const int b0 = blockIdx.z * 8;
+    float acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = 0.f;
+    if (c < m)
+        for (long r = r0; r < r1; ++r) {
+            const float w = W[r * ldw + c];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[b] += (b0 + b < nb ? x[(long)(b0 + b) * ldx + r] : 0.f) * w;
+        }
+    if (c < m)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (b0 + b < nb) part[((long)blockIdx.x * nb + b0 + b) * m + c] = acc[b];
+}
+__global__ void k32_skinny_final(const float* __restrict__ part, int nslice, long count, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int z = 0; z < nslice; ++z) s += part[(long)z * count + i];
+    out[i] = s;
+}
+bool launch32_skinny_wt(const float* x, int ldx, const float* W, int ldw, int nb, int m, long K, float* out, float* part,
+                        size_t part_floats, hipStream_t s) {
+    const long nslice = (K + 63) / 64;
+    if ((size_t)nslice * nb * m > part_floats) return false;
+    hipLaunchKernelGGL(k32_skinny_wt, dim3((unsigned)nslice, (unsigned)((m + 127) / 128), (unsigned)((nb + 7) / 8)), dim3(128), 0, s, x,
+                       ldx, W, ldw, nb, m, K, part);
+    const long count = (long)nb * m;
+    hipLaunchKernelGGL(k32_skinny_final, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part, (int)nslice, count, out);
+    return true;
 }
 
 // ---- grouped column sums ----------------------------------------------------------------------------------------------
@@ -727,8 +787,11 @@ __global__ void k32_sum_frames(const float* __restrict__ a, int B, int T, int L,
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------
-void launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,
-                 size_t part_floats, hipStream_t s) {
+// dW of nseg layers that share the input x and whose dY sit side by side (dy[n][j mseg + i]): one pass over x and dY,
+// m = nseg * mseg.  dw[j] / db[j] may be null.  Returns true if the bias gradients were computed by the same pass.
+bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, int mseg, int nseg, int k, float* const* dw,
+                     float* const* db, float* part, size_t part_floats, hipStream_t s) {
+    const int m = mseg * nseg;
     // enough slices to fill the chip with 128 x 128 tiles (a 384 x 384 weight is only 9 of them)
     const int tiles = ((m + 127) / 128) * ((k + 127) / 128);
     int nsplit = (int)((n + 511) / 512);
@@ -736,14 +799,30 @@ void launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int 
     if (nsplit > want) nsplit = want;
     if (nsplit > 128) nsplit = 128;
     if (nsplit < 1) nsplit = 1;
-    while (nsplit > 1 && (size_t)nsplit * m * k > part_floats) --nsplit;
+    while (nsplit > 1 && (size_t)nsplit * m * (k + 1) > part_floats) --nsplit;
     const dim3 grid((m + 127) / 128, (k + 127) / 128, nsplit);
     const bool fast = ((ldy | m | ldx | k) & 7) == 0 && (((unsigned long long)dy | (unsigned long long)x) & 15) == 0;
-    if (g_k32_bf16_operands && fast) hipLaunchKernelGGL(k16_dw<true>, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
-    else if (g_k32_bf16_operands) hipLaunchKernelGGL(k16_dw<false>, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
+    bool want_db = false;
+    for (int j = 0; j < nseg; ++j) want_db = want_db || (db && db[j]);
+    // bf16-operand fast path: the bias gradient (column sums of dY) rides along, partials behind the dW partials
+    float* bpart = (g_k32_bf16_operands && fast && want_db && (size_t)nsplit * m * (k + 1) <= part_floats) ? part + (size_t)nsplit * m * k : nullptr;
+    if (g_k32_bf16_operands && fast) hipLaunchKernelGGL(k16_dw<true>, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part, bpart);
+    else if (g_k32_bf16_operands) hipLaunchKernelGGL(k16_dw<false>, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part, bpart);
     else hipLaunchKernelGGL(k32_dw, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
-    const long count = (long)m * k;
-    hipLaunchKernelGGL(k32_reduce_add, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part, nsplit, count, dw);
+    const long count = (long)mseg * k;
+    for (int j = 0; j < nseg; ++j) {
+        if (dw[j])
+            hipLaunchKernelGGL(k32_reduce_add, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part + (size_t)j * count, nsplit,
+                               (long)m * k, count, dw[j]);
+        if (bpart && db[j])
+            hipLaunchKernelGGL(k32_reduce_add, dim3((unsigned)((mseg + 255) / 256)), dim3(256), 0, s, bpart + (size_t)j * mseg, nsplit,
+                               (long)m, (long)mseg, db[j]);
+    }
+    return bpart != nullptr;
+}
+bool launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,
+                 size_t part_floats, hipStream_t s, float* db) {
+    return launch32_dw_seg(dy, ldy, x, ldx, n, m, 1, k, &dw, &db, part, part_floats, s);
 }
 // out[g][c] (ldo) += sum_{t in group g} a[t][c] * B(t, c); groups of tokens_per_group rows
 void launch32_colsum(const float* a, int lda, const float* b, int ldb, const float* roww, int mode, long nrows, int ncols,

@@ -176,8 +176,12 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
                      int wtrans = 0, float* c2 = nullptr);
 // backward kernels of the training step (k_fp32_bwd.hip)
-void launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,
-                 size_t part_floats, hipStream_t s);
+// db != nullptr: the bias gradient db[m] += column sums of dY may be computed by the same pass (returns true if it was;
+// otherwise the caller runs launch32_colsum)
+bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, int mseg, int nseg, int k, float* const* dw,
+                     float* const* db, float* part, size_t part_floats, hipStream_t s);   // nseg layers sharing x, dY side by side
+bool launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,
+                 size_t part_floats, hipStream_t s, float* db = nullptr);
 void launch32_colsum(const float* a, int lda, const float* b, int ldb, const float* roww, int mode, long nrows, int ncols,
                      long tokens_per_group, float eps, float* out, long ldo, float* part, size_t part_floats, hipStream_t s);
 void launch32_ln_bwd(const float* x, const float* dy, long nrows, const ModMap& mm, int scale_chunk, int affine, float eps,
@@ -201,7 +205,12 @@ void launch32_embed_rows_bwd(const float* dx0, const int64_t* aatype, int ngroup
 void launch32_temb_bwd(const float* t_rows, int nrows, float tmul, const float* w0, const float* b0, const float* w2,
                        const float* b2, const float* dst, float* emb, float* h1, float* dpre1, float* dpre2, hipStream_t s);
 void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, hipStream_t s);
-void launch32_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s);   // dst[c][r] = src[r][c]
+// out[nb][m] = x[nb][K] W[K][m], nb small and K long (split over K); false: partial buffer too small, nothing launched
+bool launch32_skinny_wt(const float* x, int ldx, const float* W, int ldw, int nb, int m, long K, float* out, float* part,
+                        size_t part_floats, hipStream_t s);
+void launch32_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s, int ldd = 0);   // dst[c][r] (ld ldd, default rows) = src[r][c]
+bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ldw, const float* const* bias, const float* scale,
+                          long n, int mseg, int k, float* c, int ldc, int col0, hipStream_t s);
 // bf16-operand (MFMA) attention of the training step, k_attn16.hip: same arguments as launch32_attn / launch32_attn_bwd; the
 // backward needs the forward's log-sum-exp tape (lse_in != nullptr).
 void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
