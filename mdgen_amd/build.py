@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmdgen_amd.so")
-SOURCES = ["api.hip", "k_gemm.hip", "k_rows.hip", "k_flash.hip", "k_small.hip", "k_se3.hip", "k_fp32.hip", "k_optim.hip", "k_fp32_bwd.hip", "k_attn16.hip"]
-HEADERS = ["common.h", "dev.h", "panel.h", "rows.h", "kernels.h", "train.inc", os.path.join("..", "..", "include", "mdgen_amd.h")]
+SOURCES = ["api.hip", "k_gemm.hip", "k_rows.hip", "k_flash.hip", "k_small.hip", "k_se3.hip", "k_fp32.hip", "k_optim.hip", "k_fp32_bwd.hip", "k_attn16.hip", "k_wide16.hip"]
+HEADERS = ["common.h", "dev.h", "panel.h", "rows.h", "linear.h", "kernels.h", "train.inc", os.path.join("..", "..", "include", "mdgen_amd.h")]
 # -fno-slp-vectorize: keeps hipcc from fusing scalar fp32 math into v_pk_{mul,add,fma}_f32.  On MI355X those
 # packed ops (a) are an anti-lever beside MFMAs (MI355X_MICROARCH "price of one filler") and (b) produced
 # intermittently wrong results in lanes 48-63 when two waves shared a SIMD (DESIGN.md "packed-fp32 hazard").

@@ -15,6 +15,11 @@
 // 2.5 PFLOP/s bf16, an unfused structure, and a simple attention kernel).  It shares everything that is fp32 already: time embedding, adaLN table,
 // token embedding, IPA point attention, SE(3) kernels.
 #include "kernels.h"
+#include "linear.h"
+
+namespace mdg {
+bool launch16_linear_wide(const LinearParams& p, hipStream_t s);   // k_wide16.hip; false: shape not eligible, nothing launched
+}
 
 namespace mdg {
 
@@ -46,101 +51,6 @@ __global__ __launch_bounds__(256) void k32_ln_mod(const float* __restrict__ x, l
         const int c = lane + 64 * i;
         const float sc = mod[scale_chunk * kC + c], sh = mod[shift_chunk * kC + c];
         y[row * kC + c] = v[i] * rstd * (affine ? sc : 1.0f + sc) + sh;
-    }
-}
-
-// C[n][col0 + m] (ldc) = sum_k A[n][k] (lda) W[m][k] (ldw) + bias[m].
-struct LinearParams {
-    const float* a; int lda;
-    const float* w; int ldw;
-    const float* bias;
-    long n; int m, k;
-    int mode;             // 0 store, 1 GELU store, 2 gated residual into c, 3 Euler: c += dt * val, 4 store * scale,
-                          // 5 accumulate (c += val), 6 store val AND GELU(val) (second copy at c2: training tape),
-                          // 7 store val * gelu'(c2[..]) (c2 = the taped pre-activation, read only: backward of the GELU)
-    int wtrans;           // 1: the weight operand is stored [k][m] (ldw = row stride): y = x W, used for dX = dY W
-    float* c; int ldc; int col0;
-    ModMap mm; int gate_chunk; int gated;   // mode 2
-    float scalar;                           // mode 3: dt; mode 4: scale
-    float* c2;                              // mode 6: GELU output
-    // column segments (k16_linear_fast only; 0 = off): output columns [j seg_cols, (j + 1) seg_cols) are the layer
-    // (w_seg[j], bias_seg[j]) times scale_seg[j] -- q, k and v projections of one LayerNorm output as ONE pass over it
-    int seg_cols;
-    const float* w_seg[3];
-    const float* bias_seg[3];
-    float scale_seg[3];
-};
-
-// epilogue shared by k32_linear and k16_linear: bias, then store / GELU / gated residual / Euler / scale / accumulate (LinearParams::mode)
-// One instantiation per mode, the mode test outside the element loops: each (column, 32-row tile) is 16 independent
-// elements whose read-modify-write loads (modes 2, 3, 5) are all issued before the first one is needed.
-template <int MODE>
-__device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, const f32x16 (&acc)[2][2], long row0, int colt, int wr,
-                                                     int wc) {
-    const int lane = lane_id();
-    const int hh = lane >> 5;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int col = colt + wc * 64 + u * 32 + (lane & 31);
-        if (col >= p.m) continue;
-        const int sg = p.seg_cols ? col / p.seg_cols : 0;
-        const float* bp = p.seg_cols ? p.bias_seg[sg] : p.bias;
-        const float bias = bp ? bp[col - sg * p.seg_cols] : 0.f;
-        const float sscale = p.seg_cols ? p.scale_seg[sg] : 1.0f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const long rbase = row0 + wr * 64 + t * 32;
-            float old[16], g[16];
-            if (MODE == 2 || MODE == 3 || MODE == 5) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long row = rbase + mfma_row(r, hh);
-                    const long rc = row < p.n ? row : p.n - 1;
-                    old[r] = p.c[rc * p.ldc + p.col0 + col];
-                    g[r] = (MODE == 2 && p.gated) ? p.mm.mod[p.mm.row_off(rc) + p.gate_chunk * kC + col] : 1.0f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long row = rbase + mfma_row(r, hh);
-                if (row >= p.n) continue;
-                const float v = acc[t][u][r] + bias;
-                float* dst = p.c + row * p.ldc + p.col0 + col;
-                if (MODE == 0) {
-                    *dst = p.seg_cols ? v * sscale : v;
-                } else if (MODE == 1) {
-                    *dst = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                } else if (MODE == 2) {
-                    *dst = old[r] + g[r] * v;
-                } else if (MODE == 3) {
-                    *dst = old[r] + p.scalar * v;
-                } else if (MODE == 4) {
-                    *dst = v * p.scalar;
-                } else if (MODE == 5) {
-                    *dst = old[r] + v;
-                } else if (MODE == 7) {   // d pre = d hid * gelu'(pre), gelu'(x) = Phi(x) + x phi(x)   (layers.py:77-84 exact-erf GELU)
-                    const float x = p.c2[row * p.ldc + p.col0 + col];
-                    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-                    const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
-                    *dst = v * (cdf + x * pdf);
-                } else {
-                    *dst = v;
-                    p.c2[row * p.ldc + p.col0 + col] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                }
-            }
-        }
-    }
-}
-__device__ __forceinline__ void linear_epilogue(const LinearParams& p, const f32x16 (&acc)[2][2], long row0, int colt, int wr, int wc) {
-    switch (p.mode) {
-        case 0: linear_epilogue_mode<0>(p, acc, row0, colt, wr, wc); break;
-        case 1: linear_epilogue_mode<1>(p, acc, row0, colt, wr, wc); break;
-        case 2: linear_epilogue_mode<2>(p, acc, row0, colt, wr, wc); break;
-        case 3: linear_epilogue_mode<3>(p, acc, row0, colt, wr, wc); break;
-        case 4: linear_epilogue_mode<4>(p, acc, row0, colt, wr, wc); break;
-        case 5: linear_epilogue_mode<5>(p, acc, row0, colt, wr, wc); break;
-        case 7: linear_epilogue_mode<7>(p, acc, row0, colt, wr, wc); break;
-        default: linear_epilogue_mode<6>(p, acc, row0, colt, wr, wc); break;
     }
 }
 
@@ -644,6 +554,7 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
         return;
     }
     const auto al = [](const void* q) { return ((unsigned long long)q & 15) == 0; };
+    if (launch16_linear_wide(p, s)) return;    // 128 x 384 tiles: every trunk-sized layer (k_wide16.hip)
     const bool fast = !wtrans && k % 64 == 0 && (lda & 3) == 0 && (ldw & 3) == 0 && al(a) && al(w);
     if (!fast) {
         hipLaunchKernelGGL(k16_linear, grid, dim3(256), 0, s, p);
@@ -661,6 +572,7 @@ bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ld
         return false;
     LinearParams p{a, lda, w[0], ldw, nullptr, n, 3 * mseg, k, 0, 0, c, ldc, col0, ModMap{nullptr, 1, 1, 0, 0}, 0, 0, 0.f, nullptr,
                    mseg, {w[0], w[1], w[2]}, {bias[0], bias[1], bias[2]}, {scale[0], scale[1], scale[2]}};
+    if (launch16_linear_wide(p, s)) return true;
     const int nrt = (int)((n + 127) / 128), nct = 3 * mseg / 128;
     hipLaunchKernelGGL(k16_linear_fast, dim3((unsigned)(8 * ((nrt + 7) / 8) * nct)), dim3(256), 0, s, p, nrt, nct);
     return true;

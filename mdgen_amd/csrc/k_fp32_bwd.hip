@@ -789,35 +789,48 @@ __global__ void k32_sum_frames(const float* __restrict__ a, int B, int T, int L,
 // ---- launchers ------------------------------------------------------------------------------------------------------
 // dW of nseg layers that share the input x and whose dY sit side by side (dy[n][j mseg + i]): one pass over x and dY,
 // m = nseg * mseg.  dw[j] / db[j] may be null.  Returns true if the bias gradients were computed by the same pass.
+int launch16_dw_wide(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* part, size_t part_floats,
+                     bool want_db, float** bpart_out, hipStream_t s);   // k_wide16.hip
 bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, int mseg, int nseg, int k, float* const* dw,
                      float* const* db, float* part, size_t part_floats, hipStream_t s) {
     const int m = mseg * nseg;
-    // enough slices to fill the chip with 128 x 128 tiles (a 384 x 384 weight is only 9 of them)
+    bool want_db = false;
+    for (int j = 0; j < nseg; ++j) want_db = want_db || (db && db[j]);
+    const long count = (long)mseg * k;
+    auto reduce = [&](int nsplit, float* bpart) {
+        for (int j = 0; j < nseg; ++j) {
+            if (dw[j])
+                hipLaunchKernelGGL(k32_reduce_add, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part + (size_t)j * count, nsplit,
+                                   (long)m * k, count, dw[j]);
+            if (bpart && db[j])
+                hipLaunchKernelGGL(k32_reduce_add, dim3((unsigned)((mseg + 255) / 256)), dim3(256), 0, s, bpart + (size_t)j * mseg, nsplit,
+                                   (long)m, (long)mseg, db[j]);
+        }
+    };
+    if (g_k32_bf16_operands) {   // 128 x 384 tiles (k_wide16.hip): each dY tile read once
+        float* bpart = nullptr;
+        if (const int ns = launch16_dw_wide(dy, ldy, x, ldx, n, m, k, part, part_floats, want_db, &bpart, s)) {
+            reduce(ns, bpart);
+            return bpart != nullptr;
+        }
+    }
+    // enough slices to fill the chip ONCE with 128 x 128 tiles at two workgroups per CU (a 384 x 384 weight is only 9 of
+    // them); more slices only add partial-sum traffic (113 slices of a 384 x 384 weight: 66 MB written and read back)
     const int tiles = ((m + 127) / 128) * ((k + 127) / 128);
     int nsplit = (int)((n + 511) / 512);
-    const int want = (1024 + tiles - 1) / tiles;
+    const int want = (512 + tiles - 1) / tiles;
     if (nsplit > want) nsplit = want;
     if (nsplit > 128) nsplit = 128;
     if (nsplit < 1) nsplit = 1;
     while (nsplit > 1 && (size_t)nsplit * m * (k + 1) > part_floats) --nsplit;
     const dim3 grid((m + 127) / 128, (k + 127) / 128, nsplit);
     const bool fast = ((ldy | m | ldx | k) & 7) == 0 && (((unsigned long long)dy | (unsigned long long)x) & 15) == 0;
-    bool want_db = false;
-    for (int j = 0; j < nseg; ++j) want_db = want_db || (db && db[j]);
     // bf16-operand fast path: the bias gradient (column sums of dY) rides along, partials behind the dW partials
     float* bpart = (g_k32_bf16_operands && fast && want_db && (size_t)nsplit * m * (k + 1) <= part_floats) ? part + (size_t)nsplit * m * k : nullptr;
     if (g_k32_bf16_operands && fast) hipLaunchKernelGGL(k16_dw<true>, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part, bpart);
     else if (g_k32_bf16_operands) hipLaunchKernelGGL(k16_dw<false>, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part, bpart);
     else hipLaunchKernelGGL(k32_dw, grid, dim3(256), 0, s, dy, ldy, x, ldx, n, m, k, part);
-    const long count = (long)mseg * k;
-    for (int j = 0; j < nseg; ++j) {
-        if (dw[j])
-            hipLaunchKernelGGL(k32_reduce_add, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part + (size_t)j * count, nsplit,
-                               (long)m * k, count, dw[j]);
-        if (bpart && db[j])
-            hipLaunchKernelGGL(k32_reduce_add, dim3((unsigned)((mseg + 255) / 256)), dim3(256), 0, s, bpart + (size_t)j * mseg, nsplit,
-                               (long)m, (long)mseg, db[j]);
-    }
+    reduce(nsplit, bpart);
     return bpart != nullptr;
 }
 bool launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,

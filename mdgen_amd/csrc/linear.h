@@ -1,0 +1,106 @@
+// The fp32 / bf16-operand linear layer's parameter block and epilogue, shared by k_fp32.hip (k32_linear, k16_linear,
+// k16_linear_fast) and k_wide16.hip (k16_linear_wide).
+#pragma once
+#include "common.h"
+
+namespace mdg {
+
+// C[n][col0 + m] (ldc) = sum_k A[n][k] (lda) W[m][k] (ldw) + bias[m].
+struct LinearParams {
+    const float* a; int lda;
+    const float* w; int ldw;
+    const float* bias;
+    long n; int m, k;
+    int mode;             // 0 store, 1 GELU store, 2 gated residual into c, 3 Euler: c += dt * val, 4 store * scale,
+                          // 5 accumulate (c += val), 6 store val AND GELU(val) (second copy at c2: training tape),
+                          // 7 store val * gelu'(c2[..]) (c2 = the taped pre-activation, read only: backward of the GELU)
+    int wtrans;           // 1: the weight operand is stored [k][m] (ldw = row stride): y = x W, used for dX = dY W
+    float* c; int ldc; int col0;
+    ModMap mm; int gate_chunk; int gated;   // mode 2
+    float scalar;                           // mode 3: dt; mode 4: scale
+    float* c2;                              // mode 6: GELU output
+    // column segments (k16_linear_fast only; 0 = off): output columns [j seg_cols, (j + 1) seg_cols) are the layer
+    // (w_seg[j], bias_seg[j]) times scale_seg[j] -- q, k and v projections of one LayerNorm output as ONE pass over it
+    int seg_cols;
+    const float* w_seg[3];
+    const float* bias_seg[3];
+    float scale_seg[3];
+};
+
+// epilogue shared by k32_linear and k16_linear: bias, then store / GELU / gated residual / Euler / scale / accumulate (LinearParams::mode)
+// One instantiation per mode, the mode test outside the element loops: each (column, 32-row tile) is 16 independent
+// elements whose read-modify-write loads (modes 2, 3, 5) are all issued before the first one is needed.
+template <int MODE, int NU>
+__device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, const f32x16 (&acc)[2][NU], long row0, int colt, int wr,
+                                                     int wc) {
+    const int lane = lane_id();
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int col = colt + wc * 32 * NU + u * 32 + (lane & 31);
+        if (col >= p.m) continue;
+        const int sg = p.seg_cols ? col / p.seg_cols : 0;
+        const float* bp = p.seg_cols ? p.bias_seg[sg] : p.bias;
+        const float bias = bp ? bp[col - sg * p.seg_cols] : 0.f;
+        const float sscale = p.seg_cols ? p.scale_seg[sg] : 1.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const long rbase = row0 + wr * 64 + t * 32;
+            float old[16], g[16];
+            if (MODE == 2 || MODE == 3 || MODE == 5) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = rbase + mfma_row(r, hh);
+                    const long rc = row < p.n ? row : p.n - 1;
+                    old[r] = p.c[rc * p.ldc + p.col0 + col];
+                    g[r] = (MODE == 2 && p.gated) ? p.mm.mod[p.mm.row_off(rc) + p.gate_chunk * kC + col] : 1.0f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = rbase + mfma_row(r, hh);
+                if (row >= p.n) continue;
+                const float v = acc[t][u][r] + bias;
+                float* dst = p.c + row * p.ldc + p.col0 + col;
+                if (MODE == 0) {
+                    *dst = p.seg_cols ? v * sscale : v;
+                } else if (MODE == 1) {
+                    *dst = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                } else if (MODE == 2) {
+                    *dst = old[r] + g[r] * v;
+                } else if (MODE == 3) {
+                    *dst = old[r] + p.scalar * v;
+                } else if (MODE == 4) {
+                    *dst = v * p.scalar;
+                } else if (MODE == 5) {
+                    *dst = old[r] + v;
+                } else if (MODE == 7) {   // d pre = d hid * gelu'(pre), gelu'(x) = Phi(x) + x phi(x)   (layers.py:77-84 exact-erf GELU)
+                    const float x = p.c2[row * p.ldc + p.col0 + col];
+                    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+                    const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+                    *dst = v * (cdf + x * pdf);
+                } else {
+                    *dst = v;
+                    p.c2[row * p.ldc + p.col0 + col] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                }
+            }
+        }
+    }
+}
+// wave (wr, wc) of the workgroup holds rows 64 wr .. + 63, columns 32 NU wc .. of the tile at (row0, colt)
+template <int NU>
+__device__ __forceinline__ void linear_epilogue(const LinearParams& p, const f32x16 (&acc)[2][NU], long row0, int colt, int wr, int wc) {
+    switch (p.mode) {
+        case 0: linear_epilogue_mode<0, NU>(p, acc, row0, colt, wr, wc); break;
+        case 1: linear_epilogue_mode<1, NU>(p, acc, row0, colt, wr, wc); break;
+        case 2: linear_epilogue_mode<2, NU>(p, acc, row0, colt, wr, wc); break;
+        case 3: linear_epilogue_mode<3, NU>(p, acc, row0, colt, wr, wc); break;
+        case 4: linear_epilogue_mode<4, NU>(p, acc, row0, colt, wr, wc); break;
+        case 5: linear_epilogue_mode<5, NU>(p, acc, row0, colt, wr, wc); break;
+        case 7: linear_epilogue_mode<7, NU>(p, acc, row0, colt, wr, wc); break;
+        default: linear_epilogue_mode<6, NU>(p, acc, row0, colt, wr, wc); break;
+    }
+}
+
+
+}  // namespace mdg
