@@ -24,8 +24,10 @@ bool launch16_linear_wide(const LinearParams& p, hipStream_t s);   // k_wide16.h
 namespace mdg {
 
 // one wave per row; rows in natural token order
+// keep != nullptr: the input rows are also copied there (the training tape's h_in: the row is in registers anyway)
 __global__ __launch_bounds__(256) void k32_ln_mod(const float* __restrict__ x, long nrows, ModMap mm, int shift_chunk,
-                                                  int scale_chunk, int affine, float eps, float* __restrict__ y) {
+                                                  int scale_chunk, int affine, float eps, float* __restrict__ y,
+                                                  float* __restrict__ keep) {
     const long row = (long)blockIdx.x * 4 + wave_id();
     if (row >= nrows) return;
     const int lane = lane_id();
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(256) void k32_ln_mod(const float* __restrict__ x, l
     for (int i = 0; i < 6; ++i) {
         v[i] = xr[lane + 64 * i];
         s += v[i];
+        if (keep) keep[row * kC + lane + 64 * i] = v[i];
     }
     const float mean = wave_sum(s) * (1.0f / kC);
     float q = 0.f;
@@ -540,9 +543,9 @@ __global__ __launch_bounds__(256) void k32_attn(const float* __restrict__ qkv, i
 // IPA attention kernels (IpaAttnParams::feat32).
 
 void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chunk, int scale_chunk, int affine, float eps,
-                     float* y, hipStream_t s) {
+                     float* y, hipStream_t s, float* keep) {
     hipLaunchKernelGGL(k32_ln_mod, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, x, nrows, mm, shift_chunk, scale_chunk,
-                       affine, eps, y);
+                       affine, eps, y, keep);
 }
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,

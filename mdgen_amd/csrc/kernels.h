@@ -171,7 +171,7 @@ void launch_ipa_attn(const IpaAttnParams& p, hipStream_t s);
 // fp32-operand path (k_fp32.hip)
 extern int g_k32_bf16_operands;   // 1: k32_linear / k32_dw multiply bf16-rounded operands (training option train_precision = 16)
 void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chunk, int scale_chunk, int affine, float eps,
-                     float* y, hipStream_t s);
+                     float* y, hipStream_t s, float* keep = nullptr);   // keep: copy of x (training tape)
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
                      int wtrans = 0, float* c2 = nullptr);

@@ -1581,6 +1581,58 @@ def test_training_gradients_bf16_operands_vs_reference_fixture():
     tm.model.set_option("train_precision", 32)
 
 
+def test_training_bf16_operand_kernels_vs_exact_mode_at_tile_sizes():
+    """The golden-fixture gradient tests above run shapes of a few dozen tokens, which the launchers route to the general
+    kernels.  This one is sized for the kernels the real workload runs -- the 128 x 384-tile linear layer and weight gradient
+    (k_wide16.hip: >= 1024 / 4096 token rows, with row tails), the one-pass q|k|v forms, the MFMA attention forward and its
+    two backward passes (k_attn16.hip) on both axes with ragged tiles (24 frames, 203 residues: partial 32-row tiles, the bias
+    key inside a tile) and key padding -- and compares train_precision 16 against the exact fp32 mode (itself gated against
+    the reference's autograd above) on identical inputs: loss to 1e-2 relative, every parameter's gradient to rel-L2 5e-2 and
+    cosine 0.999 (gradients at the noise floor excepted)."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict, synth_forward_inputs
+    from mdgen_amd.train import TrainableModel
+    dev = _cuda()
+    B, T, L = 1, 24, 203
+    cfg = ModelConfig.atlas(num_frames=T, crop=L)
+    sd = synth_state_dict(cfg, 11)
+    inp = synth_forward_inputs(cfg, B, T, L, 37, 5)          # 37 padded residues
+    gen = torch.Generator().manual_seed(9)
+    ut = torch.randn(B, T, L, cfg.latent_dim, generator=gen)
+    lm = (torch.rand(B, T, L, cfg.latent_dim, generator=gen) > 0.1).float() * inp["mask"][..., None]
+    args = (inp["x"].to(dev), inp["t"].to(dev), ut.to(dev), lm.to(dev), inp["mask"].to(dev),
+            (inp["start_rot"].to(dev), inp["start_trans"].to(dev)), inp["x_cond"].to(dev), inp["x_cond_mask"].to(dev),
+            inp["aatype"].to(dev))
+    res = {}
+    for prec in (32, 16):
+        tm = TrainableModel(cfg, dev).load_state_dict(sd)
+        tm.model.set_option("train_precision", prec)
+        tm.zero_grad()
+        loss, _ = tm.forward_backward(*args)
+        torch.cuda.synchronize()
+        res[prec] = (float(loss), {k: v.detach().float().cpu().clone() for k, v in tm.params.state_dict(tm.grads).items()})
+        tm.model.set_option("train_precision", 32)
+    l32, g32 = res[32]
+    l16, g16 = res[16]
+    assert abs(l16 - l32) <= 1e-2 * abs(l32), (l16, l32)
+    gmax = max(float(v.norm()) for v in g32.values())
+    rep = []
+    for k, ref in g32.items():
+        mine = g16[k].reshape(-1).double()
+        r = ref.reshape(-1).double()
+        assert torch.isfinite(mine).all(), k
+        e = float((mine - r).norm() / (r.norm() + 1e-300))
+        cos = float((mine @ r) / (mine.norm() * r.norm() + 1e-300))
+        rep.append((e, cos, k, float(r.norm())))
+    rep.sort(reverse=True)
+    print(f"train_precision 16 vs 32 at B{B} T{T} L{L}: loss {l16:.5f} vs {l32:.5f}; worst gradients (rel-L2, cosine, tensor):",
+          [(f"{e:.1e}", f"{c:.5f}", k) for e, c, k, _ in rep[:6]])
+    for e, cos, k, nrm in rep:
+        if nrm < 1e-4 * gmax:
+            continue
+        assert e < 5e-2 and cos > 0.999, (k, e, cos)
+
+
 def test_row_owner_mlp_paths_agree():
     """The MLP block has three forms: the 64-row resident-panel kernel (`mlp_path` 0), the row-owner kernel (`mlp_path` 2:
     activations in registers, LDS-DMA weight stream) and the row-owner kernel with the temporal out-projection fused in front
