@@ -60,9 +60,9 @@ extern "C" int mdgen_dev_wide_stamps(unsigned long long* host, int n) {
 
 // Tile order as in k16_linear_fast: the column groups of one 128-row slice run back to back on one XCD.
 // Requires (launcher): k % 64 == 0, 16-byte aligned operands and row strides, weight stored [m][k].
-__global__ __launch_bounds__(512) void k16_linear_wide(const LinearParams p, int nrt, int ncg) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (kWideP + kWideQ)];   // [2][P | Q]
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+// One tile (virtual block index vb of the XCD-aware order).  lds: [2][P | Q].
+__device__ __forceinline__ void linear_wide_tile(const LinearParams& p, int vb, int nrt, int ncg, unsigned char* lds) {
+    const int xcd = vb & 7, slot = vb >> 3;
     const int rt = (slot / ncg) * 8 + xcd, cg = slot % ncg;
     if (rt >= nrt) return;
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
@@ -157,9 +157,17 @@ __global__ __launch_bounds__(512) void k16_linear_wide(const LinearParams p, int
 #endif
 #ifdef MDGEN_DEV_WIDE_STAMPS
     WIDE_STAMP();
-    if (p.k == 384 && p.m == 384 && !p.seg_cols && blockIdx.x < 512 && (tid & 63) == 0 && (w == 0 || w == 5))
-        for (int i = 0; i < 24; ++i) g_wide_stamps[(blockIdx.x * 2 + (w ? 1 : 0)) * 24 + i] = i < sti ? st[i] : 0ull;
+    if (p.k == 384 && p.m == 384 && !p.seg_cols && vb < 512 && (tid & 63) == 0 && (w == 0 || w == 5))
+        for (int i = 0; i < 24; ++i) g_wide_stamps[(vb * 2 + (w ? 1 : 0)) * 24 + i] = i < sti ? st[i] : 0ull;
 #endif
+}
+
+// (A persistent form -- 256 workgroups walking the tiles, so that a tile's store phase could overlap the next tile's loads --
+// and a phase offset between neighbouring workgroups were both measured and changed nothing: 199.7 / 198.8 vs 199.1 us average;
+// what adds up is per CU)
+__global__ __launch_bounds__(512) void k16_linear_wide(const LinearParams p, int nrt, int ncg) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (kWideP + kWideQ)];
+    linear_wide_tile(p, blockIdx.x, nrt, ncg, lds);
 }
 
 // part[z][m][k] = sum_{n in slice z} dY[n][m] X[n][k] for the 128 gradient rows m0.. and the 384 columns k0.. of this
