@@ -54,7 +54,7 @@ def check_isa(cc: str, src: str) -> None:
             raise RuntimeError("ISA check failed to compile " + src + "\n" + r.stderr)
         pat = re.compile(r"v_mfma_\w+ ([va])\[(\d+):(\d+)\], ([va])\[(\d+):(\d+)\], ([va])\[(\d+):(\d+)\], (.*)$")
         n = 0
-        own_m0 = os.path.basename(src) == "k_rows.hip"   # rows.h dma_frag owns M0 there (not saved / restored)
+        own_m0 = os.path.basename(src) in ("k_rows.hip", "k_wide16.hip")   # rows.h dma_frag owns M0 there (not saved / restored)
         in_asm = False
         for line in open(out):
             if own_m0:

@@ -549,8 +549,9 @@ void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chu
 }
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
-                     int wtrans, float* c2) {
-    LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, wtrans, c, ldc, col0, mm, gate_chunk, gated, scalar, c2, 0, {}, {}, {}};
+                     int wtrans, float* c2, const void* wpack) {
+    LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, wtrans, c, ldc, col0, mm, gate_chunk, gated, scalar, c2, 0, {}, {}, {},
+                   static_cast<const unsigned char*>(wpack)};
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128));
     if (!g_k32_bf16_operands) {
         hipLaunchKernelGGL(k32_linear, grid, dim3(256), 0, s, p);
@@ -569,12 +570,13 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
 // q | k | v (three [mseg][k] layers of the same input) in one pass of k16_linear_fast: c[n][col0 + j mseg + i] =
 // (a . w[j][i] + bias[j][i]) * scale[j].  false: shape not eligible (or exact-fp32 mode), nothing launched.
 bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ldw, const float* const* bias, const float* scale,
-                          long n, int mseg, int k, float* c, int ldc, int col0, hipStream_t s) {
+                          long n, int mseg, int k, float* c, int ldc, int col0, hipStream_t s, const void* wpack) {
     const auto al = [](const void* q) { return ((unsigned long long)q & 15) == 0; };
     if (!g_k32_bf16_operands || mseg % 128 || k % 64 || (lda & 3) || (ldw & 3) || !al(a) || !al(w[0]) || !al(w[1]) || !al(w[2]))
         return false;
     LinearParams p{a, lda, w[0], ldw, nullptr, n, 3 * mseg, k, 0, 0, c, ldc, col0, ModMap{nullptr, 1, 1, 0, 0}, 0, 0, 0.f, nullptr,
-                   mseg, {w[0], w[1], w[2]}, {bias[0], bias[1], bias[2]}, {scale[0], scale[1], scale[2]}};
+                   mseg, {w[0], w[1], w[2]}, {bias[0], bias[1], bias[2]}, {scale[0], scale[1], scale[2]},
+                   static_cast<const unsigned char*>(wpack)};
     if (launch16_linear_wide(p, s)) return true;
     const int nrt = (int)((n + 127) / 128), nct = 3 * mseg / 128;
     hipLaunchKernelGGL(k16_linear_fast, dim3((unsigned)(8 * ((nrt + 7) / 8) * nct)), dim3(256), 0, s, p, nrt, nct);

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "linear.h"
+#include "rows.h"
 
 namespace mdg {
 namespace {
@@ -170,6 +171,143 @@ __global__ __launch_bounds__(512) void k16_linear_wide(const LinearParams p, int
     linear_wide_tile(p, blockIdx.x, nrt, ncg, lds);
 }
 
+// ---- the same tile with the weight brought in by LDS-DMA ---------------------------------------------------------------
+// What the ablation builds of k16_linear_wide show: per CU, the time of the global loads that return
+// through the register file and the time of the LDS-fed MFMA part ADD UP (35 + 75 -> 122 us).  Three quarters of those
+// register-returned bytes are the weight, which every workgroup re-reads (from L2) and re-rounds to bf16.  Here it is
+// rounded and laid out ONCE per use by k16_pack_wstream -- 1 KiB MFMA B-operand fragments in exactly the order a
+// workgroup consumes them: [column group][k-step of 64][16-wide k-step ks][32-column tile] -- and the kernel's eight waves
+// copy a k-step's 48 fragments straight into LDS (global_load_lds_dwordx4: no registers, no conversion, no ds_write;
+// fragment reads are lane-linear, hence conflict-free without padding).  Only the 128 token rows still pass through
+// registers (4 loads per thread per step instead of 16).
+constexpr int kWideQD = 48 * 1024;   // one k-step of the weight stream: 4 ks x 12 column tiles x 1 KiB
+
+__global__ __launch_bounds__(256) void k16_pack_wstream(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                        const float* __restrict__ s2, int seg, int ld, int m, int k, int turned,
+                                                        u32x4* __restrict__ out) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)m * k / 8) return;
+    const int lane = (int)(gid & 63);
+    const long frag = gid >> 6;
+    const int nk = k / 64;
+    const int ct = (int)(frag % 12), ks = (int)((frag / 12) & 3), kstep = (int)((frag / 48) % nk), cg = (int)(frag / (48L * nk));
+    const int col = cg * kWideCols + ct * 32 + (lane & 31);
+    const int kk0 = kstep * 64 + ks * 16 + 8 * (lane >> 5);
+    float v[8];
+    if (!turned) {
+        const int si = col / seg;
+        const float* src = (si == 0 ? s0 : si == 1 ? s1 : s2) + (long)(col - si * seg) * ld + kk0;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = a[j];
+            v[4 + j] = b[j];
+        }
+    } else {
+        const int si = kk0 / seg;    // 8 consecutive kk never straddle a segment (seg is a multiple of 64)
+        const float* src = (si == 0 ? s0 : si == 1 ? s1 : s2) + (long)(kk0 - si * seg) * ld + col;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(long)j * ld];
+    }
+    out[gid] = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+}
+
+bool launch16_pack_wstream(const float* const* src, int nsrc, int seg, int ld, long n, int m, int k, int turned, void* out,
+                           hipStream_t s) {
+    const auto al = [](const void* q) { return ((unsigned long long)q & 15) == 0; };
+    if (n < 1024 || m % kWideCols || k % 64 || seg % 64 || nsrc < 1 || nsrc > 3 || (ld & 3)) return false;
+    if ((long)nsrc * seg != (turned ? k : m)) return false;
+    for (int i = 0; i < nsrc; ++i)
+        if (!al(src[i])) return false;
+    const long items = (long)m * k / 8;
+    hipLaunchKernelGGL(k16_pack_wstream, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, src[0], src[nsrc > 1 ? 1 : 0],
+                       src[nsrc > 2 ? 2 : 0], seg, ld, m, k, turned, static_cast<u32x4*>(out));
+    return true;
+}
+
+// Requires (launcher): p.wpack (k16_pack_wstream of this layer), k % 64 == 0, m % 384 == 0, 16-byte aligned token operand.
+__global__ __launch_bounds__(512) void k16_linear_wdma(const LinearParams p, int nrt, int ncg) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (kWideP + kWideQD)];   // [2][Q (48 KiB) | P]
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int rt = (slot / ncg) * 8 + xcd, cg = slot % ncg;
+    if (rt >= nrt) return;
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const long row0 = (long)rt * kWideRows;
+    const int colt = cg * kWideCols;
+    const int wr = w >> 2, wc = w & 3;
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = opaque_zero();
+    const int r0 = tid >> 4, piece = tid & 15;        // token rows r0 + 32 q, k0 + 4 piece .. + 3
+    const float* abase = p.a + 4 * piece;
+    long aoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) aoff[q] = (row0 + r0 + 32 * q < p.n ? row0 + r0 + 32 * q : p.n - 1) * p.lda;   // past the end: clamped, never stored
+    f32x4 av[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const f32x4*>(abase + aoff[q] + k0);
+    };
+    auto stage = [&](int buf) {
+        unsigned char* P = lds + buf * (kWideP + kWideQD) + kWideQD;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<u32x2*>(P + (r0 + 32 * q) * kWideRowB + piece * 8) = pack4(av[q][0], av[q][1], av[q][2], av[q][3]);
+    };
+    // this wave's six fragments of a k-step: two DMA groups (an instruction offset moves both ends, rows.h dma_frag)
+    const int nk = p.k / kWideBK;
+    const unsigned char* qsrc = p.wpack + ((long)cg * nk) * kWideQD + wu * 6144;
+    const unsigned voff = lane * 16;
+    const unsigned qdst = lds_addr(lds) + wu * 6144;
+    auto issue_q = [&](int kstep, int buf) {
+        const unsigned char* src = qsrc + (long)kstep * kWideQD;
+        const unsigned dst = qdst + buf * (kWideP + kWideQD);
+        dma_frag<0, true>(src, voff, dst);
+        dma_frag<1024, false>(src, voff, dst);
+        dma_frag<2048, false>(src, voff, dst);
+        dma_frag<3072, false>(src, voff, dst);
+        dma_frag<0, true>(src + 4096, voff, dst + 4096);
+        dma_frag<1024, false>(src + 4096, voff, dst + 4096);
+    };
+    const int i = lane & 31, kh = lane >> 5;
+    fetch(0);
+    issue_q(0, 0);
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMAs are inline asm: hipcc neither counts nor drains them
+    __syncthreads();
+    int buf = 0;
+    for (int kstep = 0; kstep < nk; ++kstep, buf ^= 1) {
+        const bool more = kstep + 1 < nk;
+        if (more) {   // the register loads first: the waits hipcc puts between them (it cannot see the DMAs) must not find DMAs in the queue
+            fetch((kstep + 1) * kWideBK);
+            issue_q(kstep + 1, buf ^ 1);
+        }
+        const unsigned char* Q = lds + buf * (kWideP + kWideQD);
+        const unsigned char* P = Q + kWideQD;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[2], b[3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const bf16x8*>(P + (wr * 64 + t * 32 + i) * kWideRowB + ks * 32 + kh * 16);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) b[u] = *reinterpret_cast<const bf16x8*>(Q + (ks * 12 + wc * 3 + u) * 1024 + lane * 16);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 3; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b[u], acc[t][u], 0, 0, 0);
+        }
+        if (more) stage(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    linear_epilogue(p, acc, row0, colt, wr, wc);
+}
+
 // part[z][m][k] = sum_{n in slice z} dY[n][m] X[n][k] for the 128 gradient rows m0.. and the 384 columns k0.. of this
 // workgroup; bpart[z][m] = sum_n dY[n][m] (bias gradient; the workgroups of the first column group, when bpart != nullptr).
 // Both operands are read along their contiguous dimension and transposed on the way into LDS: a thread carries four adjacent
@@ -290,6 +428,10 @@ bool launch16_linear_wide(const LinearParams& p, hipStream_t s) {
     else ok = ok && al(p.w);
     if (!ok) return false;
     const int nrt = (int)((p.n + kWideRows - 1) / kWideRows), ncg = (p.m + kWideCols - 1) / kWideCols;
+    if (p.wpack && p.m % kWideCols == 0) {
+        hipLaunchKernelGGL(k16_linear_wdma, dim3((unsigned)(8 * ((nrt + 7) / 8) * ncg)), dim3(512), 0, s, p, nrt, ncg);
+        return true;
+    }
     hipLaunchKernelGGL(k16_linear_wide, dim3((unsigned)(8 * ((nrt + 7) / 8) * ncg)), dim3(512), 0, s, p, nrt, ncg);
     return true;
 }

@@ -174,7 +174,8 @@ void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chu
                      float* y, hipStream_t s, float* keep = nullptr);   // keep: copy of x (training tape)
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
-                     int wtrans = 0, float* c2 = nullptr);
+                     int wtrans = 0, float* c2 = nullptr,
+                     const void* wpack = nullptr);   // wpack: launch16_pack_wstream's bf16 fragment stream of w (k_wide16.hip)
 // backward kernels of the training step (k_fp32_bwd.hip)
 // db != nullptr: the bias gradient db[m] += column sums of dY may be computed by the same pass (returns true if it was;
 // otherwise the caller runs launch32_colsum)
@@ -210,7 +211,12 @@ bool launch32_skinny_wt(const float* x, int ldx, const float* W, int ldw, int nb
                         size_t part_floats, hipStream_t s);
 void launch32_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s, int ldd = 0);   // dst[c][r] (ld ldd, default rows) = src[r][c]
 bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ldw, const float* const* bias, const float* scale,
-                          long n, int mseg, int k, float* c, int ldc, int col0, hipStream_t s);
+                          long n, int mseg, int k, float* c, int ldc, int col0, hipStream_t s, const void* wpack = nullptr);
+// bf16 fragment stream of a weight for k16_linear_wdma: W(col, kk), col < m (a multiple of 384), kk < k (a multiple of 64),
+// from nsrc <= 3 fp32 matrices of row stride ld: turned == 0: src[col / seg] is [seg][k] (layers side by side along the
+// columns); turned == 1: src[kk / seg] is [seg][m] (dX = dY W: the contraction runs over the weights' rows).
+// false: shape not eligible for the streamed kernel (nothing launched).  out: m * k * 2 bytes.
+bool launch16_pack_wstream(const float* const* src, int nsrc, int seg, int ld, long n, int m, int k, int turned, void* out, hipStream_t s);
 // bf16-operand (MFMA) attention of the training step, k_attn16.hip: same arguments as launch32_attn / launch32_attn_bwd; the
 // backward needs the forward's log-sum-exp tape (lse_in != nullptr).
 void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,

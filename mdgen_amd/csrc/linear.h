@@ -25,6 +25,9 @@ struct LinearParams {
     const float* w_seg[3];
     const float* bias_seg[3];
     float scale_seg[3];
+    // k16_linear_wdma only: the weight(s) as a bf16 stream of 1 KiB MFMA fragments in the kernel's consumption order
+    // (launch16_pack_wstream, k_wide16.hip), brought in by LDS-DMA; nullptr: the weight is read as fp32 rows
+    const unsigned char* wpack;
 };
 
 // epilogue shared by k32_linear and k16_linear: bias, then store / GELU / gated residual / Euler / scale / accumulate (LinearParams::mode)
