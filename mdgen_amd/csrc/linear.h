@@ -50,12 +50,12 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
         for (int t = 0; t < 2; ++t) {
             const long rbase = row0 + wr * 64 + t * 32;
             float old[16], g[16];
-            if (MODE == 2 || MODE == 3 || MODE == 5) {
+            if (MODE == 2 || MODE == 3 || MODE == 5 || MODE == 7) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const long row = rbase + mfma_row(r, hh);
                     const long rc = row < p.n ? row : p.n - 1;
-                    old[r] = p.c[rc * p.ldc + p.col0 + col];
+                    old[r] = (MODE == 7 ? p.c2 : p.c)[rc * p.ldc + p.col0 + col];   // mode 7: the taped pre-activation
                     g[r] = (MODE == 2 && p.gated) ? p.mm.mod[p.mm.row_off(rc) + p.gate_chunk * kC + col] : 1.0f;
                 }
             }
@@ -78,7 +78,7 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
                 } else if (MODE == 5) {
                     *dst = old[r] + v;
                 } else if (MODE == 7) {   // d pre = d hid * gelu'(pre), gelu'(x) = Phi(x) + x phi(x)   (layers.py:77-84 exact-erf GELU)
-                    const float x = p.c2[row * p.ldc + p.col0 + col];
+                    const float x = old[r];
                     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
                     const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
                     *dst = v * (cdf + x * pdf);
