@@ -551,7 +551,7 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
                      int wtrans, float* c2, const void* wpack) {
     LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, wtrans, c, ldc, col0, mm, gate_chunk, gated, scalar, c2, 0, {}, {}, {},
-                   static_cast<const unsigned char*>(wpack)};
+                   static_cast<const unsigned char*>(wpack), g_k32_bf16_operands};
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128));
     if (!g_k32_bf16_operands) {
         hipLaunchKernelGGL(k32_linear, grid, dim3(256), 0, s, p);
@@ -576,7 +576,7 @@ bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ld
         return false;
     LinearParams p{a, lda, w[0], ldw, nullptr, n, 3 * mseg, k, 0, 0, c, ldc, col0, ModMap{nullptr, 1, 1, 0, 0}, 0, 0, 0.f, nullptr,
                    mseg, {w[0], w[1], w[2]}, {bias[0], bias[1], bias[2]}, {scale[0], scale[1], scale[2]},
-                   static_cast<const unsigned char*>(wpack)};
+                   static_cast<const unsigned char*>(wpack), 1};
     if (launch16_linear_wide(p, s)) return true;
     const int nrt = (int)((n + 127) / 128), nct = 3 * mseg / 128;
     hipLaunchKernelGGL(k16_linear_fast, dim3((unsigned)(8 * ((nrt + 7) / 8) * nct)), dim3(256), 0, s, p, nrt, nct);

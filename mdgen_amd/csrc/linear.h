@@ -28,7 +28,22 @@ struct LinearParams {
     // k16_linear_wdma only: the weight(s) as a bf16 stream of 1 KiB MFMA fragments in the kernel's consumption order
     // (launch16_pack_wstream, k_wide16.hip), brought in by LDS-DMA; nullptr: the weight is read as fp32 rows
     const unsigned char* wpack;
+    // 1 (bf16-operand training mode): GELU and its derivative (modes 1, 6, 7) through the logistic-polynomial Phi of
+    // common.h gelu_erf (abs. error 5e-6, 1/400 of the bf16 rounding their results get as GEMM operands) instead of erff / expf:
+    // the exact forms cost ~100 us (mode 6) / ~170 us (mode 7) of VALU time per 64 000 x 1536 launch
+    int fast_gelu;
 };
+
+// Phi(x) and x of gelu_erf's fit (see common.h): Phi = 1 / (1 + exp2(x P(x^2)))
+__device__ __forceinline__ float phi_cdf_fast(float x) {
+    const float x2 = x * x;
+    float p = -3.936969279e-06f;
+    p = p * x2 + 1.012880530e-04f;
+    p = p * x2 + 2.890509495e-04f;
+    p = p * x2 - 1.051034182e-01f;
+    p = p * x2 - 2.302086592e+00f;
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
+}
 
 // epilogue shared by k32_linear and k16_linear: bias, then store / GELU / gated residual / Euler / scale / accumulate (LinearParams::mode)
 // One instantiation per mode, the mode test outside the element loops: each (column, 32-row tile) is 16 independent
@@ -50,12 +65,12 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
         for (int t = 0; t < 2; ++t) {
             const long rbase = row0 + wr * 64 + t * 32;
             float old[16], g[16];
-            if (MODE == 2 || MODE == 3 || MODE == 5 || MODE == 7) {
+            if (MODE == 2 || MODE == 3 || MODE == 5 || MODE == 7 || MODE == 17) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const long row = rbase + mfma_row(r, hh);
                     const long rc = row < p.n ? row : p.n - 1;
-                    old[r] = (MODE == 7 ? p.c2 : p.c)[rc * p.ldc + p.col0 + col];   // mode 7: the taped pre-activation
+                    old[r] = (MODE == 7 || MODE == 17 ? p.c2 : p.c)[rc * p.ldc + p.col0 + col];   // mode 7: the taped pre-activation
                     g[r] = (MODE == 2 && p.gated) ? p.mm.mod[p.mm.row_off(rc) + p.gate_chunk * kC + col] : 1.0f;
                 }
             }
@@ -82,6 +97,15 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
                     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
                     const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
                     *dst = v * (cdf + x * pdf);
+                } else if (MODE == 11) {
+                    *dst = v * phi_cdf_fast(v);
+                } else if (MODE == 16) {
+                    *dst = v;
+                    p.c2[row * p.ldc + p.col0 + col] = v * phi_cdf_fast(v);
+                } else if (MODE == 17) {
+                    const float x = old[r];
+                    const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
+                    *dst = v * (phi_cdf_fast(x) + x * pdf);
                 } else {
                     *dst = v;
                     p.c2[row * p.ldc + p.col0 + col] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
@@ -93,7 +117,10 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
 // wave (wr, wc) of the workgroup holds rows 64 wr .. + 63, columns 32 NU wc .. of the tile at (row0, colt)
 template <int NU>
 __device__ __forceinline__ void linear_epilogue(const LinearParams& p, const f32x16 (&acc)[2][NU], long row0, int colt, int wr, int wc) {
-    switch (p.mode) {
+    switch (p.fast_gelu && (p.mode == 1 || p.mode == 6 || p.mode == 7) ? p.mode + 10 : p.mode) {
+        case 11: linear_epilogue_mode<11, NU>(p, acc, row0, colt, wr, wc); break;
+        case 16: linear_epilogue_mode<16, NU>(p, acc, row0, colt, wr, wc); break;
+        case 17: linear_epilogue_mode<17, NU>(p, acc, row0, colt, wr, wc); break;
         case 0: linear_epilogue_mode<0, NU>(p, acc, row0, colt, wr, wc); break;
         case 1: linear_epilogue_mode<1, NU>(p, acc, row0, colt, wr, wc); break;
         case 2: linear_epilogue_mode<2, NU>(p, acc, row0, colt, wr, wc); break;
