@@ -104,6 +104,18 @@ class TrainableModel:
                "linear_q.weight", "linear_kv.weight", "linear_q_points.weight", "linear_kv_points.weight",
                "linear_out.weight", "emb_to_latent.linear.weight")
 
+    # the parameters whose fp32 values the training kernels read from tables the CONTEXT owns (api.hip setters that copy_f32
+    # into wl / bl / wc / bc / mask_emb / aa_emb / t_* / pos_embed / wf7.. / ada_w / ada_b / gamma_beta / head_w); every other
+    # parameter is read through its bound pointer.  test_mark_updated_refreshes_every_table_the_training_step_reads holds this
+    # list against a full hand-over.
+    _TABLE_KEYS = frozenset((
+        "latent_to_emb.weight", "latent_to_emb.bias", "cond_to_emb.weight", "cond_to_emb.bias", "mask_to_emb.weight",
+        "aatype_to_emb.weight", "t_embedder.mlp.0.weight", "t_embedder.mlp.0.bias", "t_embedder.mlp.2.weight",
+        "t_embedder.mlp.2.bias", "pos_embed", "latent_to_emb_f.weight", "latent_to_emb_f.bias", "latent_to_emb_r.weight",
+        "latent_to_emb_r.bias"))
+    _TABLE_SUFFIXES = ("adaLN_modulation.1.weight", "adaLN_modulation.1.bias", "ipa_norm.weight", "ipa_norm.bias",
+                       "ipa.head_weights")
+
     def mark_updated(self):
         """The flat parameters changed (optimiser step, checkpoint load).  The tensors the training kernels read from the
         context's OWN fp32 tables (time embedder, the concatenated adaLN table, token / residue embeddings, IPA norm and head
@@ -116,8 +128,8 @@ class TrainableModel:
         with torch.cuda.device(self.device):
             s = L.stream_ptr()
             for k, v in sd.items():
-                if k.endswith(self._PACKED):
-                    continue
+                if not (k in self._TABLE_KEYS or k.endswith(self._TABLE_SUFFIXES)):
+                    continue   # read in place from the bound flat buffer; its sampler-side copies wait for sync_weights()
                 shp = (C.c_int64 * v.dim())(*v.shape)
                 check(lib.mdgen_ctx_set_weight(m._ctx, k.encode(), ptr(v), shp, v.dim(), s))
             check(lib.mdgen_ctx_finalize(m._ctx, s))

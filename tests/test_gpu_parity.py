@@ -1633,6 +1633,52 @@ def test_training_bf16_operand_kernels_vs_exact_mode_at_tile_sizes():
         assert e < 5e-2 and cos > 0.999, (k, e, cos)
 
 
+def test_mark_updated_refreshes_every_table_the_training_step_reads():
+    """`TrainableModel.mark_updated()` hands over only the parameters that the training kernels read through context-owned
+    tables (time embedder, adaLN table, embeddings, IPA norm / head weights); everything else is read in place from the bound
+    flat buffer.  A parameter missing from that list would train on a stale copy without any error, so: perturb EVERY
+    parameter in place, mark_updated(), and require loss and all gradients to be bit-identical to a fresh model loaded from
+    the perturbed state dict (a full hand-over) -- for both model kinds and both operand precisions."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.train import TrainableModel
+    dev = _cuda()
+    for name in ("train_grads_sim", "train_grads_tps"):
+        g = load_golden(name)
+        cfg, sd = weights_for(g)
+        xt, ut = O.path_plan(g["t"], g["x0"], g["x1"], "GVP")
+        ends = (g["end_rot"].to(dev), g["end_trans"].to(dev)) if "end_rot" in g else None
+        args = (xt.to(dev), g["t"].to(dev), ut.to(dev), g["loss_mask"].to(dev), g["mask"].to(dev),
+                (g["start_rot"].to(dev), g["start_trans"].to(dev)), g["x_cond"].to(dev), g["x_cond_mask"].to(dev), g["aatype"].to(dev))
+        kw = {"end_frames": ends} if ends is not None else {}
+        for prec in (32, 16):
+            tm = TrainableModel(cfg, dev).load_state_dict(sd)
+            tm.model.set_option("train_precision", prec)
+            tm.zero_grad()
+            tm.forward_backward(*args, **kw)              # tables in use once, as in a running job
+            gen = torch.Generator().manual_seed(3)
+            flat = tm.params.data
+            flat += 0.02 * flat.abs().mean() * torch.randn(flat.numel(), generator=gen).to(flat)
+            tm.mark_updated()
+            tm.zero_grad()
+            loss, _ = tm.forward_backward(*args, **kw)
+            torch.cuda.synchronize()
+            got = {k: v.detach().cpu().clone() for k, v in tm.params.state_dict(tm.grads).items()}
+            sd2 = {k: v.detach().cpu().clone() for k, v in tm.params.state_dict().items()}
+            for k, v in sd.items():   # frozen buffers etc.
+                sd2.setdefault(k, v)
+            ref = TrainableModel(cfg, dev).load_state_dict(sd2)
+            ref.model.set_option("train_precision", prec)
+            ref.zero_grad()
+            loss_ref, _ = ref.forward_backward(*args, **kw)
+            torch.cuda.synchronize()
+            want = ref.params.state_dict(ref.grads)
+            assert torch.equal(loss.cpu(), loss_ref.cpu()), (name, prec, loss, loss_ref)
+            for k in got:
+                assert torch.equal(got[k], want[k].cpu()), (name, prec, k)
+            tm.model.set_option("train_precision", 32)
+            ref.model.set_option("train_precision", 32)
+
+
 def test_row_owner_mlp_paths_agree():
     """The MLP block has three forms: the 64-row resident-panel kernel (`mlp_path` 0), the row-owner kernel (`mlp_path` 2:
     activations in registers, LDS-DMA weight stream) and the row-owner kernel with the temporal out-projection fused in front
