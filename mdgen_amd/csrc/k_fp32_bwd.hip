@@ -489,6 +489,103 @@ __global__ __launch_bounds__(256) void k32_ln_bwd(const float* __restrict__ x, c
     }
 }
 
+// LayerNorm + modulate backward WITH the two adaLN column sums of the same rows (d shift[g] += sum dy, d scale[g] += sum dy
+// xhat): the separate k32_colsum passes re-read dy twice and x once.  A workgroup owns one slice of rows_per_slice rows of one
+// group (four waves, wave w the rows w, w + 4, ...), keeps the column sums of its rows in registers, and writes one partial
+// row [shift(384) | scale(384)] that k32_colsum_final reduces in a fixed order (same two-stage determinism as k32_colsum).
+__global__ __launch_bounds__(256) void k32_ln_bwd_sums(const float* __restrict__ x, const float* __restrict__ dy, long nrows, ModMap mm,
+                                                       int scale_chunk, float eps, float* __restrict__ dx, int accumulate,
+                                                       long tokens_per_group, int rps, int spg, float* __restrict__ partial) {
+    __shared__ float red[4][2 * kC];
+    const long grp = blockIdx.x / spg;
+    const int si = blockIdx.x % spg;
+    const long lo = grp * tokens_per_group + (long)si * rps;
+    long hi = lo + rps;
+    if (hi > (grp + 1) * tokens_per_group) hi = (grp + 1) * tokens_per_group;
+    if (hi > nrows) hi = nrows;
+    const int lane = lane_id(), w = wave_id();
+    float c1[6], c2[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c1[i] = c2[i] = 0.f;
+    for (long row = lo + w; row < hi; row += 4) {
+        float v[6], g[6], d[6];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            v[i] = x[row * kC + lane + 64 * i];
+            d[i] = dy[row * kC + lane + 64 * i];
+            s += v[i];
+        }
+        const float mean = wave_sum(s) * (1.0f / kC);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            v[i] -= mean;
+            q += v[i] * v[i];
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kC) + eps);
+        const float* mod = mm.mod + mm.row_off(row);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = lane + 64 * i;
+            v[i] *= rstd;                                          // xhat
+            g[i] = d[i] * (1.0f + mod[scale_chunk * kC + c]);      // dxhat
+            s1 += g[i];
+            s2 += g[i] * v[i];
+            c1[i] += d[i];
+            c2[i] += d[i] * v[i];
+        }
+        s1 = wave_sum(s1) * (1.0f / kC);
+        s2 = wave_sum(s2) * (1.0f / kC);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = lane + 64 * i;
+            const float r = rstd * (g[i] - s1 - v[i] * s2);
+            dx[row * kC + c] = accumulate ? dx[row * kC + c] + r : r;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        red[w][lane + 64 * i] = c1[i];
+        red[w][kC + lane + 64 * i] = c2[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * kC; c += 256)
+        partial[(long)blockIdx.x * 2 * kC + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// du = gate * dh AND d gate[g] += sum dh * u over the same rows (one pass over dh instead of two); slices as above.
+__global__ __launch_bounds__(256) void k32_gate_bwd_sums(const float* __restrict__ dh, const float* __restrict__ u, long nrows,
+                                                         ModMap mm, int gate_chunk, float* __restrict__ du, long tokens_per_group,
+                                                         int rps, int spg, float* __restrict__ partial) {
+    __shared__ float red[4][kC];
+    const long grp = blockIdx.x / spg;
+    const int si = blockIdx.x % spg;
+    const long lo = grp * tokens_per_group + (long)si * rps;
+    long hi = lo + rps;
+    if (hi > (grp + 1) * tokens_per_group) hi = (grp + 1) * tokens_per_group;
+    if (hi > nrows) hi = nrows;
+    const int lane = lane_id(), w = wave_id();
+    float c1[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c1[i] = 0.f;
+    for (long row = lo + w; row < hi; row += 4) {
+        const float* mod = mm.mod + mm.row_off(row) + gate_chunk * kC;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = lane + 64 * i;
+            const float d = dh[row * kC + c];
+            c1[i] += d * u[row * kC + c];
+            du[row * kC + c] = d * mod[c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) red[w][lane + 64 * i] = c1[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < kC; c += 256) partial[(long)blockIdx.x * kC + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
 // out[t][c] = a[t][c] * gate[g(t)][c]   (du = gate * dh; gate == null -> copy)
 __global__ void k32_gate_mul(const float* __restrict__ a, long nrows, ModMap mm, int gate_chunk, int gated,
                              float* __restrict__ out) {
@@ -855,6 +952,37 @@ void launch32_ln_bwd(const float* x, const float* dy, long nrows, const ModMap& 
                      float* dx, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(k32_ln_bwd, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, x, dy, nrows, mm, scale_chunk, affine,
                        eps, dx, accumulate);
+}
+static bool slice_plan(long nrows, long tokens_per_group, int ncols, size_t part_floats, long* ng, int* rps, int* spg) {
+    *ng = (nrows + tokens_per_group - 1) / tokens_per_group;
+    *rps = 64;
+    *spg = (int)((tokens_per_group + *rps - 1) / *rps);
+    while ((size_t)*ng * *spg * ncols > part_floats && *rps < (1 << 24)) {
+        *rps *= 2;
+        *spg = (int)((tokens_per_group + *rps - 1) / *rps);
+    }
+    return (size_t)*ng * *spg * ncols <= part_floats;
+}
+// dx (+)= LN'(dy (1 + scale)); out[g][0:384] += sum dy, out[g][384:768] += sum dy xhat  (out = the shift chunk of the group's
+// modulation-gradient row, the scale chunk right behind it).  false: partial buffer too small, nothing launched.
+bool launch32_ln_bwd_sums(const float* x, const float* dy, long nrows, const ModMap& mm, int scale_chunk, float eps, float* dx,
+                          int accumulate, long tokens_per_group, float* out, long ldo, float* part, size_t part_floats, hipStream_t s) {
+    long ng; int rps, spg;
+    if (!slice_plan(nrows, tokens_per_group, 2 * kC, part_floats, &ng, &rps, &spg)) return false;
+    hipLaunchKernelGGL(k32_ln_bwd_sums, dim3((unsigned)(ng * spg)), dim3(256), 0, s, x, dy, nrows, mm, scale_chunk, eps, dx, accumulate,
+                       tokens_per_group, rps, spg, part);
+    hipLaunchKernelGGL(k32_colsum_final, dim3((unsigned)(ng * ((2 * kC + 15) / 16))), dim3(256), 0, s, part, (int)ng, spg, 2 * kC, out, ldo);
+    return true;
+}
+// du = gate * dh; out[g][0:384] += sum dh u
+bool launch32_gate_bwd_sums(const float* dh, const float* u, long nrows, const ModMap& mm, int gate_chunk, float* du,
+                            long tokens_per_group, float* out, long ldo, float* part, size_t part_floats, hipStream_t s) {
+    long ng; int rps, spg;
+    if (!slice_plan(nrows, tokens_per_group, kC, part_floats, &ng, &rps, &spg)) return false;
+    hipLaunchKernelGGL(k32_gate_bwd_sums, dim3((unsigned)(ng * spg)), dim3(256), 0, s, dh, u, nrows, mm, gate_chunk, du, tokens_per_group,
+                       rps, spg, part);
+    hipLaunchKernelGGL(k32_colsum_final, dim3((unsigned)(ng * ((kC + 15) / 16))), dim3(256), 0, s, part, (int)ng, spg, kC, out, ldo);
+    return true;
 }
 void launch32_gate_mul(const float* a, long nrows, const ModMap& mm, int gate_chunk, int gated, float* out, hipStream_t s) {
     const long n = nrows * kC;

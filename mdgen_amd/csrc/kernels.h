@@ -209,6 +209,11 @@ void launch32_rope(float* buf, long ntok, int ld, long pos_div, int pos_mod, con
 // out[nb][m] = x[nb][K] W[K][m], nb small and K long (split over K); false: partial buffer too small, nothing launched
 bool launch32_skinny_wt(const float* x, int ldx, const float* W, int ldw, int nb, int m, long K, float* out, float* part,
                         size_t part_floats, hipStream_t s);
+// fused element-wise backward + adaLN column sums (k_fp32_bwd.hip); false: partial buffer too small, nothing launched
+bool launch32_ln_bwd_sums(const float* x, const float* dy, long nrows, const ModMap& mm, int scale_chunk, float eps, float* dx,
+                          int accumulate, long tokens_per_group, float* out, long ldo, float* part, size_t part_floats, hipStream_t s);
+bool launch32_gate_bwd_sums(const float* dh, const float* u, long nrows, const ModMap& mm, int gate_chunk, float* du,
+                            long tokens_per_group, float* out, long ldo, float* part, size_t part_floats, hipStream_t s);
 void launch32_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s, int ldd = 0);   // dst[c][r] (ld ldd, default rows) = src[r][c]
 bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ldw, const float* const* bias, const float* scale,
                           long n, int mseg, int k, float* c, int ldc, int col0, hipStream_t s, const void* wpack = nullptr);
