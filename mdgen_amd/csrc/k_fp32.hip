@@ -14,6 +14,7 @@
 // It is a tolerance mode, not a fast path: ~30x slower than the bf16 kernels at cfg-2 (157 TFLOP/s fp32 MFMA peak vs
 // 2.5 PFLOP/s bf16, an unfused structure, and a simple attention kernel).  It shares everything that is fp32 already: time embedding, adaLN table,
 // token embedding, IPA point attention, SE(3) kernels.
+#include <type_traits>
 #include "kernels.h"
 #include "linear.h"
 
@@ -405,6 +406,50 @@ __global__ __launch_bounds__(256, 2) void k16_linear_fast(const LinearParams p, 
     linear_epilogue(p, acc, row0, colt, wr, wc);
 }
 
+// Launches of a few hundred rows (the IPA stack works on B * L rows: 86 linear layers per training step at cfg-5's size,
+// 6 .. 24 workgroups each): with 128 x 128 tiles they are a handful of workgroups walking k in six dependent load -> LDS ->
+// barrier steps (~25 us per launch).  Here ONE WAVE owns a 32 x 32 output tile and the whole contraction: both operands come
+// straight from global memory in MFMA fragment shape (lane = row / column, eight consecutive k = two 16-byte loads), 128 of k
+// at a time (32 loads in flight per lane), rounded to bf16 in registers; no LDS, no barrier, 96 waves for 256 x 384.
+__global__ __launch_bounds__(64) void k16_linear_small(const LinearParams p) {
+    const int lane = threadIdx.x, i = lane & 31, kh = lane >> 5;
+    const long row0 = (long)blockIdx.y * 32;
+    const int colt = blockIdx.x * 32;
+    const int sg = p.seg_cols ? colt / p.seg_cols : 0;
+    const float* wbase = p.seg_cols ? p.w_seg[sg] : p.w;
+    const int ccol = colt - sg * p.seg_cols, mseg = p.seg_cols ? p.seg_cols : p.m;
+    const long ar = row0 + i < p.n ? row0 + i : p.n - 1;           // past the end: clamped loads, results never stored
+    const int wc = ccol + i < mseg ? ccol + i : mseg - 1;
+    const float* ap = p.a + ar * p.lda + 8 * kh;
+    const float* wp = wbase + (long)wc * p.ldw + 8 * kh;
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = opaque_zero();
+    auto chunk = [&](int k0, auto nks) {
+        constexpr int NKS = decltype(nks)::value;
+        f32x4 a[NKS][2], b[NKS][2];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                a[ks][h] = *reinterpret_cast<const f32x4*>(ap + k0 + 16 * ks + 4 * h);
+                b[ks][h] = *reinterpret_cast<const f32x4*>(wp + k0 + 16 * ks + 4 * h);
+            }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, u32x4{pack_bf16(a[ks][0][0], a[ks][0][1]), pack_bf16(a[ks][0][2], a[ks][0][3]),
+                                                               pack_bf16(a[ks][1][0], a[ks][1][1]), pack_bf16(a[ks][1][2], a[ks][1][3])});
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, u32x4{pack_bf16(b[ks][0][0], b[ks][0][1]), pack_bf16(b[ks][0][2], b[ks][0][3]),
+                                                               pack_bf16(b[ks][1][0], b[ks][1][1]), pack_bf16(b[ks][1][2], b[ks][1][3])});
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[0][0], 0, 0, 0);
+        }
+    };
+    int k0 = 0;
+    for (; k0 + 128 <= p.k; k0 += 128) chunk(k0, std::integral_constant<int, 8>{});
+    if (k0 < p.k) chunk(k0, std::integral_constant<int, 4>{});     // k is a multiple of 64 (launcher)
+    linear_epilogue(p, acc, row0, colt, 0, 0);
+}
+
 // dst[c][r] (row stride ldd) = src[r][c]: the weight of a dX = dY W product, turned once per use so that the product runs through the same
 // [m][k] kernel as the forward layer (64 x 64 tiles through LDS; a 384 x 384 weight is 36 workgroups, ~3 us).
 __global__ __launch_bounds__(256) void k32_transpose(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst,
@@ -559,6 +604,11 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
     }
     const auto al = [](const void* q) { return ((unsigned long long)q & 15) == 0; };
     if (launch16_linear_wide(p, s)) return;    // 128 x 384 tiles: every trunk-sized layer (k_wide16.hip)
+    if (n <= 2048 && !wtrans && k % 64 == 0 && (lda & 3) == 0 && (ldw & 3) == 0 && ((unsigned long long)a & 15) == 0 &&
+        ((unsigned long long)w & 15) == 0) {   // a few hundred rows: one wave per 32 x 32 tile
+        hipLaunchKernelGGL(k16_linear_small, dim3((unsigned)((m + 31) / 32), (unsigned)((n + 31) / 32)), dim3(64), 0, s, p);
+        return;
+    }
     const bool fast = !wtrans && k % 64 == 0 && (lda & 3) == 0 && (ldw & 3) == 0 && al(a) && al(w);
     if (!fast) {
         hipLaunchKernelGGL(k16_linear, grid, dim3(256), 0, s, p);
@@ -578,6 +628,10 @@ bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ld
                    mseg, {w[0], w[1], w[2]}, {bias[0], bias[1], bias[2]}, {scale[0], scale[1], scale[2]},
                    static_cast<const unsigned char*>(wpack), 1};
     if (launch16_linear_wide(p, s)) return true;
+    if (n <= 2048) {
+        hipLaunchKernelGGL(k16_linear_small, dim3((unsigned)(3 * mseg / 32), (unsigned)((n + 31) / 32)), dim3(64), 0, s, p);
+        return true;
+    }
     const int nrt = (int)((n + 127) / 128), nct = 3 * mseg / 128;
     hipLaunchKernelGGL(k16_linear_fast, dim3((unsigned)(8 * ((nrt + 7) / 8) * nct)), dim3(256), 0, s, p, nrt, nct);
     return true;

@@ -49,8 +49,8 @@ __device__ __forceinline__ float phi_cdf_fast(float x) {
 // epilogue shared by k32_linear and k16_linear: bias, then store / GELU / gated residual / Euler / scale / accumulate (LinearParams::mode)
 // One instantiation per mode, the mode test outside the element loops: each (column, 32-row tile) is 16 independent
 // elements whose read-modify-write loads (modes 2, 3, 5) are all issued before the first one is needed.
-template <int MODE, int NU>
-__device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, const f32x16 (&acc)[2][NU], long row0, int colt, int wr,
+template <int MODE, int NT, int NU>
+__device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, const f32x16 (&acc)[NT][NU], long row0, int colt, int wr,
                                                      int wc) {
     const int lane = lane_id();
     const int hh = lane >> 5;
@@ -63,8 +63,8 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
         const float bias = bp ? bp[col - sg * p.seg_cols] : 0.f;
         const float sscale = p.seg_cols ? p.scale_seg[sg] : 1.0f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const long rbase = row0 + wr * 64 + t * 32;
+        for (int t = 0; t < NT; ++t) {
+            const long rbase = row0 + wr * 32 * NT + t * 32;
             float old[16], g[16];
             if (MODE == 2 || MODE == 3 || MODE == 5 || MODE == 7 || MODE == 17 || MODE == 8) {
 #pragma unroll
@@ -118,22 +118,22 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
         }
     }
 }
-// wave (wr, wc) of the workgroup holds rows 64 wr .. + 63, columns 32 NU wc .. of the tile at (row0, colt)
-template <int NU>
-__device__ __forceinline__ void linear_epilogue(const LinearParams& p, const f32x16 (&acc)[2][NU], long row0, int colt, int wr, int wc) {
+// wave (wr, wc) of the workgroup holds rows 32 NT wr .., columns 32 NU wc .. of the tile at (row0, colt)
+template <int NT, int NU>
+__device__ __forceinline__ void linear_epilogue(const LinearParams& p, const f32x16 (&acc)[NT][NU], long row0, int colt, int wr, int wc) {
     switch (p.fast_gelu && (p.mode == 1 || p.mode == 6 || p.mode == 7) ? p.mode + 10 : p.mode) {
-        case 11: linear_epilogue_mode<11, NU>(p, acc, row0, colt, wr, wc); break;
-        case 16: linear_epilogue_mode<16, NU>(p, acc, row0, colt, wr, wc); break;
-        case 17: linear_epilogue_mode<17, NU>(p, acc, row0, colt, wr, wc); break;
-        case 0: linear_epilogue_mode<0, NU>(p, acc, row0, colt, wr, wc); break;
-        case 1: linear_epilogue_mode<1, NU>(p, acc, row0, colt, wr, wc); break;
-        case 2: linear_epilogue_mode<2, NU>(p, acc, row0, colt, wr, wc); break;
-        case 3: linear_epilogue_mode<3, NU>(p, acc, row0, colt, wr, wc); break;
-        case 4: linear_epilogue_mode<4, NU>(p, acc, row0, colt, wr, wc); break;
-        case 5: linear_epilogue_mode<5, NU>(p, acc, row0, colt, wr, wc); break;
-        case 7: linear_epilogue_mode<7, NU>(p, acc, row0, colt, wr, wc); break;
-        case 8: linear_epilogue_mode<8, NU>(p, acc, row0, colt, wr, wc); break;
-        default: linear_epilogue_mode<6, NU>(p, acc, row0, colt, wr, wc); break;
+        case 11: linear_epilogue_mode<11, NT, NU>(p, acc, row0, colt, wr, wc); break;
+        case 16: linear_epilogue_mode<16, NT, NU>(p, acc, row0, colt, wr, wc); break;
+        case 17: linear_epilogue_mode<17, NT, NU>(p, acc, row0, colt, wr, wc); break;
+        case 0: linear_epilogue_mode<0, NT, NU>(p, acc, row0, colt, wr, wc); break;
+        case 1: linear_epilogue_mode<1, NT, NU>(p, acc, row0, colt, wr, wc); break;
+        case 2: linear_epilogue_mode<2, NT, NU>(p, acc, row0, colt, wr, wc); break;
+        case 3: linear_epilogue_mode<3, NT, NU>(p, acc, row0, colt, wr, wc); break;
+        case 4: linear_epilogue_mode<4, NT, NU>(p, acc, row0, colt, wr, wc); break;
+        case 5: linear_epilogue_mode<5, NT, NU>(p, acc, row0, colt, wr, wc); break;
+        case 7: linear_epilogue_mode<7, NT, NU>(p, acc, row0, colt, wr, wc); break;
+        case 8: linear_epilogue_mode<8, NT, NU>(p, acc, row0, colt, wr, wc); break;
+        default: linear_epilogue_mode<6, NT, NU>(p, acc, row0, colt, wr, wc); break;
     }
 }
 
