@@ -443,8 +443,9 @@ int launch16_dw_wide(const float* dy, int ldy, const float* x, int ldx, long n, 
     const bool fast = ((ldy | m | ldx | k) & 7) == 0 && (((unsigned long long)dy | (unsigned long long)x) & 15) == 0;
     if (!fast || n < 4096) return 0;
     const int mt = (m + kWideRows - 1) / kWideRows, kg = (k + kWideCols - 1) / kWideCols, nt = mt * kg;
-    // one workgroup per CU: enough n-slices to fill the chip once (more only add partial-sum traffic)
-    int nsplit = (256 + nt - 1) / nt;
+    // one workgroup per CU (147 KB of LDS): as many n-slices as fill the chip ONCE -- rounded DOWN: with 86 slices x 3 tiles =
+    // 258 workgroups on 256 CUs the last two wait for a free CU and the launch takes two rounds instead of one
+    int nsplit = 256 / nt;
     const int cap = (int)((n + 255) / 256);
     if (nsplit > cap) nsplit = cap;
     if (nsplit < 1) nsplit = 1;
