@@ -115,9 +115,10 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      which fill the chip, and the panel kernel below that; 2 the row-owner kernel always.
  *   "fuse_proj"        0 (default) / 1: with the row-owner MLP kernel, run the temporal attention's out-projection +
  *                      gated residual (mha.py:397, latent_model.py:476) inside it, ahead of the MLP.
- *   "train_precision"  operands of the linear layers and weight gradients of mdgen_train_forward_backward: 32 (default)
- *                      fp32, the exact mode; 16 rounded to bf16, fp32 accumulation, fp32 master weights (train.py:13
- *                      set_float32_matmul_precision('medium')); everything else stays fp32.
+ *   "train_precision"  operands of the matrix products of mdgen_train_forward_backward (linear layers, weight gradients,
+ *                      the attention's q k^T / p v and their backward): 32 (default) fp32, the exact mode; 16 rounded to
+ *                      bf16 on the MFMA, fp32 accumulation, fp32 master weights and activations (train.py:13
+ *                      set_float32_matmul_precision('medium')); softmax, LayerNorm, reductions stay fp32, GELU to 5e-6.
  * Returns -4 for an unknown name, -2 for a value out of range. */
 int32_t mdgen_ctx_set_option(mdgen_ctx* ctx, const char* name, int32_t value);
 /* number of state_dict keys the model needs; name of the i-th (for loaders / tests) */
