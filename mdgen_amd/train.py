@@ -350,6 +350,9 @@ def main(argv=None):
     ap.add_argument("--val_batches", type=int, default=None)
     ap.add_argument("--no_validate", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--matmul_precision", default="medium", choices=["medium", "highest"],
+                    help="medium (what the reference's train.py:13 sets): bf16-operand matrix products, fp32 accumulation / "
+                         "weights / activations (library option train_precision = 16); highest: exact fp32 products")
     ap.add_argument("--single_device", action="store_true",
                     help="every rank on cuda:0 (with --backend gloo: lets a one-GPU box run the multi-rank path; RCCL refuses it)")
     a = ap.parse_args(argv)
@@ -377,6 +380,7 @@ def main(argv=None):
     tr = Trainer(w, lr=a.lr, adamw=a.adamW, grad_clip=a.grad_clip, ema_decay=a.ema_decay if a.ema else None, dist=dist)
     if a.ckpt:
         tr.load_checkpoint(a.ckpt)
+    tr.tm.model.set_option("train_precision", 16 if a.matmul_precision == "medium" else 32)
     import numpy as np
     np.random.seed(a.seed + rank)
     torch.manual_seed(a.seed + rank)

@@ -1542,9 +1542,10 @@ def test_time_embedding_and_adaln_table_all_steps():
 
 
 def test_training_gradients_bf16_operands_vs_reference_fixture():
-    """Option train_precision = 16: the training step's linear layers and weight gradients multiply bf16-rounded operands on
-    the bf16 MFMA with fp32 accumulation and fp32 master weights -- the precision class the reference trains with (train.py:13
-    `set_float32_matmul_precision('medium')`); LayerNorm, softmax / attention, GELU, reductions stay fp32.  Gate against the
+    """Option train_precision = 16: the training step's matrix products (linear layers, weight gradients, the attention's
+    q k^T / p v and their backward) multiply bf16-rounded operands on the bf16 MFMA with fp32 accumulation, fp32 master weights
+    and activations -- the precision class the reference trains with (train.py:13 `set_float32_matmul_precision('medium')`);
+    LayerNorm, softmax, reductions stay fp32 (GELU to 5e-6).  Gate against the
     reference's own fp32 autograd gradients (train_grads_sim.npz): loss to 1e-2 relative, every tensor's gradient samples to
     rel-L2 5e-2 and cosine 0.999 (tensors whose gradient is at the noise floor excepted), the exact mode (32) stays as tested
     above."""
