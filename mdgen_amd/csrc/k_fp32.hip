@@ -14,6 +14,8 @@
 // It is a tolerance mode, not a fast path: ~30x slower than the bf16 kernels at cfg-2 (157 TFLOP/s fp32 MFMA peak vs
 // 2.5 PFLOP/s bf16, an unfused structure, and a simple attention kernel).  It shares everything that is fp32 already: time embedding, adaLN table,
 // token embedding, IPA point attention, SE(3) kernels.
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include "kernels.h"
 #include "linear.h"
@@ -594,9 +596,13 @@ void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chu
 }
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
-                     int wtrans, float* c2, const void* wpack) {
+                     int wtrans, float* c2, const void* wpack, int flags) {
     LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, wtrans, c, ldc, col0, mm, gate_chunk, gated, scalar, c2, 0, {}, {}, {},
-                   static_cast<const unsigned char*>(wpack), g_k32_bf16_operands};
+                   static_cast<const unsigned char*>(wpack), g_k32_bf16_operands, flags & 1, (flags >> 1) & 1};
+    if ((flags & 3) && !(g_k32_bf16_operands && (!(flags & 1) || wpack))) {
+        std::fprintf(stderr, "mdgen_amd: launch32_linear: bf16 operand storage outside the streamed bf16-operand kernel\n");
+        std::abort();
+    }
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128));
     if (!g_k32_bf16_operands) {
         hipLaunchKernelGGL(k32_linear, grid, dim3(256), 0, s, p);
@@ -604,6 +610,10 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
     }
     const auto al = [](const void* q) { return ((unsigned long long)q & 15) == 0; };
     if (launch16_linear_wide(p, s)) return;    // 128 x 384 tiles: every trunk-sized layer (k_wide16.hip)
+    if (flags & 1) {
+        std::fprintf(stderr, "mdgen_amd: launch32_linear: bf16 token rows need the streamed kernel (n >= 1024, m %% 384 == 0)\n");
+        std::abort();
+    }
     if (n <= 2048 && !wtrans && k % 64 == 0 && (lda & 3) == 0 && (ldw & 3) == 0 && ((unsigned long long)a & 15) == 0 &&
         ((unsigned long long)w & 15) == 0) {   // a few hundred rows: one wave per 32 x 32 tile
         hipLaunchKernelGGL(k16_linear_small, dim3((unsigned)((m + 31) / 32), (unsigned)((n + 31) / 32)), dim3(64), 0, s, p);
@@ -626,7 +636,7 @@ bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ld
         return false;
     LinearParams p{a, lda, w[0], ldw, nullptr, n, 3 * mseg, k, 0, 0, c, ldc, col0, ModMap{nullptr, 1, 1, 0, 0}, 0, 0, 0.f, nullptr,
                    mseg, {w[0], w[1], w[2]}, {bias[0], bias[1], bias[2]}, {scale[0], scale[1], scale[2]},
-                   static_cast<const unsigned char*>(wpack), 1};
+                   static_cast<const unsigned char*>(wpack), 1, 0, 0};
     if (launch16_linear_wide(p, s)) return true;
     if (n <= 2048) {
         hipLaunchKernelGGL(k16_linear_small, dim3((unsigned)(3 * mseg / 32), (unsigned)((n + 31) / 32)), dim3(64), 0, s, p);

@@ -11,6 +11,8 @@
 //   k32_rope_bwd                inverse rotation of dq, dk and the q scale
 //   k32_loss_grad               d(mean_b masked-MSE_b) / d pred
 //   k32_sum_frames              d ipa_out[b,l] = sum_t dh0[b,t,l]
+#include <cstdio>
+#include <cstdlib>
 #include "kernels.h"
 
 namespace mdg {
@@ -887,9 +889,9 @@ __global__ void k32_sum_frames(const float* __restrict__ a, int B, int T, int L,
 // dW of nseg layers that share the input x and whose dY sit side by side (dy[n][j mseg + i]): one pass over x and dY,
 // m = nseg * mseg.  dw[j] / db[j] may be null.  Returns true if the bias gradients were computed by the same pass.
 int launch16_dw_wide(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* part, size_t part_floats,
-                     bool want_db, float** bpart_out, hipStream_t s);   // k_wide16.hip
+                     bool want_db, float** bpart_out, hipStream_t s, bool x_bf16);   // k_wide16.hip
 bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, int mseg, int nseg, int k, float* const* dw,
-                     float* const* db, float* part, size_t part_floats, hipStream_t s) {
+                     float* const* db, float* part, size_t part_floats, hipStream_t s, bool x_bf16) {
     const int m = mseg * nseg;
     bool want_db = false;
     for (int j = 0; j < nseg; ++j) want_db = want_db || (db && db[j]);
@@ -906,10 +908,14 @@ bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, 
     };
     if (g_k32_bf16_operands) {   // 128 x 384 tiles (k_wide16.hip): each dY tile read once
         float* bpart = nullptr;
-        if (const int ns = launch16_dw_wide(dy, ldy, x, ldx, n, m, k, part, part_floats, want_db, &bpart, s)) {
+        if (const int ns = launch16_dw_wide(dy, ldy, x, ldx, n, m, k, part, part_floats, want_db, &bpart, s, x_bf16)) {
             reduce(ns, bpart);
             return bpart != nullptr;
         }
+    }
+    if (x_bf16) {
+        std::fprintf(stderr, "mdgen_amd: launch32_dw: bf16 X rows need the wide kernel (bf16-operand mode, n >= 4096)\n");
+        std::abort();
     }
     // enough slices to fill the chip ONCE with 128 x 128 tiles at two workgroups per CU (a 384 x 384 weight is only 9 of
     // them); more slices only add partial-sum traffic (113 slices of a 384 x 384 weight: 66 MB written and read back)
@@ -931,8 +937,8 @@ bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, 
     return bpart != nullptr;
 }
 bool launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,
-                 size_t part_floats, hipStream_t s, float* db) {
-    return launch32_dw_seg(dy, ldy, x, ldx, n, m, 1, k, &dw, &db, part, part_floats, s);
+                 size_t part_floats, hipStream_t s, float* db, bool x_bf16) {
+    return launch32_dw_seg(dy, ldy, x, ldx, n, m, 1, k, &dw, &db, part, part_floats, s, x_bf16);
 }
 // out[g][c] (ldo) += sum_{t in group g} a[t][c] * B(t, c); groups of tokens_per_group rows
 void launch32_colsum(const float* a, int lda, const float* b, int ldb, const float* roww, int mode, long nrows, int ncols,

@@ -226,6 +226,10 @@ bool launch16_pack_wstream(const float* const* src, int nsrc, int seg, int ld, l
 }
 
 // Requires (launcher): p.wpack (k16_pack_wstream of this layer), k % 64 == 0, m % 384 == 0, 16-byte aligned token operand.
+// ABF: the token operand is stored as bf16 rows (p.a reinterpreted, lda in elements) -- a tensor that is only ever a GEMM
+// operand (the GELU output) is written rounded by its producer: the same values enter the MFMA, half the bytes cross HBM
+// and the register file, no conversion here.
+template <bool ABF>
 __global__ __launch_bounds__(512) void k16_linear_wdma(const LinearParams p, int nrt, int ncg) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (kWideP + kWideQD)];   // [2][Q (48 KiB) | P]
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -243,21 +247,38 @@ __global__ __launch_bounds__(512) void k16_linear_wdma(const LinearParams p, int
         for (int u = 0; u < 3; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = opaque_zero();
-    const int r0 = tid >> 4, piece = tid & 15;        // token rows r0 + 32 q, k0 + 4 piece .. + 3
+    // fp32 rows: token rows r0 + 32 q (q < 4), k0 + 4 piece .. + 3;  bf16 rows: token rows rb + 64 q (q < 2), k0 + 8 pb .. + 7
+    const int r0 = tid >> 4, piece = tid & 15;
+    const int rb = tid >> 3, pb = tid & 7;
     const float* abase = p.a + 4 * piece;
+    const uint16_t* abase16 = reinterpret_cast<const uint16_t*>(p.a) + 8 * pb;
     long aoff[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) aoff[q] = (row0 + r0 + 32 * q < p.n ? row0 + r0 + 32 * q : p.n - 1) * p.lda;   // past the end: clamped, never stored
+    for (int q = 0; q < 4; ++q) {   // past the end: clamped, never stored
+        const long r = ABF ? row0 + rb + 64 * (q & 1) : row0 + r0 + 32 * q;
+        aoff[q] = (r < p.n ? r : p.n - 1) * p.lda;
+    }
     f32x4 av[4];
+    u32x4 av16[2];
     auto fetch = [&](int k0) {
+        if (ABF) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const f32x4*>(abase + aoff[q] + k0);
+            for (int q = 0; q < 2; ++q) av16[q] = *reinterpret_cast<const u32x4*>(abase16 + aoff[q] + k0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const f32x4*>(abase + aoff[q] + k0);
+        }
     };
     auto stage = [&](int buf) {
         unsigned char* P = lds + buf * (kWideP + kWideQD) + kWideQD;
+        if (ABF) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<u32x2*>(P + (r0 + 32 * q) * kWideRowB + piece * 8) = pack4(av[q][0], av[q][1], av[q][2], av[q][3]);
+            for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4*>(P + (rb + 64 * q) * kWideRowB + pb * 16) = av16[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<u32x2*>(P + (r0 + 32 * q) * kWideRowB + piece * 8) = pack4(av[q][0], av[q][1], av[q][2], av[q][3]);
+        }
     };
     // this wave's six fragments of a k-step: two DMA groups (an instruction offset moves both ends, rows.h dma_frag)
     const int nk = p.k / kWideBK;
@@ -314,6 +335,8 @@ __global__ __launch_bounds__(512) void k16_linear_wdma(const LinearParams p, int
 // token rows of four columns, so that the four token values of a column are one 8-byte LDS store.
 // Tile order: the (row tile, column group) pairs of one n-slice run back to back on one XCD.
 // Requires (launcher): ldy, ldx, m, k multiples of 8, 16-byte aligned operands.
+// XBF: X is stored as bf16 rows (x reinterpreted, ldx in elements): see k16_linear_wdma.
+template <bool XBF>
 __global__ __launch_bounds__(512) void k16_dw_wide(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
                                                    long n, int m, int k, int nsplit, float* __restrict__ part,
                                                    float* __restrict__ bpart) {
@@ -345,17 +368,25 @@ __global__ __launch_bounds__(512) void k16_dw_wide(const float* __restrict__ dy,
 #pragma unroll
     for (int e = 0; e < 3; ++e) kc[e] = k0 + 4 * (pc + 32 * e) < k ? k0 + 4 * (pc + 32 * e) : 0;   // past the end: clamped, never stored
     f32x4 av[4], bv[3][4];
+    u32x2 bh[3][4];    // XBF: four bf16 per (piece, token row)
+    const uint16_t* x16 = reinterpret_cast<const uint16_t*>(x);
     auto fetch_quarter = [&](long n0, int r) {   // token row 4 g + r of the step: one dY piece, three X pieces
         {
             const long rw = n0 + 4 * g + r;
             const long row = rw < nhi ? rw : nhi - 1;
             av[r] = *reinterpret_cast<const f32x4*>(dy + row * ldy + mc);
 #pragma unroll
-            for (int e = 0; e < 3; ++e) bv[e][r] = *reinterpret_cast<const f32x4*>(x + row * ldx + kc[e]);
+            for (int e = 0; e < 3; ++e) {
+                if (XBF) bh[e][r] = *reinterpret_cast<const u32x2*>(x16 + row * ldx + kc[e]);
+                else bv[e][r] = *reinterpret_cast<const f32x4*>(x + row * ldx + kc[e]);
+            }
             if (rw >= nhi) {
                 av[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 3; ++e) bv[e][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int e = 0; e < 3; ++e) {
+                    bv[e][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    bh[e][r] = u32x2{0u, 0u};
+                }
             }
         }
     };
@@ -375,8 +406,17 @@ __global__ __launch_bounds__(512) void k16_dw_wide(const float* __restrict__ dy,
         for (int j = 0; j < 4; ++j) {
             *reinterpret_cast<u32x2*>(P + (4 * pc + j) * kWideRowB + 8 * g) = pack4(av[0][j], av[1][j], av[2][j], av[3][j]);
 #pragma unroll
-            for (int e = 0; e < 3; ++e)
-                *reinterpret_cast<u32x2*>(Q + (4 * (pc + 32 * e) + j) * kWideRowB + 8 * g) = pack4(bv[e][0][j], bv[e][1][j], bv[e][2][j], bv[e][3][j]);
+            for (int e = 0; e < 3; ++e) {
+                u32x2 q4;
+                if (XBF) {   // column j of the four token rows: halves j & 1 of words j >> 1, gathered with two byte permutes
+                    const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
+                    q4 = u32x2{__builtin_amdgcn_perm(bh[e][1][j >> 1], bh[e][0][j >> 1], sel),
+                               __builtin_amdgcn_perm(bh[e][3][j >> 1], bh[e][2][j >> 1], sel)};
+                } else {
+                    q4 = pack4(bv[e][0][j], bv[e][1][j], bv[e][2][j], bv[e][3][j]);
+                }
+                *reinterpret_cast<u32x2*>(Q + (4 * (pc + 32 * e) + j) * kWideRowB + 8 * g) = q4;
+            }
         }
     };
     if (nlo < nhi) {
@@ -423,15 +463,18 @@ __global__ __launch_bounds__(512) void k16_dw_wide(const float* __restrict__ dy,
 
 bool launch16_linear_wide(const LinearParams& p, hipStream_t s) {
     const auto al = [](const void* q) { return ((unsigned long long)q & 15) == 0; };
-    bool ok = !p.wtrans && p.k % 64 == 0 && (p.lda & 3) == 0 && (p.ldw & 3) == 0 && al(p.a) && p.m > 128 && p.n >= 1024;
+    bool ok = !p.wtrans && p.k % 64 == 0 && (p.lda & (p.a_bf16 ? 7 : 3)) == 0 && (p.ldw & 3) == 0 && al(p.a) && p.m > 128 && p.n >= 1024;
     if (p.seg_cols) ok = ok && p.seg_cols % kWideCols == 0 && al(p.w_seg[0]) && al(p.w_seg[1]) && al(p.w_seg[2]);
     else ok = ok && al(p.w);
     if (!ok) return false;
     const int nrt = (int)((p.n + kWideRows - 1) / kWideRows), ncg = (p.m + kWideCols - 1) / kWideCols;
     if (p.wpack && p.m % kWideCols == 0) {
-        hipLaunchKernelGGL(k16_linear_wdma, dim3((unsigned)(8 * ((nrt + 7) / 8) * ncg)), dim3(512), 0, s, p, nrt, ncg);
+        const dim3 grid((unsigned)(8 * ((nrt + 7) / 8) * ncg));
+        if (p.a_bf16) hipLaunchKernelGGL(k16_linear_wdma<true>, grid, dim3(512), 0, s, p, nrt, ncg);
+        else hipLaunchKernelGGL(k16_linear_wdma<false>, grid, dim3(512), 0, s, p, nrt, ncg);
         return true;
     }
+    if (p.a_bf16) return false;   // only the streamed kernel reads bf16 rows (the caller checks eligibility first)
     hipLaunchKernelGGL(k16_linear_wide, dim3((unsigned)(8 * ((nrt + 7) / 8) * ncg)), dim3(512), 0, s, p, nrt, ncg);
     return true;
 }
@@ -439,7 +482,7 @@ bool launch16_linear_wide(const LinearParams& p, hipStream_t s) {
 // Same contract as the k16_dw launch inside launch32_dw_seg (k_fp32_bwd.hip): fills part[nsplit][m][k] (and bpart[nsplit][m]).
 // Returns the number of slices used, 0 if the shape is not eligible (nothing launched).
 int launch16_dw_wide(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* part, size_t part_floats,
-                     bool want_db, float** bpart_out, hipStream_t s) {
+                     bool want_db, float** bpart_out, hipStream_t s, bool x_bf16) {
     const bool fast = ((ldy | m | ldx | k) & 7) == 0 && (((unsigned long long)dy | (unsigned long long)x) & 15) == 0;
     if (!fast || n < 4096) return 0;
     const int mt = (m + kWideRows - 1) / kWideRows, kg = (k + kWideCols - 1) / kWideCols, nt = mt * kg;
@@ -452,8 +495,9 @@ int launch16_dw_wide(const float* dy, int ldy, const float* x, int ldx, long n, 
     while (nsplit > 1 && (size_t)nsplit * m * (k + 1) > part_floats) --nsplit;
     if ((size_t)nsplit * m * (k + 1) > part_floats) return 0;
     float* bpart = want_db ? part + (size_t)nsplit * m * k : nullptr;
-    hipLaunchKernelGGL(k16_dw_wide, dim3((unsigned)(8 * ((nsplit + 7) / 8) * nt)), dim3(512), 0, s, dy, ldy, x, ldx, n,
-                       m, k, nsplit, part, bpart);
+    const dim3 grid((unsigned)(8 * ((nsplit + 7) / 8) * nt));
+    if (x_bf16) hipLaunchKernelGGL(k16_dw_wide<true>, grid, dim3(512), 0, s, dy, ldy, x, ldx, n, m, k, nsplit, part, bpart);
+    else hipLaunchKernelGGL(k16_dw_wide<false>, grid, dim3(512), 0, s, dy, ldy, x, ldx, n, m, k, nsplit, part, bpart);
     *bpart_out = bpart;
     return nsplit;
 }

@@ -175,14 +175,16 @@ void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chu
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
                      int wtrans = 0, float* c2 = nullptr,
-                     const void* wpack = nullptr);   // wpack: launch16_pack_wstream's bf16 fragment stream of w (k_wide16.hip)
+                     const void* wpack = nullptr,    // launch16_pack_wstream's bf16 fragment stream of w (k_wide16.hip)
+                     int flags = 0);                 // 1: a is bf16 rows (needs wpack), 2: c2 (mode 6) is written as bf16
 // backward kernels of the training step (k_fp32_bwd.hip)
 // db != nullptr: the bias gradient db[m] += column sums of dY may be computed by the same pass (returns true if it was;
 // otherwise the caller runs launch32_colsum)
 bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, int mseg, int nseg, int k, float* const* dw,
-                     float* const* db, float* part, size_t part_floats, hipStream_t s);   // nseg layers sharing x, dY side by side
+                     float* const* db, float* part, size_t part_floats, hipStream_t s,
+                     bool x_bf16 = false);   // nseg layers sharing x, dY side by side
 bool launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,
-                 size_t part_floats, hipStream_t s, float* db = nullptr);
+                 size_t part_floats, hipStream_t s, float* db = nullptr, bool x_bf16 = false);   // x_bf16: x is bf16 rows (wide kernel only)
 void launch32_colsum(const float* a, int lda, const float* b, int ldb, const float* roww, int mode, long nrows, int ncols,
                      long tokens_per_group, float eps, float* out, long ldo, float* part, size_t part_floats, hipStream_t s);
 void launch32_ln_bwd(const float* x, const float* dy, long nrows, const ModMap& mm, int scale_chunk, int affine, float eps,

@@ -33,6 +33,9 @@ struct LinearParams {
     // common.h gelu_erf (abs. error 5e-6, 1/400 of the bf16 rounding their results get as GEMM operands) instead of erff / expf:
     // the exact forms cost ~100 us (mode 6) / ~170 us (mode 7) of VALU time per 64 000 x 1536 launch
     int fast_gelu;
+    // storage of two GEMM-only tensors in the bf16-operand mode: a_bf16: the token operand is bf16 rows (k16_linear_wdma<true>
+    // only); c2_bf16: the GELU output of mode 6 is written as bf16 (same element indexing as c)
+    int a_bf16, c2_bf16;
 };
 
 // Phi(x) and x of gelu_erf's fit (see common.h): Phi = 1 / (1 + exp2(x P(x^2)))
@@ -105,7 +108,9 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
                     *dst = v * phi_cdf_fast(v);
                 } else if (MODE == 16) {
                     *dst = v;
-                    p.c2[row * p.ldc + p.col0 + col] = v * phi_cdf_fast(v);
+                    const float gl = v * phi_cdf_fast(v);
+                    if (p.c2_bf16) reinterpret_cast<uint16_t*>(p.c2)[row * p.ldc + p.col0 + col] = (uint16_t)pack_bf16(gl, 0.f);
+                    else p.c2[row * p.ldc + p.col0 + col] = gl;
                 } else if (MODE == 17) {
                     const float x = old[r];
                     const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
