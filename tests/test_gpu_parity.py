@@ -1582,22 +1582,24 @@ def test_training_gradients_bf16_operands_vs_reference_fixture():
     tm.model.set_option("train_precision", 32)
 
 
-def test_training_bf16_operand_kernels_vs_exact_mode_at_tile_sizes():
+@pytest.mark.parametrize("shape", [(1, 24, 203, 37), (1, 300, 5, 1)], ids=["T24_L203", "T300_L5"])
+def test_training_bf16_operand_kernels_vs_exact_mode_at_tile_sizes(shape):
     """The golden-fixture gradient tests above run shapes of a few dozen tokens, which the launchers route to the general
     kernels.  This one is sized for the kernels the real workload runs -- the 128 x 384-tile linear layer and weight gradient
     (k_wide16.hip: >= 1024 / 4096 token rows, with row tails), the one-pass q|k|v forms, the MFMA attention forward and its
     two backward passes (k_attn16.hip) on both axes with ragged tiles (24 frames, 203 residues: partial 32-row tiles, the bias
-    key inside a tile) and key padding -- and compares train_precision 16 against the exact fp32 mode (itself gated against
+    key inside a tile; 300 frames: three 128-query blocks, five 64-key chunks; 5 residues: one partial tile) and key padding,
+    the bf16-stored GELU output (>= 4096 rows) -- and compares train_precision 16 against the exact fp32 mode (itself gated against
     the reference's autograd above) on identical inputs: loss to 1e-2 relative, every parameter's gradient to rel-L2 5e-2 and
     cosine 0.999 (gradients at the noise floor excepted)."""
     from mdgen_amd.config import ModelConfig
     from mdgen_amd.synthetic import synth_state_dict, synth_forward_inputs
     from mdgen_amd.train import TrainableModel
     dev = _cuda()
-    B, T, L = 1, 24, 203
+    B, T, L, npad = shape
     cfg = ModelConfig.atlas(num_frames=T, crop=L)
     sd = synth_state_dict(cfg, 11)
-    inp = synth_forward_inputs(cfg, B, T, L, 37, 5)          # 37 padded residues
+    inp = synth_forward_inputs(cfg, B, T, L, npad, 5)        # the last `npad` residues are padding
     gen = torch.Generator().manual_seed(9)
     ut = torch.randn(B, T, L, cfg.latent_dim, generator=gen)
     lm = (torch.rand(B, T, L, cfg.latent_dim, generator=gen) > 0.1).float() * inp["mask"][..., None]
