@@ -116,9 +116,10 @@ __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *rei
 // up to two source matrices; threads 192..255 carry one per-row scalar (or two) each.
 struct Item {
     int pair, quad;
-    bool on;
+    bool on;      // threads 0 .. 191: a (row pair, feature quad) of the chunk
+    bool scalar;  // threads 192 .. 255: one per-row scalar (or two); threads past 255 (eight-wave workgroups) stage nothing
 };
-__device__ __forceinline__ Item item_of(int tid) { return Item{tid / 6, tid % 6, tid < 192}; }
+__device__ __forceinline__ Item item_of(int tid) { return Item{tid / 6, tid % 6, tid < 192, tid >= 192 && tid < 256}; }
 
 __device__ __forceinline__ void put_rowmajor(unsigned char* tile, const Item& it, const f32x4 (&v)[2]) {
 #pragma unroll
@@ -135,10 +136,10 @@ __device__ __forceinline__ void put_transposed(unsigned char* tile, const Item& 
 }
 // zero what the fills never write: features 24..31 of the row-major tiles, feature rows 24..31 of the transposed ones
 __device__ __forceinline__ void clear_rowmajor(unsigned char* tile) {
-    for (int e = threadIdx.x; e < kChunk; e += 256) *reinterpret_cast<u32x4*>(tile + e * kRowB + 48) = u32x4{0, 0, 0, 0};
+    for (int e = threadIdx.x; e < kChunk; e += blockDim.x) *reinterpret_cast<u32x4*>(tile + e * kRowB + 48) = u32x4{0, 0, 0, 0};
 }
 __device__ __forceinline__ void clear_transposed(unsigned char* tile) {
-    for (int e = threadIdx.x; e < 8 * (kTrB / 16); e += 256) *reinterpret_cast<u32x4*>(tile + 24 * kTrB + e * 16) = u32x4{0, 0, 0, 0};
+    for (int e = threadIdx.x; e < 8 * (kTrB / 16); e += blockDim.x) *reinterpret_cast<u32x4*>(tile + 24 * kTrB + e * 16) = u32x4{0, 0, 0, 0};
 }
 
 struct Wg {   // which rows this workgroup / wave owns
@@ -151,7 +152,8 @@ __device__ __forceinline__ Wg wg_of(int nblk) {
 }  // namespace
 
 // ---- forward -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k16_attn(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
                                                    const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                    const float* __restrict__ inv_freq, float* __restrict__ out,
                                                    float* __restrict__ lse_out) {
@@ -160,11 +162,11 @@ __global__ __launch_bounds__(256, 2) void k16_attn(const float* __restrict__ qkv
     __shared__ __attribute__((aligned(16))) float sM[kChunk];
     __shared__ __attribute__((aligned(16))) float sB[2 * kDH];
     const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5;
-    const Wg g = wg_of((len + 127) / 128);
+    const Wg g = wg_of((len + NW * 32 - 1) / (NW * 32));
     fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
     clear_rowmajor(sK);
     clear_transposed(sVt);
-    const int qi = g.blk * 128 + wave_id() * 32 + l31;
+    const int qi = g.blk * NW * 32 + wave_id() * 32 + l31;
     const long qtok = ax.token(g.seq, qi < len ? qi : len - 1);
     const Own q = own_row(qkv + qtok * ld + g.hd * kDH, hh);
     const Item it = item_of(tid);
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void k16_attn(const float* __restrict__ qkv
                     vf[e] = *reinterpret_cast<const f32x4*>(row + 2 * kC);
                 }
             }
-        } else {
+        } else if (it.scalar) {
             const int j = c0 + tid - 192;
             mval = j < len ? (mk.at(ax.token(g.seq, j)) != 0.f ? 0.f : kMasked) : (j == len ? 0.f : kMasked);
         }
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void k16_attn(const float* __restrict__ qkv
                 }
             put_rowmajor(sK, it, kf);
             put_transposed(sVt, it, vf);
-        } else {
+        } else if (it.scalar) {
             sM[tid - 192] = mval;
         }
         __syncthreads();
@@ -248,7 +250,8 @@ __global__ __launch_bounds__(256, 2) void k16_attn(const float* __restrict__ qkv
 
 // ---- backward, query pass ------------------------------------------------------------------------------------------
 // dq into dqkv[:, 0:384]; (lse, delta) into stats[token][head][2] for the key pass.
-__global__ __launch_bounds__(256, 2) void k16_attn_bwd_q(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_q(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
                                                          const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                          const float* __restrict__ inv_freq, const float* __restrict__ o,
                                                          const float* __restrict__ dout, float* __restrict__ dqkv,
@@ -259,12 +262,12 @@ __global__ __launch_bounds__(256, 2) void k16_attn_bwd_q(const float* __restrict
     __shared__ __attribute__((aligned(16))) float sM[kChunk];
     __shared__ __attribute__((aligned(16))) float sB[2 * kDH];
     const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5;
-    const Wg g = wg_of((len + 127) / 128);
+    const Wg g = wg_of((len + NW * 32 - 1) / (NW * 32));
     fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
     clear_rowmajor(sK);
     clear_rowmajor(sV);
     clear_transposed(sKt);
-    const int qi = g.blk * 128 + wave_id() * 32 + l31;
+    const int qi = g.blk * NW * 32 + wave_id() * 32 + l31;
     const long qtok = ax.token(g.seq, qi < len ? qi : len - 1);
     const Own q = own_row(qkv + qtok * ld + g.hd * kDH, hh);
     float delta;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void k16_attn_bwd_q(const float* __restrict
                     vf[e] = *reinterpret_cast<const f32x4*>(row + 2 * kC);
                 }
             }
-        } else {
+        } else if (it.scalar) {
             const int j = c0 + tid - 192;
             mval = j < len ? (mk.at(ax.token(g.seq, j)) != 0.f ? 0.f : kMasked) : (j == len ? 0.f : kMasked);
         }
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void k16_attn_bwd_q(const float* __restrict
             put_rowmajor(sK, it, kf);
             put_rowmajor(sV, it, vf);
             put_transposed(sKt, it, kf);
-        } else {
+        } else if (it.scalar) {
             sM[tid - 192] = mval;
         }
         __syncthreads();
@@ -347,7 +350,8 @@ __global__ __launch_bounds__(256, 2) void k16_attn_bwd_q(const float* __restrict
 
 // ---- backward, key pass --------------------------------------------------------------------------------------------
 // Real keys write dqkv[:, 384:1152]; the bias key writes dbias[seq][dk rotated back: head x 24 | dv: head x 24].
-__global__ __launch_bounds__(256, 2) void k16_attn_bwd_kv(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_kv(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
                                                           const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                           const float* __restrict__ inv_freq, const float* __restrict__ dout,
                                                           const float* __restrict__ stats, float* __restrict__ dqkv,
@@ -360,16 +364,16 @@ __global__ __launch_bounds__(256, 2) void k16_attn_bwd_kv(const float* __restric
     __shared__ __attribute__((aligned(16))) float sDel[kChunk];
     __shared__ __attribute__((aligned(16))) float sB[2 * kDH];
     const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5;
-    const Wg g = wg_of((len + 1 + 127) / 128);
+    const Wg g = wg_of((len + NW * 32) / (NW * 32));
     fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
     clear_rowmajor(sQ);
     clear_rowmajor(sdO);
     clear_transposed(sQt);
     clear_transposed(sdOt);
-    const int j = g.blk * 128 + wave_id() * 32 + l31;
+    const int j = g.blk * NW * 32 + wave_id() * 32 + l31;
     const long ktok = ax.token(g.seq, j < len ? j : len - 1);
     const bool valid = j < len ? mk.at(ktok) != 0.f : j == len;
-    const bool has_bias = g.blk * 128 <= len && len < g.blk * 128 + 128;   // workgroup-uniform
+    const bool has_bias = g.blk * NW * 32 <= len && len < (g.blk + 1) * NW * 32;   // workgroup-uniform
     const Item it = item_of(tid);
     f32x4 qf[2], df[2];
     float lval = 0.f, dval = 0.f;
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void k16_attn_bwd_kv(const float* __restric
                     df[e] = *reinterpret_cast<const f32x4*>(dout + t * kC + g.hd * kDH + 4 * it.quad);
                 }
             }
-        } else {
+        } else if (it.scalar) {
             const int i = c0 + tid - 192;
             const long t = ax.token(g.seq, i < len ? i : len - 1);
             lval = i < len ? stats[(t * kH + g.hd) * 2] : 3.0e38f;     // beyond len: p = exp(-inf) = 0
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void k16_attn_bwd_kv(const float* __restric
             put_rowmajor(sdO, it, df);
             put_transposed(sQt, it, qf);
             put_transposed(sdOt, it, df);
-        } else {
+        } else if (it.scalar) {
             sLse[tid - 192] = lval;
             sDel[tid - 192] = dval;
         }
@@ -481,19 +485,28 @@ __global__ __launch_bounds__(256, 2) void k16_attn_bwd_kv(const float* __restric
     }
 }
 
+// Forward: 256 queries per workgroup (eight waves) once an axis is longer than 128 -- K / V are then staged once per
+// (sequence, head) at the ATLAS lengths instead of once per 128-query block (124 -> 104 us); four waves below that.
 void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
                    const float* inv_freq, float* out, hipStream_t s, float* lse_out) {
-    const int nqb = (ax.len + 127) / 128;
-    hipLaunchKernelGGL(k16_attn, dim3((unsigned)((long)ax.nseq * kH * nqb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
-                       inv_freq, out, lse_out);
+    if (ax.len > 128) {
+        const int nqb = (ax.len + 255) / 256;
+        hipLaunchKernelGGL(k16_attn<8>, dim3((unsigned)((long)ax.nseq * kH * nqb)), dim3(512), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
+                           inv_freq, out, lse_out);
+    } else {
+        hipLaunchKernelGGL(k16_attn<4>, dim3((unsigned)((long)ax.nseq * kH)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k, bias_v, inv_freq,
+                           out, lse_out);
+    }
 }
+// (the backward passes stay at four waves: with eight -- 148 registers, one workgroup per CU, staging done by 192 of 512
+// threads -- the query pass went 168 -> 186 us and the key pass 172 -> 221 us at the ATLAS lengths)
 void launch16_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
                        const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
                        float* stats, float* dbias, hipStream_t s, const float* lse_in) {
-    const int nqb = (ax.len + 127) / 128, nkb = (ax.len + 1 + 127) / 128;
-    hipLaunchKernelGGL(k16_attn_bwd_q, dim3((unsigned)((long)ax.nseq * kH * nqb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k,
-                       bias_v, inv_freq, o, dout, dqkv, stats, lse_in);
-    hipLaunchKernelGGL(k16_attn_bwd_kv, dim3((unsigned)((long)ax.nseq * kH * nkb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k,
+    const int nqb = (ax.len + 127) / 128, nkb = (ax.len + 128) / 128;
+    hipLaunchKernelGGL(k16_attn_bwd_q<4>, dim3((unsigned)((long)ax.nseq * kH * nqb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
+                       inv_freq, o, dout, dqkv, stats, lse_in);
+    hipLaunchKernelGGL(k16_attn_bwd_kv<4>, dim3((unsigned)((long)ax.nseq * kH * nkb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k,
                        bias_v, inv_freq, dout, stats, dqkv, dbias);
 }
 
