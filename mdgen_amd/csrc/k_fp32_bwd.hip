@@ -1171,7 +1171,13 @@ struct IpaBwdParams {
     float* dproj;             // [M][672]
     float* dhw;               // [M][4]
     float* qrec;              // [M][4][49]
+    // nsplit > 1: the key loop of the query pass / the query loop of the key pass is cut into nsplit slices (blockIdx.y) whose
+    // partial sums land in part[slice][M][672 + 4] (dproj row | dhw) and are added in slice order by k32_ipa_bwd_reduce: with
+    // one thread per query / key and B * 4 heads that is 4 workgroups at B = 1 -- 303 us of one wave per SIMD
+    int nsplit;
+    float* part;
 };
+constexpr int kIpaPartRow = kIpaProj + 4;
 
 __global__ __launch_bounds__(256) void k32_ipa_bwd_q(const IpaBwdParams bp) {
     const IpaAttnParams& p = bp.f;
@@ -1236,7 +1242,10 @@ __global__ __launch_bounds__(256) void k32_ipa_bwd_q(const IpaBwdParams bp) {
     }
     float dhw = 0.f;
     const int skey = tid >> 3, ssub = tid & 7;
-    for (int j0 = 0; j0 < p.L; j0 += kIpaKT) {
+    const int sl = blockIdx.y;
+    const int per = ((p.L + kIpaKT - 1) / kIpaKT + bp.nsplit - 1) / bp.nsplit * kIpaKT;    // whole tiles per slice
+    const int jlo = sl * per, jhi = jlo + per < p.L ? jlo + per : p.L;
+    for (int j0 = jlo; j0 < jhi; j0 += kIpaKT) {
         __syncthreads();
         stage_ipa_keys(p, g, b, hd, j0, skey, ssub, sk, sv, skp, svp, sm);
         __syncthreads();
@@ -1273,10 +1282,11 @@ __global__ __launch_bounds__(256) void k32_ipa_bwd_q(const IpaBwdParams bp) {
         }
     }
     if (!qok) return;
-    float* dp = bp.dproj + gi * kIpaProj;
+    const long mtot = (long)p.ngroups * p.L;
+    float* dp = bp.nsplit > 1 ? bp.part + ((long)sl * mtot + gi) * kIpaPartRow : bp.dproj + gi * kIpaProj;
 #pragma unroll
     for (int c = 0; c < 32; ++c) dp[hd * 32 + c] = dq[c] * qk_scale;
-    float* rec = bp.qrec + (gi * 4 + hd) * kIpaRec;
+    float* rec = bp.qrec + (gi * 4 + hd) * kIpaRec;    // the same values from every slice
 #pragma unroll
     for (int pt = 0; pt < 8; ++pt) {
         // local q-point gradient: R^T d Qp
@@ -1290,7 +1300,8 @@ __global__ __launch_bounds__(256) void k32_ipa_bwd_q(const IpaBwdParams bp) {
         }
     }
     rec[48] = delta;
-    bp.dhw[gi * 4 + hd] = dhw;
+    if (bp.nsplit > 1) dp[kIpaProj + hd] = dhw;
+    else bp.dhw[gi * 4 + hd] = dhw;
 }
 
 // Key pass (thread = key j): over query tiles  dk_j += c_qk dl_ij q_i;  dv_j += a_ij do_i;  dVp_j += a_ij dOp_i;
@@ -1346,7 +1357,10 @@ __global__ __launch_bounds__(256) void k32_ipa_bwd_kv(const IpaBwdParams bp) {
 #pragma unroll
         for (int x = 0; x < 3; ++x) dkp[pt][x] = dvp[pt][x] = 0.f;
     }
-    for (int i0 = 0; i0 < p.L; i0 += QT) {
+    const int sl = blockIdx.y;
+    const int per = ((p.L + QT - 1) / QT + bp.nsplit - 1) / bp.nsplit * QT;
+    const int ilo = sl * per, ihi = ilo + per < p.L ? ilo + per : p.L;
+    for (int i0 = ilo; i0 < ihi; i0 += QT) {
         __syncthreads();
         for (int e = tid; e < QT * 32; e += 256) {
             const int ii = e >> 5, c = e & 31;
@@ -1405,7 +1419,7 @@ __global__ __launch_bounds__(256) void k32_ipa_bwd_kv(const IpaBwdParams bp) {
         }
     }
     if (!kok) return;
-    float* dp = bp.dproj + gj * kIpaProj;
+    float* dp = bp.nsplit > 1 ? bp.part + ((long)sl * p.ngroups * p.L + gj) * kIpaPartRow : bp.dproj + gj * kIpaProj;
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
         dp[128 + hd * 64 + c] = dk[c];          // sq already carries c_qk
@@ -1434,13 +1448,36 @@ __global__ void k32_ipa_headw_bwd(const float* __restrict__ dhw, long ntok, cons
     g[hd] += s * (-0.5f * 0.09622504486493763f) * sig;
 }
 
+// dproj[row][0:672], dhw[row][0:4] = sum over slices (fixed order) of part[slice][row][676]
+__global__ void k32_ipa_bwd_reduce(const float* __restrict__ part, int nsplit, long mtot, float* __restrict__ dproj,
+                                   float* __restrict__ dhw) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mtot * kIpaPartRow) return;
+    const long row = i / kIpaPartRow;
+    const int c = (int)(i % kIpaPartRow);
+    float v = 0.f;
+    for (int z = 0; z < nsplit; ++z) v += part[(long)z * mtot * kIpaPartRow + i];
+    if (c < kIpaProj) dproj[row * kIpaProj + c] = v;
+    else dhw[row * 4 + c - kIpaProj] = v;
+}
 void launch32_ipa_bwd(const IpaAttnParams& f, const float* dfeat, float* dproj, float* dhw, float* qrec, float* dheadw,
-                      hipStream_t s) {
-    IpaBwdParams bp{f, dfeat, dproj, dhw, qrec};
+                      hipStream_t s, float* part, size_t part_floats) {
     const int nqt = (f.L + 255) / 256;
     const long nblk = (long)f.ngroups * 4 * nqt;
-    hipLaunchKernelGGL(k32_ipa_bwd_q, dim3((unsigned)nblk), dim3(256), 0, s, bp);
-    hipLaunchKernelGGL(k32_ipa_bwd_kv, dim3((unsigned)nblk), dim3(256), 0, s, bp);
+    const long mtot = (long)f.ngroups * f.L;
+    // enough slices for ~64 workgroups, at most one 32-row tile per slice, within the partial buffer
+    int nsplit = (int)((64 + nblk - 1) / nblk);
+    const int ntile = (f.L + 31) / 32;
+    if (nsplit > ntile) nsplit = ntile;
+    if (nsplit > 16) nsplit = 16;
+    while (nsplit > 1 && (!part || (size_t)nsplit * mtot * kIpaPartRow > part_floats)) --nsplit;
+    IpaBwdParams bp{f, dfeat, dproj, dhw, qrec, nsplit, part};
+    hipLaunchKernelGGL(k32_ipa_bwd_q, dim3((unsigned)nblk, (unsigned)nsplit), dim3(256), 0, s, bp);
+    hipLaunchKernelGGL(k32_ipa_bwd_kv, dim3((unsigned)nblk, (unsigned)nsplit), dim3(256), 0, s, bp);
+    if (nsplit > 1) {
+        const long n = mtot * kIpaPartRow;
+        hipLaunchKernelGGL(k32_ipa_bwd_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nsplit, mtot, dproj, dhw);
+    }
     if (dheadw) hipLaunchKernelGGL(k32_ipa_headw_bwd, dim3(1), dim3(64), 0, s, dhw, (long)f.ngroups * f.L, f.head_w, dheadw);
 }
 

@@ -201,7 +201,7 @@ void launch32_loss_grad(const float* pred, const float* target, const float* mas
                         float* dpred, hipStream_t s);
 void launch32_sum_frames(const float* a, int B, int T, int L, float* out, hipStream_t s);
 void launch32_ipa_bwd(const IpaAttnParams& f, const float* dfeat, float* dproj, float* dhw, float* qrec, float* dheadw,
-                      hipStream_t s);
+                      hipStream_t s, float* part = nullptr, size_t part_floats = 0);   // part: scratch for the sliced form
 void launch32_gated_add(float* h, const float* u, long nrows, const ModMap& mm, int gate_chunk, int gated, hipStream_t s);
 void launch32_indicator(const int64_t* cm, long n, float* ind0, float* ind1, hipStream_t s);
 void launch32_embed_rows_bwd(const float* dx0, const int64_t* aatype, int ngroups, int B, int L, float* dw, hipStream_t s);
