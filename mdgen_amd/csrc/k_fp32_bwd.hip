@@ -319,12 +319,22 @@ __global__ __launch_bounds__(128) void k32_skinny_wt(const float* __restrict__ x
         for (int b = 0; b < 8; ++b)
             if (b0 + b < nb) part[((long)blockIdx.x * nb + b0 + b) * m + c] = acc[b];
 }
-__global__ void k32_skinny_final(const float* __restrict__ part, int nslice, long count, float* __restrict__ out) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+// 16 outputs per workgroup, 16 threads per output walking the slices z = sl, sl + 16, ..., their sums added in a fixed order
+__global__ __launch_bounds__(256) void k32_skinny_final(const float* __restrict__ part, int nslice, long count, float* __restrict__ out) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + cl;
     float s = 0.f;
-    for (int z = 0; z < nslice; ++z) s += part[(long)z * count + i];
-    out[i] = s;
+    if (i < count)
+        for (int z = sl; z < nslice; z += 16) s += part[(long)z * count + i];
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && i < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        out[i] = t;
+    }
 }
 bool launch32_skinny_wt(const float* x, int ldx, const float* W, int ldw, int nb, int m, long K, float* out, float* part,
                         size_t part_floats, hipStream_t s) {
@@ -333,7 +343,7 @@ bool launch32_skinny_wt(const float* x, int ldx, const float* W, int ldw, int nb
     hipLaunchKernelGGL(k32_skinny_wt, dim3((unsigned)nslice, (unsigned)((m + 127) / 128), (unsigned)((nb + 7) / 8)), dim3(128), 0, s, x,
                        ldx, W, ldw, nb, m, K, part);
     const long count = (long)nb * m;
-    hipLaunchKernelGGL(k32_skinny_final, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part, (int)nslice, count, out);
+    hipLaunchKernelGGL(k32_skinny_final, dim3((unsigned)((count + 15) / 16)), dim3(256), 0, s, part, (int)nslice, count, out);
     return true;
 }
 
@@ -962,6 +972,7 @@ void launch32_ln_bwd(const float* x, const float* dy, long nrows, const ModMap& 
 static bool slice_plan(long nrows, long tokens_per_group, int ncols, size_t part_floats, long* ng, int* rps, int* spg) {
     *ng = (nrows + tokens_per_group - 1) / tokens_per_group;
     *rps = 64;
+    while (*rps > 4 && *ng * ((tokens_per_group + *rps - 1) / *rps) < 256) *rps /= 2;   // a few hundred rows: still fill the chip
     *spg = (int)((tokens_per_group + *rps - 1) / *rps);
     while ((size_t)*ng * *spg * ncols > part_floats && *rps < (1 << 24)) {
         *rps *= 2;
@@ -1016,8 +1027,11 @@ void launch32_rope_bwd(float* buf, long ntok, int ld, long pos_div, int pos_mod,
                        inv_freq, qscale);
 }
 void launch32_loss_grad(const float* pred, const float* target, const float* mask, long per_sample, long B, float* den,
-                        float* dpred, hipStream_t s) {
-    hipLaunchKernelGGL(k32_mask_sum, dim3((unsigned)B), dim3(256), 0, s, mask, per_sample, den);
+                        float* dpred, hipStream_t s, float* scratch, size_t scratch_floats) {
+    if (scratch && (size_t)(2 * B * ((per_sample + 8191) / 8192)) <= scratch_floats && per_sample > 8192)
+        launch_masked_mse(nullptr, nullptr, mask, nullptr, per_sample, B, s, scratch, scratch_floats, den);   // two-stage mask sums
+    else
+        hipLaunchKernelGGL(k32_mask_sum, dim3((unsigned)B), dim3(256), 0, s, mask, per_sample, den);
     const long total = per_sample * B;
     hipLaunchKernelGGL(k32_loss_grad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pred, target, mask, den,
                        per_sample, total, 1.0f / (float)B, dpred);

@@ -605,8 +605,66 @@ void launch_path_plan(const float* t, const float* x0, const float* x1, float* x
     hipLaunchKernelGGL(k_path_plan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t, x0, x1, xt, ut, per_sample,
                        total, gvp);
 }
+// The same sums in two stages for big samples (a training step at B = 1 is ONE sample of 1.3 M elements: one workgroup
+// walking it took 0.4 ms): chunks of 8192 elements -> (num, den) partials, added per sample in a fixed order.
+// pred == nullptr: only den (the mask sum).
+constexpr int kMseChunk = 8192;
+__global__ __launch_bounds__(256) void k_masked_mse_partial(const float* __restrict__ pred, const float* __restrict__ target,
+                                                            const float* __restrict__ mask, long per_sample, int nchunk,
+                                                            float* __restrict__ part) {
+    __shared__ float red[2][4];
+    const long b = blockIdx.y;
+    const long lo = (long)blockIdx.x * kMseChunk, hi = lo + kMseChunk < per_sample ? lo + kMseChunk : per_sample;
+    const long base = b * per_sample;
+    float num = 0.f, den = 0.f;
+#pragma unroll 8
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const float m = mask[base + i];
+        den += m;
+        if (pred) {
+            const float d = pred[base + i] - target[base + i];
+            num += d * d * m;
+        }
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if (lane_id() == 0) {
+        red[0][wave_id()] = num;
+        red[1][wave_id()] = den;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = part + (b * nchunk + blockIdx.x) * 2;
+        o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+__global__ __launch_bounds__(64) void k_masked_mse_final(const float* __restrict__ part, int nchunk, float* __restrict__ loss,
+                                                         float* __restrict__ den_out) {
+    const float* p = part + (long)blockIdx.x * nchunk * 2;
+    float num = 0.f, den = 0.f;
+    for (int i = threadIdx.x; i < nchunk; i += 64) {
+        num += p[2 * i];
+        den += p[2 * i + 1];
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if (threadIdx.x == 0) {
+        if (loss) loss[blockIdx.x] = num / den;
+        if (den_out) den_out[blockIdx.x] = den;
+    }
+}
+// loss[b] = sum((pred - target)^2 mask) / sum(mask) (loss may be null), den_out[b] = sum(mask) (may be null).  scratch: >= 2 * B *
+// ceil(per_sample / 8192) floats enables the two-stage form; without it one workgroup per sample (loss only).
 void launch_masked_mse(const float* pred, const float* target, const float* mask, float* loss, long per_sample, long B,
-                       hipStream_t s) {
+                       hipStream_t s, float* scratch, size_t scratch_floats, float* den_out) {
+    const long nchunk = (per_sample + kMseChunk - 1) / kMseChunk;
+    if (scratch && nchunk > 1 && (size_t)(2 * B * nchunk) <= scratch_floats) {
+        hipLaunchKernelGGL(k_masked_mse_partial, dim3((unsigned)nchunk, (unsigned)B), dim3(256), 0, s, pred, target, mask, per_sample,
+                           (int)nchunk, scratch);
+        hipLaunchKernelGGL(k_masked_mse_final, dim3((unsigned)B), dim3(64), 0, s, scratch, (int)nchunk, loss, den_out);
+        return;
+    }
     hipLaunchKernelGGL(k_masked_mse, dim3((unsigned)B), dim3(256), 0, s, pred, target, mask, loss, per_sample);
 }
 void launch_embed(const EmbedParams& p, hipStream_t s) {

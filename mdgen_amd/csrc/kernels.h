@@ -165,7 +165,7 @@ void launch_embed(const EmbedParams& p, hipStream_t s);
 void launch_path_plan(const float* t, const float* x0, const float* x1, float* xt, float* ut, long per_sample, long B,
                       int gvp, hipStream_t s);
 void launch_masked_mse(const float* pred, const float* target, const float* mask, float* loss, long per_sample, long B,
-                       hipStream_t s);
+                       hipStream_t s, float* scratch = nullptr, size_t scratch_floats = 0, float* den_out = nullptr);
 void launch_ipa_attn(const IpaAttnParams& p, hipStream_t s);
 
 // fp32-operand path (k_fp32.hip)
@@ -198,7 +198,7 @@ void launch32_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMa
 void launch32_rope_bwd(float* buf, long ntok, int ld, long pos_div, int pos_mod, const float* inv_freq, float qscale,
                        hipStream_t s);
 void launch32_loss_grad(const float* pred, const float* target, const float* mask, long per_sample, long B, float* den,
-                        float* dpred, hipStream_t s);
+                        float* dpred, hipStream_t s, float* scratch = nullptr, size_t scratch_floats = 0);
 void launch32_sum_frames(const float* a, int B, int T, int L, float* out, hipStream_t s);
 void launch32_ipa_bwd(const IpaAttnParams& f, const float* dfeat, float* dproj, float* dhw, float* qrec, float* dheadw,
                       hipStream_t s, float* part = nullptr, size_t part_floats = 0);   // part: scratch for the sliced form
