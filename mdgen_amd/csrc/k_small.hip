@@ -436,7 +436,10 @@ __global__ __launch_bounds__(256) void k_ipa_attn_tiled(const IpaAttnParams p) {
     float mrun = -3.0e38f, den = 0.f;
     // staging roles: thread -> (key of the tile, 8-float slice / point index)
     const int skey = tid >> 3, ssub = tid & 7;
-    for (int j0 = 0; j0 < p.L; j0 += kIpaKT) {
+    const int nsl = p.nsplit > 1 ? p.nsplit : 1, sl = blockIdx.y;
+    const int per = ((p.L + kIpaKT - 1) / kIpaKT + nsl - 1) / nsl * kIpaKT;      // whole tiles per slice
+    const int jlo = sl * per, jhi = jlo + per < p.L ? jlo + per : p.L;
+    for (int j0 = jlo; j0 < jhi; j0 += kIpaKT) {
         __syncthreads();   // the previous tile has been consumed
         {
             const int j = j0 + skey;
@@ -511,8 +514,58 @@ __global__ __launch_bounds__(256) void k_ipa_attn_tiled(const IpaAttnParams p) {
         }
     }
     if (!qok) return;
+    if (nsl > 1) {   // this slice's softmax state; k_ipa_attn_merge finishes the row
+        float* rec = p.part + (((long)sl * p.ngroups * p.L + gi) * 4 + hd) * kIpaFwdRec;
+        rec[0] = mrun;
+        rec[1] = den;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) rec[2 + c] = o[c];
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) rec[34 + 3 * pt + x] = op[pt][x];
+        return;
+    }
     const float inv = 1.0f / den;
     if (p.stats) p.stats[gi * 4 + hd] = mrun + logf(den);
+    ipa_store_features(p, gi, hd, o, op, inv, Ri, ti);
+}
+
+// One thread per (token, head): the slices' states merged in slice order (m = max m_z; everything scaled by exp(m_z - m)),
+// then exactly the epilogue of the one-slice kernel.
+__global__ __launch_bounds__(256) void k_ipa_attn_merge(const IpaAttnParams p) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long mtot = (long)p.ngroups * p.L;
+    if (idx >= mtot * 4) return;
+    const int hd = (int)(idx & 3);
+    const long gi = idx >> 2;
+    const int i = (int)(gi % p.L);
+    const int b = (int)((gi / p.L) % p.B);
+    float Ri[9], ti[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ri[k] = p.rot[((long)b * p.L + i) * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ti[k] = p.trans[((long)b * p.L + i) * 3 + k];
+    float m = -3.0e38f;
+    for (int z = 0; z < p.nsplit; ++z) m = fmaxf(m, p.part[(((long)z * mtot + gi) * 4 + hd) * kIpaFwdRec]);
+    float o[32], op[8][3], den = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int pt = 0; pt < 8; ++pt) op[pt][0] = op[pt][1] = op[pt][2] = 0.f;
+    for (int z = 0; z < p.nsplit; ++z) {
+        const float* rec = p.part + (((long)z * mtot + gi) * 4 + hd) * kIpaFwdRec;
+        const float a = expf(rec[0] - m);     // an empty slice has m_z = -3e38 and den = o = 0
+        den += a * rec[1];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) o[c] += a * rec[2 + c];
+#pragma unroll
+        for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) op[pt][x] += a * rec[34 + 3 * pt + x];
+    }
+    const float inv = 1.0f / den;
+    if (p.stats) p.stats[gi * 4 + hd] = m + logf(den);
     ipa_store_features(p, gi, hd, o, op, inv, Ri, ti);
 }
 
@@ -693,7 +746,16 @@ void launch_add_inplace(float* dst, const float* src, long n, hipStream_t s) {
 void launch_ipa_attn(const IpaAttnParams& p, hipStream_t s) {
     if (p.L >= 24) {   // long sequences: keys staged through LDS, one thread per query
         const int nqt = (p.L + 255) / 256;
-        hipLaunchKernelGGL(k_ipa_attn_tiled, dim3((unsigned)((long)p.ngroups * 4 * nqt)), dim3(256), 0, s, p);
+        const long nblk = (long)p.ngroups * 4 * nqt, mtot = (long)p.ngroups * p.L;
+        IpaAttnParams q = p;
+        int nsplit = p.part ? (int)((64 + nblk - 1) / nblk) : 1;     // ~64 workgroups, whole 32-key tiles per slice
+        const int ntile = (p.L + kIpaKT - 1) / kIpaKT;
+        if (nsplit > ntile) nsplit = ntile;
+        if (nsplit > 16) nsplit = 16;
+        while (nsplit > 1 && (size_t)nsplit * mtot * 4 * kIpaFwdRec > p.part_floats) --nsplit;
+        q.nsplit = nsplit;
+        hipLaunchKernelGGL(k_ipa_attn_tiled, dim3((unsigned)nblk, (unsigned)nsplit), dim3(256), 0, s, q);
+        if (nsplit > 1) hipLaunchKernelGGL(k_ipa_attn_merge, dim3((unsigned)((mtot * 4 + 255) / 256)), dim3(256), 0, s, q);
         return;
     }
     const long total = (long)p.ngroups * p.L * 4;

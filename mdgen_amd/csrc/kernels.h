@@ -144,7 +144,14 @@ struct IpaAttnParams {
     float* feat32;          // fp32 mode: features written here (fp32) instead of `feat`
     float* stats;           // training tape (nullable): [M][4 heads] log-sum-exp of the logits (m + log(sum exp))
     int ngroups, B, L;
+    // k_ipa_attn_tiled with few groups (training at B = 1: four workgroups, one wave per SIMD, 185 us): the key loop cut
+    // into `nsplit` slices (blockIdx.y) that leave (running max, denominator, o, o_pt) per (slice, token, head) in `part`
+    // ([nsplit][M][4][58] floats) for k_ipa_attn_merge.  Set by launch_ipa_attn when `part` is given; 0 / null: one slice.
+    int nsplit;
+    float* part;
+    size_t part_floats;
 };
+constexpr int kIpaFwdRec = 58;   // m | den | o(32) | o_pt(24)
 
 struct FloatChunk {
     float v[128];

@@ -1409,7 +1409,11 @@ def test_training_step_cfg5_size():
     out = tm.model.forward(x=args[0], t=args[1], mask=args[4], start_frames=args[5], x_cond=args[6], x_cond_mask=args[7],
                            aatype=args[8])
     tm.model.set_precision("bf16")
-    assert rel_l2(out.cpu(), pred.cpu()) < 1e-6
+    e_fwd = rel_l2(out.cpu(), pred.cpu())
+    print(f"training forward vs the fp32 sampler forward: rel-L2 {e_fwd:.2e}")
+    # same fp32 kernels, except that the training step slices the IPA attention's key loop over workgroups (B = 1: four
+    # workgroups otherwise) and merges the slices' softmax states: a different, equally valid summation order
+    assert e_fwd < 5e-6
     nz = [k for k, v in tm.params.state_dict(tm.grads).items() if float(v.abs().max()) == 0.0]
     assert not nz, nz
     before = tm.params.data.clone()
