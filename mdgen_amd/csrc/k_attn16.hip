@@ -142,6 +142,32 @@ __device__ __forceinline__ void clear_transposed(unsigned char* tile) {
     for (int e = threadIdx.x; e < 8 * (kTrB / 16); e += blockDim.x) *reinterpret_cast<u32x4*>(tile + 24 * kTrB + e * 16) = u32x4{0, 0, 0, 0};
 }
 
+// Inverse RoPE (and a scale) of a gradient held as D[feature][own row] -- what k32_rope_bwd does in a pass of its own
+// (mha.py:356-357 backward; the q gradient also takes the q scale).  Lane (row, hh) holds features 8 gq + 4 hh + i in
+// v[4 gq + i] (gq < 3); the rotation pairs feature f < 12 with f + 12, which sits in lane ^ 32: three exchanges of four
+// registers (hh 0 sends group e, hh 1 group (e + 1) % 3), then y1 c + y2 s for the lower member, y2 c - y1 s for the upper.
+// `pos` = the row's position in its sequence (what k32_rope rotates by: the axis index of the token).
+__device__ __forceinline__ void unrope(f32x16& v, int pos, const float* __restrict__ inv_freq, int hh, float scale) {
+    float recv[3][4];
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) recv[e][i] = __shfl_xor(hh ? v[4 * ((e + 1) % 3) + i] : v[4 * e + i], 32, 64);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int base = e == 0 ? 0 : e == 1 ? 8 : 4;           // pair indices base .. base + 3
+        const int grp = hh ? (e + 1) % 3 : e;                   // this lane's register group of the exchange
+        const bool lower = hh ? e == 2 : e < 2;                 // it holds the pair's lower member (feature < 12)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ang = (float)pos * inv_freq[base + i];
+            const float c = cosf(ang), sn = sinf(ang);
+            const float own = v[4 * grp + i], oth = recv[e][i];
+            v[4 * grp + i] = (lower ? own * c + oth * sn : own * c - oth * sn) * scale;
+        }
+    }
+}
+
 struct Wg {   // which rows this workgroup / wave owns
     int seq, hd, blk;
 };
@@ -249,7 +275,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn(const float
 }
 
 // ---- backward, query pass ------------------------------------------------------------------------------------------
-// dq into dqkv[:, 0:384]; (lse, delta) into stats[token][head][2] for the key pass.
+// dq -- already taken back through RoPE and the q scale (no k32_rope_bwd pass after these kernels) -- into dqkv[:, 0:384];
+// (lse, delta) into stats[token][head][2] for the key pass.
 template <int NW>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_q(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
                                                          const float* __restrict__ bias_k, const float* __restrict__ bias_v,
@@ -337,6 +364,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_q(const
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(tr + 32), d1, dq, 0, 0, 0);
         }
     }
+    unrope(dq, qi < len ? qi : len - 1, inv_freq, hh, 0.20412414523193151f);   // back through RoPE and the q scale 24^-1/2
     if (qi >= len) return;
     float* dst = dqkv + qtok * ld + g.hd * kDH + 4 * hh;
 #pragma unroll
@@ -349,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_q(const
 }
 
 // ---- backward, key pass --------------------------------------------------------------------------------------------
-// Real keys write dqkv[:, 384:1152]; the bias key writes dbias[seq][dk rotated back: head x 24 | dv: head x 24].
+// Real keys write dqkv[:, 384:1152] (dk taken back through RoPE); the bias key writes dbias[seq][dk rotated back: head x 24 | dv: head x 24].
 template <int NW>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_kv(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
                                                           const float* __restrict__ bias_k, const float* __restrict__ bias_v,
@@ -452,11 +480,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_kv(cons
             dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(qt + 32), d1, dk, 0, 0, 0);
         }
     }
+    f32x16 dku = dk;    // real keys: back through RoPE at their position (the bias key's own path below keeps dk)
+    unrope(dku, j < len ? j : 0, inv_freq, hh, 1.0f);
     if (j < len) {
         float* dst = dqkv + ktok * ld + kC + g.hd * kDH + 4 * hh;
 #pragma unroll
         for (int gq = 0; gq < 3; ++gq) {
-            *reinterpret_cast<f32x4*>(dst + 8 * gq) = f32x4{dk[4 * gq], dk[4 * gq + 1], dk[4 * gq + 2], dk[4 * gq + 3]};
+            *reinterpret_cast<f32x4*>(dst + 8 * gq) = f32x4{dku[4 * gq], dku[4 * gq + 1], dku[4 * gq + 2], dku[4 * gq + 3]};
             *reinterpret_cast<f32x4*>(dst + kC + 8 * gq) = f32x4{dv[4 * gq], dv[4 * gq + 1], dv[4 * gq + 2], dv[4 * gq + 3]};
         }
     }
