@@ -3,12 +3,15 @@
 // The training step differentiates the fp32 form of the network (k_fp32.hip): every reference op group is one kernel
 // there, so every derivative is one kernel here, and gradients can be checked against the reference's own autograd at
 // fp32 tolerance.  All reductions over tokens are two-stage with fixed slices (bit-reproducible run to run).
-//   k32_dw / k32_reduce_add     dW[m][k] += sum_n dY[n][m] X[n][k]   (v_mfma_f32_32x32x2_f32, split over n)
+//   k32_dw / k32_reduce_add     dW[m][k] += sum_n dY[n][m] X[n][k]   (v_mfma_f32_32x32x2_f32, split over n); k16_dw: bf16 operands
 //   k32_colsum / _final         per-group column sums  sum_t a[t][c] * b[t][c]  (biases, adaLN shift / scale / gate)
-//   k32_ln_bwd                  LayerNorm (+ modulate / affine) backward
-//   k32_gate_mul, k32_gelu_*    gated residual, exact-erf GELU
+//   k32_ln_bwd (_sums)          LayerNorm (+ modulate / affine) backward (with the two adaLN column sums of the same rows)
+//   k32_gate_mul, k32_gate_bwd_sums   gated residual backward (with its adaLN column sum); the GELU derivative is an epilogue
+//                               of the dX product (linear.h mode 7)
 //   k32_attn_bwd_q / _kv        softmax attention backward (query pass: dq; key pass: dk, dv incl. the bias key)
 //   k32_rope_bwd                inverse rotation of dq, dk and the q scale
+//   k32_ipa_bwd_q / _kv         invariant point attention backward (sliced over workgroups when the groups are few)
+//   k32_skinny_wt               [B rows] x [long contraction] product behind the time embedder
 //   k32_loss_grad               d(mean_b masked-MSE_b) / d pred
 //   k32_sum_frames              d ipa_out[b,l] = sum_t dh0[b,t,l]
 #include <cstdio>
@@ -609,22 +612,6 @@ __global__ void k32_gate_mul(const float* __restrict__ a, long nrows, ModMap mm,
     out[i] = a[i] * g;
 }
 
-// exact-erf GELU (layers.py:77-84) from the saved pre-activation, and its derivative Phi(x) + x phi(x)
-__global__ void k32_gelu_from_pre(const float* __restrict__ pre, long n, float* __restrict__ out) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float v = pre[i];
-    out[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-}
-__global__ void k32_gelu_bwd(const float* __restrict__ pre, long n, float* __restrict__ d) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float v = pre[i];
-    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
-    d[i] *= cdf + v * pdf;
-}
-
 // ---- attention backward ------------------------------------------------------------------------------------------------
 // Shared helpers: staging of one (sequence, head) key tile as in k32_attn (bias key at position len, rotated there).
 __device__ __forceinline__ void bias_kv(const float* bias_k, const float* bias_v, const float* inv_freq, int hd, int len, int d,
@@ -1004,12 +991,6 @@ bool launch32_gate_bwd_sums(const float* dh, const float* u, long nrows, const M
 void launch32_gate_mul(const float* a, long nrows, const ModMap& mm, int gate_chunk, int gated, float* out, hipStream_t s) {
     const long n = nrows * kC;
     hipLaunchKernelGGL(k32_gate_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, nrows, mm, gate_chunk, gated, out);
-}
-void launch32_gelu_from_pre(const float* pre, long n, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k32_gelu_from_pre, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, n, out);
-}
-void launch32_gelu_bwd(const float* pre, long n, float* d, hipStream_t s) {
-    hipLaunchKernelGGL(k32_gelu_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, n, d);
 }
 void launch32_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
                        const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,

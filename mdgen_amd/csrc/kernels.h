@@ -197,8 +197,6 @@ void launch32_colsum(const float* a, int lda, const float* b, int ldb, const flo
 void launch32_ln_bwd(const float* x, const float* dy, long nrows, const ModMap& mm, int scale_chunk, int affine, float eps,
                      float* dx, int accumulate, hipStream_t s);
 void launch32_gate_mul(const float* a, long nrows, const ModMap& mm, int gate_chunk, int gated, float* out, hipStream_t s);
-void launch32_gelu_from_pre(const float* pre, long n, float* out, hipStream_t s);
-void launch32_gelu_bwd(const float* pre, long n, float* d, hipStream_t s);
 void launch32_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
                        const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
                        float* stats, float* dbias, hipStream_t s, const float* lse_in = nullptr);
