@@ -13,7 +13,6 @@ struct LinearParams {
     long n; int m, k;
     int mode;             // 0 store, 1 GELU store, 2 gated residual into c, 3 Euler: c += dt * val, 4 store * scale,
                           // 5 accumulate (c += val), 6 store val AND GELU(val) (second copy at c2: training tape),
-                          // 8 gated residual into c (as 2) AND the un-gated val stored at c2 (same row stride as c),
                           // 7 store val * gelu'(c2[..]) (c2 = the taped pre-activation, read only: backward of the GELU)
     int wtrans;           // 1: the weight operand is stored [k][m] (ldw = row stride): y = x W, used for dX = dY W
     float* c; int ldc; int col0;
@@ -69,13 +68,13 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
         for (int t = 0; t < NT; ++t) {
             const long rbase = row0 + wr * 32 * NT + t * 32;
             float old[16], g[16];
-            if (MODE == 2 || MODE == 3 || MODE == 5 || MODE == 7 || MODE == 17 || MODE == 8) {
+            if (MODE == 2 || MODE == 3 || MODE == 5 || MODE == 7 || MODE == 17) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const long row = rbase + mfma_row(r, hh);
                     const long rc = row < p.n ? row : p.n - 1;
                     old[r] = (MODE == 7 || MODE == 17 ? p.c2 : p.c)[rc * p.ldc + p.col0 + col];   // mode 7: the taped pre-activation
-                    g[r] = ((MODE == 2 || MODE == 8) && p.gated) ? p.mm.mod[p.mm.row_off(rc) + p.gate_chunk * kC + col] : 1.0f;
+                    g[r] = (MODE == 2 && p.gated) ? p.mm.mod[p.mm.row_off(rc) + p.gate_chunk * kC + col] : 1.0f;
                 }
             }
 #pragma unroll
@@ -89,9 +88,6 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
                 } else if (MODE == 1) {
                     *dst = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
                 } else if (MODE == 2) {
-                    *dst = old[r] + g[r] * v;
-                } else if (MODE == 8) {   // gated residual with the un-gated value kept (training tape: d gate = sum dh * u)
-                    p.c2[row * p.ldc + p.col0 + col] = v;
                     *dst = old[r] + g[r] * v;
                 } else if (MODE == 3) {
                     *dst = old[r] + p.scalar * v;
@@ -137,7 +133,6 @@ __device__ __forceinline__ void linear_epilogue(const LinearParams& p, const f32
         case 4: linear_epilogue_mode<4, NT, NU>(p, acc, row0, colt, wr, wc); break;
         case 5: linear_epilogue_mode<5, NT, NU>(p, acc, row0, colt, wr, wc); break;
         case 7: linear_epilogue_mode<7, NT, NU>(p, acc, row0, colt, wr, wc); break;
-        case 8: linear_epilogue_mode<8, NT, NU>(p, acc, row0, colt, wr, wc); break;
         default: linear_epilogue_mode<6, NT, NU>(p, acc, row0, colt, wr, wc); break;
     }
 }
