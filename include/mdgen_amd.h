@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 /* Bumped whenever a public struct or signature changes; mdgen_amd/_lib.py refuses a library whose version differs. */
-#define MDGEN_ABI_VERSION 3
+#define MDGEN_ABI_VERSION 4
 
 typedef struct mdgen_ctx mdgen_ctx;
 
@@ -227,6 +227,21 @@ int32_t mdgen_debug_layout_maps(int32_t* map_qk, int32_t* map_vflash, int32_t* m
  * out[f] = mat << 16 | row_tile << 8 | k_step for fragment f (2304 of them); mat 0 = fc1 (layers.py:77-84 `fc1`), 1 = fc2.
  * Returns the number of entries, or a negative status. */
 int32_t mdgen_debug_mlp_stream_table(int32_t* out, int32_t capacity);
+
+/* Test hooks (GPU): the training step's linear layer and weight gradient on raw device buffers, through exactly the
+ * kernel dispatch of mdgen_train_forward_backward -- precision 32: fp32 products (k32_linear / k32_dw); 16: bf16-rounded
+ * operands with fp32 accumulation (128 x 384-tile streamed kernels for >= 1024 / 4096 rows, one-wave tiles for a few
+ * hundred rows, the general kernels otherwise).  All pointers are fp32 device memory.
+ *   linear: c[n][m] (row stride ldc) = a[n][k] (lda) . w[m][k]^T (ldw) + bias[m] (bias may be NULL);
+ *           scratch: >= m * k * 2 bytes (the bf16 weight stream of the streamed kernel), may be NULL (then the weight is
+ *           read as fp32 rows);
+ *   dw:     dw[m][k] += dy[n][m]^T (ldy) . x[n][k] (ldx), db[m] += column sums of dy (db may be NULL);
+ *           part: scratch of part_floats floats for the split partial sums (>= 2 m (k + 1)).
+ * Reference: torch.nn.functional.linear and its autograd (mdgen/model/layers.py Mlp, mha.py projections). */
+int32_t mdgen_debug_train_linear(int32_t precision, const float* a, int32_t lda, const float* w, int32_t ldw, const float* bias,
+                                 int64_t n, int32_t m, int32_t k, float* c, int32_t ldc, void* scratch, void* stream);
+int32_t mdgen_debug_train_dw(int32_t precision, const float* dy, int32_t ldy, const float* x, int32_t ldx, int64_t n, int32_t m,
+                             int32_t k, float* dw, float* db, float* part, int64_t part_floats, void* stream);
 
 /* ---- SE(3) frame algebra, fp32 (mdgen/rigid_utils.py) --------------------------------------
  * n = number of frames; rot: [n][3][3]; trans/pts: [n][3]; quat: [n][4] (w,x,y,z). */

@@ -1686,6 +1686,87 @@ def test_mark_updated_refreshes_every_table_the_training_step_reads():
             ref.model.set_option("train_precision", 32)
 
 
+def _bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("shape", [
+    (64000 // 8 + 37, 384, 384, "streamed 128 x 384 tiles, row tail"),
+    (4100, 1536, 384, "streamed, four column groups"),
+    (5000, 384, 1536, "streamed, 24 k-steps"),
+    (3000, 21, 384, "128 x 128 branch-free kernel (more than 2048 rows, narrow output)"),
+    (300, 672, 384, "one wave per 32 x 32 tile"),
+    (257, 96, 256, "one wave per tile, ragged"),
+    (77, 50, 100, "general kernel (k not a multiple of 64)"),
+], ids=lambda s: f"n{s[0]}_m{s[1]}_k{s[2]}")
+def test_training_linear_kernels_unit(shape):
+    """Every kernel family behind the training step's linear layer (`mdgen_debug_train_linear`: the dispatch of
+    `mdgen_train_forward_backward`), alone, against torch on the same operands: exact mode (fp32 products) to 5e-6 relative,
+    bf16-operand mode against the product of the bf16-ROUNDED operands accumulated in fp64 (the only difference left is the fp32
+    summation order: 1e-5).  Shapes pick each kernel: the streamed 128 x 384-tile kernel with its LDS-DMA weight stream (row
+    tails, one to four column groups, 6 / 24 k-steps), the branch-free 128 x 128 kernel, the one-wave tiles, the general one."""
+    from mdgen_amd import _lib as L
+    dev = _cuda()
+    n, m, k, _ = shape
+    gen = torch.Generator().manual_seed(n + m + k)
+    a = torch.randn(n, k, generator=gen).to(dev)
+    w = (torch.randn(m, k, generator=gen) / k ** 0.5).to(dev)
+    bias = torch.randn(m, generator=gen).to(dev)
+    scratch = torch.empty(m * k, dtype=torch.bfloat16, device=dev)
+    s = L.stream_ptr()
+    for prec in (32, 16):
+        c = torch.full((n, m), float("nan"), device=dev)
+        L.check(L.lib.mdgen_debug_train_linear(prec, L.ptr(a), k, L.ptr(w), k, L.ptr(bias), n, m, k, L.ptr(c), m, L.ptr(scratch), s))
+        torch.cuda.synchronize()
+        if prec == 32:
+            ref = a.double() @ w.double().T + bias.double()
+            tol = 5e-6
+        else:
+            ref = _bf16_round(a).double() @ _bf16_round(w).double().T + bias.double()
+            tol = 1e-5
+        assert torch.isfinite(c).all()
+        e = float((c.double() - ref).norm() / ref.norm())
+        assert e < tol, (shape, prec, e)
+
+
+@pytest.mark.parametrize("shape", [
+    (8000 + 13, 384, 384, "wide tiles, row tail"),
+    (5000, 1152, 384, "wide, nine row tiles (q | k | v)"),
+    (4500, 384, 1536, "wide, four column groups"),
+    (1500, 384, 384, "128 x 128 split kernel"),
+    (257, 96, 256, "small"),
+    (77, 50, 100, "general (unaligned)"),
+], ids=lambda s: f"n{s[0]}_m{s[1]}_k{s[2]}")
+def test_training_weight_gradient_kernels_unit(shape):
+    """The weight / bias gradient kernels (`mdgen_debug_train_dw`) alone: dW += dY^T X, db += colsum(dY), against torch in fp64 on
+    the same (exact mode) or the bf16-rounded (bf16-operand mode; the bias gradient sums the unrounded dY) operands, starting
+    from non-zero accumulators; run twice for bit-reproducibility of the split reduction."""
+    from mdgen_amd import _lib as L
+    dev = _cuda()
+    n, m, k, _ = shape
+    gen = torch.Generator().manual_seed(n * 3 + m + k)
+    dy = torch.randn(n, m, generator=gen).to(dev)
+    x = torch.randn(n, k, generator=gen).to(dev)
+    dw0 = torch.randn(m, k, generator=gen).to(dev)
+    db0 = torch.randn(m, generator=gen).to(dev)
+    part = torch.empty(16 << 20, device=dev)
+    s = L.stream_ptr()
+    for prec in (32, 16):
+        outs = []
+        for _ in range(2):
+            dw, db = dw0.clone(), db0.clone()
+            L.check(L.lib.mdgen_debug_train_dw(prec, L.ptr(dy), m, L.ptr(x), k, n, m, k, L.ptr(dw), L.ptr(db), L.ptr(part), part.numel(), s))
+            torch.cuda.synchronize()
+            outs.append((dw, db))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        dyr, xr = (dy, x) if prec == 32 else (_bf16_round(dy), _bf16_round(x))
+        ref_w = dw0.double() + dyr.double().T @ xr.double()
+        ref_b = db0.double() + dy.double().sum(0)
+        ew = float((outs[0][0].double() - ref_w).norm() / ref_w.norm())
+        eb = float((outs[0][1].double() - ref_b).norm() / ref_b.norm())
+        assert ew < (5e-6 if prec == 32 else 1e-5) and eb < 5e-6, (shape, prec, ew, eb)
+
+
 def test_row_owner_mlp_paths_agree():
     """The MLP block has three forms: the 64-row resident-panel kernel (`mlp_path` 0), the row-owner kernel (`mlp_path` 2:
     activations in registers, LDS-DMA weight stream) and the row-owner kernel with the temporal out-projection fused in front
