@@ -243,6 +243,18 @@ int32_t mdgen_debug_train_linear(int32_t precision, const float* a, int32_t lda,
 int32_t mdgen_debug_train_dw(int32_t precision, const float* dy, int32_t ldy, const float* x, int32_t ldx, int64_t n, int32_t m,
                              int32_t k, float* dw, float* db, float* part, int64_t part_floats, void* stream);
 
+/* Test hook (GPU): the training step's attention of one axis, forward + backward, on raw device buffers (fp32):
+ *   qkv[ntok][1152]: q (already scaled and rotated) | k (rotated) | v of 16 heads x 24 (mha.py:258-268); sequence `s`, position
+ *   `i` is token (s / inner) * outer_stride + (s % inner) * inner_stride + i * pos_stride; mask[ntok]: 0 = padded key;
+ *   bias_k, bias_v[384]: the learned bias key / value (rotated at position len by the kernels); inv_freq[12].
+ * Forward: out[ntok][384], lse[ntok][16].  Backward from dout[ntok][384]: dqkv[ntok][1152] = (d q, d k taken back through RoPE,
+ * d q also through the q scale; d v), dbias[nseq][768] = per-sequence (d bias_k | d bias_v); stats[ntok][16][2] scratch.
+ * precision 32: k32_attn* + k32_rope_bwd; 16: k16_attn* (bf16 operands on the MFMA, inverse RoPE in the store stage). */
+int32_t mdgen_debug_train_attention(int32_t precision, const float* qkv, int64_t ntok, int32_t nseq, int32_t len, int32_t inner,
+                                    int32_t outer_stride, int32_t inner_stride, int32_t pos_stride, const float* mask,
+                                    const float* bias_k, const float* bias_v, const float* inv_freq, const float* dout,
+                                    float* out, float* lse, float* dqkv, float* dbias, float* stats, void* stream);
+
 /* ---- SE(3) frame algebra, fp32 (mdgen/rigid_utils.py) --------------------------------------
  * n = number of frames; rot: [n][3][3]; trans/pts: [n][3]; quat: [n][4] (w,x,y,z). */
 int32_t mdgen_rigid_compose(int64_t n, const float* r1, const float* t1, const float* r2, const float* t2,

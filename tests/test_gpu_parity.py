@@ -1767,6 +1767,121 @@ def test_training_weight_gradient_kernels_unit(shape):
         assert ew < (5e-6 if prec == 32 else 1e-5) and eb < 5e-6, (shape, prec, ew, eb)
 
 
+def _attn_axis_reference(qkv, mask, bias_k, bias_v, inv_freq, dout, tok):
+    """torch fp64 reference of one attention axis as the training kernels see it (mha.py:258-268, 359-396): q (scaled, rotated) |
+    k (rotated) | v per token, learned bias key (rotated at position len) / value appended, padded keys masked; autograd for the
+    backward, then d q / d k taken back through RoPE (d q also through the q scale) as the kernels return them.
+    tok[s][i] = token index.  Returns out, lse, dqkv, dbias."""
+    with torch.enable_grad():      # (this module runs with gradients off)
+        return _attn_axis_reference_impl(qkv, mask, bias_k, bias_v, inv_freq, dout, tok)
+
+
+def _attn_axis_reference_impl(qkv, mask, bias_k, bias_v, inv_freq, dout, tok):
+    nseq, ln = tok.shape
+    H, DH = 16, 24
+    qkv = qkv.double().clone().requires_grad_(True)
+    bk = bias_k.double().clone().requires_grad_(True)
+    bv = bias_v.double().clone().requires_grad_(True)
+    f = inv_freq.double()
+
+    def rot(x, pos, sign=1.0):      # x [..., 24], rotate-half RoPE by angle sign * pos * inv_freq
+        ang = pos[..., None] * f
+        c, sn = torch.cos(ang), torch.sin(ang) * sign
+        x1, x2 = x[..., :12], x[..., 12:]
+        return torch.cat([x1 * c - x2 * sn, x2 * c + x1 * sn], -1)
+
+    out = torch.zeros(qkv.shape[0], H * DH, dtype=torch.float64)
+    lse = torch.zeros(qkv.shape[0], H, dtype=torch.float64)
+    outs, lses = [], []
+    for s_ in range(nseq):
+        t = tok[s_]
+        q = qkv[t, 0:384].view(ln, H, DH)
+        k = qkv[t, 384:768].view(ln, H, DH)
+        v = qkv[t, 768:1152].view(ln, H, DH)
+        kb = rot(bk.view(H, DH), torch.full((H,), float(ln), dtype=torch.float64))
+        K = torch.cat([k, kb[None]], 0)
+        V = torch.cat([v, bv.view(1, H, DH)], 0)
+        valid = torch.cat([mask[t] != 0, torch.ones(1, dtype=torch.bool)])
+        logit = torch.einsum("ihd,jhd->hij", q, K).masked_fill(~valid[None, None, :], float("-inf"))
+        outs.append((t, torch.einsum("hij,jhd->ihd", torch.softmax(logit, -1), V).reshape(ln, H * DH)))
+        lses.append((t, torch.logsumexp(logit, -1).T))
+    out = torch.zeros(qkv.shape[0], H * DH, dtype=torch.float64)
+    lse = torch.zeros(qkv.shape[0], H, dtype=torch.float64)
+    loss = 0.0
+    for (t, o), (_, l_) in zip(outs, lses):
+        loss = loss + (o * dout.double()[t]).sum()
+        out[t] = o.detach()
+        lse[t] = l_.detach()
+    # per-sequence bias gradients: differentiate each sequence's contribution separately
+    dbias = torch.zeros(nseq, 768, dtype=torch.float64)
+    for s_, (t, o) in enumerate(outs):
+        gk, gv = torch.autograd.grad((o * dout.double()[t]).sum(), (bk, bv), retain_graph=True)
+        dbias[s_, :384] = gk
+        dbias[s_, 384:] = gv
+    (g,) = torch.autograd.grad(loss, qkv)
+    dq = torch.zeros_like(g)
+    for s_ in range(nseq):
+        t = tok[s_]
+        pos = torch.arange(ln, dtype=torch.float64)[:, None].expand(ln, H)
+        dq[t, 0:384] = (rot(g[t, 0:384].view(ln, H, DH), pos, -1.0) * 24 ** -0.5).reshape(ln, 384)
+        dq[t, 384:768] = rot(g[t, 384:768].view(ln, H, DH), pos, -1.0).reshape(ln, 384)
+        dq[t, 768:] = g[t, 768:]
+    return out, lse, dq, dbias
+
+
+@pytest.mark.parametrize("ln", [1, 5, 31, 32, 33, 64, 65, 127, 128, 129, 250, 257, 300])
+@pytest.mark.parametrize("layout", ["residue", "temporal"])
+def test_training_attention_kernels_unit(ln, layout):
+    """The attention kernels of the training step alone (`mdgen_debug_train_attention`), forward and backward, both precisions,
+    against a torch fp64 reference with autograd: sequence lengths around every tile / chunk / block boundary (32-row tiles, 64-row
+    chunks, 128- and 256-row workgroups; the bias key first / last in a tile), both token layouts of the trunk, random key
+    padding plus a sequence whose first 40 keys are all padded (whole masked tiles) and one with every real key padded (only
+    the bias key left).  Exact mode to 2e-5; bf16 operands: output 1e-2, gradients 3e-2, the bias key's 1e-1 (rel-L2 per tensor)."""
+    from mdgen_amd import _lib as L
+    dev = _cuda()
+    nseq = 4
+    ntok = nseq * ln
+    gen = torch.Generator().manual_seed(1000 + ln)
+    if layout == "residue":     # token = s * len + i
+        tok = torch.arange(ntok).view(nseq, ln)
+        ax = (nseq, ln, 1, ln, 0, 1)
+    else:                       # token = i * nseq + s
+        tok = torch.arange(ntok).view(ln, nseq).T.contiguous()
+        ax = (nseq, ln, nseq, ln * nseq, 1, nseq)
+    qkv = torch.randn(ntok, 1152, generator=gen)
+    qkv[:, :384] *= 24 ** -0.5 * 2.0
+    mask = (torch.rand(ntok, generator=gen) > 0.2).float()
+    mask[tok[1][:40]] = 0.0
+    mask[tok[2]] = 0.0
+    bias_k = torch.randn(384, generator=gen)
+    bias_v = torch.randn(384, generator=gen)
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, 24, 2).float() / 24))
+    dout = torch.randn(ntok, 384, generator=gen)
+    r_out, r_lse, r_dqkv, r_dbias = _attn_axis_reference(qkv, mask, bias_k, bias_v, inv_freq, dout, tok)
+    d = lambda t: t.to(dev).contiguous()
+    g = dict(qkv=d(qkv), mask=d(mask), bk=d(bias_k), bv=d(bias_v), f=d(inv_freq), dout=d(dout))
+    s = L.stream_ptr()
+    for prec, tol_o, tol_g in ((32, 2e-5, 2e-5), (16, 1e-2, 3e-2)):
+        out = torch.full((ntok, 384), float("nan"), device=dev)
+        lse = torch.full((ntok, 16), float("nan"), device=dev)
+        dqkv = torch.full((ntok, 1152), float("nan"), device=dev)
+        dbias = torch.full((nseq, 768), float("nan"), device=dev)
+        stats = torch.empty(ntok, 16, 2, device=dev)
+        L.check(L.lib.mdgen_debug_train_attention(prec, L.ptr(g["qkv"]), ntok, *ax, L.ptr(g["mask"]), L.ptr(g["bk"]), L.ptr(g["bv"]),
+                                                  L.ptr(g["f"]), L.ptr(g["dout"]), L.ptr(out), L.ptr(lse), L.ptr(dqkv), L.ptr(dbias),
+                                                  L.ptr(stats), s))
+        torch.cuda.synchronize()
+        for name, got, ref, tol in (("out", out, r_out, tol_o), ("lse", lse, r_lse, tol_o), ("dq", dqkv[:, :384], r_dqkv[:, :384], tol_g),
+                                    ("dk", dqkv[:, 384:768], r_dqkv[:, 384:768], tol_g), ("dv", dqkv[:, 768:], r_dqkv[:, 768:], tol_g),
+                                    # the bias key is attended by EVERY query: its d k is the longest, most cancelling sum of
+                                    # bf16-rounded d s terms (3e-2 .. 6e-2 on these random inputs, growing with the length)
+                                    ("dbias_k", dbias[:, :384], r_dbias[:, :384], tol_g if prec == 32 else 1e-1),
+                                    ("dbias_v", dbias[:, 384:], r_dbias[:, 384:], tol_g)):
+            assert torch.isfinite(got).all(), (name, prec)
+            e = float((got.double().cpu() - ref).norm() / (ref.norm() + 1e-300))
+            assert e < tol, (ln, layout, prec, name, e)
+
+
 def test_row_owner_mlp_paths_agree():
     """The MLP block has three forms: the 64-row resident-panel kernel (`mlp_path` 0), the row-owner kernel (`mlp_path` 2:
     activations in registers, LDS-DMA weight stream) and the row-owner kernel with the temporal out-projection fused in front
