@@ -261,6 +261,34 @@ def gen_inference(name, cfg, seed, B, T, L, steps, data_seed, n_blocks=1, slim=F
     save(name, **out)
 
 
+def gen_inference_big(name, cfg, seed, B, T, L, S, data_seed, sub_t):
+    """One block of the reference's own inference() (wrapper.py:405-484) at a BASELINE size (e.g. cfg-2's regime: 1000
+    frames, S = 49 Euler steps).  zs is NOT stored: torch.randn(B, T, L, D, generator=manual_seed(137)), checksummed;
+    atom14 is stored at frames [::sub_t]."""
+    g = torch.Generator().manual_seed(data_seed)
+    m, chk = build(cfg, seed)
+    seqres = torch.randint(0, 20, (B, L), generator=g)
+    atom14_0 = synth_structure(g, B, 1, L, seqres)
+    batch = get_batch_like_sim_inference(atom14_0, seqres)
+    ex = dict(batch)
+    ex["torsions"] = batch["torsions"].expand(-1, T, -1, -1, -1)
+    ex["trans"] = batch["trans"].expand(-1, T, -1, -1)
+    ex["rots"] = batch["rots"].expand(-1, T, -1, -1, -1)
+    zs = torch.randn(B, T, L, cfg.latent_dim, generator=torch.Generator().manual_seed(137))
+    orig_sample_ode = m.transport_sampler.sample_ode
+    m.transport_sampler.sample_ode = lambda **k: orig_sample_ode(sampling_method="euler", num_steps=S + 1)
+    orig_randn = torch.randn
+    torch.randn = lambda *a, **k: zs.clone()
+    try:
+        atom14, aa = m.inference(ex)
+    finally:
+        torch.randn = orig_randn
+        del m.transport_sampler.sample_ode
+    save(name, cfg=str(cfg.to_dict()), seed=seed, weight_checksum=chk, S=np.array(S), sub_t=np.array(sub_t),
+         shape=np.array([B, T, L]), zs_checksum=tensor_checksum({"zs": zs}), atom14_init=atom14_0,
+         **{"in_" + k: v for k, v in batch.items()}, atom14=atom14[:, ::sub_t])
+
+
 def gen_rigid(name, data_seed):
     g = torch.Generator().manual_seed(data_seed)
     n = 64
@@ -322,6 +350,12 @@ if __name__ == "__main__":
         # BASELINE.json configs[3] at its full size: ATLAS crop 256 x 250 frames, B 1, 16 padded residues
         "fwd_cfg4_atlas_full": lambda: gen_forward_big("fwd_cfg4_atlas_full", ModelConfig.atlas(num_frames=250, crop=256),
                                                        6, B=1, T=250, L=256, n_pad=16, data_seed=27, sub=(10, 8)),
+        # BASELINE.json configs[1]'s regime: tetrapeptide, 1000 frames (1001 temporal keys = 32 key tiles, RoPE positions up
+        # to 999), B 2 with distinct t; configs[0]'s exact forward shape (B1 T100 L4) as well
+        "fwd_cfg2_T1000": lambda: gen_forward_big("fwd_cfg2_T1000", ModelConfig.forward_sim(num_frames=1000, crop=4),
+                                                  5, B=2, T=1000, L=4, n_pad=0, data_seed=28, sub=(8, 1)),
+        "fwd_cfg1_T100": lambda: gen_forward_big("fwd_cfg1_T100", ModelConfig.forward_sim(num_frames=100, crop=4),
+                                                 5, B=1, T=100, L=4, n_pad=0, data_seed=29, sub=(1, 1)),
         "prep_sim": lambda: gen_prep("prep_sim", ModelConfig.forward_sim(num_frames=6, crop=5), B=2, T=6, L=5, data_seed=31),
         "prep_tps": lambda: gen_prep("prep_tps", ModelConfig.tps(num_frames=6, crop=5), B=2, T=6, L=5, data_seed=32),
         # S = 49 is the reference's hard-coded step count (wrapper.py:441-442) and the product default
@@ -330,6 +364,12 @@ if __name__ == "__main__":
         # the README run chains 10 blocks (sim_inference.py:110-113, README.md:72 --num_rollouts 10): error growth per block
         "rollout10_sim": lambda: gen_inference("rollout10_sim", ModelConfig.forward_sim(num_frames=8, crop=4), 8, B=1,
                                                T=8, L=4, steps=[10], data_seed=43, n_blocks=10, slim=True),
+        # BASELINE.json configs[1]'s regime end to end (B 1 of the 16): 1000 frames, the reference's 49 Euler steps
+        "inference_cfg2_T1000": lambda: gen_inference_big("inference_cfg2_T1000", ModelConfig.forward_sim(num_frames=1000, crop=4),
+                                                          8, B=1, T=1000, L=4, S=49, data_seed=45, sub_t=4),
+        # BASELINE.json configs[0]'s exact shape: single tetrapeptide, 100 frames, 10 Euler steps
+        "inference_cfg1": lambda: gen_inference_big("inference_cfg1", ModelConfig.forward_sim(num_frames=100, crop=4),
+                                                    8, B=1, T=100, L=4, S=10, data_seed=46, sub_t=1),
         "inference_tiny": lambda: gen_inference("inference_tiny", ModelConfig(crop=4, num_frames=10, **tiny), 9, B=1,
                                                 T=10, L=4, steps=[10, 49], data_seed=42, n_blocks=1),
     }

@@ -17,6 +17,14 @@ from conftest import ROOT, load_golden, weights_for, rel_l2, model_config_from
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 TOL_FWD = 1e-2
+# BASELINE.md section 3, end-to-end atom14 of the bf16-operand path at the BASELINE step counts (S = 10 / 49): rms <= 0.02 A,
+# max <= 0.5 A.  S = 1 (one Euler step of size 1: the error of a single network evaluation at full weight, not a BASELINE
+# configuration) is gated at 0.03 A rms -- measured 0.0196 A.
+TOL_RMS, TOL_MAX = 0.02, 0.5
+
+
+def tol_rms(S):
+    return TOL_RMS if S >= 10 else 0.03
 
 
 def _cuda():
@@ -257,7 +265,7 @@ def test_inference_end_to_end_vs_reference():
             print(f"S={S} graph={use_graph} samples rel-L2 {e_s:.2e}  atom14 rms {d.pow(2).mean().sqrt():.4f} A max {d.max():.4f} A")
             assert e_s < 2e-2
             # bf16-operand kernels are reported against rms <= 0.02 A / max <= 0.5 A
-            assert d.pow(2).mean().sqrt() < 0.05 and d.max() < 0.5
+            assert d.pow(2).mean().sqrt() < tol_rms(S) and d.max() < TOL_MAX
             assert torch.equal(aa.cpu(), g["in_seqres"][:, None].expand_as(aa.cpu()))
         nxt = atom14_to_cond(g[f"S{S}_b0_atom14"][:, -1].to(dev), batch0["seqres"])
         assert torch.allclose(nxt["trans"].cpu(), g[f"S{S}_b0_next_trans"][:, 0], atol=1e-5)
@@ -323,7 +331,7 @@ def test_tps_inference_end_to_end_vs_oracle():
     print(f"TPS end-to-end S={S}: samples rel-L2 {e_s:.2e}  atom14 rms {d.pow(2).mean().sqrt():.4f} A max {d.max():.4f} A")
     assert torch.isfinite(atom14).all()
     assert e_s < 2e-2
-    assert d.pow(2).mean().sqrt() < 0.05 and d.max() < 0.5
+    assert d.pow(2).mean().sqrt() < tol_rms(S) and d.max() < TOL_MAX
 
 
 def test_attention_fixed_anchor_and_robust_loops_agree():
@@ -603,6 +611,91 @@ def test_forward_cfg4_full_size_vs_reference_and_oracle():
     assert torch.equal(out2[:, :, :L - n_pad], out[:, :, :L - n_pad])
 
 
+@pytest.mark.parametrize("name", ["fwd_cfg2_T1000", "fwd_cfg1_T100"])
+def test_forward_headline_regime_vs_reference_and_oracle(name):
+    """BASELINE.json configs[1]'s regime -- tetrapeptide, **1000 frames**: 1001 temporal keys = 32 key tiles per query in
+    k_flash (the fixed-anchor softmax runs 31 tiles past its anchor), RoPE positions up to 999 (mha.py:356-396), B 2 with
+    distinct t -- and configs[0]'s exact shape (B 1, 100 frames).  (a) vs the REFERENCE's own run (outputs stored
+    sub-sampled, inputs regenerated from the seed and checksummed), bf16 operands <= 1e-2 and fp32 mode <= 1e-5;
+    (b) vs the CPU oracle run here, every element of the velocity and of every layer's residual stream."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.model import LatentMDGenModel
+    from mdgen_amd.synthetic import synth_forward_inputs, tensor_checksum
+    dev = _cuda()
+    g = load_golden(name)
+    cfg, sd = weights_for(g)
+    B, T, L, n_pad = (int(v) for v in g["shape"])
+    inp = synth_forward_inputs(cfg, B, T, L, n_pad, int(g["data_seed"]))
+    np.testing.assert_allclose(tensor_checksum(inp), g["input_checksum"].numpy(), rtol=1e-12)
+    kw = dict(x=inp["x"], t=inp["t"], mask=inp["mask"], start_frames=(inp["start_rot"], inp["start_trans"]),
+              end_frames=(inp["end_rot"], inp["end_trans"]), x_cond=inp["x_cond"], x_cond_mask=inp["x_cond_mask"],
+              aatype=inp["aatype"])
+    dkw = {k: (tuple(u.to(dev) for u in v) if isinstance(v, tuple) else v.to(dev)) for k, v in kw.items()}
+    st, sl = (int(v) for v in g["sub"])
+    ht, hl = (int(v) for v in g["sub_h"])
+    nl = cfg.num_layers
+    ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
+    for prec, tol in (("bf16", TOL_FWD), ("fp32", 1e-5)):
+        m = LatentMDGenModel(cfg, precision=prec)
+        m.load_state_dict(sd)
+        out, tr = m.forward(**dkw, return_trace=True)
+        torch.cuda.synchronize()
+        out = out.cpu()
+        tr = {k: v.cpu() for k, v in tr.items()}
+        assert torch.isfinite(out).all()
+        rep = {"out": rel_l2(out[:, ::st, ::sl], g["out"]), "ipa_out": rel_l2(tr["ipa_out"][:, ::sl], g["ipa_out"]),
+               "h0": rel_l2(tr["h0"][:, ::ht, ::hl], g["h0"]), f"h{nl}": rel_l2(tr[f"h{nl}"][:, ::ht, ::hl], g[f"h{nl}"])}
+        print(f"{name} {prec} vs reference (sub-sampled):", {k: f"{v:.2e}" for k, v in rep.items()})
+        rep2 = {k: rel_l2(tr[k], rtr[k]) for k in ["ipa_out"] + [f"h{i}" for i in range(nl + 1)]}
+        rep2["out"] = rel_l2(out, ref)
+        # worst single frame of the velocity: a defect confined to the late key tiles / large RoPE positions cannot hide
+        # in the average over 1000 frames
+        per_t = ((out - ref).double().pow(2).sum((0, 2, 3)) / ref.double().pow(2).sum((0, 2, 3))).sqrt()
+        rep2["out_worst_frame"] = float(per_t.max())
+        print(f"{name} {prec} vs oracle (all elements):", {k: f"{v:.2e}" for k, v in rep2.items()})
+        for k, v in list(rep.items()) + list(rep2.items()):
+            assert v < (3 * tol if k == "out_worst_frame" else tol), (prec, k, v)
+        del m
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", ["inference_cfg2_T1000", "inference_cfg1"])
+def test_inference_headline_regime_vs_reference(name):
+    """End-to-end `inference()` (noise -> S Euler steps -> atom14) at BASELINE.json configs[1]'s regime (one sample of the 16:
+    1000 frames, the reference's 49 Euler steps) and at configs[0]'s exact shape (B 1, 100 frames, 10 steps), against the
+    REFERENCE's own run (sim_inference.py:109-115 region; atom14 stored at frames [::sub_t]); gated at BASELINE.md section
+    3's bounds: bf16 operands rms <= 0.02 A / max <= 0.5 A, fp32 mode max <= 1e-3 A."""
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    from mdgen_amd.synthetic import tensor_checksum
+    dev = _cuda()
+    g = load_golden(name)
+    cfg, sd = weights_for(g)
+    B, T, L = (int(v) for v in g["shape"])
+    S, sub_t = int(g["S"]), int(g["sub_t"])
+    zs = torch.randn(B, T, L, cfg.latent_dim, generator=torch.Generator().manual_seed(137))
+    np.testing.assert_allclose(tensor_checksum({"zs": zs}), g["zs_checksum"].numpy(), rtol=1e-12)
+    batch0 = {k[3:]: v.to(dev) for k, v in g.items() if k.startswith("in_")}
+    ex = dict(batch0)
+    ex["torsions"] = batch0["torsions"].expand(-1, T, -1, -1, -1)
+    ex["trans"] = batch0["trans"].expand(-1, T, -1, -1)
+    ex["rots"] = batch0["rots"].expand(-1, T, -1, -1, -1)
+    for prec in ("bf16", "fp32"):
+        w = NewMDGenWrapper(cfg, precision=prec)
+        w.model.load_state_dict(sd)
+        atom14, _ = w.inference(ex, zs=zs.to(dev), num_steps=S)
+        torch.cuda.synchronize()
+        assert torch.isfinite(atom14).all()
+        d = (atom14.cpu()[:, ::sub_t] - g["atom14"]).abs()
+        rms, mx = float(d.pow(2).mean().sqrt()), float(d.max())
+        print(f"{name} S={S} {prec}: atom14 rms {rms:.4f} A max {mx:.4f} A")
+        if prec == "bf16":
+            assert rms < TOL_RMS and mx < TOL_MAX, (rms, mx)
+        else:
+            assert mx < 1e-3, mx
+        del w
+    torch.cuda.empty_cache()
+
+
 def test_tps_cfg3_size_properties():
     """BASELINE.json configs[2] at its per-GPU size: TPS model (D = 28, two-sided conditioning, dual-stream IPA),
     crop 4, 100 frames, batch 256 / 8 GPUs = 32.  Size-independent properties of the Euler rollout through
@@ -689,7 +782,8 @@ def test_inference_S49_error_growth():
         d = (atom14.cpu() - g[f"S{S}_b0_atom14"]).abs()
         rows[S] = (rel_l2(w.last_samples.cpu(), g[f"S{S}_b0_samples"]), float(d.pow(2).mean().sqrt()), float(d.max()))
         print(f"S={S:2d}: samples rel-L2 {rows[S][0]:.2e}  atom14 rms {rows[S][1]:.4f} A  max {rows[S][2]:.4f} A")
-    assert rows[49][0] < 2e-2 and rows[49][1] < 0.05 and rows[49][2] < 0.5
+    assert rows[49][0] < 2e-2 and rows[49][1] < TOL_RMS and rows[49][2] < TOL_MAX
+    assert rows[10][1] < TOL_RMS and rows[10][2] < TOL_MAX and rows[1][1] < tol_rms(1)
 
 
 def test_multi_block_rollout_one_graph():
@@ -728,7 +822,7 @@ def test_multi_block_rollout_one_graph():
         d = (one_g[:, r * T:(r + 1) * T].cpu() - g[f"S{S}_b{r}_atom14"]).abs()
         rms, mx = float(d.pow(2).mean().sqrt()), float(d.max())
         print(f"rollout block {r} vs reference: atom14 rms {rms:.4f} A max {mx:.4f} A")
-        assert rms < 0.05 * (r + 1) and mx < 0.5 * (r + 1)
+        assert rms < TOL_RMS * (r + 1) and mx < TOL_MAX * (r + 1)
 
 
 def test_many_views_beyond_the_32bit_offset_limit():
@@ -1497,7 +1591,7 @@ def test_ten_chained_blocks_error_growth():
             if prec == "fp32":   # block 1 already starts from OUR block-0 end frame: the glue's amplification applies from there on
                 assert (mx < 1e-3 if r < 1 else rms < 0.1), (prec, r, rms, mx)
             else:
-                assert (rms < 0.05 and mx < 0.5) if r == 0 else rms < 0.25, (prec, r, rms, mx)
+                assert (rms < TOL_RMS and mx < TOL_MAX) if r == 0 else rms < 0.25, (prec, r, rms, mx)
         print(f"{prec} operands: first block whose max deviation exceeds 0.5 A: {left}")
         del w
 
@@ -1829,12 +1923,12 @@ def _attn_axis_reference_impl(qkv, mask, bias_k, bias_v, inv_freq, dout, tok):
     return out, lse, dq, dbias
 
 
-@pytest.mark.parametrize("ln", [1, 5, 31, 32, 33, 64, 65, 127, 128, 129, 250, 257, 300])
+@pytest.mark.parametrize("ln", [1, 5, 31, 32, 33, 64, 65, 127, 128, 129, 250, 257, 300, 1000, 1001])
 @pytest.mark.parametrize("layout", ["residue", "temporal"])
 def test_training_attention_kernels_unit(ln, layout):
     """The attention kernels of the training step alone (`mdgen_debug_train_attention`), forward and backward, both precisions,
     against a torch fp64 reference with autograd: sequence lengths around every tile / chunk / block boundary (32-row tiles, 64-row
-    chunks, 128- and 256-row workgroups; the bias key first / last in a tile), both token layouts of the trunk, random key
+    chunks, 128- and 256-row workgroups; the bias key first / last in a tile; 1000 / 1001 = the tetrapeptide headline's temporal length), both token layouts of the trunk, random key
     padding plus a sequence whose first 40 keys are all padded (whole masked tiles) and one with every real key padded (only
     the bias key left).  Exact mode to 2e-5; bf16 operands: output 1e-2, gradients 3e-2, the bias key's 1e-1 (rel-L2 per tensor)."""
     from mdgen_amd import _lib as L

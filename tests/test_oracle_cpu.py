@@ -192,14 +192,18 @@ def test_training_losses_vs_reference(name):
     assert torch.allclose(ut0, (math.pi / 2) * g["x1"], atol=1e-5)
 
 
-def test_forward_cfg4_full_size_matches_reference():
-    """BASELINE.json configs[3] at its FULL size (ATLAS crop 256 x 250 frames, B 1, 16 padded residues): the oracle
-    vs the reference's own run (fixture fwd_cfg4_atlas_full: seeded inputs regenerated here, checked by checksum;
+@pytest.mark.parametrize("name,shape", [("fwd_cfg4_atlas_full", (1, 250, 256, 16)), ("fwd_cfg2_T1000", (2, 1000, 4, 0)),
+                                        ("fwd_cfg1_T100", (1, 100, 4, 0))])
+def test_forward_full_size_matches_reference(name, shape):
+    """BASELINE.json configs at their FULL per-sample size -- configs[3] (ATLAS crop 256 x 250 frames, B 1, 16 padded
+    residues), configs[1]'s regime (tetrapeptide, 1000 frames = 1001 temporal keys, B 2 with distinct t) and configs[0]'s
+    shape (B 1, 100 frames): the oracle vs the reference's own run (seeded inputs regenerated here, checked by checksum;
     reference outputs stored sub-sampled)."""
     from mdgen_amd.synthetic import synth_forward_inputs, tensor_checksum
-    g = load_golden("fwd_cfg4_atlas_full")
+    g = load_golden(name)
     cfg, sd = weights_for(g)
     B, T, L, n_pad = (int(v) for v in g["shape"])
+    assert (B, T, L, n_pad) == shape
     inp = synth_forward_inputs(cfg, B, T, L, n_pad, int(g["data_seed"]))
     np.testing.assert_allclose(tensor_checksum(inp), g["input_checksum"].numpy(), rtol=1e-12)
     out, tr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, x=inp["x"], t=inp["t"], mask=inp["mask"],
@@ -215,6 +219,24 @@ def test_forward_cfg4_full_size_matches_reference():
     norms = [float(out.double().norm()), float(tr["ipa_out"].double().norm()), float(tr["h0"].double().norm()),
              float(tr[f"h{nl}"].double().norm())]
     np.testing.assert_allclose(norms, g["norms"].numpy(), rtol=1e-5)
+
+
+def test_inference_cfg1_shape_matches_reference():
+    """BASELINE.json configs[0] (single tetrapeptide, 100 frames, 10 Euler steps, the reference's CPU-runnable case):
+    the oracle's inference() vs the reference's own run at that exact shape."""
+    g = load_golden("inference_cfg1")
+    cfg, sd = weights_for(g)
+    B, T, L = (int(v) for v in g["shape"])
+    assert (B, T, L, int(g["S"])) == (1, 100, 4, 10)
+    batch0 = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+    ex = dict(batch0)
+    ex["torsions"] = batch0["torsions"].expand(-1, T, -1, -1, -1)
+    ex["trans"] = batch0["trans"].expand(-1, T, -1, -1)
+    ex["rots"] = batch0["rots"].expand(-1, T, -1, -1, -1)
+    zs = torch.randn(B, T, L, cfg.latent_dim, generator=torch.Generator().manual_seed(137))
+    a14, _, _ = O.inference(sd, O.cfg_dict(cfg), ex, zs, int(g["S"]))
+    d = (a14[:, ::int(g["sub_t"])] - g["atom14"]).abs()
+    assert float(d.max()) < 1e-3, float(d.max())
 
 
 @pytest.mark.parametrize("name,nparams", [("train_grads_sim", 124), ("train_grads_tps", 128)])
