@@ -49,36 +49,7 @@ WORKLOADS = {
 }
 
 
-def synth_batch(B, T, L, n_pad, dev, seed, tps=False):
-    """Self-consistent synthetic conditioning batch: random frames + torsions ->
-    atom14 (sampler post-processing kernel) -> conditioning frame (rollout-glue kernel), first frame
-    expanded over T (sim_inference.py:72-79); trailing `n_pad` residues padded (dataset.py:80-89)."""
-    from mdgen_amd.geometry import atom14_to_cond, samples_to_atom14
-    g = torch.Generator().manual_seed(seed)
-    q = torch.randn(B, L, 4, generator=g)
-    q = (q / q.norm(dim=-1, keepdim=True)).to(dev)
-    from mdgen_amd.rigid_utils import Rotation
-    R = Rotation(quats=q).get_rot_mats()
-    tr = torch.cumsum(2.2 * torch.randn(B, L, 3, generator=g), 1).to(dev)
-    ang = 6.283185307 * torch.rand(B, L, 7, generator=g)
-    seqres = torch.randint(0, 20, (B, L), generator=g).to(dev)
-    lat = torch.zeros(B, 1, L, 21, device=dev)
-    lat[..., 0] = 1.0
-    lat[..., 7:21] = torch.stack([ang.sin(), ang.cos()], -1).reshape(B, 1, L, 14).to(dev)
-    atom14 = samples_to_atom14(lat, R, tr, seqres, tps=False)[:, 0]
-    c = atom14_to_cond(atom14, seqres)
-    mask = torch.ones(B, L, device=dev)
-    if n_pad:
-        mask[:, L - n_pad:] = 0
-        seqres[:, L - n_pad:] = 0
-    out = {"torsions": c["torsions"][:, None].expand(B, T, L, 7, 2).contiguous(),
-           "torsion_mask": c["torsion_mask"], "trans": c["trans"][:, None].expand(B, T, L, 3).contiguous(),
-           "rots": c["rots"][:, None].expand(B, T, L, 3, 3).contiguous(), "seqres": seqres, "mask": mask}
-    if tps:   # two-sided conditioning: frame -1 is a second, different conformation (tps_inference.py:58-66)
-        e = synth_batch(B, 1, L, n_pad, dev, seed + 7919)
-        for k in ("torsions", "trans", "rots"):
-            out[k][:, -1] = e[k][:, 0]
-    return out
+from mdgen_amd.synthetic import synth_batch  # noqa: E402  (shared with `python -m mdgen_amd.train --synthetic`)
 
 
 def algorithmic_flops(cls, B, T, L):
@@ -188,7 +159,9 @@ def _dominant(rep, B, T, L, workload):
     traffic, traffic_src = pmc_traffic(dom, workload)
     return {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-            "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "launches": rep[dom]["count"],
+            # PMC counters cannot be read in-process: `traffic` is the committed rocprofv3 --pmc measurement of this kernel
+            # class (scripts/pmc_traffic.sh -> profiles/pmc_traffic.json), a constant of the build, not of this run
+            "traffic_source": traffic_src, "traffic_measured_in_run": False, "avg_launch_ms": round(avg_ms, 4), "launches": rep[dom]["count"],
             "share_of_event_time": round(rep[dom]["ms"] / tot, 3),
             "by_kernel_ms_per_call": {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}}
 
@@ -396,12 +369,14 @@ def main():
     for _ in range(a.steps):
         atom14, _ = step()
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank's own K steps (before it waits for the others)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    from mdgen_amd.sharding import max_over_ranks
+    from mdgen_amd.sharding import gather_over_ranks, max_over_ranks
     dt = max_over_ranks(dt, dist, dev)
+    per_rank = [B * T * a.steps / s for s in gather_over_ranks(dt_own, dist, dev)]
     if not torch.isfinite(atom14).all():
         smp = w.last_samples
         bad_a = (~torch.isfinite(atom14)).nonzero()
@@ -464,6 +439,9 @@ def main():
             "data": "synthetic (seeded random-init weights, synthetic peptide frames/torsions, CPU-seeded noise)",
             "config": {"workload": a.workload, "batch_per_gpu": B, "num_frames": T, "crop": L,
                        "euler_steps": S, "hipgraph": use_graph, "parallelism": f"batch-sharded x{world}, no collective"},
+            # every rank's own rate over its K steps and the fastest / slowest ratio: a straggler GPU shows up here
+            "per_rank_frames_per_s": [round(v, 1) for v in per_rank],
+            "rank_max_over_min": round(max(per_rank) / min(per_rank), 4),
             "roofline": roof, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(out))

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 /* Bumped whenever a public struct or signature changes; mdgen_amd/_lib.py refuses a library whose version differs. */
-#define MDGEN_ABI_VERSION 4
+#define MDGEN_ABI_VERSION 5
 
 typedef struct mdgen_ctx mdgen_ctx;
 
@@ -138,13 +138,18 @@ int32_t mdgen_workspace_layout(const mdgen_ctx* ctx, const mdgen_shape* shape, i
  * x, x_cond, out: fp32 (B,T,L,D); t: fp32 (B); mask: fp32 (B,T,L) in {0,1};
  * x_cond_mask: int64 (B,T,L) in {0,1}; aatype: int64 (B,L) in [0,20];
  * start/end frames: rot (B,L,3,3) + trans (B,L,3) fp32 (the fields of the reference's `Rigid`);
- * end_* may be NULL unless tps_condition.  trace_h (nullable): fp32 [(num_layers+1)][N][384],
+ * end_* may be NULL unless tps_condition.  rel7 (nullable; two-sided models only): fp32 (2,B,L,7), the relative-frame inputs
+ * of latent_to_emb_f / _r exactly as the caller's reference computes them -- rel7[0] = (start^-1 o end).to_tensor_7(),
+ * rel7[1] = (end^-1 o start).to_tensor_7() (latent_model.py:193-195).  Their quaternion SIGN is whatever torch.linalg.eigh
+ * returns (rigid_utils.py:191-210, never canonicalised on this path) and it reaches a Linear, so a checkpoint trained with
+ * the reference sees exactly its own inputs only when they are handed over; NULL: the library computes them from the
+ * frames with the sign fixed to w >= 0.  trace_h (nullable): fp32 [(num_layers+1)][N][384],
  * the residual stream before layer 0 and after every trunk layer; trace_ipa (nullable): fp32
  * [B*L][384], the IPA-stack output (latent_model.py:245-246). */
 int32_t mdgen_denoiser_forward(mdgen_ctx* ctx, const mdgen_shape* shape,
                                const float* x, const float* t, const float* mask,
                                const float* start_rot, const float* start_trans,
-                               const float* end_rot, const float* end_trans,
+                               const float* end_rot, const float* end_trans, const float* rel7,
                                const float* x_cond, const int64_t* x_cond_mask, const int64_t* aatype,
                                float* out, float* trace_h, float* trace_ipa,
                                void* workspace, size_t workspace_bytes, void* stream);
@@ -158,7 +163,7 @@ int32_t mdgen_denoiser_forward(mdgen_ctx* ctx, const mdgen_shape* shape,
 int32_t mdgen_sample_euler(mdgen_ctx* ctx, const mdgen_shape* shape, int32_t n_steps,
                            float* x, const float* mask,
                            const float* start_rot, const float* start_trans,
-                           const float* end_rot, const float* end_trans,
+                           const float* end_rot, const float* end_trans, const float* rel7,
                            const float* x_cond, const int64_t* x_cond_mask, const int64_t* aatype,
                            void* workspace, size_t workspace_bytes, int32_t use_graph, void* stream);
 
@@ -273,10 +278,11 @@ int32_t mdgen_from_3_points(int64_t n, const float* p_neg_x, const float* origin
 /* ---- sampler pre/post-processing (mdgen/wrapper.py) ----------------------------------------
  * `NewMDGenWrapper.prep_batch` latents (wrapper.py:298-327, 339-342, 362) incl. `utils.get_offsets`
  * (utils.py:7-14): offsets = rigid[b,0]^-1 o rigid[b,t] as [quat(w>=0) | trans], TPS appends the
- * offsets w.r.t. frame T-1; latents = [offsets | torsions(14)]; cond frames = 0 (and T-1 for TPS).
+ * offsets w.r.t. frame T-1; latents = [offsets | torsions(14)]; cond frames = 0 (and T-1 for TPS), plus every
+ * cond_interval-th frame when cond_interval > 0 (`--cond_interval`, wrapper.py:343-344: the upsampling models; 0 = none).
  * rots (B,T,L,3,3), trans (B,T,L,3), torsions (B,T,L,7,2) -> latents, x_cond (B,T,L,D),
  * x_cond_mask int64 (B,T,L). */
-int32_t mdgen_prep_latents(const mdgen_shape* shape, int32_t tps, const float* rots, const float* trans,
+int32_t mdgen_prep_latents(const mdgen_shape* shape, int32_t tps, int32_t cond_interval, const float* rots, const float* trans,
                            const float* torsions, float* latents, float* x_cond, int64_t* x_cond_mask,
                            void* stream);
 
@@ -357,7 +363,7 @@ int32_t mdgen_train_num_milestones(const mdgen_ctx* ctx);
 int32_t mdgen_train_set_milestone_events(mdgen_ctx* ctx, void* const* events, int32_t n);
 int32_t mdgen_train_forward_backward(mdgen_ctx* ctx, const mdgen_shape* shape, const float* xt, const float* t,
                                      const float* mask, const float* start_rot, const float* start_trans,
-                                     const float* end_rot, const float* end_trans,
+                                     const float* end_rot, const float* end_trans, const float* rel7,
                                      const float* x_cond, const int64_t* x_cond_mask, const int64_t* aatype,
                                      const float* target, const float* loss_mask, float* loss, float* pred,
                                      float* grads, const int64_t* grad_offsets, void* workspace, size_t workspace_bytes,

@@ -10,7 +10,7 @@ import torch  # noqa: F401  -- must be imported first: provides the process-wide
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDGEN_AMD_LIB", os.path.join(_HERE, "libmdgen_amd.so"))   # override: debugging builds only
 
-ABI_VERSION = 4   # include/mdgen_amd.h MDGEN_ABI_VERSION
+ABI_VERSION = 5   # include/mdgen_amd.h MDGEN_ABI_VERSION
 
 EXPORTS = [
     "mdgen_last_error", "mdgen_abi_version", "mdgen_dev_build", "mdgen_ctx_create", "mdgen_ctx_destroy", "mdgen_ctx_set_weight",
@@ -67,8 +67,8 @@ def _load():
     lib.mdgen_ctx_weight_name.argtypes = [vp, i32]
     lib.mdgen_ctx_weight_name.restype = C.c_char_p
     lib.mdgen_workspace_layout.argtypes = [vp, C.POINTER(Shape), i32, i32, C.POINTER(WsLayout)]
-    lib.mdgen_denoiser_forward.argtypes = [vp, C.POINTER(Shape)] + [vp] * 14 + [sz, vp]
-    lib.mdgen_sample_euler.argtypes = [vp, C.POINTER(Shape), i32] + [vp] * 10 + [sz, i32, vp]
+    lib.mdgen_denoiser_forward.argtypes = [vp, C.POINTER(Shape)] + [vp] * 15 + [sz, vp]
+    lib.mdgen_sample_euler.argtypes = [vp, C.POINTER(Shape), i32] + [vp] * 11 + [sz, i32, vp]
     lib.mdgen_rollout_euler.argtypes = [vp, C.POINTER(Shape), i32, i32] + [vp] * 8 + [C.POINTER(ResidueTables), vp, vp, sz, i32, vp]
     lib.mdgen_profile_enable.argtypes = [vp, i32]
     lib.mdgen_profile_phase_trace.argtypes = [vp, vp, i64]
@@ -83,7 +83,7 @@ def _load():
     lib.mdgen_rigid_apply.argtypes = [i64, i64, vp, vp, vp, vp, i32, vp]
     lib.mdgen_quat_to_rot.argtypes = [i64, vp, i32, vp, vp]
     lib.mdgen_rot_to_quat.argtypes = [i64, vp, vp, vp]
-    lib.mdgen_prep_latents.argtypes = [C.POINTER(Shape), i32] + [vp] * 7
+    lib.mdgen_prep_latents.argtypes = [C.POINTER(Shape), i32, i32] + [vp] * 7
     lib.mdgen_samples_to_atom14.argtypes = [C.POINTER(Shape), i32, i32] + [vp] * 10
     lib.mdgen_atom14_to_cond.argtypes = [i32, i32] + [vp] * 11
     lib.mdgen_from_3_points.argtypes = [i64] + [vp] * 6
@@ -97,7 +97,7 @@ def _load():
     lib.mdgen_train_num_milestones.argtypes = [vp]
     lib.mdgen_train_bind_params.argtypes = [vp, vp, C.POINTER(i64)]
     lib.mdgen_train_set_milestone_events.argtypes = [vp, C.POINTER(vp), i32]
-    lib.mdgen_train_forward_backward.argtypes = [vp, C.POINTER(Shape)] + [vp] * 16 + [vp, sz, vp, sz, vp]
+    lib.mdgen_train_forward_backward.argtypes = [vp, C.POINTER(Shape)] + [vp] * 17 + [vp, sz, vp, sz, vp]
     for n in EXPORTS:
         getattr(lib, n)
         if n not in ("mdgen_last_error", "mdgen_ctx_weight_name"):

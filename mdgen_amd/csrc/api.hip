@@ -716,6 +716,7 @@ struct Run {
     unsigned char* ws;
     mdgen_ws_layout lay;
     const float *mask, *start_rot, *start_trans, *end_rot, *end_trans, *x_cond;
+    const float* rel7_in;        // caller-supplied relative-frame 7-vectors (2,B,L,7) of the two-sided model, or null
     const int64_t *x_cond_mask, *aatype;
     hipStream_t s;
     // trunk buffers (a sub-batch view shifts these; see sub_run)
@@ -816,11 +817,22 @@ static int mlp_sublayer_fp32(const Run& r, const std::string& pre, float* h, lon
     return 0;
 }
 
+// Every token-local kernel addresses the residual stream with 32-bit byte offsets (token * 1536; rows.h, panel.h): one
+// launch may cover at most kMaxViewTokens rows.  The trunk is cut into views accordingly (plan_views); this guard is for
+// whatever reaches a launcher directly (the IPA stack's S * B * L rows).
+static int check_launch_rows(long nrows) {
+    if (nrows > kMaxViewTokens)
+        return fail(-7, "%ld token rows in one launch exceed the 32-bit offset limit of %ld (use a smaller batch per call)", nrows,
+                    kMaxViewTokens);
+    return 0;
+}
+
 // `defer`: when non-null and the sub-layer takes the tiled-attention path, its out-projection is NOT launched; *defer receives
 // what the fused kernel (k_mlp_rows<NW, true>) needs to run it ahead of the MLP (a_bf16 stays null otherwise).
 static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, const AxisMap& ax, const ModMap& mm,
                          int shift, int scale, int gate, const MaskMap& mk, bool residue_axis, bool trunk,
                          ProjParams* defer = nullptr) {
+    if (int e = check_launch_rows(nrows)) return e;
     const char* c_qkv = !trunk ? "ipa.ln_qkv" : residue_axis ? "ln_qkv_L" : "ln_qkv_T";
     const char* c_att = !trunk ? "ipa.flash" : residue_axis ? "flash_L" : "flash_T";
     const char* c_prj = !trunk ? "ipa.proj" : residue_axis ? "proj_L" : "proj_T";
@@ -931,6 +943,7 @@ static bool mlp_uses_rows(const mdgen_ctx* c, long nrows) {
 // `proj`: a deferred out-projection (attn_sublayer) to run inside the row-owner kernel, ahead of the MLP
 static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const ModMap& mm, int shift, int scale,
                         int gate, bool trunk, const ProjParams* proj = nullptr, const bf16x8* wo_stream = nullptr) {
+    if (int e = check_launch_rows(nrows)) return e;
     if (mlp_uses_rows(r.c, nrows)) {
         MlpRowsParams q{};
         q.h = h;
@@ -1096,9 +1109,16 @@ static int prepare(const Run& r, const float* t_dev, const float* t_host) {
         float* rel = (float*)(r.ws + r.lay.rel7);
         const long BL = (long)r.B * r.L;
         // x_f = (start^-1 o end).to_tensor_7(), x_r = (end^-1 o start).to_tensor_7()   (latent_model.py:194-195)
-        launch_rel7(r.start_rot, r.start_trans, r.end_rot, r.end_trans, rel, BL, r.s);
-        launch_rel7(r.end_rot, r.end_trans, r.start_rot, r.start_trans, rel + BL * 7, BL, r.s);
-        LAUNCHCHK();
+        // The quaternion's SIGN is whatever torch.linalg.eigh returns in the reference (rigid_utils.py:191-210) and it does
+        // reach a Linear: a caller that needs the reference's exact inputs passes its own to_tensor_7() outputs (rel7_in);
+        // otherwise the library computes them with the sign fixed to w >= 0.
+        if (r.rel7_in) {
+            HIPCHK(hipMemcpyAsync(rel, r.rel7_in, (size_t)2 * BL * 7 * 4, hipMemcpyDeviceToDevice, r.s));
+        } else {
+            launch_rel7(r.start_rot, r.start_trans, r.end_rot, r.end_trans, rel, BL, r.s);
+            launch_rel7(r.end_rot, r.end_trans, r.start_rot, r.start_trans, rel + BL * 7, BL, r.s);
+            LAUNCHCHK();
+        }
         float* h2 = (float*)(r.ws + r.lay.h_ipa);
         // x_r stream runs on the start frames, x_f stream on the end frames (latent_model.py:203-205)
         if (int e = ipa_stack(r, ipa_out, rel + BL * 7, c->wr7, c->br7, r.start_rot, r.start_trans)) return e;
@@ -1220,8 +1240,8 @@ static int make_run(Run* r, mdgen_ctx* c, const mdgen_shape* sh, int S, int t_sh
 
 extern "C" int32_t mdgen_denoiser_forward(mdgen_ctx* c, const mdgen_shape* sh, const float* x, const float* t,
                                           const float* mask, const float* start_rot, const float* start_trans,
-                                          const float* end_rot, const float* end_trans, const float* x_cond,
-                                          const int64_t* x_cond_mask, const int64_t* aatype, float* out,
+                                          const float* end_rot, const float* end_trans, const float* rel7,
+                                          const float* x_cond, const int64_t* x_cond_mask, const int64_t* aatype, float* out,
                                           float* trace_h, float* trace_ipa, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !t || !mask || !start_rot || !start_trans || !x_cond || !x_cond_mask || !aatype || !out)
         return fail(-1, "null tensor argument");
@@ -1233,6 +1253,7 @@ extern "C" int32_t mdgen_denoiser_forward(mdgen_ctx* c, const mdgen_shape* sh, c
     r.start_trans = start_trans;
     r.end_rot = end_rot;
     r.end_trans = end_trans;
+    r.rel7_in = rel7;
     r.x_cond = x_cond;
     r.x_cond_mask = x_cond_mask;
     r.aatype = aatype;
@@ -1349,9 +1370,9 @@ static int replay_or_capture(mdgen_ctx* c, const std::vector<uint64_t>& key, hip
 
 extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32_t S, float* x, const float* mask,
                                       const float* start_rot, const float* start_trans, const float* end_rot,
-                                      const float* end_trans, const float* x_cond, const int64_t* x_cond_mask,
-                                      const int64_t* aatype, void* ws, size_t ws_bytes, int32_t use_graph,
-                                      void* stream) {
+                                      const float* end_trans, const float* rel7, const float* x_cond,
+                                      const int64_t* x_cond_mask, const int64_t* aatype, void* ws, size_t ws_bytes,
+                                      int32_t use_graph, void* stream) {
     if (!x || !mask || !start_rot || !start_trans || !x_cond || !x_cond_mask || !aatype)
         return fail(-1, "null tensor argument");
     Run r{};
@@ -1361,6 +1382,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     r.start_trans = start_trans;
     r.end_rot = end_rot;
     r.end_trans = end_trans;
+    r.rel7_in = rel7;
     r.x_cond = x_cond;
     r.x_cond_mask = x_cond_mask;
     r.aatype = aatype;
@@ -1371,7 +1393,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
                                  (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12), (uint64_t)c->opt_precision,
-                                 (uint64_t)c->opt_attn_path};
+                                 (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
 
@@ -1411,7 +1433,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     auto body = [&]() -> int {
         for (int b = 0; b < n_blocks; ++b) {
             float* x = zs + (long)b * blk;
-            launch_prep_latents(r.B, r.T, r.L, 0, 1, cond_rots, cond_trans, cond_torsions, nullptr, x_cond, x_cond_mask, r.s);
+            launch_prep_latents(r.B, r.T, r.L, 0, 1, 0, cond_rots, cond_trans, cond_torsions, nullptr, x_cond, x_cond_mask, r.s);
             LAUNCHCHK();
             if (int e = euler_body(r, tg, x)) return e;
             launch_samples_to_atom14(r.B, r.T, r.L, r.D, 0, x, cond_rots, cond_trans, seqres, t.default_frames,
@@ -1530,13 +1552,14 @@ extern "C" int32_t mdgen_rot_to_quat(int64_t n, const float* rot, float* q, void
     LAUNCHCHK();
     return 0;
 }
-extern "C" int32_t mdgen_prep_latents(const mdgen_shape* sh, int32_t tps, const float* rots, const float* trans,
+extern "C" int32_t mdgen_prep_latents(const mdgen_shape* sh, int32_t tps, int32_t cond_interval, const float* rots, const float* trans,
                                       const float* torsions, float* latents, float* x_cond, int64_t* x_cond_mask,
                                       void* stream) {
     if (!sh) return fail(-1, "null shape");
     NONNULL(rots, trans, torsions, latents, x_cond, x_cond_mask);
     if (sh->B < 1 || sh->T < 1 || sh->L < 1) return fail(-2, "B, T, L must be >= 1");
-    launch_prep_latents(sh->B, sh->T, sh->L, tps, 0, rots, trans, torsions, latents, x_cond, x_cond_mask,
+    if (cond_interval < 0) return fail(-2, "cond_interval must be >= 0 (0 = none)");
+    launch_prep_latents(sh->B, sh->T, sh->L, tps, 0, cond_interval, rots, trans, torsions, latents, x_cond, x_cond_mask,
                         (hipStream_t)stream);
     LAUNCHCHK();
     return 0;

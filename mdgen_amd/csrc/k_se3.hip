@@ -265,7 +265,9 @@ __global__ void k_rel7(const float* r1, const float* t1, const float* r2, const 
 // NewMDGenWrapper.prep_batch latents (wrapper.py:298-327,339-342,362) + get_offsets (utils.py:7-14)
 // BCAST: rots / trans / tors hold ONE frame per (b, l) that stands for every t (the rollout's conditioning frame
 // expanded over T, sim_inference.py:72-79) -- same arithmetic on the same values, without materialising the copies.
-__global__ void k_prep_latents(int B, int T, int L, int tps, int bcast, const float* rots, const float* trans,
+// cond_interval > 0: additionally every cond_interval-th frame is a conditioning frame (wrapper.py:343-344, the
+// upsampling models).
+__global__ void k_prep_latents(int B, int T, int L, int tps, int bcast, int cond_interval, const float* rots, const float* trans,
                                const float* tors, float* latents, float* x_cond, int64_t* x_cond_mask) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long N = (long)B * T * L;
@@ -305,7 +307,7 @@ __global__ void k_prep_latents(int B, int T, int L, int tps, int bcast, const fl
     const int toff = tps ? 14 : 7;
 #pragma unroll
     for (int k = 0; k < 14; ++k) lat[toff + k] = tors[src * 14 + k];
-    const bool cond = (t == 0) || (tps && t == T - 1);
+    const bool cond = (t == 0) || (tps && t == T - 1) || (cond_interval > 0 && t % cond_interval == 0);
     for (int k = 0; k < D; ++k) {
         if (latents) latents[i * D + k] = lat[k];
         x_cond[i * D + k] = cond ? lat[k] : 0.f;
@@ -491,10 +493,10 @@ void launch_rot_to_quat(long n, const float* rot, float* q, hipStream_t s) {
 void launch_rel7(const float* r1, const float* t1, const float* r2, const float* t2, float* out7, long n, hipStream_t s) {
     hipLaunchKernelGGL(k_rel7, GRID1D(n), r1, t1, r2, t2, out7, n);
 }
-void launch_prep_latents(int B, int T, int L, int tps, int bcast, const float* rots, const float* trans,
+void launch_prep_latents(int B, int T, int L, int tps, int bcast, int cond_interval, const float* rots, const float* trans,
                          const float* tors, float* latents, float* x_cond, int64_t* x_cond_mask, hipStream_t s) {
     const long n = (long)B * T * L;
-    hipLaunchKernelGGL(k_prep_latents, GRID1D(n), B, T, L, tps, bcast, rots, trans, tors, latents, x_cond, x_cond_mask);
+    hipLaunchKernelGGL(k_prep_latents, GRID1D(n), B, T, L, tps, bcast, cond_interval, rots, trans, tors, latents, x_cond, x_cond_mask);
 }
 void launch_samples_to_atom14(int B, int T, int L, int D, int tps, const float* samples, const float* rot0,
                               const float* trans0, const int64_t* seqres, const float* default_frames,

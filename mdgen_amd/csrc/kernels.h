@@ -270,7 +270,7 @@ void launch_quat_to_rot(long n, const float* q, int normalize, float* rot, hipSt
 void launch_from_3_points(long n, const float* pnx, const float* org, const float* pxy, float* rot, float* trans,
                           hipStream_t s);
 void launch_rot_to_quat(long n, const float* rot, float* q, hipStream_t s);
-void launch_prep_latents(int B, int T, int L, int tps, int bcast, const float* rots, const float* trans,
+void launch_prep_latents(int B, int T, int L, int tps, int bcast, int cond_interval, const float* rots, const float* trans,
                          const float* tors, float* latents, float* x_cond, int64_t* x_cond_mask, hipStream_t s);
 void launch_samples_to_atom14(int B, int T, int L, int D, int tps, const float* samples, const float* rot0,
                               const float* trans0, const int64_t* seqres, const float* default_frames,

@@ -180,8 +180,21 @@ class LatentMDGenModel:
             raise L.MdgenError(f"mask must be (B,T,L)={B, T, L_}, got {tuple(mask.shape)}")
         return B, T, L_
 
+    def _rel7(self, rel_quats, B, L_):
+        """Optional relative-frame inputs of the two-sided model, (2,B,L,7): [0] = (start^-1 o end).to_tensor_7(), [1] =
+        (end^-1 o start).to_tensor_7() (latent_model.py:193-195) as the CALLER's reference computed them -- their quaternion
+        sign is torch.linalg.eigh's (rigid_utils.py:191-210).  None: the library computes them with w >= 0."""
+        if rel_quats is None:
+            return None
+        if not self.cfg.tps_condition:
+            raise L.MdgenError("rel_quats is an input of tps_condition models only")
+        if tuple(rel_quats.shape) != (2, B, L_, 7):
+            raise L.MdgenError(f"rel_quats must be (2,B,L,7)={(2, B, L_, 7)}, got {tuple(rel_quats.shape)}")
+        require_cuda(rel_quats)
+        return rel_quats.to(torch.float32).contiguous()
+
     def forward(self, x, t, mask, start_frames=None, end_frames=None, x_cond=None, x_cond_mask=None, aatype=None,
-                return_trace: bool = False):
+                return_trace: bool = False, rel_quats=None):
         """latent_model.py:212-260 (non-design path).  Returns the velocity (B,T,L,D) fp32."""
         if self._pre_run is not None:
             self._pre_run()
@@ -203,9 +216,10 @@ class LatentMDGenModel:
         tr_h = torch.empty(nl + 1, B * T * L_, self.cfg.embed_dim, device=x.device) if return_trace else None
         tr_i = torch.empty(B * L_, self.cfg.embed_dim, device=x.device) if return_trace else None
         sh = L.Shape(B, T, L_)
+        rel7 = self._rel7(rel_quats, B, L_)
         with torch.cuda.device(self.device):
             check(lib.mdgen_denoiser_forward(self._ctx, C.byref(sh), ptr(x), ptr(t), ptr(mask), ptr(sr), ptr(st),
-                                             ptr(er), ptr(et), ptr(x_cond), ptr(x_cond_mask), ptr(aatype), ptr(out),
+                                             ptr(er), ptr(et), ptr(rel7), ptr(x_cond), ptr(x_cond_mask), ptr(aatype), ptr(out),
                                              ptr(tr_h), ptr(tr_i), ptr(ws), ws.numel(), L.stream_ptr()))
         if return_trace:
             C_ = self.cfg.embed_dim
@@ -220,7 +234,7 @@ class LatentMDGenModel:
 
     # ---- Euler rollout ----------------------------------------------------------------------
     def sample_euler(self, zs, num_steps: int, mask=None, start_frames=None, end_frames=None, x_cond=None,
-                     x_cond_mask=None, aatype=None, use_graph: bool = True):
+                     x_cond_mask=None, aatype=None, use_graph: bool = True, rel_quats=None):
         """x <- zs; for i < S: x += (t[i+1]-t[i]) * model(x, t[i]) on t = linspace(0,1,S+1); returns x.
         (transport.py:408-451 + integrators.py:95-114 + torchdiffeq fixed-grid Euler.)"""
         if self._pre_run is not None:
@@ -247,7 +261,8 @@ class LatentMDGenModel:
                 er=torch.empty(B, L_, 3, 3, device=dev), et=torch.empty(B, L_, 3, device=dev),
                 x_cond=torch.empty(B, T, L_, self.cfg.latent_dim, device=dev),
                 x_cond_mask=torch.empty(B, T, L_, dtype=torch.int64, device=dev),
-                aatype=torch.empty(B, L_, dtype=torch.int64, device=dev))
+                aatype=torch.empty(B, L_, dtype=torch.int64, device=dev),
+                rel7=torch.empty(2, B, L_, 7, device=dev) if self.cfg.tps_condition else None)
             self._stage[key] = stg
         stg["x"].copy_(zs)
         stg["mask"].copy_(mask)
@@ -260,6 +275,9 @@ class LatentMDGenModel:
         stg["x_cond_mask"].copy_(x_cond_mask)
         stg["aatype"].copy_(aatype)
         has_end = er is not None
+        rel7 = self._rel7(rel_quats, B, L_)
+        if rel7 is not None:
+            stg["rel7"].copy_(rel7)
         sh = L.Shape(B, T, L_)
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream()
@@ -272,7 +290,8 @@ class LatentMDGenModel:
                 stream = cur
             check(lib.mdgen_sample_euler(
                 self._ctx, C.byref(sh), S, ptr(stg["x"]), ptr(stg["mask"]), ptr(stg["sr"]), ptr(stg["st"]),
-                ptr(stg["er"]) if has_end else None, ptr(stg["et"]) if has_end else None, ptr(stg["x_cond"]),
+                ptr(stg["er"]) if has_end else None, ptr(stg["et"]) if has_end else None,
+                ptr(stg["rel7"]) if rel7 is not None else None, ptr(stg["x_cond"]),
                 ptr(stg["x_cond_mask"]), ptr(stg["aatype"]), ptr(ws), ws.numel(), int(use_graph),
                 C.c_void_p(stream.cuda_stream)))
             if use_graph:

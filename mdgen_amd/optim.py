@@ -53,6 +53,36 @@ class FlatParams:
         return OrderedDict((k, self.view(buf, k)) for k in self.shapes)
 
 
+def adam_state_to_torch(named: dict, order: Sequence[str]) -> dict:
+    """The by-name optimiser state of `Adam.state_dict` -> the layout `torch.optim.Adam.state_dict()` has in a Lightning
+    checkpoint of the reference (`optimizer_states[0]`): `state[i]` for the i-th parameter of `model.parameters()` (= `order`,
+    the reference's registration order, `train.trainable_shapes`) and one param group."""
+    state = {i: {"step": torch.tensor(float(named["step"])), "exp_avg": named["exp_avg"][k], "exp_avg_sq": named["exp_avg_sq"][k]}
+             for i, k in enumerate(order)}
+    group = {"lr": named["lr"], "betas": tuple(named["betas"]), "eps": named["eps"], "weight_decay": named["weight_decay"],
+             "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+             "params": list(range(len(order)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def adam_state_from_torch(sd: dict, order: Sequence[str]) -> dict:
+    """Inverse of `adam_state_to_torch`: accepts what torch.optim.Adam / AdamW saved (a reference checkpoint).  A parameter
+    without state (never stepped) gets zero moments; the step count is the largest per-parameter step."""
+    ids = [i for g in sd["param_groups"] for i in g["params"]]
+    if len(ids) != len(order):
+        raise MdgenError(f"optimizer state has {len(ids)} parameters, the model has {len(order)}")
+    g0 = sd["param_groups"][0]
+    out = {"step": 0, "lr": g0.get("lr"), "betas": tuple(g0.get("betas", (0.9, 0.999))), "eps": g0.get("eps", 1e-8),
+           "weight_decay": g0.get("weight_decay", 0.0), "exp_avg": OrderedDict(), "exp_avg_sq": OrderedDict()}
+    for i, k in zip(ids, order):
+        st = sd["state"].get(i)
+        out["exp_avg"][k] = None if st is None else st["exp_avg"]
+        out["exp_avg_sq"][k] = None if st is None else st["exp_avg_sq"]
+        if st is not None:
+            out["step"] = max(out["step"], int(float(st["step"])))
+    return out
+
+
 class Adam:
     """torch.optim.Adam / AdamW over a `FlatParams` (wrapper.py:167-172: `cls(params, lr=args.lr)` with torch's
     defaults betas (0.9, 0.999), eps 1e-8, weight_decay 0 / 0.01), with Lightning's `gradient_clip_val` (train.py:56:
@@ -81,11 +111,21 @@ class Adam:
                 "exp_avg": OrderedDict((k, v.detach().cpu().clone()) for k, v in self.params.state_dict(self.exp_avg).items()),
                 "exp_avg_sq": OrderedDict((k, v.detach().cpu().clone()) for k, v in self.params.state_dict(self.exp_avg_sq).items())}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, order: Optional[Sequence[str]] = None):
+        """`sd`: this class's by-name layout, or torch.optim's ({"state", "param_groups"}: a reference checkpoint) -- then
+        `order` names the parameters in the reference's `model.parameters()` order."""
+        if "param_groups" in sd:
+            if order is None:
+                raise MdgenError("a torch-format optimizer state needs the parameter order")
+            sd = adam_state_from_torch(sd, order)
         self.step_count = int(sd["step"])
         for name, buf in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
             for k in self.params.shapes:
-                self.params.view(buf, k).copy_(sd[name][k].to(torch.float32))
+                v = sd[name][k]
+                if v is None:
+                    self.params.view(buf, k).zero_()
+                else:
+                    self.params.view(buf, k).copy_(v.to(torch.float32).reshape(self.params.shapes[k]))
         return self
 
     def grad_norm(self, grads: torch.Tensor, grad_scale: float = 1.0) -> torch.Tensor:

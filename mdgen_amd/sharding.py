@@ -42,3 +42,16 @@ def sum_over_ranks(value: float, dist=None, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_over_ranks(value: float, dist=None, device=None) -> List[float]:
+    """`value` of every rank, in rank order (per-rank timings of a weak-scaling run: stragglers show up here)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    import torch
+    if device is None and dist.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]

@@ -185,3 +185,35 @@ def tensor_checksum(d: dict) -> np.ndarray:
     """[sum, sum of |.|] over all tensors of a dict in float64: detects drift of a seeded generator."""
     return np.array([sum(float(v.double().sum()) for v in d.values()),
                      sum(float(v.double().abs().sum()) for v in d.values())])
+
+
+def synth_batch(B, T, L, n_pad, dev, seed, tps=False):
+    """Self-consistent synthetic conditioning batch: random frames + torsions ->
+    atom14 (sampler post-processing kernel) -> conditioning frame (rollout-glue kernel), first frame
+    expanded over T (sim_inference.py:72-79); trailing `n_pad` residues padded (dataset.py:80-89)."""
+    from .geometry import atom14_to_cond, samples_to_atom14
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, L, 4, generator=g)
+    q = (q / q.norm(dim=-1, keepdim=True)).to(dev)
+    from .rigid_utils import Rotation
+    R = Rotation(quats=q).get_rot_mats()
+    tr = torch.cumsum(2.2 * torch.randn(B, L, 3, generator=g), 1).to(dev)
+    ang = 6.283185307 * torch.rand(B, L, 7, generator=g)
+    seqres = torch.randint(0, 20, (B, L), generator=g).to(dev)
+    lat = torch.zeros(B, 1, L, 21, device=dev)
+    lat[..., 0] = 1.0
+    lat[..., 7:21] = torch.stack([ang.sin(), ang.cos()], -1).reshape(B, 1, L, 14).to(dev)
+    atom14 = samples_to_atom14(lat, R, tr, seqres, tps=False)[:, 0]
+    c = atom14_to_cond(atom14, seqres)
+    mask = torch.ones(B, L, device=dev)
+    if n_pad:
+        mask[:, L - n_pad:] = 0
+        seqres[:, L - n_pad:] = 0
+    out = {"torsions": c["torsions"][:, None].expand(B, T, L, 7, 2).contiguous(),
+           "torsion_mask": c["torsion_mask"], "trans": c["trans"][:, None].expand(B, T, L, 3).contiguous(),
+           "rots": c["rots"][:, None].expand(B, T, L, 3, 3).contiguous(), "seqres": seqres, "mask": mask}
+    if tps:   # two-sided conditioning: frame -1 is a second, different conformation (tps_inference.py:58-66)
+        e = synth_batch(B, 1, L, n_pad, dev, seed + 7919)
+        for k in ("torsions", "trans", "rots"):
+            out[k][:, -1] = e[k][:, 0]
+    return out

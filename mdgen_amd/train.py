@@ -19,7 +19,7 @@ from . import _lib as L
 from ._lib import lib, check, ptr, require_cuda
 from .config import ModelConfig
 from .model import LatentMDGenModel, _frames
-from .optim import Adam, EMA, FlatParams, GradBucketer
+from .optim import Adam, EMA, FlatParams, GradBucketer, adam_state_to_torch
 from .synthetic import state_shapes
 
 FROZEN = ("pos_embed",)          # registered as buffers in the reference (latent_model.py:116-121): no gradient
@@ -141,11 +141,14 @@ class TrainableModel:
     def zero_grad(self):
         self.grads.zero_()
 
-    def forward_backward(self, xt, t, target, loss_mask, mask, start_frames, x_cond, x_cond_mask, aatype, end_frames=None):
+    def forward_backward(self, xt, t, target, loss_mask, mask, start_frames, x_cond, x_cond_mask, aatype, end_frames=None,
+                         rel_quats=None):
         """loss[b] and pred; d mean_b(loss) / d theta is ADDED into self.grads.  `end_frames`: the two-sided (TPS) model's
-        second conditioning frames (latent_model.py:193-205)."""
+        second conditioning frames (latent_model.py:193-205); `rel_quats`: optionally its relative-frame 7-vectors as the
+        caller's reference computed them (`LatentMDGenModel._rel7`)."""
         m = self.model
         B, T, L_, D = xt.shape
+        rel7 = m._rel7(rel_quats, B, L_)
         xt = xt.to(torch.float32).contiguous()
         t = t.to(torch.float32).contiguous()
         target = target.to(torch.float32).contiguous()
@@ -170,8 +173,8 @@ class TrainableModel:
         pred = torch.empty_like(xt)
         with torch.cuda.device(self.device):
             check(lib.mdgen_train_forward_backward(
-                m._ctx, C.byref(sh), ptr(xt), ptr(t), ptr(mask), ptr(sr), ptr(st), ptr(er), ptr(et), ptr(x_cond), ptr(x_cond_mask),
-                ptr(aatype),
+                m._ctx, C.byref(sh), ptr(xt), ptr(t), ptr(mask), ptr(sr), ptr(st), ptr(er), ptr(et), ptr(rel7), ptr(x_cond),
+                ptr(x_cond_mask), ptr(aatype),
                 ptr(target), ptr(loss_mask), ptr(loss), ptr(pred), ptr(self.grads), self._goff, ptr(ws), ws.numel(),
                 ptr(self._tape), self._tape.numel(), L.stream_ptr()))
         return loss, pred
@@ -189,6 +192,7 @@ class Trainer:
     def __init__(self, wrapper, lr: float = 1e-4, adamw: bool = False, grad_clip: Optional[float] = 1.0,
                  ema_decay: Optional[float] = None, dist=None, state_dict=None):
         self.wrapper = wrapper                    # a NewMDGenWrapper whose .model is replaced by the trainable model's
+        wrapper.trainer = self                    # (load_ema_weights caches the trainer's CURRENT weights, not the loaded ones)
         sd = state_dict if state_dict is not None else getattr(wrapper, "model_state_dict", None)
         if sd is None:
             raise L.MdgenError("Trainer needs the model's state dict: load the wrapper with load_model_state_dict() / "
@@ -227,6 +231,8 @@ class Trainer:
         if ctx is not None and getattr(ctx, "_ctx", None) and getattr(self, "_events", None):
             lib.mdgen_train_set_milestone_events(ctx._ctx, None, 0)
         self._events = []
+        if getattr(getattr(self, "wrapper", None), "trainer", None) is self:
+            self.wrapper.trainer = None
 
     def __del__(self):
         try:
@@ -287,7 +293,9 @@ class Trainer:
         sd = self.tm.state_dict()
         ckpt = {"state_dict": OrderedDict(("model." + k, v.detach().cpu().clone()) for k, v in sd.items()),
                 "hyper_parameters": {"args": self.wrapper.args},
-                "optimizer_states": [self.opt.state_dict()], "global_step": self.global_step}
+                # torch.optim.Adam's own layout (what Lightning stores and the reference's trainer can resume from)
+                "optimizer_states": [adam_state_to_torch(self.opt.state_dict(), list(trainable_shapes(self.wrapper.cfg)))],
+                "global_step": self.global_step}
         if self.ema is not None:
             e = self.ema.state_dict()
             ckpt["ema"] = {"params": OrderedDict((k, v.detach().cpu().clone()) for k, v in e["params"].items()),
@@ -300,11 +308,19 @@ class Trainer:
         self.tm.params.load_state_dict(sd)
         self.tm.mark_updated()
         if ckpt.get("optimizer_states"):
-            self.opt.load_state_dict(ckpt["optimizer_states"][0])
+            self.opt.load_state_dict(ckpt["optimizer_states"][0], order=list(trainable_shapes(self.wrapper.cfg)))
         if self.ema is not None and "ema" in ckpt:
             self.ema.load_state_dict(ckpt["ema"])
         self.global_step = int(ckpt.get("global_step", 0))
         return self
+
+
+def shard_epoch(order, rank: int, world: int, batch_size: int):
+    """Rank `rank`'s strided shard of an epoch's (already permuted) item list and its step count -- the SAME count on every
+    rank: the list is cut to n * batch_size * world items first (DistributedSampler(drop_last) semantics), so no rank enters a
+    bucketed all-reduce the others have already left behind."""
+    n = (len(order) // world) // batch_size
+    return order[:n * batch_size * world][rank::world], n
 
 
 def main(argv=None):
@@ -385,7 +401,7 @@ def main(argv=None):
     np.random.seed(a.seed + rank)
     torch.manual_seed(a.seed + rank)
     if a.synthetic:
-        import bench as _bench   # repository root: synthetic conditioning batch (frames, torsions) shared with bench.py
+        from . import synthetic as _bench   # synthetic conditioning batch (frames, torsions) shared with bench.py
         def batches(epoch):
             for i in range(a.synthetic):
                 yield _bench.synth_batch(a.batch_size, a.num_frames, a.crop, 16 if a.crop >= 64 else 0, dev,
@@ -395,8 +411,7 @@ def main(argv=None):
         ds = MDGenDataset(a, split=a.train_split, device=dev)
         def batches(epoch):
             g = torch.Generator().manual_seed(a.seed + epoch)      # same permutation on every rank, disjoint strided shards
-            order = torch.randperm(len(ds), generator=g).tolist()[rank::world]
-            n = len(order) // a.batch_size
+            order, n = shard_epoch(torch.randperm(len(ds), generator=g).tolist(), rank, world, a.batch_size)
             if a.train_batches:
                 n = min(n, a.train_batches)
             for i in range(n):
@@ -413,8 +428,7 @@ def main(argv=None):
                 yield _bench.synth_batch(a.batch_size, a.num_frames, a.crop, 16 if a.crop >= 64 else 0, dev,
                                          seed=900000 + 10 * i + rank, tps=a.tps_condition)
         elif val_ds is not None:
-            idx = list(range(len(val_ds)))[rank::world]
-            n = len(idx) // a.batch_size
+            idx, n = shard_epoch(list(range(len(val_ds))), rank, world, a.batch_size)
             if a.val_batches:
                 n = min(n, a.val_batches)
             for i in range(n):

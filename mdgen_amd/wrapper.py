@@ -23,7 +23,7 @@ _BACKFILL = ["inpainting", "no_torsion", "hyena", "no_aa_emb", "supervise_all_to
              "design_key_frames", "no_design_torsion", "cond_interval", "mpnn", "dynamic_mpnn", "no_offsets",
              "no_frames", "design", "tps_condition", "sim_condition", "abs_pos_emb", "prepend_ipa", "oracle"]
 _UNSUPPORTED = ["inpainting", "hyena", "no_aa_emb", "design_key_frames", "mpnn", "dynamic_mpnn", "no_offsets",
-                "no_frames", "design", "no_torsion", "no_design_torsion", "cond_interval", "interleave_ipa",
+                "no_frames", "design", "no_torsion", "no_design_torsion", "interleave_ipa",
                 "abs_time_emb", "oracle", "no_rope"]
 
 
@@ -79,7 +79,10 @@ class NewMDGenWrapper:
             ema_params = self.ema_state["params"]
         if not hasattr(self, "model_state_dict"):
             raise L.MdgenError("load_ema_weights needs the raw weights to restore later: use load_model_state_dict()")
-        self.cached_weights = self.model_state_dict
+        # the weights to restore are the CURRENT ones: a Trainer attached to this wrapper has moved on from what was loaded
+        tr = getattr(self, "trainer", None)
+        self.cached_weights = ({k: v.detach().clone() for k, v in tr.tm.state_dict().items()} if tr is not None
+                               else self.model_state_dict)
         self.model.load_state_dict({k: v for k, v in ema_params.items()})
         return self
 
@@ -117,7 +120,8 @@ class NewMDGenWrapper:
         x_cond = torch.empty(B, T, L_, D, device=dev)
         cond_mask = torch.empty(B, T, L_, dtype=torch.int64, device=dev)
         sh = L.Shape(B, T, L_)
-        launch(lib.mdgen_prep_latents, trans, C.byref(sh), int(tps), ptr(rots), ptr(trans), ptr(tors), ptr(latents),
+        launch(lib.mdgen_prep_latents, trans, C.byref(sh), int(tps), int(getattr(self.args, "cond_interval", 0) or 0),
+               ptr(rots), ptr(trans), ptr(tors), ptr(latents),
                ptr(x_cond), ptr(cond_mask))
         rigids = Rigid(Rotation(rot_mats=rots), trans)
         mask = batch["mask"].to(torch.float32)
@@ -154,10 +158,11 @@ class NewMDGenWrapper:
                                              mask=prep["loss_mask"], model_kwargs=prep["model_kwargs"], t=t, x0=x0)
         return out["loss"], out
 
-    def inference(self, batch, zs=None, num_steps=None, use_graph=True):
+    def inference(self, batch, zs=None, num_steps=None, use_graph=True, rel_quats=None):
         """wrapper.py:405-484.  Extra keywords (defaults reproduce the reference): `zs` explicit noise
         (reference: device randn, wrapper.py:439), `num_steps` Euler steps S (reference: 50 grid points = 49
-        steps, wrapper.py:441-442 / transport.py:412)."""
+        steps, wrapper.py:441-442 / transport.py:412), `rel_quats` (two-sided models): the relative-frame 7-vectors
+        (2,B,L,7) as the caller's reference computes them (`LatentMDGenModel._rel7`; default: w >= 0 convention)."""
         prep = self.prep_batch(batch)
         rigids = prep["rigids"]
         B, T, L_ = rigids.shape
@@ -176,6 +181,8 @@ class NewMDGenWrapper:
         kw["mask"] = kw["mask"].contiguous()
         if not self.args.tps_condition:
             kw["end_frames"] = None
+        if rel_quats is not None:
+            kw["rel_quats"] = rel_quats
         sample_fn = self.transport_sampler.sample_ode(sampling_method="euler", num_steps=S + 1)
         samples = sample_fn(zs, partial(self.model.forward_inference, **kw), use_graph=use_graph)[-1]
         r0 = rigids[:, 0]
@@ -194,8 +201,8 @@ class NewMDGenWrapper:
         (reference: a fresh device randn per block, wrapper.py:439).  Returns atom14 (B, num_rollouts*T, L, 14, 3)
         [, the batch that would condition the next block]."""
         from .geometry import residue_tables
-        if self.args.tps_condition:
-            raise L.MdgenError("rollout() is the forward-simulation driver (sim_condition models)")
+        if self.args.tps_condition or getattr(self.args, "cond_interval", None):
+            raise L.MdgenError("rollout() is the forward-simulation driver (sim_condition models without cond_interval)")
         method = getattr(self.args, "sampling_method", "euler")
         if num_steps is None and method != "euler":
             raise L.MdgenError(f"checkpoint args say sampling_method={method!r}; pass num_steps=... to sample with Euler")

@@ -53,8 +53,11 @@ def ref_args(cfg: ModelConfig):
     return argparse.Namespace(**a)
 
 
-def build(cfg, seed):
-    m = NewMDGenWrapper(ref_args(cfg)).eval()
+def build(cfg, seed, **overrides):
+    a = ref_args(cfg)
+    for k, v in overrides.items():
+        setattr(a, k, v)
+    m = NewMDGenWrapper(a).eval()
     sd = synth_state_dict(cfg, seed)
     m.model.load_state_dict(sd)
     chk = np.array([sum(float(v.double().sum()) for v in sd.values()),
@@ -163,6 +166,12 @@ def gen_forward(name, cfg, seed, B, T, L, n_pad, data_seed, keep=("ipa_out", "h0
     nl = cfg.num_layers
     extra = {k: tr[k] for k in keep}
     extra[f"h{nl}"] = tr[f"h{nl}"]
+    if cfg.tps_condition:
+        # the relative-frame inputs exactly as the reference's forward computes them (latent_model.py:194-195): the quaternion
+        # SIGN is whatever torch.linalg.eigh returned here (rigid_utils.py:191-210); a caller hands them to the library as `rel7`
+        sf = Rigid(trans=st, rots=Rotation(rot_mats=sR))
+        ef = Rigid(trans=et, rots=Rotation(rot_mats=eR))
+        extra["rel7"] = torch.stack([sf.invert().compose(ef).to_tensor_7(), ef.invert().compose(sf).to_tensor_7()])
     save(name, cfg=str(cfg.to_dict()), seed=seed, weight_checksum=chk, x=x, t=t, mask=mask_btl,
          start_rot=sR, start_trans=st, end_rot=eR, end_trans=et, x_cond=x_cond, x_cond_mask=cm,
          aatype=aatype, out=out, **extra)
@@ -191,18 +200,18 @@ def gen_forward_big(name, cfg, seed, B, T, L, n_pad, data_seed, sub):
                          float(tr["h0"].double().norm()), float(tr[f"h{nl}"].double().norm())]))
 
 
-def gen_prep(name, cfg, B, T, L, data_seed):
+def gen_prep(name, cfg, B, T, L, data_seed, cond_interval=None):
     g = torch.Generator().manual_seed(data_seed)
     m, _ = build(ModelConfig(embed_dim=48, mha_heads=2, num_layers=1, crop=L, num_frames=T,
                              abs_pos_emb=cfg.abs_pos_emb, sim_condition=cfg.sim_condition,
-                             tps_condition=cfg.tps_condition), 0)
+                             tps_condition=cfg.tps_condition), 0, cond_interval=cond_interval)
     seqres = torch.randint(0, 20, (B, L), generator=g)
     atom14 = synth_structure(g, B, T, L, seqres)
     batch = get_batch_like_sim_inference(atom14, seqres)
     batch["mask"][-1, -1] = 0
     prep = m.prep_batch(batch)
     kw = prep["model_kwargs"]
-    save(name, cfg=str(cfg.to_dict()), atom14=atom14,
+    save(name, cfg=str(cfg.to_dict()), atom14=atom14, cond_interval=np.array(cond_interval or 0),
          **{"in_" + k: v for k, v in batch.items()},
          latents=prep["latents"], loss_mask=prep["loss_mask"].contiguous(), x_cond=kw["x_cond"],
          x_cond_mask=kw["x_cond_mask"], mask=kw["mask"].contiguous(), aatype=kw["aatype"],
@@ -313,6 +322,39 @@ def gen_rigid(name, data_seed):
          offsets=off, p3a=p3a, p3b=p3b, p3c=p3c, f3_R=f3.get_rots().get_rot_mats(), f3_t=f3.get_trans())
 
 
+def gen_rigid_views(name, data_seed):
+    """SURVEY rows r-7 / r-8 (view-level `Rigid` / `Rotation` operations, no arithmetic beyond a mask product) evaluated by the
+    REFERENCE's classes (rigid_utils.py:820-862, 892-942, 1122-1141, 1220-1261) on a (2, 5) batch of frames."""
+    g = torch.Generator().manual_seed(data_seed)
+    R = rand_rot(g, 2, 5)
+    t = torch.randn(2, 5, 3, generator=g)
+    q = torch.randn(2, 5, 4, generator=g)
+    mk = torch.tensor([[1., 0, 1, 0, 1], [0, 1, 0, 1, 0]])
+    r = Rigid(Rotation(rot_mats=R), t)
+    rm = lambda x: x.get_rots().get_rot_mats()
+    out = dict(R=R, t=t, q=q, mk=mk)
+    a, b = Rigid(Rotation(rot_mats=R), None), Rigid(None, t)
+    out.update(fill_t=a.get_trans(), fill_R=rm(b))
+    i = Rigid.identity((4, 3), fmt="rot_mat")
+    out.update(ident_R=rm(i), ident_t=i.get_trans())
+    for key, v in (("idx_col", r[:, 0:1]), ("idx_row", r[1]), ("idx_ell", r[..., 3]), ("idx_none", r[..., None]),
+                   ("unsq_last", r.unsqueeze(-1)), ("unsq_first", r.unsqueeze(0)),
+                   ("cat1", Rigid.cat([r, r[:, :2]], dim=1)), ("cat_last", Rigid.cat([r, r], dim=-1)), ("mul", r * mk),
+                   ("map_sum", (Rigid(Rotation(rot_mats=R), t) * mk).map_tensor_fn(lambda x: torch.sum(x, dim=-1)))):
+        out[key + "_R"], out[key + "_t"] = rm(v), v.get_trans()
+    out["rotcat_R"] = Rotation.cat([Rotation(rot_mats=R), Rotation(rot_mats=R)], dim=0).get_rot_mats()
+    rq = Rotation(quats=q, normalize_quats=True)
+    out.update(quat_norm=rq.get_quats(), quat_idx=rq[0].get_quats(), quat_unsq=rq.unsqueeze(1).get_quats(),
+               quat_raw=Rotation(quats=q, normalize_quats=False).get_quats())
+    T4 = torch.zeros(2, 5, 4, 4)
+    T4[..., :3, :3], T4[..., :3, 3], T4[..., 3, 3] = R, t, 1.0
+    f = Rigid.from_tensor_4x4(T4)
+    out.update(T4=T4, f4_R=rm(f), f4_t=f.get_trans())
+    f7 = Rigid.from_tensor_7(torch.cat([q, t], -1), normalize_quats=True)
+    out.update(f7_q=f7.get_rots().get_quats(), f7_t=f7.get_trans())
+    save(name, **out)
+
+
 def gen_geometry(name, data_seed):
     g = torch.Generator().manual_seed(data_seed)
     B, T, L = 2, 3, 20
@@ -334,6 +376,7 @@ if __name__ == "__main__":
     JOBS = {
         "rigid_ops": lambda: gen_rigid("rigid_ops", 11),
         "geometry": lambda: gen_geometry("geometry", 12),
+        "rigid_views": lambda: gen_rigid_views("rigid_views", 13),
         "fwd_tiny_sim": lambda: gen_forward("fwd_tiny_sim", ModelConfig(crop=5, num_frames=6, **tiny), 3, B=2, T=6, L=5,
                                             n_pad=2, data_seed=21, keep=("ipa_out", "h0", "h1")),
         "fwd_tiny_tps": lambda: gen_forward("fwd_tiny_tps", ModelConfig(crop=5, num_frames=6, sim_condition=False,
@@ -357,6 +400,9 @@ if __name__ == "__main__":
         "fwd_cfg1_T100": lambda: gen_forward_big("fwd_cfg1_T100", ModelConfig.forward_sim(num_frames=100, crop=4),
                                                  5, B=1, T=100, L=4, n_pad=0, data_seed=29, sub=(1, 1)),
         "prep_sim": lambda: gen_prep("prep_sim", ModelConfig.forward_sim(num_frames=6, crop=5), B=2, T=6, L=5, data_seed=31),
+        # --cond_interval 3 (wrapper.py:343-344; the upsampling models are sim_condition networks with every k-th frame given)
+        "prep_sim_interval": lambda: gen_prep("prep_sim_interval", ModelConfig.forward_sim(num_frames=8, crop=5), B=2, T=8, L=5,
+                                              data_seed=33, cond_interval=3),
         "prep_tps": lambda: gen_prep("prep_tps", ModelConfig.tps(num_frames=6, crop=5), B=2, T=6, L=5, data_seed=32),
         # S = 49 is the reference's hard-coded step count (wrapper.py:441-442) and the product default
         "inference_sim": lambda: gen_inference("inference_sim", ModelConfig.forward_sim(num_frames=12, crop=4), 8, B=2,

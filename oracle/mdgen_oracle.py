@@ -442,6 +442,8 @@ def prep_batch(batch, cfg):
     if tps:
         cond_mask[:, 0] = 1
         cond_mask[:, -1] = 1                                             # :341-342
+    if cfg.get("cond_interval"):
+        cond_mask[:, ::int(cfg["cond_interval"])] = 1                    # :343-344
     return {
         "rigids": (R, t),
         "latents": latents,

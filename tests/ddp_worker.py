@@ -1,7 +1,11 @@
-"""Worker of test_ddp_two_processes_match_one (not a test): one rank of a 2-process data-parallel training step on ONE GPU.
+"""Worker of test_ddp_two_processes_match_one / test_ddp_over_rccl_two_gpus (not a test): one rank of a 2-process
+data-parallel training step.
 
-Launched twice (RANK 0 / 1, WORLD_SIZE 2, gloo backend -- RCCL refuses two ranks on one device; gloo all-reduces CUDA
-tensors through the host, which is all the gradient exchange needs here).  Each rank builds a `Trainer(dist=...)` -- rank 1
+Launched twice (RANK 0 / 1, WORLD_SIZE 2).  DDP_BACKEND=gloo (default): both ranks on cuda:0 -- RCCL refuses two ranks on
+one device; gloo all-reduces CUDA tensors through the host, which is all the gradient exchange needs on a one-GPU box.
+DDP_BACKEND=nccl (= RCCL; boxes with >= 2 GPUs): rank r on cuda:r, the production path.  DDP_TIMING=1 additionally runs
+steps at BASELINE.json configs[4]'s per-GPU shape (B 1, T 250, L 256) and records the step time and the exposed all-reduce
+wait.  Each rank builds a `Trainer(dist=...)` -- rank 1
 deliberately from DIFFERENT initial weights, so the construction-time broadcast is what makes the ranks agree -- runs
 `Trainer.training_step` (the `launch_on_events` path: bucketed all-reduce on a communication stream behind the library's
 gradient milestones) on ITS item of a 2-item batch, and rank 0 writes the resulting flat parameters to argv[1]."""
@@ -23,10 +27,11 @@ from mdgen_amd.wrapper import NewMDGenWrapper
 
 def run(out_path, steps=2):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dev = torch.device("cuda", 0)
+    backend = os.environ.get("DDP_BACKEND", "gloo")
+    dev = torch.device("cuda", rank if backend == "nccl" and world > 1 else 0)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("gloo")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     B, T, L = 2, 6, 5
     cfg = ModelConfig(crop=L, num_frames=T, num_layers=1, abs_pos_emb=True, sim_condition=True)
     w = NewMDGenWrapper(cfg, device=dev)
@@ -47,9 +52,33 @@ def run(out_path, steps=2):
             loss = tr.training_step(batch, t=t, x0=x0)
     torch.cuda.synchronize()
     assert len(launched) == steps * len(tr.buckets.buckets)
-    if rank == 0:
-        torch.save({"params": tr.tm.params.data.cpu(), "ema": tr.ema.data.cpu(), "loss": float(loss), "world": world}, out_path)
+    res = {"params": tr.tm.params.data.cpu(), "ema": tr.ema.data.cpu(), "loss": float(loss), "world": world, "backend": backend}
     tr.close()
+    if os.environ.get("DDP_TIMING") == "1":   # cfg-5's per-GPU shape: how much of the all-reduce is NOT hidden behind the backward pass
+        import time
+        from mdgen_amd.synthetic import synth_batch
+        del tr, w
+        cfg5 = ModelConfig.atlas(num_frames=250, crop=256)
+        w5 = NewMDGenWrapper(cfg5, device=dev)
+        w5.load_model_state_dict(synth_state_dict(cfg5, 5))
+        tr5 = Trainer(w5, lr=1e-4, grad_clip=1.0, ema_decay=0.999, dist=dist if world > 1 else None)
+        tr5.tm.model.set_option("train_precision", 16)
+        b5 = synth_batch(1, 250, 256, 16, dev, seed=100 + rank)
+        comm, n = 0.0, 0
+        for i in range(5):
+            if i == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            tr5.training_step(b5)
+            if i >= 2:
+                comm += tr5.exposed_comm_ms
+                n += 1
+        torch.cuda.synchronize()
+        res["step_ms"] = (time.perf_counter() - t0) * 1e3 / n
+        res["exposed_comm_ms"] = comm / n
+        tr5.close()
+    if rank == 0:
+        torch.save(res, out_path)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -17,7 +17,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, n_items, q):
-    from mdgen_amd.sharding import shard_list, max_over_ranks, sum_over_ranks
+    from mdgen_amd.sharding import gather_over_ranks, shard_list, max_over_ranks, sum_over_ranks
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,8 +27,9 @@ def _worker(rank, world, port, n_items, q):
     dist.barrier()
     dt = max_over_ranks(0.1 * (rank + 1), dist)    # pretend rank r took 0.1*(r+1) s
     total = sum_over_ranks(frames, dist)
+    per_rank = gather_over_ranks(0.1 * (rank + 1), dist)    # bench.py's per-rank rates (stragglers)
     dist.barrier()
-    q.put((rank, mine, dt, total))
+    q.put((rank, mine, dt, total, per_rank))
     dist.destroy_process_group()
 
 
@@ -48,6 +49,7 @@ def test_two_rank_batch_sharding():
     assert sorted(sum(shards, [])) == sorted(f"pep{i}" for i in range(n_items))     # disjoint cover
     assert abs(len(shards[0]) - len(shards[1])) <= 1
     assert all(abs(r[2] - 0.2) < 1e-9 for r in res)                                   # max over ranks
+    assert all(len(r[4]) == 2 and abs(r[4][0] - 0.1) < 1e-9 and abs(r[4][1] - 0.2) < 1e-9 for r in res)   # every rank sees all
     assert all(r[3] == 1000 * n_items for r in res)                                   # whole-job frames
 
 

@@ -83,11 +83,13 @@ def test_geometry():
     assert torch.allclose(R2, R, atol=1e-4) and torch.allclose(t2, t, atol=1e-4)
 
 
-@pytest.mark.parametrize("name", ["prep_sim", "prep_tps"])
+@pytest.mark.parametrize("name", ["prep_sim", "prep_tps", "prep_sim_interval"])
 def test_prep_batch(name):
     g = load_golden(name)
     batch = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
-    prep = O.prep_batch(batch, g["cfg"])
+    prep = O.prep_batch(batch, dict(g["cfg"], cond_interval=int(g["cond_interval"])))
+    if name == "prep_sim_interval":   # --cond_interval 3 on 8 frames: frames 0, 3, 6 are given (wrapper.py:343-344)
+        assert g["x_cond_mask"][0, :, 0].tolist() == [1, 0, 0, 1, 0, 0, 1, 0]
     assert torch.allclose(prep["latents"], g["latents"], atol=2e-5)
     assert torch.allclose(prep["model_kwargs"]["x_cond"], g["x_cond"], atol=2e-5)
     assert torch.equal(prep["model_kwargs"]["x_cond_mask"], g["x_cond_mask"])
