@@ -115,6 +115,10 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      which fill the chip, and the panel kernel below that; 2 the row-owner kernel always.
  *   "fuse_proj"        0 (default) / 1: with the row-owner MLP kernel, run the temporal attention's out-projection +
  *                      gated residual (mha.py:397, latent_model.py:476) inside it, ahead of the MLP.
+ *   "chain_path"       tetrapeptide trunk (L == 4, T a multiple of 8): the residue-axis attention sub-layer and the temporal
+ *                      sub-layer's LN -> q, k, v -> fragments (latent_model.py:457-475) as ONE row-owner kernel
+ *                      (csrc/k_chain.hip k_chain_l4) instead of two panel kernels: 0 off, 1 (default) for launches of >= 768
+ *                      row tiles, 2 whenever the shape allows.
  *   "train_precision"  operands of the matrix products of mdgen_train_forward_backward (linear layers, weight gradients,
  *                      the attention's q k^T / p v and their backward): 32 (default) fp32, the exact mode; 16 rounded to
  *                      bf16 on the MFMA, fp32 accumulation, fp32 master weights and activations (train.py:13
@@ -232,6 +236,10 @@ int32_t mdgen_debug_layout_maps(int32_t* map_qk, int32_t* map_vflash, int32_t* m
  * out[f] = mat << 16 | row_tile << 8 | k_step for fragment f (2304 of them); mat 0 = fc1 (layers.py:77-84 `fc1`), 1 = fc2.
  * Returns the number of entries, or a negative status. */
 int32_t mdgen_debug_mlp_stream_table(int32_t* out, int32_t capacity);
+/* The same for the weight streams of k_chain_l4 (csrc/k_chain.hip): stages of 3 row tiles x 24 k-steps, k-step major.
+ * which 0: residue axis q | k | v head group by head group (864 entries), 1: temporal axis q, k, v (864), 2: out-projection
+ * (288); mat 0 = q, 1 = k, 2 = v, 3 = out-projection. */
+int32_t mdgen_debug_chain_stream_table(int32_t which, int32_t* out, int32_t capacity);
 
 /* Test hooks (GPU): the training step's linear layer and weight gradient on raw device buffers, through exactly the
  * kernel dispatch of mdgen_train_forward_backward -- precision 32: fp32 products (k32_linear / k32_dw); 16: bf16-rounded

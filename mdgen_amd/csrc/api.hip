@@ -57,6 +57,10 @@ constexpr size_t kPackCC = (size_t)12 * kKS * 64;  // bf16x8 elements of a packe
 
 struct MhaW {
     bf16x8 *wq = nullptr, *wk = nullptr, *wv_flash = nullptr, *wv_small = nullptr, *wo = nullptr;
+    // k_chain_l4's weight streams (trunk layers only; chain_tables): q|k|v head group by head group with the SMALL-layout V
+    // (residue axis, attention in registers), q, k, v with the FLASH-layout V (temporal axis), W_o in the k order of the
+    // attention output registers
+    bf16x8 *ws_qkv_l4 = nullptr, *ws_qkv_flash = nullptr, *ws_o_l4 = nullptr;
     bf16x8* wo_stream = nullptr;   // W_o as the 288-fragment prefix of the row-owner MLP kernel's weight stream (proj_stream_table)
     float *bq = nullptr, *bk = nullptr, *bv_flash = nullptr, *bv_small = nullptr, *bo = nullptr;
     float *bias_k = nullptr, *bias_v = nullptr;
@@ -115,6 +119,7 @@ struct mdgen_ctx {
     int *perm_qk = nullptr, *perm_vsmall = nullptr;
     int* mlp_tab = nullptr;     // device copy of mlp_stream_table()
     int* proj_tab = nullptr;    // device copy of proj_stream_table()
+    int* chain_tab[3] = {nullptr, nullptr, nullptr};   // device copies of chain_table(0..2)
     std::vector<GraphEntry> graphs;
     bool inv_freq_set = false;
     bool prof_on = false;
@@ -127,6 +132,8 @@ struct mdgen_ctx {
     int opt_attn_path = 0;      // tiled attention: 0 fixed-anchor fast loop with overflow check + fallback, 1 robust loop always
     int opt_mlp_path = 1;       // MLP block: 0 resident-panel kernel (k_mlp), 1 row-owner kernel (k_mlp_rows) when the launch
                                 // fills the chip, 2 row-owner kernel always
+    int opt_chain = 1;          // tetrapeptide trunk (L == 4, T % 8 == 0): residue-axis sub-layer + temporal LN / q, k, v as ONE row-owner
+                                // kernel (k_chain_l4): 0 off, 1 for launches that fill the chip, 2 whenever the shape allows
     int opt_fuse_proj = 0;      // with the row-owner MLP kernel: run the temporal attention's out-projection inside it (same wall time)
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
@@ -265,6 +272,36 @@ static std::vector<int> proj_stream_table() {
     return t;
 }
 constexpr int kProjFrags = 288;
+// Weight streams of k_chain_l4 (csrc/k_chain.hip): stages of 3 row tiles x 24 k-steps, fragment order k-step major, tile
+// minor.  Entry = mat << 16 | row tile << 8 | k-step, mat 0 = q, 1 = k, 2 = v, 3 = out-projection.
+//   which 0: residue axis, head group g = tiles 3 g .. 3 g + 2: [q g][k g][v g] for g = 0..3              (864 fragments)
+//   which 1: temporal axis: [q 0..3][k 0..3][v 0..3]                                                          (864)
+//   which 2: out-projection: feature tiles 3 st .. 3 st + 2 for st = 0..3                                     (288)
+static std::vector<int> chain_table(int which) {
+    std::vector<int> t;
+    auto stage = [&](int mat, int g) {
+        for (int ks = 0; ks < 24; ++ks)
+            for (int tl = 0; tl < 3; ++tl) t.push_back(mat << 16 | (3 * g + tl) << 8 | ks);
+    };
+    if (which == 0) {
+        for (int g = 0; g < 4; ++g)
+            for (int mat = 0; mat < 3; ++mat) stage(mat, g);
+    } else if (which == 1) {
+        for (int mat = 0; mat < 3; ++mat)
+            for (int g = 0; g < 4; ++g) stage(mat, g);
+    } else {
+        for (int st = 0; st < 4; ++st) stage(3, st);
+    }
+    return t;
+}
+constexpr int kChainQkvFrags = 864;
+extern "C" int32_t mdgen_debug_chain_stream_table(int32_t which, int32_t* out, int32_t capacity) {
+    if (which < 0 || which > 2) return fail(-2, "which must be 0 (residue q|k|v), 1 (temporal q, k, v) or 2 (out-projection)");
+    const std::vector<int> t = chain_table(which);
+    if (!out || capacity < (int)t.size()) return fail(-1, "need room for %d entries", (int)t.size());
+    for (size_t i = 0; i < t.size(); ++i) out[i] = t[i];
+    return (int32_t)t.size();
+}
 
 extern "C" int32_t mdgen_debug_mlp_stream_table(int32_t* out, int32_t capacity) {
     const std::vector<int> t = mlp_stream_table();
@@ -298,8 +335,13 @@ static int copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
     return 0;
 }
 
-static int register_mha(mdgen_ctx* c, const std::string& pre, MhaW* m) {
+static int register_mha(mdgen_ctx* c, const std::string& pre, MhaW* m, bool chain = false) {
     const float qscale = (1.0f / std::sqrt((float)kDH)) * kLog2e;
+    if (chain) {
+        if (int r = c->dalloc(&m->ws_qkv_l4, (size_t)kChainQkvFrags * 64)) return r;
+        if (int r = c->dalloc(&m->ws_qkv_flash, (size_t)kChainQkvFrags * 64)) return r;
+        if (int r = c->dalloc(&m->ws_o_l4, (size_t)kProjFrags * 64)) return r;
+    }
     if (int r = c->dalloc(&m->wq, kPackCC)) return r;
     if (int r = c->dalloc(&m->wk, kPackCC)) return r;
     if (int r = c->dalloc(&m->wv_flash, kPackCC)) return r;
@@ -307,14 +349,32 @@ static int register_mha(mdgen_ctx* c, const std::string& pre, MhaW* m) {
     if (int r = c->dalloc(&m->wo, kPackCC)) return r;
     for (float** p : {&m->bq, &m->bk, &m->bv_flash, &m->bv_small, &m->bo, &m->bias_k, &m->bias_v})
         if (int r = c->dalloc(p, (size_t)kC)) return r;
-    SETTER(pre + "q_proj.weight", { WANT(kC, kC); launch_pack_rows(data, kC, c->map_qk, 12, kKS, qscale, m->wq, s); });
+    SETTER(pre + "q_proj.weight", {
+        WANT(kC, kC);
+        launch_pack_rows(data, kC, c->map_qk, 12, kKS, qscale, m->wq, s);
+        if (chain) {
+            launch_pack_stream(data, kC, 0, c->chain_tab[0], kChainQkvFrags, qscale, 1, m->ws_qkv_l4, s, c->map_qk);
+            launch_pack_stream(data, kC, 0, c->chain_tab[1], kChainQkvFrags, qscale, 1, m->ws_qkv_flash, s, c->map_qk);
+        }
+    });
     SETTER(pre + "q_proj.bias", { WANT(kC); launch_gather_f32(data, c->perm_qk, qscale, m->bq, kC, s); });
-    SETTER(pre + "k_proj.weight", { WANT(kC, kC); launch_pack_rows(data, kC, c->map_qk, 12, kKS, 1.f, m->wk, s); });
+    SETTER(pre + "k_proj.weight", {
+        WANT(kC, kC);
+        launch_pack_rows(data, kC, c->map_qk, 12, kKS, 1.f, m->wk, s);
+        if (chain) {
+            launch_pack_stream(data, kC, 1, c->chain_tab[0], kChainQkvFrags, 1.f, 1, m->ws_qkv_l4, s, c->map_qk);
+            launch_pack_stream(data, kC, 1, c->chain_tab[1], kChainQkvFrags, 1.f, 1, m->ws_qkv_flash, s, c->map_qk);
+        }
+    });
     SETTER(pre + "k_proj.bias", { WANT(kC); launch_gather_f32(data, c->perm_qk, 1.f, m->bk, kC, s); });
     SETTER(pre + "v_proj.weight", {
         WANT(kC, kC);
         launch_pack_rows(data, kC, c->map_vflash, 12, kKS, 1.f, m->wv_flash, s);
         launch_pack_rows(data, kC, c->map_vsmall, 12, kKS, 1.f, m->wv_small, s);
+        if (chain) {
+            launch_pack_stream(data, kC, 2, c->chain_tab[0], kChainQkvFrags, 1.f, 1, m->ws_qkv_l4, s, c->map_vsmall);
+            launch_pack_stream(data, kC, 2, c->chain_tab[1], kChainQkvFrags, 1.f, 1, m->ws_qkv_flash, s, c->map_vflash);
+        }
     });
     SETTER(pre + "v_proj.bias", {
         WANT(kC);
@@ -326,6 +386,7 @@ static int register_mha(mdgen_ctx* c, const std::string& pre, MhaW* m) {
         WANT(kC, kC);
         launch_pack_rows(data, kC, c->map_nat, 12, kKS, 1.f, m->wo, s);
         launch_pack_stream(data, kC, 2, c->proj_tab, kProjFrags, 1.f, 0, m->wo_stream, s);
+        if (chain) launch_pack_stream(data, kC, 3, c->chain_tab[2], kProjFrags, 1.f, 2, m->ws_o_l4, s);
     });
     SETTER(pre + "out_proj.bias", { WANT(kC); if (int r = copy_f32(m->bo, data, kC, s)) return r; });
     SETTER(pre + "bias_k", { WANT(kC); if (int r = copy_f32(m->bias_k, data, kC, s)) return r; });
@@ -390,6 +451,7 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     TRY(upload_ints(c, &c->map_fin, fin));
     TRY(upload_ints(c, &c->mlp_tab, mlp_stream_table()));
     TRY(upload_ints(c, &c->proj_tab, proj_stream_table()));
+    for (int i = 0; i < 3; ++i) TRY(upload_ints(c, &c->chain_tab[i], chain_table(i)));
     TRY(upload_ints(c, &c->perm_qk, pqk));
     TRY(upload_ints(c, &c->perm_vsmall, pvs));
     TRY(c->dalloc(&c->wl, (size_t)kC * D));
@@ -469,8 +531,8 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
         });
         SETTER(p + "adaLN_modulation.1.bias",
                { WANT(9 * kC); if (int r = copy_f32(c->ada_b + c->trunk_off(i), data, 9 * kC, s)) return r; });
-        TRY(register_mha(c, p + "mha_t.attn.", &t->mha_t));
-        TRY(register_mha(c, p + "mha_l.attn.", &t->mha_l));
+        TRY(register_mha(c, p + "mha_t.attn.", &t->mha_t, true));
+        TRY(register_mha(c, p + "mha_l.attn.", &t->mha_l, true));
         TRY(register_ffn(c, p, &t->ffn));
     }
     for (int i = 0; i < nl; ++i) {
@@ -598,6 +660,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "fuse_proj") {
         if (value != 0 && value != 1) return fail(-2, "fuse_proj must be 0 or 1");
         c->opt_fuse_proj = value;
+    } else if (n == "chain_path") {
+        if (value < 0 || value > 2) return fail(-2, "chain_path must be 0 (off), 1 (launches that fill the chip) or 2 (whenever L == 4 and T % 8 == 0)");
+        c->opt_chain = value;
     } else if (n == "mlp_path") {
         if (value < 0 || value > 2) return fail(-2, "mlp_path must be 0 (panel kernel), 1 (row-owner kernel when it fills the chip) or 2 (always)");
         c->opt_mlp_path = value;
@@ -831,7 +896,7 @@ static int check_launch_rows(long nrows) {
 // what the fused kernel (k_mlp_rows<NW, true>) needs to run it ahead of the MLP (a_bf16 stays null otherwise).
 static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, const AxisMap& ax, const ModMap& mm,
                          int shift, int scale, int gate, const MaskMap& mk, bool residue_axis, bool trunk,
-                         ProjParams* defer = nullptr) {
+                         ProjParams* defer = nullptr, bool skip_qkv = false) {
     if (int e = check_launch_rows(nrows)) return e;
     const char* c_qkv = !trunk ? "ipa.ln_qkv" : residue_axis ? "ln_qkv_L" : "ln_qkv_T";
     const char* c_att = !trunk ? "ipa.flash" : residue_axis ? "flash_L" : "flash_T";
@@ -905,8 +970,10 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         q.mk = mk;   // key-validity words for the attention kernel, in the slack behind the V^T fragments
         q.vmask = (uint32_t*)(q.vf + flash_vmask_offset(ax.nseq, ax.ntile()));
         q.vmask_stride = flash_vmask_stride(ax.ntile());
-        { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv(q, false, r.s); }
-        LAUNCHCHK();
+        if (!skip_qkv) {   // (skip_qkv: k_chain_l4 has written the fragments and the validity words of this axis already)
+            { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv(q, false, r.s); }
+            LAUNCHCHK();
+        }
         FlashParams f{};
         f.ax = ax;
         f.mk = mk;
@@ -941,6 +1008,40 @@ static bool mlp_uses_rows(const mdgen_ctx* c, long nrows) {
 }
 
 // `proj`: a deferred out-projection (attn_sublayer) to run inside the row-owner kernel, ahead of the MLP
+// k_chain_l4 (csrc/k_chain.hip): the residue-axis sub-layer of a tetrapeptide trunk layer and the front half of its temporal
+// sub-layer (LN -> q, k, v -> fragments) in one row-owner launch.
+static bool chain_eligible(const mdgen_ctx* c, const Run& r) {
+    if (c->opt_chain == 0 || c->opt_precision != 16 || c->opt_residue_l4 != 2) return false;
+    if (r.L != 4 || r.T % 8 != 0 || r.N % 32 != 0) return false;
+    return c->opt_chain == 2 || r.N / 32 >= 4 * 192;
+}
+static int chain_sublayers(const Run& r, const TrunkW& w, float* h, const AxisMap& axT, const ModMap& mm, const MaskMap& mk) {
+    if (int e = check_launch_rows(r.N)) return e;
+    ChainParams p{};
+    p.h = h;
+    p.nrows = r.N;
+    p.T = r.T;
+    p.ntile = axT.ntile();
+    p.mm = mm;
+    p.shift_l = 0; p.scale_l = 1; p.gate_l = 2;
+    p.shift_t = 3; p.scale_t = 4;
+    p.ws_l = (const unsigned char*)w.mha_l.ws_qkv_l4;
+    p.ws_o = (const unsigned char*)w.mha_l.ws_o_l4;
+    p.ws_t = (const unsigned char*)w.mha_t.ws_qkv_flash;
+    p.bq_l = w.mha_l.bq; p.bk_l = w.mha_l.bk; p.bv_l = w.mha_l.bv_small; p.bo_l = w.mha_l.bo;
+    p.bq_t = w.mha_t.bq; p.bk_t = w.mha_t.bk; p.bv_t = w.mha_t.bv_flash;
+    p.bias_k_l = w.mha_l.bias_k; p.bias_v_l = w.mha_l.bias_v;
+    p.bias_k_t = w.mha_t.bias_k; p.bias_v_t = w.mha_t.bias_v;
+    p.rope = r.c->rope;
+    p.mk = mk;
+    p.qf = r.qfp; p.kf = r.kfp; p.vf = r.vfp;
+    p.vmask = (uint32_t*)(r.vfp + flash_vmask_offset(axT.nseq, axT.ntile()));
+    p.vmask_stride = flash_vmask_stride(axT.ntile());
+    { ProfScope ps(r.c, "chain_L_qkvT", r.s); launch_chain_l4(p, r.s); }
+    LAUNCHCHK();
+    return 0;
+}
+
 static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const ModMap& mm, int shift, int scale,
                         int gate, bool trunk, const ProjParams* proj = nullptr, const bf16x8* wo_stream = nullptr) {
     if (int e = check_launch_rows(nrows)) return e;
@@ -1179,10 +1280,15 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
     for (int i = 0; i < c->nl; ++i) {
         const TrunkW& w = c->trunk[i];
         ModMap mm{modstep + c->trunk_off(i), r.T * r.L, r.B, 0, r.mod_group_stride};
-        if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true)) return er;
+        const bool chain = chain_eligible(c, r);
+        if (chain) {
+            if (int er = chain_sublayers(r, w, h, axT, mm, mk)) return er;
+        } else {
+            if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true)) return er;
+        }
         ProjParams deferred{};
         const bool fuse = c->opt_fuse_proj && mlp_uses_rows(c, r.N);
-        if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true, fuse ? &deferred : nullptr)) return er;
+        if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true, fuse ? &deferred : nullptr, chain)) return er;
         if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true, &deferred, w.mha_t.wo_stream)) return er;
         if (trace_h) HIPCHK(hipMemcpyAsync(trace_h + (size_t)(i + 1) * r.N * kC, h, hbytes, hipMemcpyDeviceToDevice, r.s));
     }
@@ -1392,7 +1498,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_chain << 16), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1452,7 +1558,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_chain << 16),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

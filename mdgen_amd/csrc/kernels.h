@@ -76,6 +76,26 @@ struct MlpRowsParams {
     long trace_cap;
 };
 
+// k_chain_l4 (k_chain.hip): residue-axis attention sub-layer (L == 4) + the temporal axis' LN -> q, k, v -> fragments, one
+// row-owner kernel.  Weight streams: 24-fragment slots in the kernel's stage order (api.hip chain_tables).
+struct ChainParams {
+    float* h;
+    long nrows;                      // B * T * 4, a multiple of 32
+    int T, ntile;                    // frames per sample (a multiple of 8); key tiles per temporal sequence (T / 32 + 1)
+    ModMap mm;
+    int shift_l, scale_l, gate_l, shift_t, scale_t;
+    const unsigned char *ws_l, *ws_o, *ws_t;   // residue q|k|v (36 slots), residue out-projection (12), temporal q, k, v (36)
+    const float *bq_l, *bk_l, *bv_l;           // lane-ordered biases (perm_qk, perm_qk, perm_vsmall)
+    const float* bo_l;                         // natural
+    const float *bq_t, *bk_t, *bv_t;           // perm_qk, perm_qk, map_vflash order
+    const float *bias_k_l, *bias_v_l, *bias_k_t, *bias_v_t;   // learned bias key / value, natural fp32 [384]
+    const float* rope;
+    MaskMap mk;
+    unsigned char *qf, *kf, *vf;
+    uint32_t* vmask;
+    int vmask_stride;
+};
+
 struct LnLinearParams {
     const float* h;
     long nrows;
@@ -163,8 +183,11 @@ void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
 void launch_mlp(const MlpParams& p, hipStream_t s);
 void launch_mlp_rows(const MlpRowsParams& p, int nw, hipStream_t s);
+void launch_chain_l4(const ChainParams& p, hipStream_t s);
+// rowmap (nullable): source row of packed row r (a permutation of the matrix's rows); kappa: K order inside a k-step -- 0
+// natural, 1 rows.h kappa (operand = LayerNorm / GELU registers), 2 the register order of k_chain_l4's attention output
 void launch_pack_stream(const float* w, int ld, int which, const int* tab, int nfrag, float scale, int kappa, bf16x8* dst,
-                        hipStream_t s);
+                        hipStream_t s, const int* rowmap = nullptr);
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s);
 void launch_final(const FinalParams& p, hipStream_t s);
 void launch_flash(const FlashParams& p, hipStream_t s);

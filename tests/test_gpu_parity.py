@@ -2114,7 +2114,9 @@ def test_training_attention_kernels_unit(ln, layout):
                                     ("dk", dqkv[:, 384:768], r_dqkv[:, 384:768], tol_g), ("dv", dqkv[:, 768:], r_dqkv[:, 768:], tol_g),
                                     # the bias key is attended by EVERY query: its d k is the longest, most cancelling sum of
                                     # bf16-rounded d s terms (3e-2 .. 6e-2 on these random inputs, growing with the length)
-                                    ("dbias_k", dbias[:, :384], r_dbias[:, :384], tol_g if prec == 32 else 1e-1),
+                                    # (measured 0.17 at len 1000, where the exact mode is at 2e-5: rounding, not logic; the whole-step
+                                    # gradients against the reference's autograd are gated separately)
+                                    ("dbias_k", dbias[:, :384], r_dbias[:, :384], tol_g if prec == 32 else (1e-1 if ln <= 300 else 2.5e-1)),
                                     ("dbias_v", dbias[:, 384:], r_dbias[:, 384:], tol_g)):
             assert torch.isfinite(got).all(), (name, prec)
             e = float((got.double().cpu() - ref).norm() / (ref.norm() + 1e-300))
@@ -2149,6 +2151,62 @@ def test_row_owner_mlp_paths_agree():
             assert e < TOL_FWD
             del m
         assert rel_l2(outs["rows"], outs["panel"]) < 6e-3 and rel_l2(outs["rows+proj"], outs["rows"]) < 6e-3
+
+
+@pytest.mark.parametrize("shape", [(1, 40, 0), (1, 64, 0), (2, 8, 0), (3, 104, 1), (2, 1000, 0), (1, 96, 2)])
+def test_chain_kernel_vs_panel_kernels_and_oracle(shape):
+    """k_chain_l4 (csrc/k_chain.hip, option `chain_path`): the tetrapeptide trunk's residue-axis attention sub-layer and the
+    temporal sub-layer's LN -> q, k, v -> fragments (latent_model.py:457-475, mha.py:258-268, 356-357) as ONE row-owner kernel,
+    against (a) the CPU oracle at the bf16 gate and (b) the two panel kernels it replaces (`chain_path` 0; different
+    summation orders only: a few 1e-3).  Shapes (B, T, padded residues): a launch whose last workgroup has idle waves
+    (T 40: 5 row tiles), T a multiple of 32 / 64 (the learned bias key opens a key tile of its own, which the kernel must
+    zero-fill), one 8-frame group per sample (T 8), key padding on the residue axis, the headline's T 1000 (32 key tiles;
+    sample boundaries inside a workgroup), T 96.  Runs on a workspace filled with 0xFF bytes."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.model import LatentMDGenModel
+    from mdgen_amd.synthetic import synth_forward_inputs, synth_state_dict
+    dev = _cuda()
+    B, T, n_pad = shape
+    cfg = ModelConfig.forward_sim(num_frames=T, crop=4)
+    sd = synth_state_dict(cfg, 5)
+    inp = synth_forward_inputs(cfg, B, T, 4, n_pad, 300 + T)
+    kw = dict(x=inp["x"], t=inp["t"], mask=inp["mask"], start_frames=(inp["start_rot"], inp["start_trans"]),
+              end_frames=(inp["end_rot"], inp["end_trans"]), x_cond=inp["x_cond"], x_cond_mask=inp["x_cond_mask"],
+              aatype=inp["aatype"])
+    dkw = {k: (tuple(u.to(dev) for u in v) if isinstance(v, tuple) else v.to(dev)) for k, v in kw.items()}
+    ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
+    outs = {}
+    for path in (0, 2):
+        m = LatentMDGenModel(cfg)
+        m.load_state_dict(sd)
+        m.set_option("chain_path", path)
+        m.forward(**dkw)
+        for ws in m._ws.values():
+            ws.view(torch.uint8).fill_(0xFF)
+        out, tr = m.forward(**dkw, return_trace=True)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all(), path
+        rep = {k: rel_l2(tr[k].cpu(), rtr[k]) for k in [f"h{i}" for i in range(cfg.num_layers + 1)]}
+        rep["out"] = rel_l2(out.cpu(), ref)
+        print(shape, "chain_path", path, {k: f"{v:.2e}" for k, v in rep.items()})
+        for k, v in rep.items():
+            assert v < TOL_FWD, (path, k, v)
+        outs[path] = (out.cpu(), tr["h1"].cpu())
+        del m
+    e_out, e_h1 = rel_l2(outs[2][0], outs[0][0]), rel_l2(outs[2][1], outs[0][1])
+    print(shape, f"chain vs panel kernels: out {e_out:.2e}  h1 {e_h1:.2e}")
+    assert e_out < 5e-3 and e_h1 < 5e-3
+    # padded residues never influence the valid ones
+    if n_pad:
+        x2 = inp["x"].clone()
+        x2[:, :, 4 - n_pad:] = 1e3
+        m = LatentMDGenModel(cfg)
+        m.load_state_dict(sd)
+        m.set_option("chain_path", 2)
+        a = m.forward(**dkw)
+        b2 = m.forward(**dict(dkw, x=x2.to(dev)))
+        assert torch.equal(a[:, :, :4 - n_pad], b2[:, :, :4 - n_pad])
 
 
 def test_validation_on_ema_weights_leaves_the_master_parameters_alone(tmp_path):
