@@ -1037,6 +1037,11 @@ static int chain_sublayers(const Run& r, const TrunkW& w, float* h, const AxisMa
     p.qf = r.qfp; p.kf = r.kfp; p.vf = r.vfp;
     p.vmask = (uint32_t*)(r.vfp + flash_vmask_offset(axT.nseq, axT.ntile()));
     p.vmask_stride = flash_vmask_stride(axT.ntile());
+    if (r.c->phase_trace) {   // one-shot (mdgen_profile_phase_trace): the next trunk launch of a row-owner kernel records its stamps
+        p.trace = r.c->phase_trace;
+        p.trace_cap = r.c->phase_trace_cap;
+        r.c->phase_trace = nullptr;
+    }
     { ProfScope ps(r.c, "chain_L_qkvT", r.s); launch_chain_l4(p, r.s); }
     LAUNCHCHK();
     return 0;
@@ -1389,9 +1394,14 @@ static void linspace01(int n, std::vector<float>* out) {
 }
 
 // Number of concurrent sub-batch streams for the Euler rollout (option "streams", default 2; 1 disables).
+// Sub-batch streams pay when every piece still fills the chip by itself (cfg-2: 2 x 500 panels, +9 ... 12 %); pieces of
+// fewer than 256 64-row panels leave CUs idle in BOTH streams (TPS shard B32 T100: 2 x 100 panels 68.3k frames/s, one stream
+// 73.4k, profiles/r04_experiments.txt): the batch is then cut into fewer pieces, down to one.
 static int n_streams(const Run& r) {
     int n = r.c->opt_streams;
     if (n > r.B) n = r.B;
+    const long fill = 256L * kPanel;
+    if ((long)n * fill > r.N) n = (int)(r.N / fill);
     if (n < 2 || r.c->prof_on || r.N < 4096 || r.c->opt_precision == 32) return 1;
     return n;
 }

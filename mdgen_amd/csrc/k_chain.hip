@@ -235,13 +235,22 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
     float* tab = reinterpret_cast<float*>(smem + kRingBytes);
     const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id(), hh = lane >> 5, n = lane & 31;
     const int l = n & 3, tt = 4 * ((n >> 2) & 1) + (n >> 3);
+    unsigned long long st[10] = {};
+#define CH_STAMP(i)                              \
+    st[i] = __builtin_amdgcn_s_memtime();        \
+    __builtin_amdgcn_sched_barrier(0)
+    CH_STAMP(0);
     ChStream ws{p.ws_l, p.ws_o, p.ws_t, lds_addr(smem), (unsigned)lane * 16u, w};
     ws.issue_slot(0);
     ws.issue_slot(1);
     ws.issue_slot(2);
     // ---- geometry: the wave's 32 rows = frames t0 .. t0 + 7 of sample b, four residues each
     const long tile = (long)blockIdx.x * NW + w;
+#ifdef MDGEN_DEV_CHAIN_NOSTORE   // (experiment build, timing only)
+    const bool live = tile * 32 < p.nrows && p.nrows < 0;
+#else
     const bool live = tile * 32 < p.nrows;
+#endif
     const int base_tok = __builtin_amdgcn_readfirstlane(live ? (int)(tile * 32) : 0);
     const int tok = base_tok + 4 * tt + l;
     const int f0 = base_tok >> 2;
@@ -289,6 +298,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
     for (int i = 0; i < 5; ++i) r.wr[i] = *reinterpret_cast<const bf16x8*>(r.lane_base + i * 1024);
     uint32_t* stash_lane = reinterpret_cast<uint32_t*>(smem + kRingBytes + kChTabBytes) + w * 24 * 64 + lane;
     f32x16 acc[3];
+    CH_STAMP(1);
     // rotary factors of the residue axis: position = residue index
     f32x4 rql[4];
     // ================= residue axis: q, k, v head group by head group; the 5-key attention in registers =================
@@ -353,6 +363,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
 #undef CH_PUT
         __builtin_amdgcn_sched_barrier(0);
     }
+    CH_STAMP(2);
     // ================= residue axis: out-projection + gated residual; the updated rows stay in registers =================
     f32x4 hn[48];   // the updated rows (rows_load's image): input of the second LayerNorm
     {
@@ -385,8 +396,10 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
             }
         }
     }
+    CH_STAMP(3);
     // ================= temporal axis: LayerNorm of the updated rows, q / k / v -> fragments =================
     rows_norm(hn, ltok, p.mm, p.shift_t, p.scale_t, 1e-6f, xf);
+    CH_STAMP(4);
     const int ntile = p.ntile;
     const int tl5 = t0 >> 5, s0 = t0 & 31;                   // key tile and first key slot of the wave's 8 frames (uniform)
     const int seq = b * 4 + l;                               // the lane's temporal sequence
@@ -407,24 +420,34 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
         for (int g = 0; g < 4; ++g) {
             ch_zero(acc);
             ch_stage<false>(r, ws, acc, xf);
+#ifndef MDGEN_DEV_CHAIN_NOEPI
             const f32x4* b3 = reinterpret_cast<const f32x4*>(tab + TB_BQT + (g * 2 + hh) * 48);
             ch_store_qk<0, false>(acc, b3, rqt, q0, q1, (long)ntile * kFragQ, 4 * g + 0, live);
             ch_store_qk<1, false>(acc, b3, rqt, q0, q1, (long)ntile * kFragQ, 4 * g + 1, live);
             ch_store_qk<2, false>(acc, b3, rqt, q0, q1, (long)ntile * kFragQ, 4 * g + 2, live);
             ch_store_qk<3, false>(acc, b3, rqt, q0, q1, (long)ntile * kFragQ, 4 * g + 3, live);
+#else
+            if (acc[0][0] == 1234.5f) q0[0] = 1;
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
+        CH_STAMP(5);
 #pragma unroll 1
         for (int g = 0; g < 4; ++g) {
             ch_zero(acc);
             ch_stage<false>(r, ws, acc, xf);
+#ifndef MDGEN_DEV_CHAIN_NOEPI
             const f32x4* b3 = reinterpret_cast<const f32x4*>(tab + TB_BKT + (g * 2 + hh) * 48);
             ch_store_qk<0, true>(acc, b3, rqt, k0, k1, (long)ntile * kFragK, 4 * g + 0, live);
             ch_store_qk<1, true>(acc, b3, rqt, k0, k1, (long)ntile * kFragK, 4 * g + 1, live);
             ch_store_qk<2, true>(acc, b3, rqt, k0, k1, (long)ntile * kFragK, 4 * g + 2, live);
             ch_store_qk<3, true>(acc, b3, rqt, k0, k1, (long)ntile * kFragK, 4 * g + 3, live);
+#else
+            if (acc[0][0] == 1234.5f) k0[0] = 1;
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
+        CH_STAMP(6);
     }
     {   // v, NON-transposed: lane (feature column n of a 32-wide tile, half hh), registers 4 a + i = frame 4 hh + a of residue i
         const int g8 = s0 >> 3;
@@ -448,6 +471,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        CH_STAMP(7);
         // the all-ones row 24 of every fragment the wave touched: 4 sequences x 16 heads x 2 key halves, 8 bytes each
         if (live) {
 #pragma unroll
@@ -488,6 +512,18 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            {
+                // query slots behind the last frame, up to the end of the 64-query chunk a k_flash wave loads: finite values
+                // (a NaN pattern in an unused query column would send the whole wave to the robust loop; k_ln_qkv's
+                // padding rows store finite values there as well)
+                const int pend = min(ntile * 32, ((len + 63) >> 6) << 6), np_ = pend - len;
+                for (int it = lane; it < 4 * kH * 2 * np_; it += 64) {
+                    const int pz = len + it % np_, h2 = (it / np_) & 1, sh = it / (2 * np_);
+                    unsigned char* base = p.qf + (((long)(b * 4 + (sh >> 4)) * kH + (sh & 15)) * ntile + (pz >> 5)) * kFragQ;
+                    *reinterpret_cast<u32x4*>(base + (h2 * 32 + (pz & 31)) * 16) = u32x4{0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x2*>(base + 1024 + (h2 * 32 + (pz & 31)) * 8) = u32x2{0u, 0u};
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {   // K: (sequence li, head, half h2) -> 12 rotated values of key slot sl
                 const int idx = lane + 64 * k, li = idx & 3, head = (idx >> 2) & 15, h2 = idx >> 6;
@@ -525,6 +561,16 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's look-ahead DMAs must not outlive the workgroup's LDS
+    CH_STAMP(8);
+    // phase stamps (measurement only, p.trace null in normal operation): collected in SGPRs, written by ONE branch
+    if (p.trace && lane == 0) {
+        const long i = ((long)blockIdx.x * NW + w) * 10;
+        if (i + 10 <= p.trace_cap) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) p.trace[i + k] = st[k];
+        }
+    }
+#undef CH_STAMP
 }
 
 void launch_chain_l4(const ChainParams& p, hipStream_t s) {

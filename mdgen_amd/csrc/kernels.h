@@ -94,6 +94,8 @@ struct ChainParams {
     unsigned char *qf, *kf, *vf;
     uint32_t* vmask;
     int vmask_stride;
+    unsigned long long* trace;       // measurement only: [wave][10] s_memtime stamps, or null
+    long trace_cap;
 };
 
 struct LnLinearParams {
