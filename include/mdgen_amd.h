@@ -95,7 +95,9 @@ int32_t mdgen_ctx_set_weight(mdgen_ctx* ctx, const char* key, const float* data,
 int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
 /* Run-time options (no environment variables are read by the library):
  *   "streams"          1..8, default 2: contiguous sub-batches of an Euler rollout run on this many concurrent
- *                      streams (the caller's + context-owned ones, fork/join by events inside the call);
+ *                      streams (the caller's + context-owned ones, fork/join by events inside the call).  While the
+ *                      option has not been set, the count is also limited to pieces of >= 256 64-row panels (a piece that
+ *                      does not fill the chip by itself gains nothing from running beside another one);
  *   "keep_fp32_weights" 0/1, default 0; set to 1 BEFORE handing weights over to keep an fp32 copy of each (137 MB);
  *   "precision"        16 (default): bf16 MFMA operands, fp32 accumulate / softmax / LayerNorm / residual stream
  *                      (rel-L2 4-6e-3 per network evaluation against the fp32 reference);
@@ -117,8 +119,9 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      gated residual (mha.py:397, latent_model.py:476) inside it, ahead of the MLP.
  *   "chain_path"       tetrapeptide trunk (L == 4, T a multiple of 8): the residue-axis attention sub-layer and the temporal
  *                      sub-layer's LN -> q, k, v -> fragments (latent_model.py:457-475) as ONE row-owner kernel
- *                      (csrc/k_chain.hip k_chain_l4) instead of two panel kernels: 0 off, 1 (default) for launches of >= 768
- *                      row tiles, 2 whenever the shape allows.
+ *                      (csrc/k_chain.hip k_chain_l4) instead of two panel kernels: 0 (default) off -- one wave per SIMD cannot
+ *                      hide the attention's vector work behind the matrix pipe, the kernel is 10-15 % slower than the two it
+ *                      replaces --, 1 for launches of >= 768 row tiles, 2 whenever the shape allows.
  *   "train_precision"  operands of the matrix products of mdgen_train_forward_backward (linear layers, weight gradients,
  *                      the attention's q k^T / p v and their backward): 32 (default) fp32, the exact mode; 16 rounded to
  *                      bf16 on the MFMA, fp32 accumulation, fp32 master weights and activations (train.py:13

@@ -129,11 +129,13 @@ struct mdgen_ctx {
     std::map<std::string, float*> w32;   // fp32 copies, natural layout, keyed by the reference's state_dict key
     std::map<std::string, bool> w32_bound;   // keys whose w32 entry points into the caller's flat parameter buffer (mdgen_train_bind_params)
     int opt_streams = 2;        // concurrent sub-batch streams of the Euler rollout (1 = caller's stream only)
+    bool opt_streams_auto = true;   // not set by the caller: the count also follows the fill of the chip (n_streams)
     int opt_attn_path = 0;      // tiled attention: 0 fixed-anchor fast loop with overflow check + fallback, 1 robust loop always
     int opt_mlp_path = 1;       // MLP block: 0 resident-panel kernel (k_mlp), 1 row-owner kernel (k_mlp_rows) when the launch
                                 // fills the chip, 2 row-owner kernel always
-    int opt_chain = 1;          // tetrapeptide trunk (L == 4, T % 8 == 0): residue-axis sub-layer + temporal LN / q, k, v as ONE row-owner
-                                // kernel (k_chain_l4): 0 off, 1 for launches that fill the chip, 2 whenever the shape allows
+    int opt_chain = 0;          // tetrapeptide trunk (L == 4, T % 8 == 0): residue-axis sub-layer + temporal LN / q, k, v as ONE row-owner
+                                // kernel (k_chain_l4): 0 off (default: measured slower than the two panel kernels), 1 for
+                                // launches that fill the chip, 2 whenever the shape allows
     int opt_fuse_proj = 0;      // with the row-owner MLP kernel: run the temporal attention's out-projection inside it (same wall time)
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
@@ -646,6 +648,7 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     if (n == "streams") {
         if (value < 1 || value > mdgen_ctx::kMaxSide + 1) return fail(-2, "streams must be in 1..%d", mdgen_ctx::kMaxSide + 1);
         c->opt_streams = value;
+        c->opt_streams_auto = false;
     } else if (n == "keep_fp32_weights") {
         if (value != 0 && value != 1) return fail(-2, "keep_fp32_weights must be 0 or 1");
         c->opt_keep_fp32 = value;
@@ -1401,7 +1404,7 @@ static int n_streams(const Run& r) {
     int n = r.c->opt_streams;
     if (n > r.B) n = r.B;
     const long fill = 256L * kPanel;
-    if ((long)n * fill > r.N) n = (int)(r.N / fill);
+    if (r.c->opt_streams_auto && (long)n * fill > r.N) n = (int)(r.N / fill);
     if (n < 2 || r.c->prof_on || r.N < 4096 || r.c->opt_precision == 32) return 1;
     return n;
 }

@@ -227,9 +227,12 @@ __device__ __forceinline__ void proj_blocks(MlpPipe& m, const bf16x8 (&xf)[24], 
 // the 288 fragments of W_o lead the weight stream (12 ring slots = three ring revolutions), the updated residual rows are
 // written once and KEPT in registers for the MLP's LayerNorm -- one kernel, one read of the rows less (98 MB at cfg-2), no
 // launch boundary (k_proj<0> was an HBM-bound 58 us kernel of its own).
-template <int NW, bool PROJ>
+// MODLDS: every 32-row tile of the launch lies inside one modulation group (launch_mlp_rows checks the ModMap): the wave's
+// scale / shift / gate chunks are DMA'd into LDS once and read from there (rows_norm_lds, rows_gate_residual_lds).
+template <int NW, bool PROJ, bool MODLDS>
 __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[kRingBytes + kF * 4 + 512];   // ring | fc1 bias | slack: the last re-arm reads the (non-existent) chunk 24
+    // ring | fc1 bias | slack: the last re-arm reads the (non-existent) chunk 24 | per wave: scale, shift, gate chunks (2 KiB slots)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kRingBytes + 8192 + NW * 6144];
     constexpr int NPRE = PROJ ? 12 : 0;   // ring slots of the out-projection ahead of the MLP stream
     using WS = WStream<NW, NPRE>;
     constexpr int FPW = WS::FPW;
@@ -244,12 +247,27 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
         if (i % NW == w)
             dma_frag<0, true>(reinterpret_cast<const unsigned char*>(p.b1) + i * 1024, (unsigned)lane * 16u,
                               lds_addr(smem) + kRingBytes + i * 1024);
+    const long t = ((long)blockIdx.x * NW + w) * 32 + n;
+    const int tok = t < p.nrows ? (int)t : -1;
+    // The wave's modulation vectors (scale, shift, gate: 1536 B each) by DMA into LDS when all its rows share them (always,
+    // unless a tile straddles two samples): two 1 KiB DMAs per chunk, the second one's upper half lands in the slot's slack.
+    float* modl = reinterpret_cast<float*>(smem + kRingBytes + 8192 + w * 6144);
+    {
+        if (MODLDS) {
+            const long t0 = ((long)blockIdx.x * NW + w) * 32;
+            const unsigned char* mb = reinterpret_cast<const unsigned char*>(p.mm.mod + p.mm.row_off(t0 < p.nrows ? t0 : 0));
+            const int chunk[3] = {p.scale_chunk, p.shift_chunk, p.gate_chunk};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dma_frag<0, true>(mb + (long)chunk[c] * (kC * 4), (unsigned)lane * 16u, lds_addr(modl) + c * 2048);
+                dma_frag<1024, false>(mb + (long)chunk[c] * (kC * 4), (unsigned)lane * 16u, lds_addr(modl) + c * 2048);
+            }
+        }
+    }
     ws.issue_slot(0);
     ws.issue_slot(1);
     ws.issue_slot(2);
     float* b1s = reinterpret_cast<float*>(smem + kRingBytes);
-    const long t = ((long)blockIdx.x * NW + w) * 32 + n;
-    const int tok = t < p.nrows ? (int)t : -1;
     bf16x8 xf[24];
     MlpPipe m;
     const unsigned char* ring_lane = smem + lane * 16;
@@ -266,7 +284,14 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
         f32x4 v[48];
         rows_gate_residual_keep(m.y, tok, p.mm, p.gate_chunk_o, p.h, v);
         ROWS_STAMP(7);
-        rows_norm(v, tok, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, xf);
+        if (MODLDS) rows_norm_lds(v, tok, modl, modl + 512, 1e-6f, xf);
+        else rows_norm(v, tok, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, xf);
+    } else if (MODLDS) {
+        f32x4 v[48];
+        rows_load(p.h, tok, v);
+        // the row loads AND this wave's modulation DMAs have landed (the asm keeps hipcc from lifting the LDS reads above it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rows_norm_lds(v, tok, modl, modl + 512, 1e-6f, xf);
     } else {
         rows_ln(p.h, tok, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, xf);
     }
@@ -339,8 +364,13 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
     pipe_block<NW, 84, 1, 3, -1, false, -1, false, 12 - kWPF>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, NPRE + 0);
     ROWS_STAMP(4);
     // ---- gated residual
-    rows_gate_residual<0, 6>(m.y, tok, p.mm, p.gate_chunk, p.h);
-    rows_gate_residual<6, 12>(m.y, tok, p.mm, p.gate_chunk, p.h);
+    if (MODLDS) {
+        rows_gate_residual_lds<0, 6>(m.y, tok, modl + 1024, p.h);
+        rows_gate_residual_lds<6, 12>(m.y, tok, modl + 1024, p.h);
+    } else {
+        rows_gate_residual<0, 6>(m.y, tok, p.mm, p.gate_chunk, p.h);
+        rows_gate_residual<6, 12>(m.y, tok, p.mm, p.gate_chunk, p.h);
+    }
     ROWS_STAMP(5);
     if (p.trace && lane == 0) {
         const long i = ((long)blockIdx.x * NW + w) * 8;
@@ -386,22 +416,25 @@ void launch_pack_stream(const float* w, int ld, int which, const int* tab, int n
                        rowmap);
 }
 
+template <int NW>
+static void launch_mlp_rows_nw(const MlpRowsParams& p, long tiles, hipStream_t s) {
+    const bool proj = p.o != nullptr;
+    // a 32-row tile never straddles two modulation groups: groups are whole tiles, or every group reads the same row
+    const bool uni = p.mm.tokens_per_group % 32 == 0 || (p.mm.step_stride == 0 && p.mm.group_stride == 0);
+    const dim3 g((unsigned)((tiles + NW - 1) / NW)), b(NW * 64);
+    if (proj) {
+        if (uni) hipLaunchKernelGGL((k_mlp_rows<NW, true, true>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((k_mlp_rows<NW, true, false>), g, b, 0, s, p);
+    } else {
+        if (uni) hipLaunchKernelGGL((k_mlp_rows<NW, false, true>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((k_mlp_rows<NW, false, false>), g, b, 0, s, p);
+    }
+}
 void launch_mlp_rows(const MlpRowsParams& p, int nw, hipStream_t s) {
     const long tiles = (p.nrows + 31) / 32;
-    const bool proj = p.o != nullptr;
-    if (nw == 4) {
-        const dim3 g((unsigned)((tiles + 3) / 4)), b(256);
-        if (proj) hipLaunchKernelGGL((k_mlp_rows<4, true>), g, b, 0, s, p);
-        else hipLaunchKernelGGL((k_mlp_rows<4, false>), g, b, 0, s, p);
-    } else if (nw == 2) {
-        const dim3 g((unsigned)((tiles + 1) / 2)), b(128);
-        if (proj) hipLaunchKernelGGL((k_mlp_rows<2, true>), g, b, 0, s, p);
-        else hipLaunchKernelGGL((k_mlp_rows<2, false>), g, b, 0, s, p);
-    } else {
-        const dim3 g((unsigned)tiles), b(64);
-        if (proj) hipLaunchKernelGGL((k_mlp_rows<1, true>), g, b, 0, s, p);
-        else hipLaunchKernelGGL((k_mlp_rows<1, false>), g, b, 0, s, p);
-    }
+    if (nw == 4) launch_mlp_rows_nw<4>(p, tiles, s);
+    else if (nw == 2) launch_mlp_rows_nw<2>(p, tiles, s);
+    else launch_mlp_rows_nw<1>(p, tiles, s);
 }
 
 }  // namespace mdg
