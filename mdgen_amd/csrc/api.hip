@@ -1040,6 +1040,7 @@ static int chain_sublayers(const Run& r, const TrunkW& w, float* h, const AxisMa
     p.qf = r.qfp; p.kf = r.kfp; p.vf = r.vfp;
     p.vmask = (uint32_t*)(r.vfp + flash_vmask_offset(axT.nseq, axT.ntile()));
     p.vmask_stride = flash_vmask_stride(axT.ntile());
+    p.dump = r.obufp;   // (the attention output of the previous layer: consumed, rewritten by the attention kernel that follows)
     if (r.c->phase_trace) {   // one-shot (mdgen_profile_phase_trace): the next trunk launch of a row-owner kernel records its stamps
         p.trace = r.c->phase_trace;
         p.trace_cap = r.c->phase_trace_cap;

@@ -62,6 +62,12 @@ struct ChStream {
     }
 };
 
+// The slices of an epilogue that ride beside the MFMAs of the next stage are pure VALU work: left alone, hipcc's instruction
+// selection orders them by their USES (everything lands in front of the stores at the end) whatever the source order says.
+// An empty volatile asm on a slice's results pins it where it is written.
+#define CH_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define CH_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
 struct ChRing {
     const unsigned char* lane_base;   // smem + lane * 16
     int slot;                         // next slot to consume
@@ -69,9 +75,14 @@ struct ChRing {
 };
 
 // One stage: 3 output tiles x 24 k-steps.  SWAP == false: D[feature][token] = W (A) x X^T (B) (transposed product: a lane is
-// a token); SWAP == true: D[token][feature] = X (A) x W^T (B) (a lane is a feature).
-template <bool SWAP>
-__device__ __forceinline__ void ch_stage(ChRing& r, const ChStream& ws, f32x16 (&acc)[3], const bf16x8 (&xf)[24]) {
+// a token); SWAP == true: D[token][feature] = X (A) x W^T (B) (a lane is a feature).  `fill(s)`, s = 0 .. 71, is called behind
+// MFMA s in the same fenced scheduling region: a slice of the PREVIOUS stage's epilogue (which reads the other accumulator
+// buffer) -- a lone wave has nobody else to fill its matrix pipe's shadow with (rows.h, k_mlp_rows' GELU stages).
+struct ChNoFill {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <bool SWAP, class Fill>
+__device__ __forceinline__ void ch_stage(ChRing& r, const ChStream& ws, f32x16 (&acc)[3], const bf16x8 (&xf)[24], Fill& fill) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         ring_barrier<6>();            // slot r.slot + 1 has landed for everybody, everybody has left slot r.slot - 1
@@ -86,10 +97,16 @@ __device__ __forceinline__ void ch_stage(ChRing& r, const ChStream& ws, f32x16 (
             const int f = 24 * j + q, ks = f / 3, tile = f % 3;
             if (SWAP) acc[tile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks], r.wr[q % 6], acc[tile], 0, 0, 0);
             else acc[tile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r.wr[q % 6], xf[ks], acc[tile], 0, 0, 0);
+            fill(f);
             __builtin_amdgcn_sched_barrier(0);
         }
         r.slot += 1;
     }
+}
+template <bool SWAP>
+__device__ __forceinline__ void ch_stage(ChRing& r, const ChStream& ws, f32x16 (&acc)[3], const bf16x8 (&xf)[24]) {
+    ChNoFill nf;
+    ch_stage<SWAP>(r, ws, acc, xf, nf);
 }
 
 __device__ __forceinline__ void ch_zero(f32x16 (&acc)[3]) {
@@ -207,24 +224,93 @@ __device__ __forceinline__ void ch_attn_out(const f32x16 (&acc)[3], const float*
     for (int q = 0; q < 6; ++q) ob[HD * 6 + q] = pack_bf16(o[2 * q], o[2 * q + 1]);
 }
 
-// ---- temporal q / k of head HD of the stage's group: bias + RoPE at the token's frame -> the token's slot of the fragment --
+// ---- temporal q / k epilogue of one stage (4 heads of head group g) as a step machine: 15 steps per head ----------------
+//   0 request the head's 12 biases (LDS) | 1..3 four accumulator values + bias | 4..9 one rotary pair each | 10..12 pack two
+//   pairs each | 13, 14 the two stores.  Branch-free: a wave without real rows stores to a dump (p0 == p1 == dump, hs == 0).
 // p0 / p1: the lane's slot in k-step 0 / k-step 1 of head 0's fragment of its (sequence, tile); q: k-step 1 is an 8-byte
 // slot; k: a 16-byte slot whose entries 4, 5 hold the constant 1.0 (they pick up the softmax shift riding in q, k_flash.hip).
-template <int HD, bool ISK>
-__device__ __forceinline__ void ch_store_qk(const f32x16 (&acc)[3], const f32x4* bias3, const f32x4 (&rq)[4], unsigned char* p0,
-                                            unsigned char* p1, long head_stride, int head, bool live) {
+struct ChQkEpi {
+    f32x4 rq[4];                 // rotary factors of the token's frame
+    unsigned char *p0, *p1;      // this stage's group: head 4 g's slots
+    long hs;                     // head stride of the fragment buffer
+    f32x4 b[3];
     float e[12];
-    ch_head12<HD>(acc, bias3 + HD * 3, e);
-    ch_rope12(e, rq);
     uint32_t u[6];
+};
+template <bool ISK>
+__device__ __forceinline__ void ch_qk_step(const f32x16 (&acc)[3], const f32x4* bias3, ChQkEpi& s, int hd, int step) {
+    if (step == 0) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) u[i] = pack_bf16(e[2 * i], e[2 * i + 1]);
-    const long ho = (long)head * head_stride;
-    if (live) {
-        *reinterpret_cast<u32x4*>(p0 + ho) = u32x4{u[0], u[1], u[2], u[3]};
-        if (ISK) *reinterpret_cast<u32x4*>(p1 + ho) = u32x4{u[4], u[5], 0x3f803f80u, 0u};
-        else *reinterpret_cast<u32x2*>(p1 + ho) = u32x2{u[4], u[5]};
+        for (int c = 0; c < 3; ++c) s.b[c] = bias3[hd * 3 + c];
+    } else if (step < 4) {
+        const int c = step - 1, ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s.e[4 * c + j] = acc[ft][4 * a + j] + s.b[c][j];
+        CH_PIN4(s.e[4 * c], s.e[4 * c + 1], s.e[4 * c + 2], s.e[4 * c + 3]);
+    } else if (step < 10) {
+        const int pp = step - 4;
+        const float cs = s.rq[pp >> 2][pp & 3], sn = s.rq[2 + (pp >> 2)][pp & 3];
+        const float x1 = s.e[2 * pp], x2 = s.e[2 * pp + 1];
+        s.e[2 * pp] = x1 * cs - x2 * sn;
+        s.e[2 * pp + 1] = x2 * cs + x1 * sn;
+        CH_PIN2(s.e[2 * pp], s.e[2 * pp + 1]);
+    } else if (step < 13) {
+        const int i = 2 * (step - 10);
+        s.u[i] = pack_bf16(s.e[2 * i], s.e[2 * i + 1]);
+        s.u[i + 1] = pack_bf16(s.e[2 * i + 2], s.e[2 * i + 3]);
+        CH_PIN2(s.u[i], s.u[i + 1]);
+    } else if (step == 13) {
+        *reinterpret_cast<u32x4*>(s.p0 + hd * s.hs) = u32x4{s.u[0], s.u[1], s.u[2], s.u[3]};
+    } else if (step == 14) {
+        if (ISK) *reinterpret_cast<u32x4*>(s.p1 + hd * s.hs) = u32x4{s.u[4], s.u[5], 0x3f803f80u, 0u};
+        else *reinterpret_cast<u32x2*>(s.p1 + hd * s.hs) = u32x2{s.u[4], s.u[5]};
     }
+}
+template <bool ISK>
+struct ChQkFill {   // slice s of 72: head s / 18, step s % 18
+    const f32x16 (&acc)[3];
+    const f32x4* bias3;          // LDS: lane-ordered biases of the stage's head group, this lane half
+    ChQkEpi& st;
+    __device__ __forceinline__ void operator()(int s) const {
+        if (s % 18 < 15) ch_qk_step<ISK>(acc, bias3, st, s / 18, s % 18);
+    }
+};
+
+// ---- temporal v epilogue (non-transposed stage): 12 items (tile j, residue i), three steps each: bias request | add | pack +
+//      store.  The lane's three columns (feature columns 32 j + n of the head group) sit in heads hd[j], V^T rows d[j].
+struct ChVEpi {
+    unsigned char* vdst;         // this stage's group: V^T fragment of (sequence (b, 0), head 4 g, this tile) + the wave's piece
+    long hs, ss;                 // head stride, sequence stride (bytes)
+    int off[3];                  // hd[j] * hs + d[j] * 16 of the lane's three columns
+    float bv[3];
+    float e[4];
+};
+__device__ __forceinline__ void ch_v_step(const f32x16 (&acc)[3], const float* bias_n, ChVEpi& s, int item, int step) {
+    const int j = item >> 2, i = item & 3;
+    if (step == 0) {
+        if (i == 0) s.bv[j] = bias_n[32 * j];
+    } else if (step == 1) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s.e[a] = acc[j][4 * a + i] + s.bv[j];
+        CH_PIN4(s.e[0], s.e[1], s.e[2], s.e[3]);
+    } else {
+        const u32x2 v = {pack_bf16(s.e[0], s.e[1]), pack_bf16(s.e[2], s.e[3])};
+        *reinterpret_cast<u32x2*>(s.vdst + s.off[j] + i * s.ss) = v;
+    }
+}
+struct ChVFill {   // slice s of 72: every second slice one of the 36 steps
+    const f32x16 (&acc)[3];
+    const float* bias_n;         // LDS: biases of the stage's head group, + lane & 31
+    ChVEpi& st;
+    __device__ __forceinline__ void operator()(int s) const {
+        if (s % 2 == 0) ch_v_step(acc, bias_n, st, (s / 2) / 3, (s / 2) % 3);
+    }
+};
+__device__ __forceinline__ void ch_v_plain(const f32x16 (&acc)[3], const float* bias_n, ChVEpi& st) {
+#pragma unroll
+    for (int item = 0; item < 12; ++item)
+#pragma unroll
+        for (int step = 0; step < 3; ++step) ch_v_step(acc, bias_n, st, item, step);
 }
 
 // =================================================================================================
@@ -364,8 +450,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
         __builtin_amdgcn_sched_barrier(0);
     }
     CH_STAMP(2);
-    // ================= residue axis: out-projection + gated residual; the updated rows stay in registers =================
-    f32x4 hn[48];   // the updated rows (rows_load's image): input of the second LayerNorm
+    // ================= residue axis: out-projection + gated residual =================
     {
         unsigned char* hb = reinterpret_cast<unsigned char*>(p.h) + (unsigned)tok * (unsigned)(kC * 4) + (unsigned)hh * 16u;
         const float* gate = tab + TB_GATE + w * kC + 4 * hh;
@@ -389,7 +474,6 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
                         f32x4 o = hq[il];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) o[j] += gv[j] * (acc[tl][4 * a + j] + bv[j]);
-                        hn[i] = o;
                         if (live) *reinterpret_cast<f32x4*>(hb + 32u * i) = o;
                     }
                 __builtin_amdgcn_sched_barrier(0);
@@ -398,79 +482,122 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
     }
     CH_STAMP(3);
     // ================= temporal axis: LayerNorm of the updated rows, q / k / v -> fragments =================
-    rows_norm(hn, ltok, p.mm, p.shift_t, p.scale_t, 1e-6f, xf);
+    // The updated rows come back from L2 (this wave's own stores, acknowledged by the wait; a 192-register image kept across
+    // the out-projection spills): 48 loads, then the same LayerNorm as the prologue.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    rows_ln(p.h, ltok, p.mm, p.shift_t, p.scale_t, 1e-6f, xf);
     CH_STAMP(4);
     const int ntile = p.ntile;
     const int tl5 = t0 >> 5, s0 = t0 & 31;                   // key tile and first key slot of the wave's 8 frames (uniform)
     const int seq = b * 4 + l;                               // the lane's temporal sequence
     const int slot = s0 + tt;
-    f32x4 rqt[4];
+    const int g8 = s0 >> 3;
+    const long seq0 = (long)b * 4 * kH * ntile + tl5;        // fragment index of (sequence (b, 0), head 0, this tile)
+    f32x16 accb[3];                                          // second accumulator buffer: stage n + 1 runs while n's epilogue reads n's
     {
-        const f32x4* rc = reinterpret_cast<const f32x4*>(tab + TB_ROPET + w * 288 + tt * 36 + 16 * hh);
+        ChQkEpi qe;
+        {
+            const f32x4* rc = reinterpret_cast<const f32x4*>(tab + TB_ROPET + w * 288 + tt * 36 + 16 * hh);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rqt[i] = rc[i];
-    }
-    {
+            for (int i = 0; i < 4; ++i) qe.rq[i] = rc[i];
+        }
+        // a wave without real rows computes like the others (it shares the ring) and stores into the attention-output buffer,
+        // which nobody reads before the attention kernel rewrites it
+        unsigned char* dump = reinterpret_cast<unsigned char*>(p.dump) + lane * 16;
         const long fq = ((long)seq * kH * ntile + tl5);
-        unsigned char* q0 = p.qf + fq * kFragQ + (hh * 32 + slot) * 16;
-        unsigned char* q1 = p.qf + fq * kFragQ + 1024 + (hh * 32 + slot) * 8;
-        unsigned char* k0 = p.kf + fq * kFragK + (hh * 32 + slot) * 16;
-        unsigned char* k1 = p.kf + fq * kFragK + 1024 + (hh * 32 + slot) * 16;
+        unsigned char* q0 = live ? p.qf + fq * kFragQ + (hh * 32 + slot) * 16 : dump;
+        unsigned char* q1 = live ? p.qf + fq * kFragQ + 1024 + (hh * 32 + slot) * 8 : dump;
+        unsigned char* k0 = live ? p.kf + fq * kFragK + (hh * 32 + slot) * 16 : dump;
+        unsigned char* k1 = live ? p.kf + fq * kFragK + 1024 + (hh * 32 + slot) * 16 : dump;
+        const long qhs = live ? (long)ntile * kFragQ : 0, khs = live ? (long)ntile * kFragK : 0;
+        const f32x4* bq3 = reinterpret_cast<const f32x4*>(tab + TB_BQT + hh * 48);   // + g * 24 (f32x4 units)
+        const f32x4* bk3 = reinterpret_cast<const f32x4*>(tab + TB_BKT + hh * 48);
+        ChVEpi ve;
+        // 8-byte piece of the V^T fragment: [k-step g8 >> 1][key half hh][row d][slots 4 (g8 & 1) .. + 3]
+        unsigned char* v0 = live ? p.vf + seq0 * kFragV + (long)(g8 >> 1) * 800 + hh * 400 + (g8 & 1) * 8 : dump;
+        ve.hs = live ? (long)ntile * kFragV : 0;
+        ve.ss = live ? (long)kH * ntile * kFragV : 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int col = 32 * j + n, hd = col / kDH, d = col - hd * kDH;
+            ve.off[j] = live ? (int)(hd * ve.hs) + d * 16 : 0;
+        }
+        const float* bvn = tab + TB_BVT + n;   // + g * 96
+        // stage n:   0 q0 -> A | 1 q1 -> B, q0's epilogue | 2 q2 -> A, q1's | 3 q3 -> B | 4 k0 -> A, q3's | 5 .. 7 k1 .. k3 |
+        //            8 v0 -> A, k3's epilogue | 9 v1 -> B, v0's | 10 v2 -> A | 11 v3 -> B, v2's | then v3's epilogue
+        ch_zero(acc);
+        ch_stage<false>(r, ws, acc, xf);
+        qe.hs = qhs;
 #pragma unroll 1
-        for (int g = 0; g < 4; ++g) {
+        for (int n2 = 0; n2 < 2; ++n2) {   // stages 2 n2 + 1 (-> B), 2 n2 + 2 (-> A): the epilogues of q stages 2 n2, 2 n2 + 1
+            {
+                qe.p0 = q0 + (long)(8 * n2) * qhs;
+                qe.p1 = q1 + (long)(8 * n2) * qhs;
+                ChQkFill<false> f{acc, bq3 + 48 * n2, qe};
+                ch_zero(accb);
+                ch_stage<false>(r, ws, accb, xf, f);
+            }
+            {
+                qe.p0 = q0 + (long)(8 * n2 + 4) * qhs;
+                qe.p1 = q1 + (long)(8 * n2 + 4) * qhs;
+                ChQkFill<false> f{accb, bq3 + 48 * n2 + 24, qe};
+                ch_zero(acc);
+                ch_stage<false>(r, ws, acc, xf, f);
+            }
+        }
+        qe.hs = khs;
+        {   // stages 5 (-> B), 6 (-> A): k0's, k1's epilogues
+            qe.p0 = k0;
+            qe.p1 = k1;
+            ChQkFill<true> f{acc, bk3, qe};
+            ch_zero(accb);
+            ch_stage<false>(r, ws, accb, xf, f);
+        }
+        {
+            qe.p0 = k0 + 4 * khs;
+            qe.p1 = k1 + 4 * khs;
+            ChQkFill<true> f{accb, bk3 + 24, qe};
             ch_zero(acc);
-            ch_stage<false>(r, ws, acc, xf);
-#ifndef MDGEN_DEV_CHAIN_NOEPI
-            const f32x4* b3 = reinterpret_cast<const f32x4*>(tab + TB_BQT + (g * 2 + hh) * 48);
-            ch_store_qk<0, false>(acc, b3, rqt, q0, q1, (long)ntile * kFragQ, 4 * g + 0, live);
-            ch_store_qk<1, false>(acc, b3, rqt, q0, q1, (long)ntile * kFragQ, 4 * g + 1, live);
-            ch_store_qk<2, false>(acc, b3, rqt, q0, q1, (long)ntile * kFragQ, 4 * g + 2, live);
-            ch_store_qk<3, false>(acc, b3, rqt, q0, q1, (long)ntile * kFragQ, 4 * g + 3, live);
-#else
-            if (acc[0][0] == 1234.5f) q0[0] = 1;
-#endif
-            __builtin_amdgcn_sched_barrier(0);
+            ch_stage<false>(r, ws, acc, xf, f);
+        }
+        {   // stages 7 (-> B), 8 (-> A; the first v stage: non-transposed product): k2's, k3's epilogues
+            qe.p0 = k0 + 8 * khs;
+            qe.p1 = k1 + 8 * khs;
+            ChQkFill<true> f{acc, bk3 + 48, qe};
+            ch_zero(accb);
+            ch_stage<false>(r, ws, accb, xf, f);
+        }
+        {
+            qe.p0 = k0 + 12 * khs;
+            qe.p1 = k1 + 12 * khs;
+            ChQkFill<true> f{accb, bk3 + 72, qe};
+            ch_zero(acc);
+            ch_stage<true>(r, ws, acc, xf, f);
         }
         CH_STAMP(5);
-#pragma unroll 1
-        for (int g = 0; g < 4; ++g) {
+        {
+            ve.vdst = v0;
+            ChVFill f{acc, bvn, ve};
+            ch_zero(accb);
+            ch_stage<true>(r, ws, accb, xf, f);
+        }
+        {
+            ve.vdst = v0 + 4 * ve.hs;
+            ChVFill f{accb, bvn + 96, ve};
             ch_zero(acc);
-            ch_stage<false>(r, ws, acc, xf);
-#ifndef MDGEN_DEV_CHAIN_NOEPI
-            const f32x4* b3 = reinterpret_cast<const f32x4*>(tab + TB_BKT + (g * 2 + hh) * 48);
-            ch_store_qk<0, true>(acc, b3, rqt, k0, k1, (long)ntile * kFragK, 4 * g + 0, live);
-            ch_store_qk<1, true>(acc, b3, rqt, k0, k1, (long)ntile * kFragK, 4 * g + 1, live);
-            ch_store_qk<2, true>(acc, b3, rqt, k0, k1, (long)ntile * kFragK, 4 * g + 2, live);
-            ch_store_qk<3, true>(acc, b3, rqt, k0, k1, (long)ntile * kFragK, 4 * g + 3, live);
-#else
-            if (acc[0][0] == 1234.5f) k0[0] = 1;
-#endif
-            __builtin_amdgcn_sched_barrier(0);
+            ch_stage<true>(r, ws, acc, xf, f);
+        }
+        {
+            ve.vdst = v0 + 8 * ve.hs;
+            ChVFill f{acc, bvn + 192, ve};
+            ch_zero(accb);
+            ch_stage<true>(r, ws, accb, xf, f);
         }
         CH_STAMP(6);
+        ve.vdst = v0 + 12 * ve.hs;
+        ch_v_plain(accb, bvn + 288, ve);
     }
-    {   // v, NON-transposed: lane (feature column n of a 32-wide tile, half hh), registers 4 a + i = frame 4 hh + a of residue i
-        const int g8 = s0 >> 3;
-        // 8-byte piece of the V^T fragment: [k-step g8 >> 1][key half hh][row d][slots 4 (g8 & 1) .. + 3]
-        const long piece = (long)(g8 >> 1) * 800 + hh * 400 + (g8 & 1) * 8;
-        const long seq0 = (long)b * 4 * kH * ntile + tl5;    // fragment index of (sequence (b, 0), head 0, this tile)
-#pragma unroll 1
-        for (int g = 0; g < 4; ++g) {
-            ch_zero(acc);
-            ch_stage<true>(r, ws, acc, xf);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int col = 32 * j + n, hd = col / kDH, d = col - hd * kDH;
-                const float bv = tab[TB_BVT + g * 96 + col];
-                unsigned char* dst = p.vf + (seq0 + (long)(4 * g + hd) * ntile) * kFragV + piece + d * 16;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {   // residue i: sequence (b, i)
-                    const u32x2 v = {pack_bf16(acc[j][i] + bv, acc[j][4 + i] + bv), pack_bf16(acc[j][8 + i] + bv, acc[j][12 + i] + bv)};
-                    if (live) *reinterpret_cast<u32x2*>(dst + (long)i * kH * ntile * kFragV) = v;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    {
         CH_STAMP(7);
         // the all-ones row 24 of every fragment the wave touched: 4 sequences x 16 heads x 2 key halves, 8 bytes each
         if (live) {
@@ -544,10 +671,11 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
             }
             {   // V^T: row d of (sequence li, head): key slot sl = register r of key half hk (k_gemm.hip write_bias_slots)
                 const int hk = (sl >> 2) & 1, rr = (sl & 3) + 4 * (sl >> 3);
-                for (int it = lane; it < 4 * kH * kDH; it += 64) {
-                    const int d = it % kDH, sh = it / kDH, li = sh >> 4, head = sh & 15;
+                // (row 24, the all-ones row, gets its 1.0 in that slot too: the bias key's P must reach the denominator)
+                for (int it = lane; it < 4 * kH * (kDH + 1); it += 64) {
+                    const int d = it % (kDH + 1), sh = it / (kDH + 1), li = sh >> 4, head = sh & 15;
                     const int dpsi = 12 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3);
-                    const uint32_t v = pack_bf16(p.bias_v_t[head * kDH + dpsi], 0.f);
+                    const uint32_t v = d == kDH ? 0x3f80u : pack_bf16(p.bias_v_t[head * kDH + (d == kDH ? 0 : dpsi)], 0.f);
                     unsigned char* base = p.vf + (((long)(b * 4 + li) * kH + head) * ntile + kt) * kFragV;
                     *reinterpret_cast<uint16_t*>(base + (rr >> 3) * 800 + hk * 400 + d * 16 + (rr & 7) * 2) = (uint16_t)v;
                 }

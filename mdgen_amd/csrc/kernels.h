@@ -94,6 +94,7 @@ struct ChainParams {
     unsigned char *qf, *kf, *vf;
     uint32_t* vmask;
     int vmask_stride;
+    void* dump;                      // >= 4 KiB nobody reads: where the waves of a partial last workgroup put their stores
     unsigned long long* trace;       // measurement only: [wave][10] s_memtime stamps, or null
     long trace_cap;
 };

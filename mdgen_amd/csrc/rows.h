@@ -187,7 +187,10 @@ __device__ __forceinline__ void rows_norm(const f32x4 (&v)[48], int tok, const M
             u[2 * h2] = pack_bf16(y0, y1);
             u[2 * h2 + 1] = pack_bf16(y2, y3);
         }
-        xf[ks] = __builtin_bit_cast(bf16x8, u32x4{u[0], u[1], u[2], u[3]});
+        u32x4 t = {u[0], u[1], u[2], u[3]};
+        asm volatile("" : "+v"(t));   // pinned: hipcc otherwise sinks the normalisation to each fragment's first use inside the
+                                      // following GEMM and keeps the raw row image alive (spilled) until then
+        xf[ks] = __builtin_bit_cast(bf16x8, t);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
