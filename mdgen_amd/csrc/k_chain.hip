@@ -143,85 +143,197 @@ __device__ __forceinline__ void ch_rope12(float (&e)[12], const f32x4 (&rq)[4]) 
     }
 }
 
-template <int HD>
-__device__ __forceinline__ void ch_attn_q(const f32x16 (&acc)[3], const float* tab, int g, int hh, const f32x4 (&rq)[4],
-                                          uint32_t* stash_lane) {
-    float e[12];
-    ch_head12<HD>(acc, reinterpret_cast<const f32x4*>(tab + TB_BQL + (g * 2 + hh) * 48) + HD * 3, e);
-    ch_rope12(e, rq);
+// ---- residue axis (L = 4): the attention of one head group as three step machines, each riding beside the MFMAs of the
+// stage that follows the one whose accumulators it reads -------------------------------------------------------------------
+//   QE (q stage's epilogue, beside the k stage): per head 13 steps: bias request | 3 x (4 values + bias) | 6 rotary pairs |
+//        3 x (pack two pairs -> the wave's LDS stash)
+//   SC (k stage's, beside the v stage): per head 36 micro-steps, two per slice: bias + q + bias-key requests | k values |
+//        rotary pairs | q unpack | 12 x (one feature: 4 quad-broadcast FMAs + the bias key's) | half-wave sums | mask | max |
+//        exp | denominator | P = five attention weights of the head
+//   PV (v stage's, beside the next q stage): per head 18 steps: bias requests | v values | 12 x (one feature of o: 5 FMAs) |
+//        2 x (pack three pairs -> ob)
+// Same arithmetic as k_ln_qkv_attn4 (k_gemm.hip): q and the bias key / value rounded to bf16, k and v fp32, softmax in fp32
+// (1 / den through v_rcp_f32 here).  The quad broadcast is folded into the FMA (v_fmac_f32_dpp, inline asm: hipcc emits a
+// v_mov_b32_dpp + v_fmac pair): its DPP source is always written at least one slice (an MFMA and an LDS read) earlier, which
+// covers the two wait states the hardware asks for between a VALU write and a DPP read of the same register.
+#define CH_FMAC_QUAD(J)                                                                                              \
+    template <>                                                                                                       \
+    __device__ __forceinline__ void ch_fmac_quad<J>(float& acc, float k, float q) {                                   \
+        asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf"           \
+            : "+v"(acc) : "v"(k), "v"(q));                                                                           \
+    }
+template <int J>
+__device__ __forceinline__ void ch_fmac_quad(float& acc, float k, float q);   // acc += (k of quad lane J) * q
+CH_FMAC_QUAD(0) CH_FMAC_QUAD(1) CH_FMAC_QUAD(2) CH_FMAC_QUAD(3)
+#undef CH_FMAC_QUAD
+
+struct ChAttn {
+    f32x4 rq[4];          // rotary factors of the residue position
+    float mq[4];          // key validity of the four residues of the frame (quad)
+    f32x4 b[3];           // requested biases of the head in flight
+    f32x4 kb[3];          // SC: rotated bias key of the head; PV: bias value of the head
+    uint32_t qu[6];       // SC: packed q of the head (from the stash)
+    float e[12];          // values of the head in flight (q, k or v)
+    float qf[12];         // SC: q of the head
+    float sc[5];          // SC: scores / exponentials
+    float t0, t1;         // SC: max, 1 / den
+    float P[20];          // attention weights of the group's four heads
+    float o[12];          // PV: output features of the head
+};
+
+__device__ __forceinline__ void ch_load4(const f32x16 (&acc)[3], ChAttn& s, int hd, int c) {
+    const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) stash_lane[(HD * 6 + q) * 64] = pack_bf16(e[2 * q], e[2 * q + 1]);
+    for (int j = 0; j < 4; ++j) s.e[4 * c + j] = acc[ft][4 * a + j] + s.b[c][j];
+    CH_PIN4(s.e[4 * c], s.e[4 * c + 1], s.e[4 * c + 2], s.e[4 * c + 3]);
+}
+__device__ __forceinline__ void ch_rope1(ChAttn& s, int pp) {
+    const float cs = s.rq[pp >> 2][pp & 3], sn = s.rq[2 + (pp >> 2)][pp & 3];
+    const float x1 = s.e[2 * pp], x2 = s.e[2 * pp + 1];
+    s.e[2 * pp] = x1 * cs - x2 * sn;
+    s.e[2 * pp + 1] = x2 * cs + x1 * sn;
+    CH_PIN2(s.e[2 * pp], s.e[2 * pp + 1]);
 }
 
-// scores of head HD against the four keys of the quad + the learned bias key, softmax -> P[5]
-template <int HD>
-__device__ __forceinline__ void ch_attn_scores(const f32x16 (&acc)[3], const float* tab, int g, int hh, const f32x4 (&rq)[4],
-                                               const uint32_t* stash_lane, float mval, float (&P)[5]) {
-    float k[12], qf[12], kb[12];
-    ch_head12<HD>(acc, reinterpret_cast<const f32x4*>(tab + TB_BKL + (g * 2 + hh) * 48) + HD * 3, k);
-    ch_rope12(k, rq);
-    {
-        const f32x4* kp = reinterpret_cast<const f32x4*>(tab + TB_KBL + ((4 * g + HD) * 2 + hh) * 12);
+// bias3: LDS, the group's lane-ordered q biases of this lane half; stash_lane: the wave's stash + lane
+__device__ __forceinline__ void ch_qe_step(const f32x16 (&acc)[3], const f32x4* bias3, uint32_t* stash_lane, ChAttn& s, int hd, int step) {
+    if (step == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s.b[c] = bias3[hd * 3 + c];
+    } else if (step < 4) {
+        ch_load4(acc, s, hd, step - 1);
+    } else if (step < 10) {
+        ch_rope1(s, step - 4);
+    } else if (step < 13) {
+        const int i = 2 * (step - 10);
+        stash_lane[(hd * 6 + i) * 64] = pack_bf16(s.e[2 * i], s.e[2 * i + 1]);
+        stash_lane[(hd * 6 + i + 1) * 64] = pack_bf16(s.e[2 * i + 2], s.e[2 * i + 3]);
+    }
+}
+struct ChQeFill {   // slice s of 72: head s / 18, step s % 18
+    const f32x16 (&acc)[3];
+    const f32x4* bias3;
+    uint32_t* stash_lane;
+    ChAttn& st;
+    __device__ __forceinline__ void operator()(int s) const {
+        if (s % 18 < 13) ch_qe_step(acc, bias3, stash_lane, st, s / 18, s % 18);
+    }
+};
+
+// bias3: the group's k biases; kb3: LDS, rotated bias key of the group's head 0 for this lane half (+ 6 f32x4 per head)
+__device__ __forceinline__ void ch_sc_step(const f32x16 (&acc)[3], const f32x4* bias3, const f32x4* kb3, const uint32_t* stash_lane,
+                                           ChAttn& s, int hd, int m) {
+    if (m == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s.b[c] = bias3[hd * 3 + c];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s.qu[q] = stash_lane[(hd * 6 + q) * 64];
+    } else if (m < 4) {
+        ch_load4(acc, s, hd, m - 1);
+    } else if (m < 10) {
+        ch_rope1(s, m - 4);
+    } else if (m < 13) {
+        const int c = m - 10;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s.qf[4 * c + 2 * j] = bf16_lo(s.qu[2 * c + j]);
+            s.qf[4 * c + 2 * j + 1] = bf16_hi(s.qu[2 * c + j]);
+        }
+        CH_PIN4(s.qf[4 * c], s.qf[4 * c + 1], s.qf[4 * c + 2], s.qf[4 * c + 3]);
+    } else if (m == 13) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s.kb[c] = kb3[hd * 6 + c];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) s.sc[j] = 0.f;
+        CH_PIN4(s.sc[0], s.sc[1], s.sc[2], s.sc[3]);
+    } else if (m < 26) {
+        const int i = m - 14;
+        ch_fmac_quad<0>(s.sc[0], s.e[i], s.qf[i]);
+        ch_fmac_quad<1>(s.sc[1], s.e[i], s.qf[i]);
+        ch_fmac_quad<2>(s.sc[2], s.e[i], s.qf[i]);
+        ch_fmac_quad<3>(s.sc[3], s.e[i], s.qf[i]);
+        s.sc[4] += s.qf[i] * s.kb[i >> 2][i & 3];
+        CH_PIN4(s.sc[0], s.sc[1], s.sc[2], s.sc[3]);
+    } else if (m == 26) {
+        s.sc[0] = half_sum2(s.sc[0]);
+        s.sc[1] = half_sum2(s.sc[1]);
+        s.sc[2] = half_sum2(s.sc[2]);
+        CH_PIN2(s.sc[0], s.sc[1]);
+    } else if (m == 27) {
+        s.sc[3] = half_sum2(s.sc[3]);
+        s.sc[4] = half_sum2(s.sc[4]);
+        CH_PIN2(s.sc[3], s.sc[4]);
+    } else if (m == 28) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s.sc[j] = s.mq[j] != 0.f ? s.sc[j] : -1e30f;
+        CH_PIN4(s.sc[0], s.sc[1], s.sc[2], s.sc[3]);
+    } else if (m == 29) {
+        s.t0 = fmaxf(fmaxf(fmaxf(s.sc[0], s.sc[1]), fmaxf(s.sc[2], s.sc[3])), s.sc[4]);   // the bias key is never masked
+        CH_PIN2(s.t0, s.sc[4]);
+    } else if (m == 30) {
+        float d[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) d[j] = __builtin_amdgcn_exp2f(s.sc[j] - s.t0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s.sc[j] = s.mq[j] != 0.f ? d[j] : 0.f;
+        s.sc[4] = d[4];
+        CH_PIN4(s.sc[0], s.sc[1], s.sc[2], s.sc[3]);
+    } else if (m == 31) {
+        s.t1 = __builtin_amdgcn_rcpf(((s.sc[0] + s.sc[1]) + (s.sc[2] + s.sc[3])) + s.sc[4]);
+        CH_PIN2(s.t1, s.sc[4]);
+    } else if (m == 32) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) s.P[5 * hd + j] = s.sc[j] * s.t1;
+        CH_PIN4(s.P[5 * hd], s.P[5 * hd + 1], s.P[5 * hd + 2], s.P[5 * hd + 3]);
+    }
+}
+struct ChScFill {   // slice s of 72: head s / 18, micro-steps 2 (s % 18), 2 (s % 18) + 1
+    const f32x16 (&acc)[3];
+    const f32x4 *bias3, *kb3;
+    const uint32_t* stash_lane;
+    ChAttn& st;
+    __device__ __forceinline__ void operator()(int s) const {
+        ch_sc_step(acc, bias3, kb3, stash_lane, st, s / 18, 2 * (s % 18));
+        ch_sc_step(acc, bias3, kb3, stash_lane, st, s / 18, 2 * (s % 18) + 1);
+    }
+};
+
+// bias3: the group's v biases (lane order); bv3: LDS, bf16-rounded bias value of the group's head 0 for this lane half (+ 6 per head)
+__device__ __forceinline__ void ch_pv_step(const f32x16 (&acc)[3], const f32x4* bias3, const f32x4* bv3, ChAttn& s, uint32_t (&ob)[24], int hd,
+                                           int step) {
+    if (step == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const f32x4 v = kp[c];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) kb[4 * c + j] = v[j];
+            s.b[c] = bias3[hd * 3 + c];
+            s.kb[c] = bv3[hd * 6 + c];
         }
+    } else if (step < 4) {
+        ch_load4(acc, s, hd, step - 1);
+    } else if (step < 16) {
+        const int i = step - 4;
+        float o = s.P[5 * hd + 4] * s.kb[i >> 2][i & 3];
+        ch_fmac_quad<0>(o, s.e[i], s.P[5 * hd + 0]);
+        ch_fmac_quad<1>(o, s.e[i], s.P[5 * hd + 1]);
+        ch_fmac_quad<2>(o, s.e[i], s.P[5 * hd + 2]);
+        ch_fmac_quad<3>(o, s.e[i], s.P[5 * hd + 3]);
+        s.o[i] = o;
+        asm volatile("" : "+v"(s.o[i]));
+    } else if (step < 18) {
+        const int q0 = 3 * (step - 16);
+#pragma unroll
+        for (int q = q0; q < q0 + 3; ++q) ob[hd * 6 + q] = pack_bf16(s.o[2 * q], s.o[2 * q + 1]);
     }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const uint32_t u = stash_lane[(HD * 6 + q) * 64];
-        qf[2 * q] = bf16_lo(u);
-        qf[2 * q + 1] = bf16_hi(u);
-    }
-    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        s[0] += qf[i] * ch_quad<0>(k[i]);
-        s[1] += qf[i] * ch_quad<1>(k[i]);
-        s[2] += qf[i] * ch_quad<2>(k[i]);
-        s[3] += qf[i] * ch_quad<3>(k[i]);
-        s[4] += qf[i] * kb[i];
-    }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) s[j] = half_sum2(s[j]);
-    const float m0 = ch_quad<0>(mval), m1 = ch_quad<1>(mval), m2 = ch_quad<2>(mval), m3 = ch_quad<3>(mval);
-    s[0] = m0 != 0.f ? s[0] : -1e30f;
-    s[1] = m1 != 0.f ? s[1] : -1e30f;
-    s[2] = m2 != 0.f ? s[2] : -1e30f;
-    s[3] = m3 != 0.f ? s[3] : -1e30f;
-    const float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), s[4]);   // the bias key is never masked
-    float den = 0.f;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        s[j] = s[j] > -1e29f ? __builtin_amdgcn_exp2f(s[j] - mx) : 0.f;
-        den += s[j];
-    }
-    const float inv = 1.0f / den;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) P[j] = s[j] * inv;
 }
-
-// o of head HD = sum_j P_j v_j + P_4 bias_v -> six packed bf16 pairs ob[6 HD .. 6 HD + 5]
-template <int HD>
-__device__ __forceinline__ void ch_attn_out(const f32x16 (&acc)[3], const float* tab, int g, int hh, const float (&Pw)[5],
-                                            uint32_t (&ob)[24]) {
-    float v[12], o[12];
-    ch_head12<HD>(acc, reinterpret_cast<const f32x4*>(tab + TB_BVL + (g * 2 + hh) * 48) + HD * 3, v);
-    const f32x4* bp = reinterpret_cast<const f32x4*>(tab + TB_BVLR + (4 * g + HD) * kDH + 12 * hh);
+struct ChPvFill {   // slice s of 72: head s / 18, step s % 18
+    const f32x16 (&acc)[3];
+    const f32x4 *bias3, *bv3;
+    ChAttn& st;
+    uint32_t (&ob)[24];
+    __device__ __forceinline__ void operator()(int s) const { ch_pv_step(acc, bias3, bv3, st, ob, s / 18, s % 18); }
+};
+__device__ __forceinline__ void ch_pv_plain(const f32x16 (&acc)[3], const f32x4* bias3, const f32x4* bv3, ChAttn& st, uint32_t (&ob)[24]) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const f32x4 bv = bp[c];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = 4 * c + j;
-            o[i] = Pw[0] * ch_quad<0>(v[i]) + Pw[1] * ch_quad<1>(v[i]) + Pw[2] * ch_quad<2>(v[i]) + Pw[3] * ch_quad<3>(v[i]) +
-                   Pw[4] * bv[j];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) ob[HD * 6 + q] = pack_bf16(o[2 * q], o[2 * q + 1]);
+    for (int s = 0; s < 72; ++s) ch_pv_step(acc, bias3, bv3, st, ob, s / 18, s % 18);
 }
 
 // ---- temporal q / k epilogue of one stage (4 heads of head group g) as a step machine: 15 steps per head ----------------
@@ -385,69 +497,83 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
     uint32_t* stash_lane = reinterpret_cast<uint32_t*>(smem + kRingBytes + kChTabBytes) + w * 24 * 64 + lane;
     f32x16 acc[3];
     CH_STAMP(1);
-    // rotary factors of the residue axis: position = residue index
-    f32x4 rql[4];
+    f32x16 accb[3];   // second accumulator buffer: stage n + 1 runs while stage n's epilogue reads stage n's
     // ================= residue axis: q, k, v head group by head group; the 5-key attention in registers =================
     bf16x8 of[24];   // attention output rows as the B operand of the out-projection (k order: lane's own value list)
-#pragma unroll 1
-    for (int g = 0; g < 4; ++g) {
-        ch_zero(acc);
-        ch_stage<false>(r, ws, acc, xf);
+    {
+        ChAttn at;
+        uint32_t ob[24];
         {
             const f32x4* rc = reinterpret_cast<const f32x4*>(tab + TB_ROPEL + l * kRopeRow + 16 * hh);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rql[i] = rc[i];
+            for (int i = 0; i < 4; ++i) at.rq[i] = rc[i];
         }
-        ch_attn_q<0>(acc, tab, g, hh, rql, stash_lane);
-        ch_attn_q<1>(acc, tab, g, hh, rql, stash_lane);
-        ch_attn_q<2>(acc, tab, g, hh, rql, stash_lane);
-        ch_attn_q<3>(acc, tab, g, hh, rql, stash_lane);
-        __builtin_amdgcn_sched_barrier(0);
-        ch_zero(acc);
-        ch_stage<false>(r, ws, acc, xf);
-        float P0[5], P1[5], P2[5], P3[5];
-        ch_attn_scores<0>(acc, tab, g, hh, rql, stash_lane, mval, P0);
-        __builtin_amdgcn_sched_barrier(0);
-        ch_attn_scores<1>(acc, tab, g, hh, rql, stash_lane, mval, P1);
-        __builtin_amdgcn_sched_barrier(0);
-        ch_attn_scores<2>(acc, tab, g, hh, rql, stash_lane, mval, P2);
-        __builtin_amdgcn_sched_barrier(0);
-        ch_attn_scores<3>(acc, tab, g, hh, rql, stash_lane, mval, P3);
-        __builtin_amdgcn_sched_barrier(0);
-        // the 20 attention weights wait in the (now free) q stash as bf16 pairs while the V stage runs
-        {
-            const float Pf[20] = {P0[0], P0[1], P0[2], P0[3], P0[4], P1[0], P1[1], P1[2], P1[3], P1[4],
-                                  P2[0], P2[1], P2[2], P2[3], P2[4], P3[0], P3[1], P3[2], P3[3], P3[4]};
+        at.mq[0] = ch_quad<0>(mval);
+        at.mq[1] = ch_quad<1>(mval);
+        at.mq[2] = ch_quad<2>(mval);
+        at.mq[3] = ch_quad<3>(mval);
 #pragma unroll
-            for (int i = 0; i < 10; ++i) stash_lane[i * 64] = pack_bf16(Pf[2 * i], Pf[2 * i + 1]);
-        }
-        ch_zero(acc);
-        ch_stage<false>(r, ws, acc, xf);
-        uint32_t ob[24];
-        {
-            float Pf[20];
+        for (int i = 0; i < 20; ++i) at.P[i] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const uint32_t u = stash_lane[i * 64];
-                Pf[2 * i] = bf16_lo(u);
-                Pf[2 * i + 1] = bf16_hi(u);
-            }
-            const float Q0[5] = {Pf[0], Pf[1], Pf[2], Pf[3], Pf[4]}, Q1[5] = {Pf[5], Pf[6], Pf[7], Pf[8], Pf[9]},
-                        Q2[5] = {Pf[10], Pf[11], Pf[12], Pf[13], Pf[14]}, Q3[5] = {Pf[15], Pf[16], Pf[17], Pf[18], Pf[19]};
-            ch_attn_out<0>(acc, tab, g, hh, Q0, ob);
-            ch_attn_out<1>(acc, tab, g, hh, Q1, ob);
-            ch_attn_out<2>(acc, tab, g, hh, Q2, ob);
-            ch_attn_out<3>(acc, tab, g, hh, Q3, ob);
-        }
-        // group g = the lane's values 48 g .. 48 g + 47 = k-steps 6 g .. 6 g + 5 of the out-projection
-#define CH_PUT(G)                                                                                                \
-    if (g == G) {                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                            \
+        for (int i = 0; i < 12; ++i) at.e[i] = 0.f;
+        ch_zero(accb);
+        const f32x4* bq3 = reinterpret_cast<const f32x4*>(tab + TB_BQL + hh * 48);    // + g * 24 (f32x4 units)
+        const f32x4* bk3 = reinterpret_cast<const f32x4*>(tab + TB_BKL + hh * 48);
+        const f32x4* bv3 = reinterpret_cast<const f32x4*>(tab + TB_BVL + hh * 48);
+        const f32x4* kbl = reinterpret_cast<const f32x4*>(tab + TB_KBL + hh * 12);    // + head * 6
+        const f32x4* bvr = reinterpret_cast<const f32x4*>(tab + TB_BVLR + hh * 12);   // + head * 6
+        // stage n = 3 g + {0 q, 1 k, 2 v} accumulates into buffer n & 1 and carries the epilogue of stage n - 1:
+        //   q_g: PV of group g - 1 | k_g: QE of g | v_g: SC of g.      Two groups per trip: the buffers alternate statically.
+#define CH_PUT(G)                                                                                                                \
+    if (gp == G) {                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                                            \
             of[6 * G + i] = __builtin_bit_cast(bf16x8, u32x4{ob[4 * i], ob[4 * i + 1], ob[4 * i + 2], ob[4 * i + 3]}); \
     }
-        CH_PUT(0) CH_PUT(1) CH_PUT(2) CH_PUT(3)
+#pragma unroll 1
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int g0 = 2 * t2, g1 = g0 + 1;
+            {   // q of g0 -> A; PV of g0 - 1 reads B (first trip: zeros, result unused)
+                const int gq = g0 == 0 ? 0 : g0 - 1;
+                ChPvFill f{accb, bv3 + 24 * gq, bvr + 24 * gq, at, ob};
+                ch_zero(acc);
+                ch_stage<false>(r, ws, acc, xf, f);
+                const int gp = g0 - 1;
+                CH_PUT(1)
+            }
+            {   // k of g0 -> B; QE of g0 reads A
+                ChQeFill f{acc, bq3 + 24 * g0, stash_lane, at};
+                ch_zero(accb);
+                ch_stage<false>(r, ws, accb, xf, f);
+            }
+            {   // v of g0 -> A; SC of g0 reads B
+                ChScFill f{accb, bk3 + 24 * g0, kbl + 24 * g0, stash_lane, at};
+                ch_zero(acc);
+                ch_stage<false>(r, ws, acc, xf, f);
+            }
+            {   // q of g1 -> B; PV of g0 reads A
+                ChPvFill f{acc, bv3 + 24 * g0, bvr + 24 * g0, at, ob};
+                ch_zero(accb);
+                ch_stage<false>(r, ws, accb, xf, f);
+                const int gp = g0;
+                CH_PUT(0) CH_PUT(2)
+            }
+            {   // k of g1 -> A; QE of g1 reads B
+                ChQeFill f{accb, bq3 + 24 * g1, stash_lane, at};
+                ch_zero(acc);
+                ch_stage<false>(r, ws, acc, xf, f);
+            }
+            {   // v of g1 -> B; SC of g1 reads A
+                ChScFill f{acc, bk3 + 24 * g1, kbl + 24 * g1, stash_lane, at};
+                ch_zero(accb);
+                ch_stage<false>(r, ws, accb, xf, f);
+            }
+        }
+        {   // the last group's PV has no stage to ride beside: the out-projection needs all of `of`
+            ch_pv_plain(accb, bv3 + 72, bvr + 72, at, ob);
+            const int gp = 3;
+            CH_PUT(3)
+        }
 #undef CH_PUT
-        __builtin_amdgcn_sched_barrier(0);
     }
     CH_STAMP(2);
     // ================= residue axis: out-projection + gated residual =================
@@ -493,7 +619,6 @@ __global__ __launch_bounds__(NW * 64, 1) void k_chain_l4(const ChainParams p) {
     const int slot = s0 + tt;
     const int g8 = s0 >> 3;
     const long seq0 = (long)b * 4 * kH * ntile + tl5;        // fragment index of (sequence (b, 0), head 0, this tile)
-    f32x16 accb[3];                                          // second accumulator buffer: stage n + 1 runs while n's epilogue reads n's
     {
         ChQkEpi qe;
         {
