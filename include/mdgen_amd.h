@@ -118,10 +118,12 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *   "fuse_proj"        0 (default) / 1: with the row-owner MLP kernel, run the temporal attention's out-projection +
  *                      gated residual (mha.py:397, latent_model.py:476) inside it, ahead of the MLP.
  *   "chain_path"       tetrapeptide trunk (L == 4, T a multiple of 8): the residue-axis attention sub-layer and the temporal
- *                      sub-layer's LN -> q, k, v -> fragments (latent_model.py:457-475) as ONE row-owner kernel
- *                      (csrc/k_chain.hip k_chain_l4) instead of two panel kernels: 0 (default) off -- one wave per SIMD cannot
- *                      hide the attention's vector work behind the matrix pipe, the kernel is 10-15 % slower than the two it
- *                      replaces --, 1 for launches of >= 768 row tiles, 2 whenever the shape allows.
+ *                      sub-layer's LN -> q, k, v -> fragments (latent_model.py:457-475) in ONE launch: 0 (default) two panel
+ *                      kernels (k_ln_qkv_attn4<true>, k_ln_qkv); 1 one panel kernel (k_ln_qkv_attn4<true, true>: the rows it has
+ *                      just updated come back from L2 instead of HBM -- but a tile of 8 frames x 4 residues writes the temporal
+ *                      fragments as 8- and 16-byte pieces: 53.6 against 52.2 ms per 245 launches); 2 / 3 the row-owner kernel csrc/k_chain.hip
+ *                      k_chain_l4 (2: launches of >= 768 row tiles, 3: always) -- measured 10-15 % slower than the two panel
+ *                      kernels (one wave per SIMD cannot hide the attention's vector work), kept for reference.
  *   "train_precision"  operands of the matrix products of mdgen_train_forward_backward (linear layers, weight gradients,
  *                      the attention's q k^T / p v and their backward): 32 (default) fp32, the exact mode; 16 rounded to
  *                      bf16 on the MFMA, fp32 accumulation, fp32 master weights and activations (train.py:13

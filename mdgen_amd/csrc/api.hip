@@ -133,9 +133,10 @@ struct mdgen_ctx {
     int opt_attn_path = 0;      // tiled attention: 0 fixed-anchor fast loop with overflow check + fallback, 1 robust loop always
     int opt_mlp_path = 1;       // MLP block: 0 resident-panel kernel (k_mlp), 1 row-owner kernel (k_mlp_rows) when the launch
                                 // fills the chip, 2 row-owner kernel always
-    int opt_chain = 0;          // tetrapeptide trunk (L == 4, T % 8 == 0): residue-axis sub-layer + temporal LN / q, k, v as ONE row-owner
-                                // kernel (k_chain_l4): 0 off (default: measured slower than the two panel kernels), 1 for
-                                // launches that fill the chip, 2 whenever the shape allows
+    int opt_chain = 0;          // tetrapeptide trunk (L == 4, T % 8 == 0): residue-axis sub-layer + temporal LN / q, k, v in ONE launch:
+                                // 0 (default) off (k_ln_qkv_attn4<true> + k_ln_qkv), 1 the panel kernel k_ln_qkv_attn4<true, true> (a tie),
+                                // 2 the row-owner kernel k_chain_l4 for launches that fill the chip (measured slower),
+                                // 3 k_chain_l4 whenever the shape allows
     int opt_fuse_proj = 0;      // with the row-owner MLP kernel: run the temporal attention's out-projection inside it (same wall time)
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
@@ -664,7 +665,8 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
         if (value != 0 && value != 1) return fail(-2, "fuse_proj must be 0 or 1");
         c->opt_fuse_proj = value;
     } else if (n == "chain_path") {
-        if (value < 0 || value > 2) return fail(-2, "chain_path must be 0 (off), 1 (launches that fill the chip) or 2 (whenever L == 4 and T % 8 == 0)");
+        if (value < 0 || value > 3)
+            return fail(-2, "chain_path must be 0 (off), 1 (panel kernel), 2 (row-owner kernel when it fills the chip) or 3 (row-owner kernel always)");
         c->opt_chain = value;
     } else if (n == "mlp_path") {
         if (value < 0 || value > 2) return fail(-2, "mlp_path must be 0 (panel kernel), 1 (row-owner kernel when it fills the chip) or 2 (always)");
@@ -1013,10 +1015,42 @@ static bool mlp_uses_rows(const mdgen_ctx* c, long nrows) {
 // `proj`: a deferred out-projection (attn_sublayer) to run inside the row-owner kernel, ahead of the MLP
 // k_chain_l4 (csrc/k_chain.hip): the residue-axis sub-layer of a tetrapeptide trunk layer and the front half of its temporal
 // sub-layer (LN -> q, k, v -> fragments) in one row-owner launch.
-static bool chain_eligible(const mdgen_ctx* c, const Run& r) {
-    if (c->opt_chain == 0 || c->opt_precision != 16 || c->opt_residue_l4 != 2) return false;
-    if (r.L != 4 || r.T % 8 != 0 || r.N % 32 != 0) return false;
-    return c->opt_chain == 2 || r.N / 32 >= 4 * 192;
+// 0: separate kernels; 1: k_ln_qkv_attn4<true, true> (panel form); 2: k_chain_l4 (row-owner form)
+static int chain_mode(const mdgen_ctx* c, const Run& r) {
+    if (c->opt_chain == 0 || c->opt_precision != 16 || c->opt_residue_l4 != 2) return 0;
+    if (r.L != 4 || r.T % 8 != 0 || r.N % 32 != 0) return 0;
+    if (c->opt_chain == 3 || (c->opt_chain == 2 && r.N / 32 >= 4 * 192)) return 2;
+    return 1;
+}
+static int chain_sublayers_panel(const Run& r, const TrunkW& w, float* h, const AxisMap& axT, const ModMap& mm, const MaskMap& mk) {
+    if (int e = check_launch_rows(r.N)) return e;
+    const MhaW &ml = w.mha_l, &mt = w.mha_t;
+    QkvParams q{};
+    q.h = h;
+    q.nrows = r.N;
+    q.mm = mm;
+    q.shift_chunk = 0; q.scale_chunk = 1;
+    q.wq = ml.wq; q.wk = ml.wk; q.wv = ml.wv_small;
+    q.bq = ml.bq; q.bk = ml.bk; q.bv = ml.bv_small;
+    q.rope = r.c->rope;
+    q.bias_k = ml.bias_k; q.bias_v = ml.bias_v;
+    q.mk = mk;
+    q.obuf = r.obufp;
+    q.h_rw = h;
+    q.wo = ml.wo; q.bo = ml.bo;
+    q.gate_chunk = 2;
+    q.qf = r.qfp; q.kf = r.kfp; q.vf = r.vfp;
+    q.vmask = (uint32_t*)(r.vfp + flash_vmask_offset(axT.nseq, axT.ntile()));
+    q.vmask_stride = flash_vmask_stride(axT.ntile());
+    q.T = r.T;
+    q.ntile_t = axT.ntile();
+    q.shift_t = 3; q.scale_t = 4;
+    q.wq_t = mt.wq; q.wk_t = mt.wk; q.wv_t = mt.wv_flash;
+    q.bq_t = mt.bq; q.bk_t = mt.bk; q.bv_t = mt.bv_flash;
+    q.bias_k_t = mt.bias_k; q.bias_v_t = mt.bias_v;
+    { ProfScope ps(r.c, "attnL_qkvT", r.s); launch_ln_qkv_attn4(q, true, r.s, true); }
+    LAUNCHCHK();
+    return 0;
 }
 static int chain_sublayers(const Run& r, const TrunkW& w, float* h, const AxisMap& axT, const ModMap& mm, const MaskMap& mk) {
     if (int e = check_launch_rows(r.N)) return e;
@@ -1289,9 +1323,12 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
     for (int i = 0; i < c->nl; ++i) {
         const TrunkW& w = c->trunk[i];
         ModMap mm{modstep + c->trunk_off(i), r.T * r.L, r.B, 0, r.mod_group_stride};
-        const bool chain = chain_eligible(c, r);
-        if (chain) {
+        const int cm = chain_mode(c, r);
+        const bool chain = cm != 0;
+        if (cm == 2) {
             if (int er = chain_sublayers(r, w, h, axT, mm, mk)) return er;
+        } else if (cm == 1) {
+            if (int er = chain_sublayers_panel(r, w, h, axT, mm, mk)) return er;
         } else {
             if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true)) return er;
         }

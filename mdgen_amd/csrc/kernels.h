@@ -27,6 +27,13 @@ struct QkvParams {
     const bf16x8* wo;               // packed out-projection weights
     const float* bo;
     int gate_chunk;
+    // k_ln_qkv_attn4<true, true>: additionally the TEMPORAL sub-layer's LN -> q, k, v -> fragments of the same 64 tokens (qf /
+    // kf / vf / vmask above are then the temporal axis'); T frames per sample (a multiple of 8), ntile_t = T / 32 + 1
+    int T, ntile_t;
+    int shift_t, scale_t;
+    const bf16x8 *wq_t, *wk_t, *wv_t;       // packed as for k_ln_qkv (FLASH-layout V)
+    const float *bq_t, *bk_t, *bv_t;
+    const float *bias_k_t, *bias_v_t;
 };
 
 struct ProjParams {
@@ -182,7 +189,7 @@ struct FloatChunk {
 };
 
 void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s);
-void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s);
+void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s, bool with_qkv_t = false);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
 void launch_mlp(const MlpParams& p, hipStream_t s);
 void launch_mlp_rows(const MlpRowsParams& p, int nw, hipStream_t s);

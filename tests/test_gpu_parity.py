@@ -2155,9 +2155,10 @@ def test_row_owner_mlp_paths_agree():
 
 @pytest.mark.parametrize("shape", [(1, 40, 0), (1, 64, 0), (2, 8, 0), (3, 104, 1), (2, 1000, 0), (1, 96, 2)])
 def test_chain_kernel_vs_panel_kernels_and_oracle(shape):
-    """k_chain_l4 (csrc/k_chain.hip, option `chain_path`): the tetrapeptide trunk's residue-axis attention sub-layer and the
-    temporal sub-layer's LN -> q, k, v -> fragments (latent_model.py:457-475, mha.py:258-268, 356-357) as ONE row-owner kernel,
-    against (a) the CPU oracle at the bf16 gate and (b) the two panel kernels it replaces (`chain_path` 0; different
+    """Option `chain_path`: the tetrapeptide trunk's residue-axis attention sub-layer and the temporal sub-layer's LN -> q, k, v
+    -> fragments (latent_model.py:457-475, mha.py:258-268, 356-357) in ONE launch -- 1 the panel kernel
+    k_ln_qkv_attn4<true, true> (the default), 3 the row-owner kernel k_chain_l4 (csrc/k_chain.hip) --
+    against (a) the CPU oracle at the bf16 gate and (b) the two panel kernels they replace (`chain_path` 0; different
     summation orders only: a few 1e-3).  Shapes (B, T, padded residues): a launch whose last workgroup has idle waves
     (T 40: 5 row tiles), T a multiple of 32 / 64 (the learned bias key opens a key tile of its own, which the kernel must
     zero-fill), one 8-frame group per sample (T 8), key padding on the residue axis, the headline's T 1000 (32 key tiles;
@@ -2177,7 +2178,7 @@ def test_chain_kernel_vs_panel_kernels_and_oracle(shape):
     dkw = {k: (tuple(u.to(dev) for u in v) if isinstance(v, tuple) else v.to(dev)) for k, v in kw.items()}
     ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
     outs = {}
-    for path in (0, 2):
+    for path in (0, 1, 3):
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
         m.set_option("chain_path", path)
@@ -2194,16 +2195,17 @@ def test_chain_kernel_vs_panel_kernels_and_oracle(shape):
             assert v < TOL_FWD, (path, k, v)
         outs[path] = (out.cpu(), tr["h1"].cpu())
         del m
-    e_out, e_h1 = rel_l2(outs[2][0], outs[0][0]), rel_l2(outs[2][1], outs[0][1])
-    print(shape, f"chain vs panel kernels: out {e_out:.2e}  h1 {e_h1:.2e}")
-    assert e_out < 5e-3 and e_h1 < 5e-3
+    for path, what in ((1, "one panel kernel"), (3, "row-owner kernel")):
+        e_out, e_h1 = rel_l2(outs[path][0], outs[0][0]), rel_l2(outs[path][1], outs[0][1])
+        print(shape, f"{what} vs the two panel kernels: out {e_out:.2e}  h1 {e_h1:.2e}")
+        assert e_out < 5e-3 and e_h1 < 5e-3
     # padded residues never influence the valid ones
     if n_pad:
         x2 = inp["x"].clone()
         x2[:, :, 4 - n_pad:] = 1e3
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
-        m.set_option("chain_path", 2)
+        m.set_option("chain_path", 3)
         a = m.forward(**dkw)
         b2 = m.forward(**dict(dkw, x=x2.to(dev)))
         assert torch.equal(a[:, :, :4 - n_pad], b2[:, :, :4 - n_pad])
