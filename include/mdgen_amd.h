@@ -117,6 +117,10 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      which fill the chip, and the panel kernel below that; 2 the row-owner kernel always.
  *   "fuse_proj"        0 (default) / 1: with the row-owner MLP kernel, run the temporal attention's out-projection +
  *                      gated residual (mha.py:397, latent_model.py:476) inside it, ahead of the MLP.
+ *   "fuse_proj_qkv"    1 (default) / 0: residue axis on the tiled-attention path (L > 8): its out-projection + gated residual
+ *                      (mha.py:397, latent_model.py:462) runs inside the temporal sub-layer's LN -> q, k, v kernel, whose panels
+ *                      then normalise rows that are still in L2 (k_ln_qkv<false, true>; one launch and one HBM read of the
+ *                      residual stream less per layer).
  *   "chain_path"       tetrapeptide trunk (L == 4, T a multiple of 8): the residue-axis attention sub-layer and the temporal
  *                      sub-layer's LN -> q, k, v -> fragments (latent_model.py:457-475) in ONE launch: 0 (default) two panel
  *                      kernels (k_ln_qkv_attn4<true>, k_ln_qkv); 1 one panel kernel (k_ln_qkv_attn4<true, true>: the rows it has

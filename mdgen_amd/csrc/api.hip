@@ -137,6 +137,7 @@ struct mdgen_ctx {
                                 // 0 (default) off (k_ln_qkv_attn4<true> + k_ln_qkv), 1 the panel kernel k_ln_qkv_attn4<true, true> (a tie),
                                 // 2 the row-owner kernel k_chain_l4 for launches that fill the chip (measured slower),
                                 // 3 k_chain_l4 whenever the shape allows
+    int opt_fuse_proj_qkv = 1;  // tiled residue axis (L > 8): its out-projection + gated residual runs inside the temporal q / k / v kernel
     int opt_fuse_proj = 0;      // with the row-owner MLP kernel: run the temporal attention's out-projection inside it (same wall time)
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
@@ -664,6 +665,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "fuse_proj") {
         if (value != 0 && value != 1) return fail(-2, "fuse_proj must be 0 or 1");
         c->opt_fuse_proj = value;
+    } else if (n == "fuse_proj_qkv") {
+        if (value != 0 && value != 1) return fail(-2, "fuse_proj_qkv must be 0 or 1");
+        c->opt_fuse_proj_qkv = value;
     } else if (n == "chain_path") {
         if (value < 0 || value > 3)
             return fail(-2, "chain_path must be 0 (off), 1 (panel kernel), 2 (row-owner kernel when it fills the chip) or 3 (row-owner kernel always)");
@@ -901,7 +905,7 @@ static int check_launch_rows(long nrows) {
 // what the fused kernel (k_mlp_rows<NW, true>) needs to run it ahead of the MLP (a_bf16 stays null otherwise).
 static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, const AxisMap& ax, const ModMap& mm,
                          int shift, int scale, int gate, const MaskMap& mk, bool residue_axis, bool trunk,
-                         ProjParams* defer = nullptr, bool skip_qkv = false) {
+                         ProjParams* defer = nullptr, bool skip_qkv = false, const ProjParams* pre = nullptr) {
     if (int e = check_launch_rows(nrows)) return e;
     const char* c_qkv = !trunk ? "ipa.ln_qkv" : residue_axis ? "ln_qkv_L" : "ln_qkv_T";
     const char* c_att = !trunk ? "ipa.flash" : residue_axis ? "flash_L" : "flash_T";
@@ -975,7 +979,17 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         q.mk = mk;   // key-validity words for the attention kernel, in the slack behind the V^T fragments
         q.vmask = (uint32_t*)(q.vf + flash_vmask_offset(ax.nseq, ax.ntile()));
         q.vmask_stride = flash_vmask_stride(ax.ntile());
-        if (!skip_qkv) {   // (skip_qkv: k_chain_l4 has written the fragments and the validity words of this axis already)
+        if (pre && pre->a_bf16) {
+            // the PREVIOUS sub-layer's deferred out-projection + gated residual runs in this kernel's panels first (option
+            // fuse_proj_qkv): its rows then come back from L2 for the LayerNorm instead of from HBM in a launch of their own
+            q.obuf = const_cast<__bf16*>(pre->a_bf16);
+            q.wo = pre->w;
+            q.bo = pre->bias;
+            q.gate_chunk = pre->gate_chunk;
+            q.h_rw = h;
+            { ProfScope ps(r.c, "projL_qkvT", r.s); launch_ln_qkv(q, false, r.s, true); }
+            LAUNCHCHK();
+        } else if (!skip_qkv) {   // (skip_qkv: k_chain_l4 has written the fragments and the validity words of this axis already)
             { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv(q, false, r.s); }
             LAUNCHCHK();
         }
@@ -1329,12 +1343,18 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
             if (int er = chain_sublayers(r, w, h, axT, mm, mk)) return er;
         } else if (cm == 1) {
             if (int er = chain_sublayers_panel(r, w, h, axT, mm, mk)) return er;
-        } else {
-            if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true)) return er;
+        }
+        // residue axis on the tiled-attention path (L > 8): its out-projection may run inside the temporal q / k / v kernel
+        ProjParams def_l{};
+        if (!chain) {
+            const bool fuse_lt = c->opt_fuse_proj_qkv && r.L > 8 && r.T > 8;
+            if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true, fuse_lt ? &def_l : nullptr)) return er;
         }
         ProjParams deferred{};
         const bool fuse = c->opt_fuse_proj && mlp_uses_rows(c, r.N);
-        if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true, fuse ? &deferred : nullptr, chain)) return er;
+        if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true, fuse ? &deferred : nullptr, chain,
+                                   def_l.a_bf16 ? &def_l : nullptr))
+            return er;
         if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true, &deferred, w.mha_t.wo_stream)) return er;
         if (trace_h) HIPCHK(hipMemcpyAsync(trace_h + (size_t)(i + 1) * r.N * kC, h, hbytes, hipMemcpyDeviceToDevice, r.s));
     }
@@ -1549,7 +1569,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_chain << 16), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_chain << 16 | c->opt_fuse_proj_qkv << 20), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1609,7 +1629,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_chain << 16),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_chain << 16 | c->opt_fuse_proj_qkv << 20),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

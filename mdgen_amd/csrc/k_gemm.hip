@@ -212,7 +212,12 @@ extern "C" int mdgen_dev_qkv_stamps(void* host, size_t bytes) {
 #define QKV_STAMP(slot)
 #endif
 
-template <bool SMALL>
+// PRE (FLASH layout only): the panel first runs the PREVIOUS sub-layer's out-projection + gated residual for its 64 tokens
+// (attention output rows p.obuf, weights p.wo / p.bo, gate chunk p.gate_chunk: what k_proj<0> does in a launch of its own,
+// mha.py:397, latent_model.py:462), then normalises the rows it has just updated -- re-read from L2 instead of HBM.  Used for
+// residue-axis out-projection -> temporal q, k, v (the verdict's item 3 (i)); the out-projection is
+// token-local, so the panel may be cut along the NEXT sub-layer's axis.
+template <bool SMALL, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
     PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
@@ -244,13 +249,23 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
     }
     QKV_STAMP(0);
     __syncthreads();
-    prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
+    const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id();
+    f32x16 acc[6];
+    if (PRE) {
+        prologue_bf16<kC>(panel, pr, p.obuf);
+        __syncthreads();
+        zero_acc<6>(acc);
+        wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
+        epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk,
+                                      true, p.h_rw);
+        __syncthreads();   // (vmcnt(0) + barrier) the updated rows are in L2; the slabs are free
+    }
+    prologue_ln<false>(panel, pr, PRE ? p.h_rw : p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
     __syncthreads();
     QKV_STAMP(1);
-    const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id();
     const int ntile = p.ax.ntile();
     const int len = p.ax.len;
-    f32x16 acc[6];
     // ---- Q (heads 4w..4w+3), transposed
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
@@ -1181,7 +1196,12 @@ __global__ __launch_bounds__(256, 2) void k_final(const FinalParams p) {
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
-void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s) {
+void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre) {
+    if (pre) {
+        const int grid = p.ax.nseq * p.panels_per_seq;
+        hipLaunchKernelGGL((k_ln_qkv<false, true>), dim3(grid), dim3(256), 0, s, p);
+        return;
+    }
     if (small) {
         const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
         hipLaunchKernelGGL(k_ln_qkv<true>, dim3(grid), dim3(256), 0, s, p);

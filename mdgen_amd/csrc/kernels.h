@@ -188,7 +188,7 @@ struct FloatChunk {
     int n;
 };
 
-void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s);
+void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre = false);
 void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s, bool with_qkv_t = false);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
 void launch_mlp(const MlpParams& p, hipStream_t s);
