@@ -663,7 +663,7 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
         if (value != 0 && value != 1) return fail(-2, "attention_path must be 0 (auto) or 1 (robust loop always)");
         c->opt_attn_path = value;
     } else if (n == "fuse_proj") {
-        if (value != 0 && value != 1) return fail(-2, "fuse_proj must be 0 or 1");
+        if (value < 0 || value > 2) return fail(-2, "fuse_proj must be 0 (off), 1 (inside the row-owner MLP kernel) or 2 (inside the panel MLP kernel)");
         c->opt_fuse_proj = value;
     } else if (n == "fuse_proj_qkv") {
         if (value != 0 && value != 1) return fail(-2, "fuse_proj_qkv must be 0 or 1");
@@ -1102,7 +1102,8 @@ static int chain_sublayers(const Run& r, const TrunkW& w, float* h, const AxisMa
 static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const ModMap& mm, int shift, int scale,
                         int gate, bool trunk, const ProjParams* proj = nullptr, const bf16x8* wo_stream = nullptr) {
     if (int e = check_launch_rows(nrows)) return e;
-    if (mlp_uses_rows(r.c, nrows)) {
+    const bool panel_fused = proj && proj->a_bf16 && r.c->opt_fuse_proj == 2;
+    if (!panel_fused && mlp_uses_rows(r.c, nrows)) {
         MlpRowsParams q{};
         q.h = h;
         q.nrows = nrows;
@@ -1128,8 +1129,13 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
         LAUNCHCHK();
         return 0;
     }
-    if (proj && proj->a_bf16) return fail(-7, "internal: deferred out-projection without the row-owner MLP kernel");
     MlpParams p{};
+    if (proj && proj->a_bf16) {   // fuse_proj = 2: the deferred out-projection runs in the panel kernel's prologue
+        p.o = proj->a_bf16;
+        p.wo = proj->w;
+        p.bo = proj->bias;
+        p.gate_chunk_o = proj->gate_chunk;
+    }
     p.h = h;
     p.nrows = nrows;
     p.mm = mm;
@@ -1145,7 +1151,7 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
         p.trace_cap = r.c->phase_trace_cap;
         r.c->phase_trace = nullptr;
     }
-    { ProfScope ps(r.c, trunk ? "mlp" : "ipa.mlp", r.s); launch_mlp(p, r.s); }
+    { ProfScope ps(r.c, !trunk ? "ipa.mlp" : p.o ? "proj_mlp" : "mlp", r.s); launch_mlp(p, r.s); }
     LAUNCHCHK();
     return 0;
 }
@@ -1351,7 +1357,7 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
             if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true, fuse_lt ? &def_l : nullptr)) return er;
         }
         ProjParams deferred{};
-        const bool fuse = c->opt_fuse_proj && mlp_uses_rows(c, r.N);
+        const bool fuse = c->opt_fuse_proj == 2 || (c->opt_fuse_proj == 1 && mlp_uses_rows(c, r.N));
         if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true, fuse ? &deferred : nullptr, chain,
                                    def_l.a_bf16 ? &def_l : nullptr))
             return er;

@@ -1033,7 +1033,9 @@ __device__ __forceinline__ void stage_y(const unsigned char* hr, const bf16x8* _
     }
 }
 
-template <int PF1>
+// PRE: the panel first runs the temporal attention sub-layer's out-projection + gated residual for its 64 tokens (k_proj<0>'s
+// work, mha.py:397, latent_model.py:476) and normalises rows that are still in L2.
+template <int PF1, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kPanelBytes + 2 * kPanel * kHRowB];
     unsigned char* panel = smem;
@@ -1047,11 +1049,22 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
     }
     setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
     __syncthreads();
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform, and the compiler knows it
+    const int lane = lane_id(), hh = lane >> 5, tk = lane & 31;
+    if (PRE) {
+        f32x16 acc[6];
+        prologue_bf16<kC>(panel, pr, p.o);
+        __syncthreads();
+        zero_acc<6>(acc);
+        wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
+        epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk_o,
+                                      true, p.h);
+        __syncthreads();   // (vmcnt(0) + barrier) the updated rows are in L2; the slabs are free
+    }
     prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
     __syncthreads();
     stamp(p, 1);
-    const int w = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform, and the compiler knows it
-    const int lane = lane_id(), hh = lane >> 5, tk = lane & 31;
     // per-lane views of the packed weights / bias: W1 fragment stream of chunk c starts at w1l + c * (4 * 24 * 64)
     const bf16x8* w1l = p.w1 + (size_t)w * 24 * 64 + lane;
     const bf16x8* w2l = p.w2 + (size_t)(3 * w) * 96 * 64 + lane;      // chunk c: + 8 c * 64
@@ -1226,7 +1239,8 @@ void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
 }
 void launch_mlp(const MlpParams& p, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-    hipLaunchKernelGGL((k_mlp<3>), dim3(grid), dim3(256), 0, s, p);
+    if (p.o) hipLaunchKernelGGL((k_mlp<3, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_mlp<3>), dim3(grid), dim3(256), 0, s, p);
 }
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);

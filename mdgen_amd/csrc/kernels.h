@@ -62,6 +62,12 @@ struct MlpParams {
     const float *b1, *b2;
     unsigned long long* trace;   // measurement only (mdgen_profile_phase_trace): [wave][32] s_memtime stamps, or null
     long trace_cap;              // capacity of `trace` in 64-bit words
+    // k_mlp<PF1, true>: the preceding (temporal) attention sub-layer's out-projection + gated residual runs in the same panels
+    // first (k_proj<0>'s work: attention output rows `o`, packed W_o, bias, gate chunk), o == null: off
+    const __bf16* o;
+    const bf16x8* wo;
+    const float* bo;
+    int gate_chunk_o;
 };
 
 // k_mlp_rows (k_rows.hip): the MLP block in row-owner form; `wstream` = both weight matrices as one fragment stream in
