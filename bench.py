@@ -56,6 +56,10 @@ def algorithmic_flops(cls, B, T, L):
     """Algorithmic flops of ONE launch of a kernel class (SURVEY.md section 8(d) per-token figures x N).
     dh padding 24->32, masked keys and tile padding are NOT counted."""
     N, C = B * T * L, 384
+    if cls == "projL_qkvT":       # k_ln_qkv<false, true>: residue-axis out-projection + the temporal q, k, v projection
+        return 2.0 * N * C * C + 2.0 * N * C * 3 * C
+    if cls == "attnL_qkvT":       # k_ln_qkv_attn4<true, true>
+        return 2.0 * N * C * 4 * C + 4.0 * N * C * 5 + 2.0 * N * C * 3 * C
     if cls == "chain_L_qkvT":     # k_chain_l4: the L == 4 residue sub-layer + the temporal q, k, v projection
         return 2.0 * N * C * 4 * C + 4.0 * N * C * 5 + 2.0 * N * C * 3 * C
     if cls in ("ln_qkv_L", "ln_qkv_T"):

@@ -14,7 +14,7 @@ dev = torch.device("cuda")
 B, T, L, abs_pos, n_pad = bench.WORKLOADS["tetrapeptide_fwdsim_crop4_T1000_B16"]
 cfg = ModelConfig(crop=L, num_frames=T, abs_pos_emb=abs_pos, sim_condition=True)
 w = NewMDGenWrapper(cfg, device=dev); w.model.load_state_dict(synth_state_dict(cfg, 0))
-w.model.set_option("streams", 1); w.model.set_option("chain_path", 1)
+w.model.set_option("streams", 1); w.model.set_option("chain_path", 2)   # the row-owner kernel (1 = the panel form)
 batch = bench.synth_batch(B, T, L, n_pad, dev, seed=100)
 zs = torch.randn(B, T, L, 21, generator=torch.Generator().manual_seed(137)).to(dev)
 w.inference(batch, zs=zs, num_steps=2, use_graph=False)
