@@ -2124,7 +2124,7 @@ def test_training_attention_kernels_unit(ln, layout):
 
 
 def test_row_owner_mlp_paths_agree():
-    """The MLP block has three forms: the 64-row resident-panel kernel (`mlp_path` 0), the row-owner kernel (`mlp_path` 2:
+    """The MLP block has these forms: the 64-row resident-panel kernel (`mlp_path` 0), the row-owner kernel (`mlp_path` 2:
     activations in registers, LDS-DMA weight stream) and the row-owner kernel with the temporal out-projection fused in front
     of it (`fuse_proj` 1).  All three against the reference golden at the bf16 gate, and against each other (different
     summation orders / GELU polynomial: a few 1e-3); the IPA stack (S*B*L rows: partial tiles, idle waves) takes the
@@ -2135,7 +2135,9 @@ def test_row_owner_mlp_paths_agree():
         g = load_golden(name)
         cfg, sd = weights_for(g)
         outs = {}
-        for key, opts in (("panel", {"mlp_path": 0}), ("rows", {"mlp_path": 2, "fuse_proj": 0}), ("rows+proj", {"mlp_path": 2, "fuse_proj": 1})):
+        for key, opts in (("panel", {"mlp_path": 0}), ("rows", {"mlp_path": 2, "fuse_proj": 0}), ("rows+proj", {"mlp_path": 2, "fuse_proj": 1}),
+                          ("panel+proj", {"mlp_path": 0, "fuse_proj": 2}), ("no-qkv-prologue", {"mlp_path": 0, "fuse_proj_qkv": 0}),
+                          ("qkv-prologue", {"mlp_path": 0, "fuse_proj_qkv": 1})):
             m = LatentMDGenModel(cfg)
             m.load_state_dict(sd)
             for k, v in opts.items():
@@ -2151,6 +2153,9 @@ def test_row_owner_mlp_paths_agree():
             assert e < TOL_FWD
             del m
         assert rel_l2(outs["rows"], outs["panel"]) < 6e-3 and rel_l2(outs["rows+proj"], outs["rows"]) < 6e-3
+        # the prologue-phase fusions (round 4): the temporal out-projection inside the panel MLP kernel (`fuse_proj` 2) and the
+        # residue out-projection inside the temporal LN -> q, k, v kernel (`fuse_proj_qkv`, default 1 for L > 8)
+        assert rel_l2(outs["panel+proj"], outs["panel"]) < 6e-3 and rel_l2(outs["qkv-prologue"], outs["no-qkv-prologue"]) < 6e-3
 
 
 @pytest.mark.parametrize("shape", [(1, 40, 0), (1, 64, 0), (2, 8, 0), (3, 104, 1), (2, 1000, 0), (1, 96, 2)])
