@@ -133,6 +133,11 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      the attention's q k^T / p v and their backward): 32 (default) fp32, the exact mode; 16 rounded to
  *                      bf16 on the MFMA, fp32 accumulation, fp32 master weights and activations (train.py:13
  *                      set_float32_matmul_precision('medium')); softmax, LayerNorm, reductions stay fp32, GELU to 5e-6.
+ *   "train_streams"    2 (default) / 1: mdgen_train_forward_backward launches the weight / bias gradients (nothing reads them
+ *                      before the optimiser) on a second stream of the context, beside the backward pass's critical path on the
+ *                      caller's stream; it joins the caller's stream before the call returns, and milestone events are recorded
+ *                      once both streams have reached them.  Bit-identical gradients; 33.9 -> 29.9 ms per step at cfg-5's
+ *                      per-GPU size.
  * Returns -4 for an unknown name, -2 for a value out of range. */
 int32_t mdgen_ctx_set_option(mdgen_ctx* ctx, const char* name, int32_t value);
 /* number of state_dict keys the model needs; name of the i-th (for loaders / tests) */

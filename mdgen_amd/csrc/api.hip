@@ -140,6 +140,10 @@ struct mdgen_ctx {
     int opt_fuse_proj_qkv = 1;  // tiled residue axis (L > 8): its out-projection + gated residual runs inside the temporal q / k / v kernel
     int opt_fuse_proj = 0;      // with the row-owner MLP kernel: run the temporal attention's out-projection inside it (same wall time)
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
+    int opt_train_streams = 2;      // training step: 2 = weight / bias gradients of the linear layers on a second stream (train.inc)
+    hipStream_t train_side = nullptr;   // that stream (created on first use, default priority)
+    std::vector<hipEvent_t> train_ev;   // event pool of that fork / join traffic (created on first use, round-robin)
+    size_t train_ev_next = 0;
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
     std::vector<void*> milestone_events;          // mdgen_train_set_milestone_events (hipEvent_t handles, caller-owned)
     unsigned long long* phase_trace = nullptr;   // mdgen_profile_phase_trace target (device), consumed by one launch
@@ -586,6 +590,8 @@ extern "C" int32_t mdgen_ctx_destroy(mdgen_ctx* c) {
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipEvent_t e : c->train_ev) (void)hipEventDestroy(e);
+    if (c->train_side) (void)hipStreamDestroy(c->train_side);
     for (int i = 0; i < mdgen_ctx::kMaxSide; ++i) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
@@ -678,6 +684,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "train_precision") {
         if (value != 16 && value != 32) return fail(-2, "train_precision must be 32 (fp32 operands, exact) or 16 (bf16 operands, fp32 accumulate)");
         c->opt_train_precision = value;
+    } else if (n == "train_streams") {
+        if (value != 1 && value != 2) return fail(-2, "train_streams must be 1 (one stream) or 2 (weight gradients on a second stream)");
+        c->opt_train_streams = value;
     } else if (n == "residue_l4_path") {
         if (value < 0 || value > 2) return fail(-2, "residue_l4_path must be 0, 1 or 2");
         c->opt_residue_l4 = value;

@@ -18,6 +18,9 @@ ut = torch.randn(B, T, L, cfg.latent_dim, generator=gen)
 lm = (torch.rand(B, T, L, cfg.latent_dim, generator=gen) > 0.1).float() * inp["mask"][..., None]
 tm = TrainableModel(cfg, dev).load_state_dict(sd)
 tm.model.set_option("train_precision", prec)
+for kv in sys.argv[6:]:   # further library options, name=value
+    k, v = kv.split("=")
+    tm.model.set_option(k, int(v))
 args = (inp["x"].to(dev), inp["t"].to(dev), ut.to(dev), lm.to(dev), inp["mask"].to(dev),
         (inp["start_rot"].to(dev), inp["start_trans"].to(dev)), inp["x_cond"].to(dev), inp["x_cond_mask"].to(dev),
         inp["aatype"].to(dev))

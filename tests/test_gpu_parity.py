@@ -1619,6 +1619,48 @@ def test_ddp_over_rccl_two_gpus(tmp_path):
     assert b["exposed_comm_ms"] < 0.10 * b["step_ms"], (b["exposed_comm_ms"], b["step_ms"])
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 72, False), (1, 250, 256, False), (2, 24, 8, True)])
+def test_training_weight_gradients_on_second_stream_are_identical(shape):
+    """Option `train_streams` (default 2): the weight / bias gradients of the linear layers, the bias-key / value sums, the adaLN
+    heads and the token embedders' gradients run on a second stream beside the backward pass's critical path (dX products,
+    attention backward, element-wise passes), reading alternating instances of the scratch the main stream would overwrite
+    (csrc/train.inc `Train::begin_sub / fork`).  Same kernels, same summation orders: gradients and loss must be BIT-identical
+    to the one-stream run, in both operand modes, after repeated steps on the same buffers (a missed hazard shows up as a
+    difference here).  Shapes: a mid-size ATLAS-like case, cfg-5's per-GPU size, and the two-sided model (two IPA passes adding
+    into the same gradients)."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict, synth_forward_inputs
+    from mdgen_amd.train import TrainableModel
+    dev = _cuda()
+    B, T, L, tps = shape
+    cfg = (ModelConfig(crop=L, num_frames=T, num_layers=2, tps_condition=True, abs_pos_emb=True) if tps
+           else ModelConfig.atlas(num_frames=T, crop=L))
+    sd = synth_state_dict(cfg, 6)
+    inp = synth_forward_inputs(cfg, B, T, L, 3, 27)
+    gen = torch.Generator().manual_seed(5)
+    ut = torch.randn(B, T, L, cfg.latent_dim, generator=gen)
+    lm = (torch.rand(B, T, L, cfg.latent_dim, generator=gen) > 0.1).float() * inp["mask"][..., None]
+    args = (inp["x"].to(dev), inp["t"].to(dev), ut.to(dev), lm.to(dev), inp["mask"].to(dev),
+            (inp["start_rot"].to(dev), inp["start_trans"].to(dev)), inp["x_cond"].to(dev), inp["x_cond_mask"].to(dev),
+            inp["aatype"].to(dev))
+    kw = {"end_frames": (inp["end_rot"].to(dev), inp["end_trans"].to(dev))} if tps else {}
+    for prec in (16, 32):
+        res = {}
+        for ns in (1, 2):
+            tm = TrainableModel(cfg, dev).load_state_dict(sd)
+            tm.model.set_option("train_precision", prec)
+            tm.model.set_option("train_streams", ns)
+            for _ in range(3):
+                tm.zero_grad()
+                loss, _ = tm.forward_backward(*args, **kw)
+            torch.cuda.synchronize()
+            res[ns] = (loss.clone(), tm.grads.clone())
+            del tm
+        assert torch.isfinite(res[2][1]).all()
+        assert torch.equal(res[1][0], res[2][0]), (shape, prec)
+        assert torch.equal(res[1][1], res[2][1]), (shape, prec, float((res[1][1] - res[2][1]).abs().max()))
+
+
 def test_trainer_checkpoint_resume_round_trip(tmp_path):
     """`Trainer.save_checkpoint` -> `load_checkpoint` (Lightning layout; the optimiser state in torch.optim.Adam's own
     state_dict layout, i.e. what a checkpoint of the reference holds under `optimizer_states[0]`): a run resumed from the
