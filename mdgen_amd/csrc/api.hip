@@ -36,6 +36,7 @@ static int fail(int code, const char* fmt, ...) {
     do {                                                                                       \
         hipError_t e_ = hipGetLastError();                                                     \
         if (e_ != hipSuccess) return fail((int)e_, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+        if (const char* m_ = k32_take_launch_error()) return fail(-7, "internal: %s (%s:%d)", m_, __FILE__, __LINE__); \
     } while (0)
 
 extern "C" const char* mdgen_last_error(void) { return g_err; }

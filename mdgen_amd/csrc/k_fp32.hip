@@ -65,8 +65,18 @@ __global__ __launch_bounds__(256) void k32_ln_mod(const float* __restrict__ x, l
 // to bf16 on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- what the reference
 // trains with (train.py:13 `torch.set_float32_matmul_precision('medium')` = bf16-class products, fp32 accumulate, fp32
 // master weights).  Set by mdgen_train_forward_backward from the context option "train_precision" for the duration of the
-// call; the sampler's fp32 tolerance mode always runs with 0.
-int g_k32_bf16_operands = 0;
+// call; the sampler's fp32 tolerance mode always runs with 0.  Per THREAD: two contexts training on two host threads do not
+// see each other's mode.
+thread_local int g_k32_bf16_operands = 0;
+
+// A launcher that is handed a shape its caller should have ruled out (bf16-stored operands outside the streamed kernels)
+// launches nothing and leaves a message here; the C-ABI entry points turn it into an error return (api.hip LAUNCHCHK).
+thread_local const char* g_k32_launch_error = nullptr;
+const char* k32_take_launch_error() {
+    const char* m = g_k32_launch_error;
+    g_k32_launch_error = nullptr;
+    return m;
+}
 
 // Workgroup tile 128 rows x 128 columns, wave tile 64 x 64 (2 x 2 MFMA tiles: every LDS operand read feeds two MFMAs),
 // k in steps of 16; the next k-step's global loads are issued before the current one's MFMAs (register prefetch), so a
@@ -600,8 +610,8 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
     LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, wtrans, c, ldc, col0, mm, gate_chunk, gated, scalar, c2, 0, {}, {}, {},
                    static_cast<const unsigned char*>(wpack), g_k32_bf16_operands, flags & 1, (flags >> 1) & 1};
     if ((flags & 3) && !(g_k32_bf16_operands && (!(flags & 1) || wpack))) {
-        std::fprintf(stderr, "mdgen_amd: launch32_linear: bf16 operand storage outside the streamed bf16-operand kernel\n");
-        std::abort();
+        g_k32_launch_error = "launch32_linear: bf16 operand storage outside the streamed bf16-operand kernel";
+        return;
     }
     const dim3 grid((unsigned)((m + 127) / 128), (unsigned)((n + 127) / 128));
     if (!g_k32_bf16_operands) {
@@ -611,8 +621,8 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
     const auto al = [](const void* q) { return ((unsigned long long)q & 15) == 0; };
     if (launch16_linear_wide(p, s)) return;    // 128 x 384 tiles: every trunk-sized layer (k_wide16.hip)
     if (flags & 1) {
-        std::fprintf(stderr, "mdgen_amd: launch32_linear: bf16 token rows need the streamed kernel (n >= 1024, m %% 384 == 0)\n");
-        std::abort();
+        g_k32_launch_error = "launch32_linear: bf16 token rows need the streamed kernel (n >= 1024, m % 384 == 0)";
+        return;
     }
     if (n <= 2048 && !wtrans && k % 64 == 0 && (lda & 3) == 0 && (ldw & 3) == 0 && ((unsigned long long)a & 15) == 0 &&
         ((unsigned long long)w & 15) == 0) {   // a few hundred rows: one wave per 32 x 32 tile

@@ -911,8 +911,8 @@ bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, 
         }
     }
     if (x_bf16) {
-        std::fprintf(stderr, "mdgen_amd: launch32_dw: bf16 X rows need the wide kernel (bf16-operand mode, n >= 4096)\n");
-        std::abort();
+        g_k32_launch_error = "launch32_dw: bf16 X rows need the wide kernel (bf16-operand mode, n >= 4096)";
+        return false;
     }
     // enough slices to fill the chip ONCE with 128 x 128 tiles at two workgroups per CU (a 384 x 384 weight is only 9 of
     // them); more slices only add partial-sum traffic (113 slices of a 384 x 384 weight: 66 MB written and read back)

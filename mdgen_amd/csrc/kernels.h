@@ -215,7 +215,9 @@ void launch_masked_mse(const float* pred, const float* target, const float* mask
 void launch_ipa_attn(const IpaAttnParams& p, hipStream_t s);
 
 // fp32-operand path (k_fp32.hip)
-extern int g_k32_bf16_operands;   // 1: k32_linear / k32_dw multiply bf16-rounded operands (training option train_precision = 16)
+extern thread_local int g_k32_bf16_operands;   // 1: k32_linear / k32_dw multiply bf16-rounded operands (training option train_precision = 16)
+extern thread_local const char* g_k32_launch_error;   // set by a launcher that refused a shape (nothing launched)
+const char* k32_take_launch_error();                  // ... and cleared by the entry point that reports it
 void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chunk, int scale_chunk, int affine, float eps,
                      float* y, hipStream_t s, float* keep = nullptr);   // keep: copy of x (training tape)
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,

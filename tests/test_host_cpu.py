@@ -63,6 +63,23 @@ def test_product_never_imports_oracle():
                 assert "mdgen_oracle" not in src, f
 
 
+def test_library_never_aborts_the_host_process_or_reads_the_environment():
+    """A shared library that a Python trainer has loaded must report through its error returns: no `abort()` / `exit()` in the
+    native sources (a launcher that refuses a shape leaves a message that the entry point's LAUNCHCHK turns into `fail(-7)`),
+    no environment variables (behaviour is set through `mdgen_ctx_set_option` only), and the per-call operand mode of the
+    training kernels is thread-local rather than a process-wide toggle."""
+    csrc = os.path.join(ROOT, "mdgen_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h", ".inc")):
+            continue
+        src = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f)).read())
+        assert not re.search(r"\b(std::)?(abort|exit|_Exit|quick_exit)\s*\(", src), f
+        assert "getenv" not in src, f
+    k = open(os.path.join(csrc, "k_fp32.hip")).read()
+    assert "thread_local int g_k32_bf16_operands" in k and "thread_local const char* g_k32_launch_error" in k
+    assert "k32_take_launch_error()" in open(os.path.join(csrc, "api.hip")).read()
+
+
 def test_config_from_reference_namespace():
     import argparse
     from mdgen_amd.config import ModelConfig
