@@ -30,6 +30,28 @@ constexpr int kTrB = 144;      // bytes of one feature row of a transposed tile:
 constexpr int kChunk = 64;     // streamed rows per LDS fill
 constexpr float kMasked = -3.0e38f;
 
+// experiment switches (csrc/dev.h; product builds define none): what one ingredient of the chunk loop costs
+#ifdef MDGEN_DEV_ATTN16_NOEXP
+#define A16_EXP2(x) (x)
+#else
+#define A16_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
+#ifdef MDGEN_DEV_ATTN16_NOMMA
+#define A16_MMA(a, b, c) (c)
+#else
+#define A16_MMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+#ifdef MDGEN_DEV_ATTN16_NOBAR
+#define A16_BARRIER() asm volatile("" ::: "memory")
+#else
+#define A16_BARRIER() __syncthreads()
+#endif
+#ifdef MDGEN_DEV_ATTN16_NOSTAGE
+#define A16_STAGE(c0) ((c0) == 0)
+#else
+#define A16_STAGE(c0) true
+#endif
+
 // Position, in the contraction order of a chained B operand, of row rho (0..31) of a tile: accumulator register
 // 8 s + j of lane-half hh holds row mfma_row(8 s + j, hh) and becomes element (k-step s, 8 hh + j).
 __device__ __forceinline__ int perm_pos(int rho) {
@@ -221,8 +243,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn(const float
     float mrun = kMasked, den = 0.f;
     fetch(0);
     for (int c0 = 0; c0 < len + 1; c0 += kChunk) {
-        __syncthreads();
-        if (it.on) {
+        A16_BARRIER();
+        if (!A16_STAGE(c0)) {
+        } else if (it.on) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
                 if (c0 + 2 * it.pair + e == len) {   // the bias key / value (LDS table, ready after the first barrier)
@@ -234,25 +257,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn(const float
         } else if (it.scalar) {
             sM[tid - 192] = mval;
         }
-        __syncthreads();
-        if (c0 + kChunk < len + 1) fetch(c0 + kChunk);
+        A16_BARRIER();
+        if (A16_STAGE(c0 + kChunk) && c0 + kChunk < len + 1) fetch(c0 + kChunk);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (c0 + 32 * t > len) break;
             f32x16 s = rows_from(sM + 32 * t, hh, 1.0f);
             const unsigned char* kr = sK + (32 * t + l31) * kRowB + hh * 16;
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(kr), q.f0, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(kr + 32), q.f1, s, 0, 0, 0);
+            s = A16_MMA(lds_frag(kr), q.f0, s);
+            s = A16_MMA(lds_frag(kr + 32), q.f1, s);
             float tmax = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
             const float mnew = fmaxf(mrun, half_max(tmax));
-            const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * kLog2e);
+            const float alpha = A16_EXP2((mrun - mnew) * kLog2e);
             mrun = mnew;
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = __builtin_amdgcn_exp2f((s[r] - mnew) * kLog2e);
+                s[r] = A16_EXP2((s[r] - mnew) * kLog2e);
                 sum += s[r];
                 o[r] *= alpha;
             }
@@ -260,8 +283,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn(const float
             bf16x8 p0, p1;
             chain(s, p0, p1);
             const unsigned char* vr = sVt + l31 * kTrB + 64 * t + hh * 16;
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(vr), p0, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(vr + 32), p1, o, 0, 0, 0);
+            o = A16_MMA(lds_frag(vr), p0, o);
+            o = A16_MMA(lds_frag(vr + 32), p1, o);
         }
     }
     den = half_sum(den);
@@ -326,8 +349,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_q(const
     for (int r = 0; r < 16; ++r) dq[r] = opaque_zero();
     fetch(0);
     for (int c0 = 0; c0 < len + 1; c0 += kChunk) {
-        __syncthreads();
-        if (it.on) {
+        A16_BARRIER();
+        if (!A16_STAGE(c0)) {
+        } else if (it.on) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
                 if (c0 + 2 * it.pair + e == len) {
@@ -340,8 +364,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_q(const
         } else if (it.scalar) {
             sM[tid - 192] = mval;
         }
-        __syncthreads();
-        if (c0 + kChunk < len + 1) fetch(c0 + kChunk);
+        A16_BARRIER();
+        if (A16_STAGE(c0 + kChunk) && c0 + kChunk < len + 1) fetch(c0 + kChunk);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (c0 + 32 * t > len) break;
@@ -351,17 +375,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_q(const
             for (int r = 0; r < 16; ++r) dp[r] = -delta;
             const unsigned char* kr = sK + (32 * t + l31) * kRowB + hh * 16;
             const unsigned char* vr = sV + (32 * t + l31) * kRowB + hh * 16;
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(kr), q.f0, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(kr + 32), q.f1, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(vr), dO.f0, dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(vr + 32), dO.f1, dp, 0, 0, 0);
+            s = A16_MMA(lds_frag(kr), q.f0, s);
+            s = A16_MMA(lds_frag(kr + 32), q.f1, s);
+            dp = A16_MMA(lds_frag(vr), dO.f0, dp);
+            dp = A16_MMA(lds_frag(vr + 32), dO.f1, dp);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f((s[r] - lse) * kLog2e) * dp[r];
+            for (int r = 0; r < 16; ++r) s[r] = A16_EXP2((s[r] - lse) * kLog2e) * dp[r];
             bf16x8 d0, d1;
             chain(s, d0, d1);
             const unsigned char* tr = sKt + l31 * kTrB + 64 * t + hh * 16;
-            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(tr), d0, dq, 0, 0, 0);
-            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(tr + 32), d1, dq, 0, 0, 0);
+            dq = A16_MMA(lds_frag(tr), d0, dq);
+            dq = A16_MMA(lds_frag(tr + 32), d1, dq);
         }
     }
     unrope(dq, qi < len ? qi : len - 1, inv_freq, hh, 0.20412414523193151f);   // back through RoPE and the q scale 24^-1/2
@@ -441,8 +465,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_kv(cons
 #pragma unroll
     for (int r = 0; r < 16; ++r) dk[r] = dv[r] = opaque_zero();
     for (int c0 = 0; c0 < len; c0 += kChunk) {
-        __syncthreads();
-        if (it.on) {
+        A16_BARRIER();
+        if (!A16_STAGE(c0)) {
+        } else if (it.on) {
             put_rowmajor(sQ, it, qf);
             put_rowmajor(sdO, it, df);
             put_transposed(sQt, it, qf);
@@ -451,8 +476,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_kv(cons
             sLse[tid - 192] = lval;
             sDel[tid - 192] = dval;
         }
-        __syncthreads();
-        if (c0 + kChunk < len) fetch(c0 + kChunk);
+        A16_BARRIER();
+        if (A16_STAGE(c0 + kChunk) && c0 + kChunk < len) fetch(c0 + kChunk);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (c0 + 32 * t >= len) break;
@@ -460,13 +485,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_kv(cons
             f32x16 dp = rows_from(sDel + 32 * t, hh, -1.0f);
             const unsigned char* qr = sQ + (32 * t + l31) * kRowB + hh * 16;
             const unsigned char* dr = sdO + (32 * t + l31) * kRowB + hh * 16;
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(qr), k.f0, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(qr + 32), k.f1, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(dr), v.f0, dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(dr + 32), v.f1, dp, 0, 0, 0);
+            s = A16_MMA(lds_frag(qr), k.f0, s);
+            s = A16_MMA(lds_frag(qr + 32), k.f1, s);
+            dp = A16_MMA(lds_frag(dr), v.f0, dp);
+            dp = A16_MMA(lds_frag(dr + 32), v.f1, dp);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = valid ? __builtin_amdgcn_exp2f(s[r] * kLog2e) : 0.f;
+                s[r] = valid ? A16_EXP2(s[r] * kLog2e) : 0.f;
                 dp[r] *= s[r];
             }
             bf16x8 p0, p1, d0, d1;
@@ -474,10 +499,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_kv(cons
             chain(dp, d0, d1);
             const unsigned char* dt = sdOt + l31 * kTrB + 64 * t + hh * 16;
             const unsigned char* qt = sQt + l31 * kTrB + 64 * t + hh * 16;
-            dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(dt), p0, dv, 0, 0, 0);
-            dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(dt + 32), p1, dv, 0, 0, 0);
-            dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(qt), d0, dk, 0, 0, 0);
-            dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(qt + 32), d1, dk, 0, 0, 0);
+            dv = A16_MMA(lds_frag(dt), p0, dv);
+            dv = A16_MMA(lds_frag(dt + 32), p1, dv);
+            dk = A16_MMA(lds_frag(qt), d0, dk);
+            dk = A16_MMA(lds_frag(qt + 32), d1, dk);
         }
     }
     f32x16 dku = dk;    // real keys: back through RoPE at their position (the bias key's own path below keeps dk)
