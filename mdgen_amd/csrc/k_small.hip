@@ -109,9 +109,11 @@ __global__ void k_pack_rows(const float* __restrict__ w, int ld, const int* __re
 // zero (every non-conditioning frame).  The epilogue adds bias, mask embedding, pos_embed / ipa_out rows (requested
 // four token rows ahead) and stores 128-byte row segments.
 // -------------------------------------------------------------------------------------------------
-constexpr int kEmbTok = 128, kEmbLd = 29, kEmbK = 14;
+constexpr int kEmbLd = 29, kEmbK = 14;
 // POS / IPA: pos_embed / ipa_out present (compile-time so that their loads are unconditional).
-template <bool POS, bool IPA>
+// kEmbTok: tokens per workgroup -- 128 when that still makes a few hundred workgroups; 32 (one row tile per workgroup) for the
+// small launches (B = 1, the TPS shard), whose time is one workgroup's latency: 40 -> ~17 us at 12 800 tokens.
+template <bool POS, bool IPA, int kEmbTok>
 __global__ __launch_bounds__(256) void k_embed(const EmbedParams p) {
     __shared__ float xs[kEmbTok * kEmbLd];
     __shared__ float cs[kEmbTok * kEmbLd];
@@ -130,11 +132,12 @@ __global__ __launch_bounds__(256) void k_embed(const EmbedParams p) {
     }
     __syncthreads();
     {   // stage x / x_cond rows: unconditional clamped loads, all in flight together
-        constexpr int NIT = kEmbTok * 28 / 256;
+        constexpr int NIT = (kEmbTok * 28 + 255) / 256;
         float a[NIT], b[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + 256 * it;
+            const int i0 = tid + 256 * it;
+            const int i = i0 < kEmbTok * 28 ? i0 : kEmbTok * 28 - 1;   // (32-token workgroups: 3.5 rounds)
             const int tk = i / 28, d = i % 28;
             long t = tok0 + tk;
             t = t < p.N ? t : p.N - 1;
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(256) void k_embed(const EmbedParams p) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + 256 * it;
+            if (i >= kEmbTok * 28) break;
             const int tk = i / 28, d = i % 28;
             const bool ok = tok0 + tk < p.N && d < p.D;
             xs[tk * kEmbLd + d] = ok ? a[it] : 0.f;
@@ -721,11 +725,20 @@ void launch_masked_mse(const float* pred, const float* target, const float* mask
     hipLaunchKernelGGL(k_masked_mse, dim3((unsigned)B), dim3(256), 0, s, pred, target, mask, loss, per_sample);
 }
 void launch_embed(const EmbedParams& p, hipStream_t s) {
-    const dim3 g((unsigned)((p.N + kEmbTok - 1) / kEmbTok)), b(256);
-    if (p.pos_embed && p.ipa_out) hipLaunchKernelGGL((k_embed<true, true>), g, b, 0, s, p);
-    else if (p.pos_embed) hipLaunchKernelGGL((k_embed<true, false>), g, b, 0, s, p);
-    else if (p.ipa_out) hipLaunchKernelGGL((k_embed<false, true>), g, b, 0, s, p);
-    else hipLaunchKernelGGL((k_embed<false, false>), g, b, 0, s, p);
+    const dim3 b(256);
+    if ((p.N + 127) / 128 >= 384) {
+        const dim3 g((unsigned)((p.N + 127) / 128));
+        if (p.pos_embed && p.ipa_out) hipLaunchKernelGGL((k_embed<true, true, 128>), g, b, 0, s, p);
+        else if (p.pos_embed) hipLaunchKernelGGL((k_embed<true, false, 128>), g, b, 0, s, p);
+        else if (p.ipa_out) hipLaunchKernelGGL((k_embed<false, true, 128>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((k_embed<false, false, 128>), g, b, 0, s, p);
+    } else {
+        const dim3 g((unsigned)((p.N + 31) / 32));
+        if (p.pos_embed && p.ipa_out) hipLaunchKernelGGL((k_embed<true, true, 32>), g, b, 0, s, p);
+        else if (p.pos_embed) hipLaunchKernelGGL((k_embed<true, false, 32>), g, b, 0, s, p);
+        else if (p.ipa_out) hipLaunchKernelGGL((k_embed<false, true, 32>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((k_embed<false, false, 32>), g, b, 0, s, p);
+    }
 }
 void launch_ipa_init(const float* aa_emb, const int64_t* aatype, const float* rel7, const float* w7, const float* b7,
                      float* h, int ngroups, int B, int L, hipStream_t s) {
