@@ -115,9 +115,10 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      (csrc/k_gemm.hip k_mlp); 1 (default) the row-owner kernel (csrc/k_rows.hip k_mlp_rows: a wave owns 32
  *                      rows, activations in registers, weights as one LDS-DMA stream) for launches of >= 768 row tiles,
  *                      which fill the chip, and the panel kernel below that; 2 the row-owner kernel always.
- *   "fuse_proj"        0 (default) / 1: with the row-owner MLP kernel, run the temporal attention's out-projection +
- *                      gated residual (mha.py:397, latent_model.py:476) inside it, ahead of the MLP / 2: the same as a
- *                      prologue phase of the 64-row panel kernel (k_mlp<3, true>; selects the panel kernel).
+ *   "fuse_proj"        the temporal attention's out-projection + gated residual (mha.py:397, latent_model.py:476) inside the
+ *                      MLP kernel, ahead of the MLP: 0 off / 1 inside the row-owner kernel / 2 as a prologue phase of the
+ *                      64-row panel kernel (k_mlp<3, true>; selects the panel kernel) / 3 (default) as 2 where the launch
+ *                      takes the panel kernel anyway (fewer than 768 row tiles: one launch less per layer, +2 %).
  *   "fuse_proj_qkv"    1 (default) / 0: residue axis on the tiled-attention path (L > 8): its out-projection + gated residual
  *                      (mha.py:397, latent_model.py:462) runs inside the temporal sub-layer's LN -> q, k, v kernel, whose panels
  *                      then normalise rows that are still in L2 (k_ln_qkv<false, true>; one launch and one HBM read of the

@@ -140,7 +140,8 @@ struct mdgen_ctx {
                                 // 2 the row-owner kernel k_chain_l4 for launches that fill the chip (measured slower),
                                 // 3 k_chain_l4 whenever the shape allows
     int opt_fuse_proj_qkv = 1;  // tiled residue axis (L > 8): its out-projection + gated residual runs inside the temporal q / k / v kernel
-    int opt_fuse_proj = 0;      // with the row-owner MLP kernel: run the temporal attention's out-projection inside it (same wall time)
+    int opt_fuse_proj = 3;      // the temporal attention's out-projection inside the MLP kernel: 0 off, 1 row-owner kernel (same wall time),
+                                // 2 panel kernel always, 3 (default) panel kernel where the launch takes the panel kernel anyway (small N: +2 %)
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_train_streams = 2;      // training step: 2 = weight / bias gradients of the linear layers on a second stream (train.inc)
     hipStream_t train_side = nullptr;   // that stream (created on first use, default priority)
@@ -671,7 +672,8 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
         if (value != 0 && value != 1) return fail(-2, "attention_path must be 0 (auto) or 1 (robust loop always)");
         c->opt_attn_path = value;
     } else if (n == "fuse_proj") {
-        if (value < 0 || value > 2) return fail(-2, "fuse_proj must be 0 (off), 1 (inside the row-owner MLP kernel) or 2 (inside the panel MLP kernel)");
+        if (value < 0 || value > 3)
+            return fail(-2, "fuse_proj must be 0 (off), 1 (inside the row-owner MLP kernel), 2 (inside the panel MLP kernel) or 3 (panel kernel where it runs anyway)");
         c->opt_fuse_proj = value;
     } else if (n == "fuse_proj_qkv") {
         if (value != 0 && value != 1) return fail(-2, "fuse_proj_qkv must be 0 or 1");
@@ -1113,7 +1115,7 @@ static int chain_sublayers(const Run& r, const TrunkW& w, float* h, const AxisMa
 static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const ModMap& mm, int shift, int scale,
                         int gate, bool trunk, const ProjParams* proj = nullptr, const bf16x8* wo_stream = nullptr) {
     if (int e = check_launch_rows(nrows)) return e;
-    const bool panel_fused = proj && proj->a_bf16 && r.c->opt_fuse_proj == 2;
+    const bool panel_fused = proj && proj->a_bf16 && r.c->opt_fuse_proj >= 2;   // (3: only handed a projection when the panel kernel runs anyway)
     if (!panel_fused && mlp_uses_rows(r.c, nrows)) {
         MlpRowsParams q{};
         q.h = h;
@@ -1368,7 +1370,8 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
             if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true, fuse_lt ? &def_l : nullptr)) return er;
         }
         ProjParams deferred{};
-        const bool fuse = c->opt_fuse_proj == 2 || (c->opt_fuse_proj == 1 && mlp_uses_rows(c, r.N));
+        const bool fuse = c->opt_fuse_proj == 2 || (c->opt_fuse_proj == 1 && mlp_uses_rows(c, r.N)) ||
+                          (c->opt_fuse_proj == 3 && !mlp_uses_rows(c, r.N));
         if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true, fuse ? &deferred : nullptr, chain,
                                    def_l.a_bf16 ? &def_l : nullptr))
             return er;

@@ -2177,9 +2177,9 @@ def test_row_owner_mlp_paths_agree():
         g = load_golden(name)
         cfg, sd = weights_for(g)
         outs = {}
-        for key, opts in (("panel", {"mlp_path": 0}), ("rows", {"mlp_path": 2, "fuse_proj": 0}), ("rows+proj", {"mlp_path": 2, "fuse_proj": 1}),
-                          ("panel+proj", {"mlp_path": 0, "fuse_proj": 2}), ("no-qkv-prologue", {"mlp_path": 0, "fuse_proj_qkv": 0}),
-                          ("qkv-prologue", {"mlp_path": 0, "fuse_proj_qkv": 1})):
+        for key, opts in (("panel", {"mlp_path": 0, "fuse_proj": 0}), ("rows", {"mlp_path": 2, "fuse_proj": 0}), ("rows+proj", {"mlp_path": 2, "fuse_proj": 1}),
+                          ("panel+proj", {"mlp_path": 0, "fuse_proj": 2}), ("no-qkv-prologue", {"mlp_path": 0, "fuse_proj": 0, "fuse_proj_qkv": 0}),
+                          ("qkv-prologue", {"mlp_path": 0, "fuse_proj": 0, "fuse_proj_qkv": 1}), ("defaults", {})):
             m = LatentMDGenModel(cfg)
             m.load_state_dict(sd)
             for k, v in opts.items():
@@ -2198,6 +2198,8 @@ def test_row_owner_mlp_paths_agree():
         # the prologue-phase fusions (round 4): the temporal out-projection inside the panel MLP kernel (`fuse_proj` 2) and the
         # residue out-projection inside the temporal LN -> q, k, v kernel (`fuse_proj_qkv`, default 1 for L > 8)
         assert rel_l2(outs["panel+proj"], outs["panel"]) < 6e-3 and rel_l2(outs["qkv-prologue"], outs["no-qkv-prologue"]) < 6e-3
+        # the defaults at this size: panel MLP kernel (fewer than 768 row tiles) with the out-projection in front (`fuse_proj` 3)
+        assert torch.equal(outs["defaults"], outs["panel+proj"]) or rel_l2(outs["defaults"], outs["panel+proj"]) < 6e-3
 
 
 @pytest.mark.parametrize("shape", [(1, 40, 0), (1, 64, 0), (2, 8, 0), (3, 104, 1), (2, 1000, 0), (1, 96, 2)])
