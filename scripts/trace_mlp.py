@@ -12,13 +12,16 @@ from mdgen_amd.synthetic import synth_state_dict
 from mdgen_amd.wrapper import NewMDGenWrapper
 torch.set_grad_enabled(False)
 dev = torch.device("cuda")
-wl = "tetrapeptide_fwdsim_crop4_T1000_B16"
+wl = sys.argv[1] if len(sys.argv) > 1 else "tetrapeptide_fwdsim_crop4_T1000_B16"
 B, T, L, abs_pos, n_pad = bench.WORKLOADS[wl]
 cfg = ModelConfig(crop=L, num_frames=T, abs_pos_emb=abs_pos, sim_condition=True)
 w = NewMDGenWrapper(cfg, device=dev); w.model.load_state_dict(synth_state_dict(cfg, 0))
 batch = bench.synth_batch(B, T, L, n_pad, dev, seed=100)
 zs = torch.randn(B, T, L, 21, generator=torch.Generator().manual_seed(137)).to(dev)
 w.model.set_option("streams", 1)
+for kv in sys.argv[2:]:   # library options, name=value (e.g. mlp_path=0 fuse_proj=0)
+    k_, v_ = kv.split("=")
+    w.model.set_option(k_, int(v_))
 w.inference(batch, zs=zs, num_steps=2, use_graph=False)
 nwg = (B * T * L + 63) // 64
 buf = torch.zeros(nwg * 4 * 32, dtype=torch.int64, device=dev)
