@@ -193,8 +193,15 @@ __device__ __forceinline__ void unrope(f32x16& v, int pos, const float* __restri
 struct Wg {   // which rows this workgroup / wave owns
     int seq, hd, blk;
 };
+// Workgroup b runs on XCD b % 8 (hardware round robin), and each XCD has its own L2: ALL workgroups of a sequence -- 16 heads x nblk
+// row blocks, every one of which streams the whole sequence's rows of the [token][1152] buffer, 96 bytes per row and head -- are
+// dealt to ONE XCD, so that a row leaves HBM once.  (With consecutive workgroups per sequence the 32 workgroups of an ATLAS
+// sequence sat on all eight XCDs and the PMC counters showed 1.3 GiB read per launch for 0.5 GiB of operands.)
+// The grid is padded to a multiple of eight sequences: seq >= nseq exits (wg_grid).
 __device__ __forceinline__ Wg wg_of(int nblk) {
-    return Wg{(int)(blockIdx.x / (nblk * kH)), (int)((blockIdx.x / nblk) % kH), (int)(blockIdx.x % nblk)};
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3, per_seq = nblk * kH;
+    const int within = rest % per_seq;
+    return Wg{(rest / per_seq) * 8 + xcd, within / nblk, within % nblk};
 }
 
 }  // namespace
@@ -211,6 +218,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn(const float
     __shared__ __attribute__((aligned(16))) float sB[2 * kDH];
     const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5;
     const Wg g = wg_of((len + NW * 32 - 1) / (NW * 32));
+    if (g.seq >= ax.nseq) return;
     fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
     clear_rowmajor(sK);
     clear_transposed(sVt);
@@ -313,6 +321,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_q(const
     __shared__ __attribute__((aligned(16))) float sB[2 * kDH];
     const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5;
     const Wg g = wg_of((len + NW * 32 - 1) / (NW * 32));
+    if (g.seq >= ax.nseq) return;
     fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
     clear_rowmajor(sK);
     clear_rowmajor(sV);
@@ -417,6 +426,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_kv(cons
     __shared__ __attribute__((aligned(16))) float sB[2 * kDH];
     const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5;
     const Wg g = wg_of((len + NW * 32) / (NW * 32));
+    if (g.seq >= ax.nseq) return;
     fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
     clear_rowmajor(sQ);
     clear_rowmajor(sdO);
@@ -540,16 +550,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_kv(cons
     }
 }
 
+static unsigned wg_grid(int nseq, int nblk) { return (unsigned)((long)((nseq + 7) / 8) * 8 * kH * nblk); }   // see wg_of
+
 // Forward: 256 queries per workgroup (eight waves) once an axis is longer than 128 -- K / V are then staged once per
 // (sequence, head) at the ATLAS lengths instead of once per 128-query block (124 -> 104 us); four waves below that.
 void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
                    const float* inv_freq, float* out, hipStream_t s, float* lse_out) {
     if (ax.len > 128) {
         const int nqb = (ax.len + 255) / 256;
-        hipLaunchKernelGGL(k16_attn<8>, dim3((unsigned)((long)ax.nseq * kH * nqb)), dim3(512), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
+        hipLaunchKernelGGL(k16_attn<8>, dim3(wg_grid(ax.nseq, nqb)), dim3(512), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
                            inv_freq, out, lse_out);
     } else {
-        hipLaunchKernelGGL(k16_attn<4>, dim3((unsigned)((long)ax.nseq * kH)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k, bias_v, inv_freq,
+        hipLaunchKernelGGL(k16_attn<4>, dim3(wg_grid(ax.nseq, 1)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k, bias_v, inv_freq,
                            out, lse_out);
     }
 }
@@ -559,9 +571,9 @@ void launch16_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMa
                        const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
                        float* stats, float* dbias, hipStream_t s, const float* lse_in) {
     const int nqb = (ax.len + 127) / 128, nkb = (ax.len + 128) / 128;
-    hipLaunchKernelGGL(k16_attn_bwd_q<4>, dim3((unsigned)((long)ax.nseq * kH * nqb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
+    hipLaunchKernelGGL(k16_attn_bwd_q<4>, dim3(wg_grid(ax.nseq, nqb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
                        inv_freq, o, dout, dqkv, stats, lse_in);
-    hipLaunchKernelGGL(k16_attn_bwd_kv<4>, dim3((unsigned)((long)ax.nseq * kH * nkb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k,
+    hipLaunchKernelGGL(k16_attn_bwd_kv<4>, dim3(wg_grid(ax.nseq, nkb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k,
                        bias_v, inv_freq, dout, stats, dqkv, dbias);
 }
 
