@@ -403,3 +403,36 @@ def test_chain_kernel_index_algebra():
                         if d < 24:
                             psi = 12 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3)
                             assert abs(got[r] - o_ref[qs - s0, psi]) < 1e-9
+
+
+def test_training_attention_workgroup_order_keeps_a_sequence_on_one_xcd():
+    """csrc/k_attn16.hip `wg_of` / `wg_grid`: workgroup b runs on XCD b % 8 (hardware round robin, one L2 per XCD).  The mapping
+    must (a) cover every (sequence, head, row block) exactly once, (b) send all 16 x nblk workgroups of a sequence to ONE XCD
+    (each of them streams the whole sequence's rows: with consecutive workgroups per sequence the PMC counters showed 1.3 GiB read
+    per launch for 0.5 GiB of operands), (c) pad the grid only with workgroups whose sequence index is past the end (they exit),
+    and (d) keep the eight XCDs equally loaded up to that padding.  Replayed here in Python for the shapes of the trunk's two
+    axes at ATLAS size, a tetrapeptide axis and sequence counts that are not multiples of eight."""
+    kH = 16
+
+    def wg_of(b, nblk):
+        xcd, rest, per_seq = b & 7, b >> 3, nblk * kH
+        within = rest % per_seq
+        return (rest // per_seq) * 8 + xcd, within // nblk, within % nblk
+
+    def wg_grid(nseq, nblk):
+        return ((nseq + 7) // 8) * 8 * kH * nblk
+
+    for nseq, nblk in ((250, 2), (256, 2), (256, 3), (64, 8), (5, 1), (9, 3), (1, 1)):
+        grid = wg_grid(nseq, nblk)
+        seen, xcd_of_seq, load = set(), {}, [0] * 8
+        for b in range(grid):
+            seq, hd, blk = wg_of(b, nblk)
+            assert 0 <= hd < kH and 0 <= blk < nblk
+            if seq >= nseq:
+                continue                                   # padding workgroup: exits before any barrier
+            assert (seq, hd, blk) not in seen
+            seen.add((seq, hd, blk))
+            assert xcd_of_seq.setdefault(seq, b & 7) == (b & 7)
+            load[b & 7] += 1
+        assert len(seen) == nseq * kH * nblk
+        assert max(load) - min(load) <= kH * nblk          # at most one sequence of difference between XCDs
