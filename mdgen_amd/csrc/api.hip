@@ -108,6 +108,7 @@ struct mdgen_ctx {
     bool finalized = false;
     // fp32 small weights
     float *wl = nullptr, *bl = nullptr, *wc = nullptr, *bc = nullptr, *mask_emb = nullptr, *aa_emb = nullptr;
+    float *wl_pack = nullptr, *wc_pack = nullptr;   // latent_to_emb / cond_to_emb in k_embed's operand order (launch_pack_embed)
     float *pos_embed = nullptr, *t_w0 = nullptr, *t_b0 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
     float *wf7 = nullptr, *bf7 = nullptr, *wr7 = nullptr, *br7 = nullptr;
     float *ada_w = nullptr, *ada_b = nullptr;
@@ -466,6 +467,8 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     TRY(upload_ints(c, &c->perm_qk, pqk));
     TRY(upload_ints(c, &c->perm_vsmall, pvs));
     TRY(c->dalloc(&c->wl, (size_t)kC * D));
+    TRY(c->dalloc(&c->wl_pack, (size_t)kEmbPackFloats));
+    TRY(c->dalloc(&c->wc_pack, (size_t)kEmbPackFloats));
     TRY(c->dalloc(&c->bl, (size_t)kC));
     TRY(c->dalloc(&c->wc, (size_t)kC * D));
     TRY(c->dalloc(&c->bc, (size_t)kC));
@@ -497,9 +500,9 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     TRY(c->dalloc(&c->bfin, (size_t)32));
     TRYHIP(hipMemset(c->bfin, 0, 32 * sizeof(float)));
 #undef TRYHIP
-    SETTER("latent_to_emb.weight", { WANT(kC, c->D); if (int r = copy_f32(c->wl, data, (size_t)kC * c->D, s)) return r; });
+    SETTER("latent_to_emb.weight", { WANT(kC, c->D); if (int r = copy_f32(c->wl, data, (size_t)kC * c->D, s)) return r; launch_pack_embed(c->wl, c->D, c->wl_pack, s); });
     SETTER("latent_to_emb.bias", { WANT(kC); if (int r = copy_f32(c->bl, data, kC, s)) return r; });
-    SETTER("cond_to_emb.weight", { WANT(kC, c->D); if (int r = copy_f32(c->wc, data, (size_t)kC * c->D, s)) return r; });
+    SETTER("cond_to_emb.weight", { WANT(kC, c->D); if (int r = copy_f32(c->wc, data, (size_t)kC * c->D, s)) return r; launch_pack_embed(c->wc, c->D, c->wc_pack, s); });
     SETTER("cond_to_emb.bias", { WANT(kC); if (int r = copy_f32(c->bc, data, kC, s)) return r; });
     SETTER("mask_to_emb.weight", { WANT(2, kC); if (int r = copy_f32(c->mask_emb, data, 2 * kC, s)) return r; });
     SETTER("aatype_to_emb.weight", { WANT(21, kC); if (int r = copy_f32(c->aa_emb, data, 21 * kC, s)) return r; });
@@ -1315,6 +1318,8 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
     e.x_cond = r.x_cond;
     e.x_cond_mask = r.x_cond_mask;
     e.wl = c->wl;
+    e.wl_pack = c->wl_pack;
+    e.wc_pack = c->wc_pack;
     e.bl = c->bl;
     e.wc = c->wc;
     e.bc = c->bc;

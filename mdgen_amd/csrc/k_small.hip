@@ -159,16 +159,17 @@ __global__ __launch_bounds__(256) void k_embed(const EmbedParams p) {
     const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id(), hh = lane >> 5, j = lane & 31;
     const int nk = (p.D + 1) >> 1;
     // B operands (k = 2 ks + hh, column = channel): this wave's three channel tiles of both weight matrices
+    // (from the packed copies, k_pack_embed: one 256-byte request per (tile, k-step) instead of 64 lines 84 bytes apart --
+    // 168 such gathers per lane were the fixed cost of every workgroup)
     float wl[3][kEmbK], wc[3][kEmbK], b0[3], me0[3], me1[3];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
         const int c = 96 * w + 32 * ct + j;
 #pragma unroll
         for (int ks = 0; ks < kEmbK; ++ks) {
-            const int d = 2 * ks + hh;
-            const float a = p.wl[(long)c * p.D + (d < p.D ? d : 0)], b = p.wc[(long)c * p.D + (d < p.D ? d : 0)];
-            wl[ct][ks] = d < p.D ? a : 0.f;
-            wc[ct][ks] = d < p.D ? b : 0.f;
+            const int o = ((w * 3 + ct) * kEmbK + ks) * 64 + lane;
+            wl[ct][ks] = p.wl_pack[o];
+            wc[ct][ks] = p.wc_pack[o];
         }
         b0[ct] = p.bl[c] + p.bc[c];
         me0[ct] = p.mask_emb[c];
@@ -723,6 +724,16 @@ void launch_masked_mse(const float* pred, const float* target, const float* mask
         return;
     }
     hipLaunchKernelGGL(k_masked_mse, dim3((unsigned)B), dim3(256), 0, s, pred, target, mask, loss, per_sample);
+}
+// pack[((w * 3 + ct) * 14 + ks) * 64 + lane] = W[96 w + 32 ct + (lane & 31)][2 ks + (lane >> 5)] (0 past D): k_embed's B operands
+__global__ void k_pack_embed(const float* __restrict__ w, int D, float* __restrict__ pack) {
+    const int lane = threadIdx.x, blk = blockIdx.x;   // blk = (w * 3 + ct) * 14 + ks
+    const int ks = blk % kEmbK, tile = blk / kEmbK;
+    const int c = 32 * tile + (lane & 31), d = 2 * ks + (lane >> 5);
+    pack[blk * 64 + lane] = d < D ? w[(long)c * D + d] : 0.f;
+}
+void launch_pack_embed(const float* w, int D, float* pack, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_embed, dim3(4 * 3 * kEmbK), dim3(64), 0, s, w, D, pack);
 }
 void launch_embed(const EmbedParams& p, hipStream_t s) {
     const dim3 b(256);

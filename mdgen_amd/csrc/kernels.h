@@ -163,6 +163,7 @@ struct EmbedParams {
     const float *x, *x_cond;
     const int64_t* x_cond_mask;
     const float *wl, *bl, *wc, *bc;  // latent_to_emb / cond_to_emb fp32 [C][D], [C]
+    const float *wl_pack, *wc_pack;  // the two weights in the kernel's B-operand order (launch_pack_embed): coalesced prologue loads
     const float* mask_emb;           // [2][C]
     const float* pos_embed;          // [crop][C] or nullptr
     const float* ipa_out;            // [B*L][C] for this step
@@ -207,6 +208,8 @@ void launch_pack_stream(const float* w, int ld, int which, const int* tab, int n
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s);
 void launch_final(const FinalParams& p, hipStream_t s);
 void launch_flash(const FlashParams& p, hipStream_t s);
+void launch_pack_embed(const float* w, int D, float* pack, hipStream_t s);   // pack: kEmbPackFloats floats
+constexpr int kEmbPackFloats = 4 * 3 * 14 * 64;
 void launch_embed(const EmbedParams& p, hipStream_t s);
 void launch_path_plan(const float* t, const float* x0, const float* x1, float* xt, float* ut, long per_sample, long B,
                       int gvp, hipStream_t s);
