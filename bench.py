@@ -301,10 +301,11 @@ def extra_legs(dev, options):
             ex[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
     run("box_probe", lambda: box_probe(dev))
     run("atlas_crop256_T250_B1", lambda: sampler_leg("atlas_crop256_T250_B1", dev, 2, 1, 49, options, roofline=True))
-    run("tetrapeptide_tps_crop4_T100_B32", lambda: sampler_leg("tetrapeptide_tps_crop4_T100_B32", dev, 3, 1, 49, options))
-    run("tetrapeptide_fwdsim_crop4_T1000_B1", lambda: sampler_leg("tetrapeptide_fwdsim_crop4_T1000_B1", dev, 3, 1, 49, options))
+    # (the two small shapes: 40 ms per call, so five timed calls behind two warm-up calls cost nothing and settle the clocks)
+    run("tetrapeptide_tps_crop4_T100_B32", lambda: sampler_leg("tetrapeptide_tps_crop4_T100_B32", dev, 5, 2, 49, options))
+    run("tetrapeptide_fwdsim_crop4_T1000_B1", lambda: sampler_leg("tetrapeptide_fwdsim_crop4_T1000_B1", dev, 5, 2, 49, options))
     run("rollout_10_blocks_T1000_B16", lambda: sampler_leg("tetrapeptide_fwdsim_crop4_T1000_B16", dev, 1, 1, 49, options, rollouts=10))
-    run("atlas_train_crop256_T250_B1", lambda: training_leg(dev, train_precision=16))
+    run("atlas_train_crop256_T250_B1", lambda: training_leg(dev, reps=4, train_precision=16))
     run("atlas_train_crop256_T250_B1_fp32", lambda: training_leg(dev, train_precision=32))
     ex["seconds"] = round(time.perf_counter() - t0, 1)
     return ex
