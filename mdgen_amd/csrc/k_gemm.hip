@@ -1131,6 +1131,113 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
     stamp(p, 27);
 }
 
+// ---- the same block for launches of at most one workgroup per CU (<= 256 panels: B = 1, the TPS shard) -------------------------------
+// There a launch lasts exactly as long as ONE workgroup, and a lone wave per SIMD leaves the SIMD idle through every latency of its
+// own chain (phase stamps, profiles/r04_experiments.txt #14: 7.0k cycles per chunk alone against 9.1k for TWO co-resident
+// panels).  k_mlp8 gives the panel to eight waves: waves 0..3 run hidden chunks 0..5, waves 4..7 chunks 6..11 (each group with
+// its own pair of hidden buffers, the same X / Y stages, the same barriers), i.e. two waves per SIMD working on one panel, and
+// the two partial fc2 sums meet in LDS: group g hands the other group its partial of row tile 1 - g and finishes row tile g
+// (bias, gate, residual).  The LayerNorm prologue is split by row batches, the out-projection prologue phase (PRE) by row tiles.
+// Summation order differs from k_mlp's (two six-chunk partials instead of twelve chunks in sequence): fp32 rounding only.
+template <bool PRE>
+__global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kPanelBytes + 4 * kPanel * kHRowB];
+    __shared__ PanelRows prs;
+    unsigned char* panel = smem;
+    PanelRows* pr = &prs;
+    const int w8 = __builtin_amdgcn_readfirstlane(wave_id());
+    const int g = w8 >> 2, w = w8 & 3;
+    const int lane = lane_id(), hh = lane >> 5, tk = lane & 31;
+    unsigned char* hb0 = smem + kPanelBytes + (2 * g) * (kPanel * kHRowB);
+    unsigned char* hb1 = hb0 + kPanel * kHRowB;
+    float* slab = reinterpret_cast<float*>(smem) + w8 * (32 * 96);   // eight 12 KiB staging slabs over panel + hidden buffers
+    setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
+    __syncthreads();
+    if (PRE) {
+        if (threadIdx.x < 256) prologue_bf16<kC>(panel, pr, p.o);
+        __syncthreads();
+        f32x16 acc[3];
+        zero_acc<3>(acc);
+        wave_gemm<1, 3, 24, false>(panel, kRowB, g, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        __syncthreads();   // every wave is done reading the panel
+        epi_stage(acc, slab);
+        epi_rmw<8>(g, pr, slab, 96 * w, p.bo, p.mm, p.gate_chunk_o, true, p.h);
+        __syncthreads();   // (vmcnt(0) + barrier) the updated rows are in L2; the slabs are free
+    }
+    if (g == 0) prologue_ln<false, 0, 2>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
+    else prologue_ln<false, 2, 4>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
+    __syncthreads();
+    const bf16x8* w1l = p.w1 + (size_t)w * 24 * 64 + lane;
+    const bf16x8* w2l = p.w2 + (size_t)(3 * w) * 96 * 64 + lane;
+    const float* b1l = p.b1 + 32 * w + 4 * hh;
+    constexpr size_t W1C = (size_t)4 * 24 * 64;
+    constexpr int NC = kNChunk / 2;
+    const int c0 = NC * g;
+    f32x16 y[6];
+    zero_acc<6>(y);
+    f32x16 a1[2];
+    XPre xp;
+    YPre yp;
+    {
+#pragma unroll
+        for (int i = 0; i < kPFX; ++i) xp.w[i] = w1l[(size_t)c0 * W1C + i * 64];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) xp.a[t] = panel_frag(panel, kRowB, t, 0);
+    }
+    f32x4 b0;
+    zero_acc<2>(a1);
+    stage_x<false>(panel, w1l + (size_t)c0 * W1C, xp, a1, b1l + c0 * kHC, b0, nullptr, nullptr, yp);
+    {   // the group's first chunk: nothing to overlap its GELU with yet
+#pragma unroll
+        for (int i = 0; i < kPFX; ++i) xp.w[i] = w1l[(size_t)(c0 + 1) * W1C + i * 64];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) xp.a[t] = panel_frag(panel, kRowB, t, 0);
+        f32x4 b4[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) b4[a] = *reinterpret_cast<const f32x4*>(b1l + c0 * kHC + 8 * a);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gelu_group(a1, b4[q >> 1], hb0, q, w, hh, tk);
+    }
+    lds_barrier();
+#pragma unroll 1
+    for (int i = 1; i < NC; ++i) {
+        const int c = c0 + i;
+        unsigned char* hw = (i & 1) ? hb1 : hb0;
+        const unsigned char* hr = (i & 1) ? hb0 : hb1;
+        zero_acc<2>(a1);
+        stage_x<true>(panel, w1l + (size_t)c * W1C, xp, a1, b1l + c * kHC, b0, w2l + (size_t)8 * (c - 1) * 64, hr, yp);
+        const int cn = i + 1 < NC ? c + 1 : c;
+        stage_y<true>(hr, w2l + (size_t)8 * (c - 1) * 64, yp, y, a1, b0, b1l + c * kHC, hw, w, hh, tk, panel, w1l + (size_t)cn * W1C, xp);
+        lds_barrier();
+    }
+    wave_gemm<2, 3, 8, false, 3>((NC & 1) ? hb0 : hb1, kHRowB, 0, 0, w2l + (size_t)8 * (c0 + NC - 1) * 64, kW2S, y);
+    __syncthreads();   // panel and hidden buffers are dead: exchange area
+    {   // this group's partial of the row tile the OTHER group finishes
+        float* dst = reinterpret_cast<float*>(smem) + (size_t)(g * 4 + w) * (3 * 16 * 64);
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(f * 16 + r) * 64 + lane] = g == 0 ? y[3 + f][r] : y[f][r];   // (constant register indices)
+    }
+    __syncthreads();
+    f32x16 z[3];
+    {
+        const float* src = reinterpret_cast<const float*>(smem) + (size_t)((1 - g) * 4 + w) * (3 * 16 * 64);
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float lo = g == 0 ? y[f][r] : src[(f * 16 + r) * 64 + lane];          // chunks 0..5
+                const float hi = g == 0 ? src[(f * 16 + r) * 64 + lane] : y[3 + f][r];      // chunks 6..11
+                z[f][r] = lo + hi;
+            }
+    }
+    __syncthreads();   // exchange area read: the slabs may overwrite it
+    epi_stage(z, slab);
+    epi_rmw<8>(g, pr, slab, 96 * w, p.b2, p.mm, p.gate_chunk, true, p.h);
+}
+
 // =================================================================================================
 // Affine LayerNorm (eps 1e-5) + the four IPA input projections in one GEMM:
 //   out[token][672] = LN_affine(h) @ [linear_q | linear_kv | linear_q_points | linear_kv_points]^T + b
@@ -1239,6 +1346,11 @@ void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
 }
 void launch_mlp(const MlpParams& p, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
+    if (grid <= 256 && !p.trace) {   // at most one workgroup per CU: eight waves per panel (the phase stamps stay with k_mlp)
+        if (p.o) hipLaunchKernelGGL((k_mlp8<true>), dim3(grid), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((k_mlp8<false>), dim3(grid), dim3(512), 0, s, p);
+        return;
+    }
     if (p.o) hipLaunchKernelGGL((k_mlp<3, true>), dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_mlp<3>), dim3(grid), dim3(256), 0, s, p);
 }
