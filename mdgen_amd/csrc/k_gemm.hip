@@ -145,7 +145,8 @@ __device__ __forceinline__ void epilogue_v_flash(const f32x16* acc /*[2 tt][3 ft
 // fragment layout covers len + 1 keys).  Written by the workgroup of a sequence's last panel, wave w for its heads
 // 4w..4w+3, AFTER the same wave's K / V epilogues (which may have stored padding-row values into that slot: same wave,
 // same address, program order).  The attention kernel then needs no special case for it.
-__device__ __forceinline__ void write_bias_slots(const QkvParams& p, int seq, int w) {
+// do_k / do_v: the K / V^T half only (k_ln_qkv8: the two halves are written by different waves).
+__device__ __forceinline__ void write_bias_slots(const QkvParams& p, int seq, int w, bool do_k = true, bool do_v = true) {
     const int lane = lane_id();
     const int len = p.ax.len, nt = p.ax.ntile();
     const int kt = len >> 5, sl = len & 31;
@@ -160,15 +161,19 @@ __device__ __forceinline__ void write_bias_slots(const QkvParams& p, int seq, in
             u32x4* kd = reinterpret_cast<u32x4*>(p.kf + ft * kFragK);
             u32x4* vd = reinterpret_cast<u32x4*>(p.vf + ft * kFragV);
             const u32x4 z = {0u, 0u, 0u, 0u}, ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-            kd[lane] = z;
-            kd[64 + lane] = u32x4{0u, 0u, 0x3f803f80u, 0u};
+            if (do_k) {
+                kd[lane] = z;
+                kd[64 + lane] = u32x4{0u, 0u, 0x3f803f80u, 0u};
+            }
             const int r0 = lane, r1 = 64 + lane;   // 16-byte rows of the V^T fragment: [k-step 2][key half 2][25]
-            vd[r0] = (r0 % 25) == kDH ? ones : z;
-            if (r1 < 100) vd[r1] = (r1 % 25) == kDH ? ones : z;
+            if (do_v) {
+                vd[r0] = (r0 % 25) == kDH ? ones : z;
+                if (r1 < 100) vd[r1] = (r1 % 25) == kDH ? ones : z;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (lane < 8) {   // K: (half hh, head hd) -> 12 rotated values = 16 B (k-step 0) + 8 B (k-step 1) of key slot sl
+    if (do_k && lane < 8) {   // K: (half hh, head hd) -> 12 rotated values = 16 B (k-step 0) + 8 B (k-step 1) of key slot sl
         const int hd = lane & 3, hh = lane >> 2, head = 4 * w + hd;
         const float* bk = p.bias_k + head * kDH;
         const float* rc = p.rope + (long)len * kRopeRow + 16 * hh;
@@ -186,7 +191,7 @@ __device__ __forceinline__ void write_bias_slots(const QkvParams& p, int seq, in
         *reinterpret_cast<u32x4*>(base + 1024 + (hh * 32 + sl) * 16) =
             u32x4{pack_bf16(e[8], e[9]), pack_bf16(e[10], e[11]), 0x3f803f80u, 0u};
     }
-    if (lane < kDH) {   // V^T: row d = lane; key slot sl = register r of lane-half hk: r = (sl & 3) + 4 (sl >> 3)
+    if (do_v && lane < kDH) {   // V^T: row d = lane; key slot sl = register r of lane-half hk: r = (sl & 3) + 4 (sl >> 3)
         const int d = lane;
         const int dpsi = 12 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3);   // feature of V^T row d (api.hip feat_vflash)
         const int hk = (sl >> 2) & 1, r = (sl & 3) + 4 * (sl >> 3);
@@ -332,6 +337,61 @@ __device__ __forceinline__ void load_head_bias(const float* bias_perm, int w, in
     for (int hd = 0; hd < 4; ++hd)
 #pragma unroll
         for (int c = 0; c < 3; ++c) bq[hd][c] = bp[hd * 3 + c];
+}
+
+// ---- LN -> q, k, v (FLASH layout) for launches of at most one workgroup per CU: eight waves per panel ------------------------------
+// (see k_mlp8.)  The split keeps 64 rows per wave -- with one row tile per wave every weight fragment feeds one MFMA instead of two and
+// the launch gets slower (profiles/r04_experiments.txt #17) -- and divides the three products instead: waves 0..3 compute q and k,
+// waves 4..7 compute v (and its all-ones row); the LayerNorm prologue is split by row batches.
+__global__ __launch_bounds__(512, 1) void k_ln_qkv8(const QkvParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
+    PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
+    unsigned char* panel = smem + sizeof(PanelRows);
+    const int seq = blockIdx.x / p.panels_per_seq;
+    const int pn = blockIdx.x - seq * p.panels_per_seq;
+    const int pos0 = pn * kPanel, tile0 = pn * 2;
+    setup_rows_axis(pr, p.ax, seq, pos0, p.mm);
+    if (wave_id() == 0) {   // key-validity words of this panel's two tiles (as k_ln_qkv<false>)
+        const int lane = lane_id(), len = p.ax.len, pos = pos0 + lane;
+        const float mv = p.mk.at(p.ax.token(seq, pos < len ? pos : len - 1));
+        const unsigned long long bal = __ballot(pos == len || (pos < len && mv != 0.f));
+        uint32_t* vm = p.vmask + (long)seq * p.vmask_stride;
+        if (lane < 2) vm[tile0 + lane] = (uint32_t)(bal >> (32 * lane));
+        if (pn == p.panels_per_seq - 1) {
+            const int idx = tile0 + 2 + lane;
+            if (idx < p.vmask_stride) vm[idx] = idx == (len >> 5) ? 1u << (len & 31) : 0u;
+            if (idx + 64 < p.vmask_stride) vm[idx + 64] = 0u;
+        }
+    }
+    __syncthreads();
+    const int w8 = __builtin_amdgcn_readfirstlane(wave_id()), g = w8 >> 2, w = w8 & 3, lane = lane_id();
+    if (g == 0) prologue_ln<false, 0, 2>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
+    else prologue_ln<false, 2, 4>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
+    __syncthreads();
+    const int ntile = p.ax.ntile(), len = p.ax.len;
+    const bool last = pn == p.panels_per_seq - 1;
+    f32x16 acc[6];
+    if (g == 0) {
+        zero_acc<6>(acc);
+        wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        epilogue_heads_T<true>(acc, pr, w, p.bq, p.rope, false, pos0, len, seq, ntile, tile0, p.qf, p.qkv_small, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        zero_acc<6>(acc);
+        wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        epilogue_heads_T<true>(acc, pr, w, p.bk, p.rope, false, pos0, len, seq, ntile, tile0, p.kf, p.qkv_small, 1);
+        if (last) {   // the learned bias key, after this wave's own K stores
+            __builtin_amdgcn_sched_barrier(0);
+            write_bias_slots(p, seq, w, true, false);
+        }
+    } else {
+        zero_acc<6>(acc);
+        wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        epilogue_v_flash(acc, w, p.bv, seq, ntile, tile0, p.vf);
+        if (last) {   // the learned bias value, after this wave's own V^T stores
+            __builtin_amdgcn_sched_barrier(0);
+            write_bias_slots(p, seq, w, false, true);
+        }
+    }
 }
 
 // PROJ: also run the sub-layer's out-projection and gated residual update here (mha.py:397, latent_model.py:462):
@@ -1326,7 +1386,9 @@ void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre) {
         const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
         hipLaunchKernelGGL(k_ln_qkv<true>, dim3(grid), dim3(256), 0, s, p);
     } else {
-        hipLaunchKernelGGL(k_ln_qkv<false>, dim3(p.ax.nseq * p.panels_per_seq), dim3(256), 0, s, p);
+        const int grid = p.ax.nseq * p.panels_per_seq;
+        if (grid <= 256) hipLaunchKernelGGL(k_ln_qkv8, dim3(grid), dim3(512), 0, s, p);   // at most one workgroup per CU
+        else hipLaunchKernelGGL(k_ln_qkv<false>, dim3(grid), dim3(256), 0, s, p);
     }
 }
 void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s, bool with_qkv_t) {
