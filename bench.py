@@ -56,12 +56,13 @@ def algorithmic_flops(cls, B, T, L):
     """Algorithmic flops of ONE launch of a kernel class (SURVEY.md section 8(d) per-token figures x N).
     dh padding 24->32, masked keys and tile padding are NOT counted."""
     N, C = B * T * L, 384
+    cls = cls.split("@")[0]       # "@p4" / "@p8": four- / eight-wave form of a panel kernel (same work)
+    if cls == "flash_proj_T":     # k_flash_proj: tiled attention + out-projection + gated residual
+        return 4.0 * N * C * (T + 1) + 2.0 * N * C * C
+    if cls == "flash_proj_L":
+        return 4.0 * N * C * (L + 1) + 2.0 * N * C * C
     if cls == "projL_qkvT":       # k_ln_qkv<false, true>: residue-axis out-projection + the temporal q, k, v projection
         return 2.0 * N * C * C + 2.0 * N * C * 3 * C
-    if cls == "attnL_qkvT":       # k_ln_qkv_attn4<true, true>
-        return 2.0 * N * C * 4 * C + 4.0 * N * C * 5 + 2.0 * N * C * 3 * C
-    if cls == "chain_L_qkvT":     # k_chain_l4: the L == 4 residue sub-layer + the temporal q, k, v projection
-        return 2.0 * N * C * 4 * C + 4.0 * N * C * 5 + 2.0 * N * C * 3 * C
     if cls in ("ln_qkv_L", "ln_qkv_T"):
         return 2.0 * N * C * 3 * C
     if cls == "proj_T":
@@ -122,9 +123,10 @@ def cpu_baseline(cfg, sd, B, T, L, S, n_pad, budget_s=20.0):
 
 
 # kernel class (hipEvent profile name) -> substring of the rocprof kernel name
-_KERNEL_OF_CLASS = {"mlp": "k_mlp", "proj_mlp": "k_mlp_rows", "flash_T": "k_flash", "flash_L": "k_flash", "ln_qkv_T": "k_ln_qkv<false>",
-                    "ln_qkv_L": "k_ln_qkv<true>", "proj_T": "k_proj<0>", "proj_L": "k_proj<2>",
-                    "attn_L_fused": "k_ln_qkv_attn4<true>"}
+_KERNEL_OF_CLASS = {"mlp": "k_mlp", "proj_mlp": "k_mlp_rows", "flash_T": "k_flash<", "flash_L": "k_flash<", "ln_qkv_T": "k_ln_qkv<false",
+                    "ln_qkv_L": "k_ln_qkv<true", "proj_T": "k_proj<0>", "proj_L": "k_proj<2>",
+                    "attn_L_fused": "k_ln_qkv_attn4<true>", "flash_proj_T": "k_flash_proj", "flash_proj_L": "k_flash_proj",
+                    "projL_qkvT": "k_ln_qkv<false, true>"}
 
 
 def pmc_traffic(kernel_class, workload):
@@ -138,7 +140,7 @@ def pmc_traffic(kernel_class, workload):
             m = json.load(f)
     except (OSError, ValueError):
         return None, None
-    sub = _KERNEL_OF_CLASS.get(kernel_class)
+    sub = _KERNEL_OF_CLASS.get(kernel_class.split("@")[0])
     kern = m.get("workloads", {}).get(workload, {}).get("kernels")
     if kern is None and m.get("workload") == workload:   # (round-1 layout of the file: one workload)
         kern = m.get("kernels")
@@ -170,6 +172,12 @@ def _dominant(rep, B, T, L, workload):
             "traffic_source": traffic_src, "traffic_measured_in_run": False, "avg_launch_ms": round(avg_ms, 4), "launches": rep[dom]["count"],
             "share_of_event_time": round(rep[dom]["ms"] / tot, 3),
             "by_kernel_ms_per_call": {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}}
+
+
+def whole_step_frac(rep, B, T, L, seconds_per_call):
+    """Algorithmic flops of every launch of one call (classes with a known figure) / wall time of one call / dense bf16 MFMA peak."""
+    fl = sum(algorithmic_flops(k, B, T, L) * v["count"] for k, v in rep.items() if algorithmic_flops(k, B, T, L))
+    return round(fl / seconds_per_call / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
 
 
 def box_probe(dev):
@@ -241,8 +249,7 @@ def sampler_leg(workload, dev, steps, warmup, S, options, roofline=False, rollou
         rep = w.model.profile_report()
         w.model.profile(False)
         res["roofline"] = _dominant(rep, B, T, L, workload)
-        fl = sum(algorithmic_flops(k, B, T, L) * v["count"] for k, v in rep.items() if algorithmic_flops(k, B, T, L))
-        res["whole_step_frac_of_mfma_peak"] = round(fl / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)
+        res["whole_step_frac_of_mfma_peak"] = whole_step_frac(rep, B, T, L, dt)
     del w
     torch.cuda.empty_cache()
     return res
@@ -311,6 +318,75 @@ def extra_legs(dev, options):
     return ex
 
 
+def self_launch(n, argv, script=None, extra_env=None):
+    """Re-execute this script under torch.distributed.run (--standalone, 127.0.0.1, N processes on this node) and return its
+    exit status; the children's stdout (rank 0's JSON line) and stderr pass through."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", f"--nproc-per-node={n}",
+           "--local-addr", "127.0.0.1", script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, **(extra_env or {}))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on these hosts
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def timed_region(step, steps, warmup, dist, sync):
+    """The contract's timed region: W untimed warm-up steps, then exactly K steps bracketed by a barrier + device
+    synchronisation on both sides.  Returns (last output, seconds incl. the wait for the slowest rank, this rank's own seconds)."""
+    out = None
+    for _ in range(warmup):
+        out = step()
+    if dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    dt_own = time.perf_counter() - t0          # this rank's own K steps (before it waits for the others)
+    if dist:
+        dist.barrier()
+    sync()
+    return out, time.perf_counter() - t0, dt_own
+
+
+def headline(a, world, B, T, L, S, dt, per_rank, use_graph, roof=None, cpu=None, extra=None, data=None):
+    value = B * T * a.steps * world / dt
+    return {
+        "metric": "sampled MD frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if a.precision == "bf16" else "f32",
+        "data": data or "synthetic (seeded random-init weights, synthetic peptide frames/torsions, CPU-seeded noise)",
+        "config": {"workload": a.workload, "batch_per_gpu": B, "num_frames": T, "crop": L,
+                   "euler_steps": S, "hipgraph": use_graph, "parallelism": f"batch-sharded x{world}, no collective"},
+        # every rank's own rate over its K steps and the fastest / slowest ratio: a straggler GPU shows up here
+        "per_rank_frames_per_s": [round(v, 1) for v in per_rank],
+        "rank_max_over_min": round(max(per_rank) / min(per_rank), 4),
+        "roofline": roof, "cpu_baseline": cpu, "extra": extra,
+    }
+
+
+def fake_sampler_main(a, rank, world):
+    """Test hook (tests/test_multiproc_cpu.py, no GPU): the launcher / rendezvous / barrier / max-over-ranks / JSON plumbing of a
+    multi-rank run with the sampler replaced by a sleep of 10 ms x (rank + 1) per step and gloo in place of RCCL."""
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist_.init_process_group("gloo")
+        dist = dist_
+    B, T, L, _, _ = WORKLOADS[a.workload]
+    from mdgen_amd.sharding import gather_over_ranks, max_over_ranks
+    _, dt, dt_own = timed_region(lambda: time.sleep(0.01 * (rank + 1)), a.steps, a.warmup, dist, lambda: None)
+    dt = max_over_ranks(dt, dist)
+    per_rank = [B * T * a.steps / s for s in gather_over_ranks(dt_own, dist)]
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(headline(a, world, B, T, L, a.euler_steps, dt, per_rank, False, data="none (fake sampler: test hook)")))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,15 +403,21 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (ATLAS, TPS, B = 1, rollout, training step, box probe)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="library run-time option (mdgen_ctx_set_option), e.g. mlp_path=1; repeatable")
+    ap.add_argument("--fake-sampler", action="store_true", help=argparse.SUPPRESS)   # test hook, see fake_sampler_main
     a = ap.parse_args()
     options = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.option}
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU) and relay rank 0's
+        # JSON line, so the bare command and the torch.distributed.run command give the same single line
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: one process per GPU (torch.distributed.run --nproc-per-node {a.gpus})")
+    if a.fake_sampler:
+        return fake_sampler_main(a, rank, world)
     torch.set_grad_enabled(False)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -367,20 +449,7 @@ def main():
     def step():
         return w.inference(batch, zs=zs, num_steps=S, use_graph=use_graph)
 
-    for _ in range(a.warmup):
-        atom14, _ = step()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        atom14, _ = step()
-    torch.cuda.synchronize()
-    dt_own = time.perf_counter() - t0          # this rank's own K steps (before it waits for the others)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    (atom14, _), dt, dt_own = timed_region(step, a.steps, a.warmup, dist, torch.cuda.synchronize)
     from mdgen_amd.sharding import gather_over_ranks, max_over_ranks
     dt = max_over_ranks(dt, dist, dev)
     per_rank = [B * T * a.steps / s for s in gather_over_ranks(dt_own, dist, dev)]
@@ -414,9 +483,6 @@ def main():
         torch.cuda.synchronize()
         print("  eager re-run nonfinite:", int((~torch.isfinite(eager)).sum()), file=sys.stderr)
         raise AssertionError("non-finite atom14")
-    frames = B * T * a.steps * world
-    value = frames / dt
-
     roof = None
     if rank == 0 and not a.no_roofline:
         # per-kernel-class durations measured with hipEvents on the launch stream (eager pass, graphs bypassed);
@@ -426,6 +492,8 @@ def main():
         rep = w.model.profile_report()
         w.model.profile(False)
         roof = _dominant(rep, B, T, L, a.workload)
+        if roof is not None:   # the whole call (all kernels, two streams, graph replay) against the same peak
+            roof["whole_step_frac_of_mfma_peak"] = whole_step_frac(rep, B, T, L, dt / a.steps)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(cfg, sd, B, T, L, S, n_pad)
@@ -438,21 +506,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        out = {
-            "metric": "sampled MD frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if a.precision == "bf16" else "f32",
-            "data": "synthetic (seeded random-init weights, synthetic peptide frames/torsions, CPU-seeded noise)",
-            "config": {"workload": a.workload, "batch_per_gpu": B, "num_frames": T, "crop": L,
-                       "euler_steps": S, "hipgraph": use_graph, "parallelism": f"batch-sharded x{world}, no collective"},
-            # every rank's own rate over its K steps and the fastest / slowest ratio: a straggler GPU shows up here
-            "per_rank_frames_per_s": [round(v, 1) for v in per_rank],
-            "rank_max_over_min": round(max(per_rank) / min(per_rank), 4),
-            "roofline": roof, "cpu_baseline": cpu, "extra": extra,
-        }
-        print(json.dumps(out))
-
+        print(json.dumps(headline(a, world, B, T, L, S, dt, per_rank, use_graph, roof, cpu, extra)))
 
 if __name__ == "__main__":
     main()

@@ -123,13 +123,17 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      (mha.py:397, latent_model.py:462) runs inside the temporal sub-layer's LN -> q, k, v kernel, whose panels
  *                      then normalise rows that are still in L2 (k_ln_qkv<false, true>; one launch and one HBM read of the
  *                      residual stream less per layer).
- *   "chain_path"       tetrapeptide trunk (L == 4, T a multiple of 8): the residue-axis attention sub-layer and the temporal
- *                      sub-layer's LN -> q, k, v -> fragments (latent_model.py:457-475) in ONE launch: 0 (default) two panel
- *                      kernels (k_ln_qkv_attn4<true>, k_ln_qkv); 1 one panel kernel (k_ln_qkv_attn4<true, true>: the rows it has
- *                      just updated come back from L2 instead of HBM -- but a tile of 8 frames x 4 residues writes the temporal
- *                      fragments as 8- and 16-byte pieces: 53.6 against 52.2 ms per 245 launches); 2 / 3 the row-owner kernel csrc/k_chain.hip
- *                      k_chain_l4 (2: launches of >= 768 row tiles, 3: always) -- measured 10-15 % slower than the two panel
- *                      kernels (one wave per SIMD cannot hide the attention's vector work), kept for reference.
+ *   "flash_proj"       tiled attention (sequence > 8 positions) and the sub-layer's out-projection + gated residual (mha.py:359-397,
+ *                      latent_model.py:462,476) in ONE launch (csrc/k_flash.hip k_flash_proj: a workgroup owns 64 queries of a
+ *                      sequence for all 16 heads, the attention output stays in LDS as the projection's A operand): 1 (default)
+ *                      for launches of >= 512 such workgroups (cfg-2, ATLAS), 0 never (k_flash, then k_proj<0> or a projection
+ *                      deferred into the next kernel per fuse_proj / fuse_proj_qkv), 2 always.  Same values as the separate
+ *                      kernels (same operands, same summation order).
+ *   "flash_proj_occ"   2 (default) / 3: workgroups per CU that kernel's register budget is cut for.
+ *   "panel_waves"      0 (default) / 4 / 8: the 64-row panel kernels that exist in a four- and an eight-wave form (k_mlp / k_mlp8,
+ *                      k_ln_qkv<false> / k_ln_qkv8) take the eight-wave form for launches of at most one workgroup per CU; 4 / 8
+ *                      force one form whatever the launch size (tests, A/B runs).  mdgen_profile_report tags the class of such
+ *                      a launch with "@p4" / "@p8".
  *   "train_precision"  operands of the matrix products of mdgen_train_forward_backward (linear layers, weight gradients,
  *                      the attention's q k^T / p v and their backward): 32 (default) fp32, the exact mode; 16 rounded to
  *                      bf16 on the MFMA, fp32 accumulation, fp32 master weights and activations (train.py:13
@@ -252,10 +256,6 @@ int32_t mdgen_debug_layout_maps(int32_t* map_qk, int32_t* map_vflash, int32_t* m
  * out[f] = mat << 16 | row_tile << 8 | k_step for fragment f (2304 of them); mat 0 = fc1 (layers.py:77-84 `fc1`), 1 = fc2.
  * Returns the number of entries, or a negative status. */
 int32_t mdgen_debug_mlp_stream_table(int32_t* out, int32_t capacity);
-/* The same for the weight streams of k_chain_l4 (csrc/k_chain.hip): stages of 3 row tiles x 24 k-steps, k-step major.
- * which 0: residue axis q | k | v head group by head group (864 entries), 1: temporal axis q, k, v (864), 2: out-projection
- * (288); mat 0 = q, 1 = k, 2 = v, 3 = out-projection. */
-int32_t mdgen_debug_chain_stream_table(int32_t which, int32_t* out, int32_t capacity);
 
 /* Test hooks (GPU): the training step's linear layer and weight gradient on raw device buffers, through exactly the
  * kernel dispatch of mdgen_train_forward_backward -- precision 32: fp32 products (k32_linear / k32_dw); 16: bf16-rounded

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmdgen_amd.so")
-SOURCES = ["api.hip", "k_gemm.hip", "k_rows.hip", "k_chain.hip", "k_flash.hip", "k_small.hip", "k_se3.hip", "k_fp32.hip", "k_optim.hip", "k_fp32_bwd.hip", "k_attn16.hip", "k_wide16.hip"]
+SOURCES = ["api.hip", "k_gemm.hip", "k_rows.hip", "k_flash.hip", "k_small.hip", "k_se3.hip", "k_fp32.hip", "k_optim.hip", "k_fp32_bwd.hip", "k_attn16.hip", "k_wide16.hip"]
 HEADERS = ["common.h", "dev.h", "panel.h", "rows.h", "linear.h", "kernels.h", "train.inc", os.path.join("..", "..", "include", "mdgen_amd.h")]
 # -fno-slp-vectorize: keeps hipcc from fusing scalar fp32 math into v_pk_{mul,add,fma}_f32.  On MI355X those
 # packed ops (a) are an anti-lever beside MFMAs (MI355X_MICROARCH "price of one filler") and (b) produced
@@ -54,7 +54,7 @@ def check_isa(cc: str, src: str) -> None:
             raise RuntimeError("ISA check failed to compile " + src + "\n" + r.stderr)
         pat = re.compile(r"v_mfma_\w+ ([va])\[(\d+):(\d+)\], ([va])\[(\d+):(\d+)\], ([va])\[(\d+):(\d+)\], (.*)$")
         n = 0
-        own_m0 = os.path.basename(src) in ("k_rows.hip", "k_wide16.hip", "k_chain.hip")   # rows.h dma_frag owns M0 there (not saved / restored)
+        own_m0 = os.path.basename(src) in ("k_rows.hip", "k_wide16.hip")   # rows.h dma_frag owns M0 there (not saved / restored)
         in_asm = False
         for line in open(out):
             if own_m0:

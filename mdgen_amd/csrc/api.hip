@@ -11,6 +11,7 @@
 #include <climits>
 #include <functional>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -59,10 +60,6 @@ constexpr size_t kPackCC = (size_t)12 * kKS * 64;  // bf16x8 elements of a packe
 
 struct MhaW {
     bf16x8 *wq = nullptr, *wk = nullptr, *wv_flash = nullptr, *wv_small = nullptr, *wo = nullptr;
-    // k_chain_l4's weight streams (trunk layers only; chain_tables): q|k|v head group by head group with the SMALL-layout V
-    // (residue axis, attention in registers), q, k, v with the FLASH-layout V (temporal axis), W_o in the k order of the
-    // attention output registers
-    bf16x8 *ws_qkv_l4 = nullptr, *ws_qkv_flash = nullptr, *ws_o_l4 = nullptr;
     bf16x8* wo_stream = nullptr;   // W_o as the 288-fragment prefix of the row-owner MLP kernel's weight stream (proj_stream_table)
     float *bq = nullptr, *bk = nullptr, *bv_flash = nullptr, *bv_small = nullptr, *bo = nullptr;
     float *bias_k = nullptr, *bias_v = nullptr;
@@ -122,7 +119,6 @@ struct mdgen_ctx {
     int *perm_qk = nullptr, *perm_vsmall = nullptr;
     int* mlp_tab = nullptr;     // device copy of mlp_stream_table()
     int* proj_tab = nullptr;    // device copy of proj_stream_table()
-    int* chain_tab[3] = {nullptr, nullptr, nullptr};   // device copies of chain_table(0..2)
     std::vector<GraphEntry> graphs;
     bool inv_freq_set = false;
     bool prof_on = false;
@@ -136,13 +132,16 @@ struct mdgen_ctx {
     int opt_attn_path = 0;      // tiled attention: 0 fixed-anchor fast loop with overflow check + fallback, 1 robust loop always
     int opt_mlp_path = 1;       // MLP block: 0 resident-panel kernel (k_mlp), 1 row-owner kernel (k_mlp_rows) when the launch
                                 // fills the chip, 2 row-owner kernel always
-    int opt_chain = 0;          // tetrapeptide trunk (L == 4, T % 8 == 0): residue-axis sub-layer + temporal LN / q, k, v in ONE launch:
-                                // 0 (default) off (k_ln_qkv_attn4<true> + k_ln_qkv), 1 the panel kernel k_ln_qkv_attn4<true, true> (a tie),
-                                // 2 the row-owner kernel k_chain_l4 for launches that fill the chip (measured slower),
-                                // 3 k_chain_l4 whenever the shape allows
     int opt_fuse_proj_qkv = 1;  // tiled residue axis (L > 8): its out-projection + gated residual runs inside the temporal q / k / v kernel
     int opt_fuse_proj = 3;      // the temporal attention's out-projection inside the MLP kernel: 0 off, 1 row-owner kernel (same wall time),
                                 // 2 panel kernel always, 3 (default) panel kernel where the launch takes the panel kernel anyway (small N: +2 %)
+    int opt_panel_waves = 0;    // 64-row panel kernels with a four- and an eight-wave form (k_mlp / k_mlp8, k_ln_qkv<false> / k_ln_qkv8): 0 (default)
+                                // eight waves where a launch is at most one workgroup per CU, 4 / 8 force one form (tests, A/B runs)
+    int ncu = 256;              // compute units of the device the context was created on (hipDeviceAttributeMultiprocessorCount)
+    int opt_flash_proj = 1;     // tiled attention + its out-projection + gated residual in ONE launch (k_flash_proj): 0 off (k_flash, then
+                                // k_proj<0> or a deferred projection), 1 (default) when the launch has >= kFlashProjMinJobs workgroups
+                                // of (sequence, 64 queries), 2 always
+    int opt_flash_proj_occ = 2; // ... built for 2 (256 registers) or 3 (168 registers) workgroups per CU
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_train_streams = 2;      // training step: 2 = weight / bias gradients of the linear layers on a second stream (train.inc)
     hipStream_t train_side = nullptr;   // that stream (created on first use, default priority)
@@ -157,6 +156,8 @@ struct mdgen_ctx {
     hipStream_t side[kMaxSide] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
 
+    std::set<std::string> cls_names;   // storage of composed profile class names (ProfRec keeps a const char*)
+    const char* intern(const std::string& n) { return cls_names.insert(n).first->c_str(); }
     template <typename T>
     int dalloc(T** p, size_t count) {
         void* q = nullptr;
@@ -284,37 +285,6 @@ static std::vector<int> proj_stream_table() {
     return t;
 }
 constexpr int kProjFrags = 288;
-// Weight streams of k_chain_l4 (csrc/k_chain.hip): stages of 3 row tiles x 24 k-steps, fragment order k-step major, tile
-// minor.  Entry = mat << 16 | row tile << 8 | k-step, mat 0 = q, 1 = k, 2 = v, 3 = out-projection.
-//   which 0: residue axis, head group g = tiles 3 g .. 3 g + 2: [q g][k g][v g] for g = 0..3              (864 fragments)
-//   which 1: temporal axis: [q 0..3][k 0..3][v 0..3]                                                          (864)
-//   which 2: out-projection: feature tiles 3 st .. 3 st + 2 for st = 0..3                                     (288)
-static std::vector<int> chain_table(int which) {
-    std::vector<int> t;
-    auto stage = [&](int mat, int g) {
-        for (int ks = 0; ks < 24; ++ks)
-            for (int tl = 0; tl < 3; ++tl) t.push_back(mat << 16 | (3 * g + tl) << 8 | ks);
-    };
-    if (which == 0) {
-        for (int g = 0; g < 4; ++g)
-            for (int mat = 0; mat < 3; ++mat) stage(mat, g);
-    } else if (which == 1) {
-        for (int mat = 0; mat < 3; ++mat)
-            for (int g = 0; g < 4; ++g) stage(mat, g);
-    } else {
-        for (int st = 0; st < 4; ++st) stage(3, st);
-    }
-    return t;
-}
-constexpr int kChainQkvFrags = 864;
-extern "C" int32_t mdgen_debug_chain_stream_table(int32_t which, int32_t* out, int32_t capacity) {
-    if (which < 0 || which > 2) return fail(-2, "which must be 0 (residue q|k|v), 1 (temporal q, k, v) or 2 (out-projection)");
-    const std::vector<int> t = chain_table(which);
-    if (!out || capacity < (int)t.size()) return fail(-1, "need room for %d entries", (int)t.size());
-    for (size_t i = 0; i < t.size(); ++i) out[i] = t[i];
-    return (int32_t)t.size();
-}
-
 extern "C" int32_t mdgen_debug_mlp_stream_table(int32_t* out, int32_t capacity) {
     const std::vector<int> t = mlp_stream_table();
     if (!out || capacity < (int)t.size()) return fail(-1, "need room for %d entries", (int)t.size());
@@ -347,13 +317,8 @@ static int copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
     return 0;
 }
 
-static int register_mha(mdgen_ctx* c, const std::string& pre, MhaW* m, bool chain = false) {
+static int register_mha(mdgen_ctx* c, const std::string& pre, MhaW* m) {
     const float qscale = (1.0f / std::sqrt((float)kDH)) * kLog2e;
-    if (chain) {
-        if (int r = c->dalloc(&m->ws_qkv_l4, (size_t)kChainQkvFrags * 64)) return r;
-        if (int r = c->dalloc(&m->ws_qkv_flash, (size_t)kChainQkvFrags * 64)) return r;
-        if (int r = c->dalloc(&m->ws_o_l4, (size_t)kProjFrags * 64)) return r;
-    }
     if (int r = c->dalloc(&m->wq, kPackCC)) return r;
     if (int r = c->dalloc(&m->wk, kPackCC)) return r;
     if (int r = c->dalloc(&m->wv_flash, kPackCC)) return r;
@@ -364,29 +329,17 @@ static int register_mha(mdgen_ctx* c, const std::string& pre, MhaW* m, bool chai
     SETTER(pre + "q_proj.weight", {
         WANT(kC, kC);
         launch_pack_rows(data, kC, c->map_qk, 12, kKS, qscale, m->wq, s);
-        if (chain) {
-            launch_pack_stream(data, kC, 0, c->chain_tab[0], kChainQkvFrags, qscale, 1, m->ws_qkv_l4, s, c->map_qk);
-            launch_pack_stream(data, kC, 0, c->chain_tab[1], kChainQkvFrags, qscale, 1, m->ws_qkv_flash, s, c->map_qk);
-        }
     });
     SETTER(pre + "q_proj.bias", { WANT(kC); launch_gather_f32(data, c->perm_qk, qscale, m->bq, kC, s); });
     SETTER(pre + "k_proj.weight", {
         WANT(kC, kC);
         launch_pack_rows(data, kC, c->map_qk, 12, kKS, 1.f, m->wk, s);
-        if (chain) {
-            launch_pack_stream(data, kC, 1, c->chain_tab[0], kChainQkvFrags, 1.f, 1, m->ws_qkv_l4, s, c->map_qk);
-            launch_pack_stream(data, kC, 1, c->chain_tab[1], kChainQkvFrags, 1.f, 1, m->ws_qkv_flash, s, c->map_qk);
-        }
     });
     SETTER(pre + "k_proj.bias", { WANT(kC); launch_gather_f32(data, c->perm_qk, 1.f, m->bk, kC, s); });
     SETTER(pre + "v_proj.weight", {
         WANT(kC, kC);
         launch_pack_rows(data, kC, c->map_vflash, 12, kKS, 1.f, m->wv_flash, s);
         launch_pack_rows(data, kC, c->map_vsmall, 12, kKS, 1.f, m->wv_small, s);
-        if (chain) {
-            launch_pack_stream(data, kC, 2, c->chain_tab[0], kChainQkvFrags, 1.f, 1, m->ws_qkv_l4, s, c->map_vsmall);
-            launch_pack_stream(data, kC, 2, c->chain_tab[1], kChainQkvFrags, 1.f, 1, m->ws_qkv_flash, s, c->map_vflash);
-        }
     });
     SETTER(pre + "v_proj.bias", {
         WANT(kC);
@@ -398,7 +351,6 @@ static int register_mha(mdgen_ctx* c, const std::string& pre, MhaW* m, bool chai
         WANT(kC, kC);
         launch_pack_rows(data, kC, c->map_nat, 12, kKS, 1.f, m->wo, s);
         launch_pack_stream(data, kC, 2, c->proj_tab, kProjFrags, 1.f, 0, m->wo_stream, s);
-        if (chain) launch_pack_stream(data, kC, 3, c->chain_tab[2], kProjFrags, 1.f, 2, m->ws_o_l4, s);
     });
     SETTER(pre + "out_proj.bias", { WANT(kC); if (int r = copy_f32(m->bo, data, kC, s)) return r; });
     SETTER(pre + "bias_k", { WANT(kC); if (int r = copy_f32(m->bias_k, data, kC, s)) return r; });
@@ -445,6 +397,11 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     HIPCHK(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(-9, "no HIP device");
     mdgen_ctx* c = new mdgen_ctx();
+    {   // "one workgroup per CU" thresholds (eight-wave panel kernels, stream count) follow the device, not a constant
+        int dev = 0, ncu = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0)
+            c->ncu = ncu;
+    }
     c->d = *d;
     c->nl = d->num_layers;
     c->D = d->latent_dim;
@@ -463,7 +420,6 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     TRY(upload_ints(c, &c->map_fin, fin));
     TRY(upload_ints(c, &c->mlp_tab, mlp_stream_table()));
     TRY(upload_ints(c, &c->proj_tab, proj_stream_table()));
-    for (int i = 0; i < 3; ++i) TRY(upload_ints(c, &c->chain_tab[i], chain_table(i)));
     TRY(upload_ints(c, &c->perm_qk, pqk));
     TRY(upload_ints(c, &c->perm_vsmall, pvs));
     TRY(c->dalloc(&c->wl, (size_t)kC * D));
@@ -545,8 +501,8 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
         });
         SETTER(p + "adaLN_modulation.1.bias",
                { WANT(9 * kC); if (int r = copy_f32(c->ada_b + c->trunk_off(i), data, 9 * kC, s)) return r; });
-        TRY(register_mha(c, p + "mha_t.attn.", &t->mha_t, true));
-        TRY(register_mha(c, p + "mha_l.attn.", &t->mha_l, true));
+        TRY(register_mha(c, p + "mha_t.attn.", &t->mha_t));
+        TRY(register_mha(c, p + "mha_l.attn.", &t->mha_l));
         TRY(register_ffn(c, p, &t->ffn));
     }
     for (int i = 0; i < nl; ++i) {
@@ -681,10 +637,15 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "fuse_proj_qkv") {
         if (value != 0 && value != 1) return fail(-2, "fuse_proj_qkv must be 0 or 1");
         c->opt_fuse_proj_qkv = value;
-    } else if (n == "chain_path") {
-        if (value < 0 || value > 3)
-            return fail(-2, "chain_path must be 0 (off), 1 (panel kernel), 2 (row-owner kernel when it fills the chip) or 3 (row-owner kernel always)");
-        c->opt_chain = value;
+    } else if (n == "panel_waves") {
+        if (value != 0 && value != 4 && value != 8) return fail(-2, "panel_waves must be 0 (by launch size), 4 or 8");
+        c->opt_panel_waves = value;
+    } else if (n == "flash_proj") {
+        if (value < 0 || value > 2) return fail(-2, "flash_proj must be 0 (off), 1 (launches that fill the chip) or 2 (always)");
+        c->opt_flash_proj = value;
+    } else if (n == "flash_proj_occ") {
+        if (value != 2 && value != 3) return fail(-2, "flash_proj_occ must be 2 or 3 (workgroups per CU)");
+        c->opt_flash_proj_occ = value;
     } else if (n == "mlp_path") {
         if (value < 0 || value > 2) return fail(-2, "mlp_path must be 0 (panel kernel), 1 (row-owner kernel when it fills the chip) or 2 (always)");
         c->opt_mlp_path = value;
@@ -917,11 +878,19 @@ static int check_launch_rows(long nrows) {
     return 0;
 }
 
+// k_flash_proj owns a (sequence, 64-query chunk) for all 16 heads: four times the work of a k_flash workgroup, a quarter of the
+// workgroups.  It pays where those still fill the chip (cfg-2: 1024 per launch, ATLAS: 1000 / 1024); small launches (B = 1: 64,
+// the IPA stack) keep the finer-grained k_flash + projection.
+constexpr long kFlashProjMinJobs = 512;
+static bool flash_proj_on(const mdgen_ctx* c, const AxisMap& ax) {
+    return c->opt_precision == 16 && (c->opt_flash_proj == 2 || (c->opt_flash_proj == 1 && flash_proj_jobs(ax) >= kFlashProjMinJobs));
+}
+
 // `defer`: when non-null and the sub-layer takes the tiled-attention path, its out-projection is NOT launched; *defer receives
 // what the fused kernel (k_mlp_rows<NW, true>) needs to run it ahead of the MLP (a_bf16 stays null otherwise).
 static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, const AxisMap& ax, const ModMap& mm,
                          int shift, int scale, int gate, const MaskMap& mk, bool residue_axis, bool trunk,
-                         ProjParams* defer = nullptr, bool skip_qkv = false, const ProjParams* pre = nullptr) {
+                         ProjParams* defer = nullptr, const ProjParams* pre = nullptr) {
     if (int e = check_launch_rows(nrows)) return e;
     const char* c_qkv = !trunk ? "ipa.ln_qkv" : residue_axis ? "ln_qkv_L" : "ln_qkv_T";
     const char* c_att = !trunk ? "ipa.flash" : residue_axis ? "flash_L" : "flash_T";
@@ -1005,8 +974,11 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
             q.h_rw = h;
             { ProfScope ps(r.c, "projL_qkvT", r.s); launch_ln_qkv(q, false, r.s, true); }
             LAUNCHCHK();
-        } else if (!skip_qkv) {   // (skip_qkv: k_chain_l4 has written the fragments and the validity words of this axis already)
-            { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv(q, false, r.s); }
+        } else {
+            // (profile class "...@p8": the eight-wave form ran -- tests assert which kernel a launch took)
+            const int pw = panel_waves_for((long)ax.nseq * q.panels_per_seq, r.c->opt_panel_waves, r.c->ncu);
+            const std::string cls = std::string(c_qkv) + (pw == 8 ? "@p8" : "");
+            { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_ln_qkv(q, false, r.s, false, pw); }
             LAUNCHCHK();
         }
         FlashParams f{};
@@ -1022,6 +994,19 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         f.force_robust = r.c->opt_attn_path;
         f.vmask = q.vmask;
         f.vmask_stride = q.vmask_stride;
+        if (flash_proj_on(r.c, ax)) {
+            // attention of all heads + out-projection + gated residual in one launch: nothing is deferred, no k_proj<0>
+            FlashProjParams fp{};
+            fp.f = f;
+            fp.h = h;
+            fp.mm = mm;
+            fp.gate_chunk = gate;
+            fp.wo = m.wo;
+            fp.bo = m.bo;
+            { ProfScope ps(r.c, !trunk ? "ipa.flash_proj" : residue_axis ? "flash_proj_L" : "flash_proj_T", r.s); launch_flash_proj(fp, r.c->opt_flash_proj_occ, r.s); }
+            LAUNCHCHK();
+            return 0;
+        }
         { ProfScope ps(r.c, c_att, r.s); launch_flash(f, r.s); }
         LAUNCHCHK();
         p.a_bf16 = f.obuf;
@@ -1042,79 +1027,7 @@ static bool mlp_uses_rows(const mdgen_ctx* c, long nrows) {
     return c->opt_mlp_path == 2 || (c->opt_mlp_path == 1 && tiles >= 4 * 192);
 }
 
-// `proj`: a deferred out-projection (attn_sublayer) to run inside the row-owner kernel, ahead of the MLP
-// k_chain_l4 (csrc/k_chain.hip): the residue-axis sub-layer of a tetrapeptide trunk layer and the front half of its temporal
-// sub-layer (LN -> q, k, v -> fragments) in one row-owner launch.
-// 0: separate kernels; 1: k_ln_qkv_attn4<true, true> (panel form); 2: k_chain_l4 (row-owner form)
-static int chain_mode(const mdgen_ctx* c, const Run& r) {
-    if (c->opt_chain == 0 || c->opt_precision != 16 || c->opt_residue_l4 != 2) return 0;
-    if (r.L != 4 || r.T % 8 != 0 || r.N % 32 != 0) return 0;
-    if (c->opt_chain == 3 || (c->opt_chain == 2 && r.N / 32 >= 4 * 192)) return 2;
-    return 1;
-}
-static int chain_sublayers_panel(const Run& r, const TrunkW& w, float* h, const AxisMap& axT, const ModMap& mm, const MaskMap& mk) {
-    if (int e = check_launch_rows(r.N)) return e;
-    const MhaW &ml = w.mha_l, &mt = w.mha_t;
-    QkvParams q{};
-    q.h = h;
-    q.nrows = r.N;
-    q.mm = mm;
-    q.shift_chunk = 0; q.scale_chunk = 1;
-    q.wq = ml.wq; q.wk = ml.wk; q.wv = ml.wv_small;
-    q.bq = ml.bq; q.bk = ml.bk; q.bv = ml.bv_small;
-    q.rope = r.c->rope;
-    q.bias_k = ml.bias_k; q.bias_v = ml.bias_v;
-    q.mk = mk;
-    q.obuf = r.obufp;
-    q.h_rw = h;
-    q.wo = ml.wo; q.bo = ml.bo;
-    q.gate_chunk = 2;
-    q.qf = r.qfp; q.kf = r.kfp; q.vf = r.vfp;
-    q.vmask = (uint32_t*)(r.vfp + flash_vmask_offset(axT.nseq, axT.ntile()));
-    q.vmask_stride = flash_vmask_stride(axT.ntile());
-    q.T = r.T;
-    q.ntile_t = axT.ntile();
-    q.shift_t = 3; q.scale_t = 4;
-    q.wq_t = mt.wq; q.wk_t = mt.wk; q.wv_t = mt.wv_flash;
-    q.bq_t = mt.bq; q.bk_t = mt.bk; q.bv_t = mt.bv_flash;
-    q.bias_k_t = mt.bias_k; q.bias_v_t = mt.bias_v;
-    { ProfScope ps(r.c, "attnL_qkvT", r.s); launch_ln_qkv_attn4(q, true, r.s, true); }
-    LAUNCHCHK();
-    return 0;
-}
-static int chain_sublayers(const Run& r, const TrunkW& w, float* h, const AxisMap& axT, const ModMap& mm, const MaskMap& mk) {
-    if (int e = check_launch_rows(r.N)) return e;
-    ChainParams p{};
-    p.h = h;
-    p.nrows = r.N;
-    p.T = r.T;
-    p.ntile = axT.ntile();
-    p.mm = mm;
-    p.shift_l = 0; p.scale_l = 1; p.gate_l = 2;
-    p.shift_t = 3; p.scale_t = 4;
-    p.ws_l = (const unsigned char*)w.mha_l.ws_qkv_l4;
-    p.ws_o = (const unsigned char*)w.mha_l.ws_o_l4;
-    p.ws_t = (const unsigned char*)w.mha_t.ws_qkv_flash;
-    p.bq_l = w.mha_l.bq; p.bk_l = w.mha_l.bk; p.bv_l = w.mha_l.bv_small; p.bo_l = w.mha_l.bo;
-    p.bq_t = w.mha_t.bq; p.bk_t = w.mha_t.bk; p.bv_t = w.mha_t.bv_flash;
-    p.bias_k_l = w.mha_l.bias_k; p.bias_v_l = w.mha_l.bias_v;
-    p.bias_k_t = w.mha_t.bias_k; p.bias_v_t = w.mha_t.bias_v;
-    p.rope = r.c->rope;
-    p.mk = mk;
-    p.qf = r.qfp; p.kf = r.kfp; p.vf = r.vfp;
-    p.vmask = (uint32_t*)(r.vfp + flash_vmask_offset(axT.nseq, axT.ntile()));
-    p.vmask_stride = flash_vmask_stride(axT.ntile());
-    p.dump = r.obufp;   // (the attention output of the previous layer: consumed, rewritten by the attention kernel that follows)
-    if (r.c->phase_trace) {   // one-shot (mdgen_profile_phase_trace): the next trunk launch of a row-owner kernel records its stamps
-        p.trace = r.c->phase_trace;
-        p.trace_cap = r.c->phase_trace_cap;
-        r.c->phase_trace = nullptr;
-    }
-    { ProfScope ps(r.c, "chain_L_qkvT", r.s); launch_chain_l4(p, r.s); }
-    LAUNCHCHK();
-    return 0;
-}
-
+// `proj`: a deferred out-projection (attn_sublayer) to run inside the MLP kernel, ahead of the MLP
 static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const ModMap& mm, int shift, int scale,
                         int gate, bool trunk, const ProjParams* proj = nullptr, const bf16x8* wo_stream = nullptr) {
     if (int e = check_launch_rows(nrows)) return e;
@@ -1167,7 +1080,9 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
         p.trace_cap = r.c->phase_trace_cap;
         r.c->phase_trace = nullptr;
     }
-    { ProfScope ps(r.c, !trunk ? "ipa.mlp" : p.o ? "proj_mlp" : "mlp", r.s); launch_mlp(p, r.s); }
+    const int pw = p.trace ? 4 : panel_waves_for((nrows + kPanel - 1) / kPanel, r.c->opt_panel_waves, r.c->ncu);
+    const std::string cls = std::string(!trunk ? "ipa.mlp" : p.o ? "proj_mlp" : "mlp") + (pw == 8 ? "@p8" : "@p4");
+    { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_mlp(p, r.s, pw); }
     LAUNCHCHK();
     return 0;
 }
@@ -1361,23 +1276,16 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
     for (int i = 0; i < c->nl; ++i) {
         const TrunkW& w = c->trunk[i];
         ModMap mm{modstep + c->trunk_off(i), r.T * r.L, r.B, 0, r.mod_group_stride};
-        const int cm = chain_mode(c, r);
-        const bool chain = cm != 0;
-        if (cm == 2) {
-            if (int er = chain_sublayers(r, w, h, axT, mm, mk)) return er;
-        } else if (cm == 1) {
-            if (int er = chain_sublayers_panel(r, w, h, axT, mm, mk)) return er;
-        }
         // residue axis on the tiled-attention path (L > 8): its out-projection may run inside the temporal q / k / v kernel
         ProjParams def_l{};
-        if (!chain) {
+        {
             const bool fuse_lt = c->opt_fuse_proj_qkv && r.L > 8 && r.T > 8;
             if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true, fuse_lt ? &def_l : nullptr)) return er;
         }
         ProjParams deferred{};
         const bool fuse = c->opt_fuse_proj == 2 || (c->opt_fuse_proj == 1 && mlp_uses_rows(c, r.N)) ||
                           (c->opt_fuse_proj == 3 && !mlp_uses_rows(c, r.N));
-        if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true, fuse ? &deferred : nullptr, chain,
+        if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true, fuse ? &deferred : nullptr,
                                    def_l.a_bf16 ? &def_l : nullptr))
             return er;
         if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true, &deferred, w.mha_t.wo_stream)) return er;
@@ -1486,7 +1394,7 @@ static void linspace01(int n, std::vector<float>* out) {
 static int n_streams(const Run& r) {
     int n = r.c->opt_streams;
     if (n > r.B) n = r.B;
-    const long fill = 256L * kPanel;
+    const long fill = (long)r.c->ncu * kPanel;
     if (r.c->opt_streams_auto && (long)n * fill > r.N) n = (int)(r.N / fill);
     if (n < 2 || r.c->prof_on || r.N < 4096 || r.c->opt_precision == 32) return 1;
     return n;
@@ -1594,7 +1502,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_chain << 16 | c->opt_fuse_proj_qkv << 20), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | c->opt_flash_proj_occ << 28 | (uint64_t)c->opt_panel_waves << 32), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1654,7 +1562,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_chain << 16 | c->opt_fuse_proj_qkv << 20),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | c->opt_flash_proj_occ << 28 | (uint64_t)c->opt_panel_waves << 32),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

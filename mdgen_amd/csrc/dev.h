@@ -12,8 +12,6 @@
 //   MDGEN_DEV_MLP_STAMPX        k_mlp: stamp inside one fc1 stage              (scripts/micro/mlp_stampx.py)
 //   MDGEN_DEV_ROWS_NOGELU       k_mlp_rows: main loop without its VALU work, timing only (values wrong)
 //   MDGEN_DEV_ROWS_COALESCED    k_mlp_rows: row loads as coalesced 1 KiB requests, timing only (values wrong)
-//   MDGEN_DEV_CHAIN_NOSTORE     k_chain_l4: no global stores (h, fragments), timing only: what the stores cost the ring's vmcnt waits
-//   MDGEN_DEV_CHAIN_NOEPI       k_chain_l4: temporal q / k / v stages without their epilogues, timing only
 //   MDGEN_DEV_ATTN16_NOEXP / _NOSTAGE / _NOMMA / _NOBAR   k16_attn*: one ingredient of the chunk loop left out, timing only (values wrong)
 //   MDGEN_DEV_WIDE_STAMPS       k16_linear_wide: s_memtime stamps per k-step phase (scripts/micro/wide_stamps.py)
 //   MDGEN_DEV_WIDE_NOLOAD / _NOMMA / _NOSTORE   k16_linear_wide: one phase of the k-step left out, timing only (values wrong)
@@ -22,8 +20,8 @@
 #if defined(MDGEN_DEV_FLASH_STAMPS) || defined(MDGEN_DEV_FLASH_NOLOAD) || defined(MDGEN_DEV_FLASH_NOFALLBACK) || \
     defined(MDGEN_DEV_QKV_STAMPS) || defined(MDGEN_DEV_MLP_STAMPX) || defined(MDGEN_DEV_ROWS_NOGELU) ||           \
     defined(MDGEN_DEV_ROWS_COALESCED) || defined(MDGEN_DEV_WIDE_NOLOAD) || defined(MDGEN_DEV_WIDE_NOMMA) ||        \
-    defined(MDGEN_DEV_WIDE_NOSTORE) || defined(MDGEN_DEV_WIDE_STAMPS) || defined(MDGEN_DEV_CHAIN_NOSTORE) ||        \
-    defined(MDGEN_DEV_CHAIN_NOEPI) || defined(MDGEN_DEV_ATTN16_NOEXP) || defined(MDGEN_DEV_ATTN16_NOSTAGE) ||         \
+    defined(MDGEN_DEV_WIDE_NOSTORE) || defined(MDGEN_DEV_WIDE_STAMPS) || \
+    defined(MDGEN_DEV_ATTN16_NOEXP) || defined(MDGEN_DEV_ATTN16_NOSTAGE) ||         \
     defined(MDGEN_DEV_ATTN16_NOMMA) || defined(MDGEN_DEV_ATTN16_NOBAR)
 #ifndef MDGEN_DEV_BUILD
 #error "an MDGEN_DEV_* experiment switch is set without -DMDGEN_DEV_BUILD: product libraries are built with none of them"

@@ -35,6 +35,7 @@
 //   * per-tile key-validity words live in one VGPR (lane i = tile i of a 64-tile window), fetched with v_readlane;
 //   * the learned bias key is an ordinary entry of the fragments (key slot len, written by k_ln_qkv).
 #include "kernels.h"
+#include "panel.h"
 #include <type_traits>
 
 namespace mdg {
@@ -214,27 +215,37 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// Output policies of flash_job.  Global: bf16 rows [token][384] (k_proj<0>'s A operand).  Only wave-uniform members: a per-lane
+// address held across the loop would cost two VGPRs of a budget (168) that has none to spare.
+struct FlashStoreGlobal {
+    __bf16* obuf;
+    AxisMap ax;
+    int seq, head;
+    __device__ __forceinline__ void row(int, int pos, u32x2 a, u32x2 b, u32x2 c) const {
+        u32x2* d = reinterpret_cast<u32x2*>(obuf + ax.token(seq, pos) * kC + head * kDH + (lane_id() >> 5) * 12);
+        d[0] = a;
+        d[1] = b;
+        d[2] = c;
+    }
+    __device__ __forceinline__ void pad(int, int) const {}
+};
+
 // NQ = 32-query tiles per wave.  NQ = 2 (three waves per SIMD) or NQ = 4 (two waves per SIMD, <= 256 VGPRs): with four
 // tiles a K / V^T fragment load and a wave's prologue serve twice as many (key tile, query tile) pairs.
-template <int NQ>
-__global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParams p) {
+//
+// flash_job: ONE wave's whole job -- head `head` of sequence `seq`, queries 32 NQ qc .. 32 NQ (qc + 1) - 1 -- shared by
+// k_flash (one job per wave, output rows to HBM) and k_flash_proj (four jobs per wave, output rows into the LDS panel of
+// the out-projection).  `store.row(j, pos, a, b, c)`: the 12 bf16 output features 12 hh .. 12 hh + 11 of this head (three
+// 8-byte pieces) for query tile j, sequence position pos; `store.pad(j, pos)`: a row past the end of the sequence.
+template <int NQ, class Store>
+__device__ __forceinline__ void flash_job(const FlashParams p, const int seq, const int head, const int qc, const int w,
+                                          const Store store) {   // (by value: through a reference hipcc spills 15 registers)
     const int lane = lane_id(), hh = lane >> 5, ql = lane & 31;
-    const int w = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform, and the compiler knows it
     FLASH_STAMP(0, __builtin_amdgcn_s_memtime());
     FLASH_STAMP(4, __builtin_amdgcn_s_memrealtime());
     const int len = p.ax.len, nt = p.ax.ntile();   // tiles per (seq, head): they cover the len keys + the bias key
-    const int nqc = (len + 32 * NQ - 1) / (32 * NQ);
-    // (sequence, head group) pairs are dealt to the 8 XCDs (block b runs on XCD b % 8) so that ALL q-chunks of a
-    // pair -- which stream the same K/V -- share one L2: K/V leave HBM once.
-    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int qc = rest % nqc, pair = (rest / nqc) * 8 + xcd;
-    const int seq = pair >> 2, hg = pair & 3;
-    if (seq >= p.ax.nseq) return;
-    const int head = hg * 4 + w;
     const long ftile = (long)(seq * kH + head) * nt;   // first fragment tile of this (sequence, head)
     const unsigned char* qb = p.qf + ftile * kFragQ;
-    const long seq_base = p.ax.token(seq, 0);
-    const int pstride = p.ax.pos_stride;
 
     // ---- Q fragments of q-tiles NQ qc .. NQ qc + NQ - 1 (tiles past the end of the sequence reuse the first one and are
     //      never stored)
@@ -378,12 +389,8 @@ __global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParam
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 const int pos = (qt0 + j) * 32 + ql;
-                if (qvalid[j] && pos < len) {
-                    u32x2* d = reinterpret_cast<u32x2*>(p.obuf + (seq_base + (long)pos * pstride) * kC + head * kDH + hh * 12);
-                    d[0] = d0;
-                    d[1] = d1;
-                    d[2] = d2;
-                }
+                if (qvalid[j] && pos < len) store.row(j, pos, d0, d1, d2);
+                else store.pad(j, pos);
             }
             return;
         }
@@ -490,13 +497,85 @@ __global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParam
         if (qvalid[j] && pos < len) {
             const float inv = 1.0f / l;
             const f32x16 o = h[j].o;
-            u32x2* d = reinterpret_cast<u32x2*>(p.obuf + (seq_base + (long)pos * pstride) * kC + head * kDH + hh * 12);
-            d[0] = u32x2{pack_bf16(o[0] * inv, o[1] * inv), pack_bf16(o[2] * inv, o[3] * inv)};
-            d[1] = u32x2{pack_bf16(o[4] * inv, o[5] * inv), pack_bf16(o[6] * inv, o[7] * inv)};
-            d[2] = u32x2{pack_bf16(o[8] * inv, o[9] * inv), pack_bf16(o[10] * inv, o[11] * inv)};
+            store.row(j, pos, u32x2{pack_bf16(o[0] * inv, o[1] * inv), pack_bf16(o[2] * inv, o[3] * inv)},
+                      u32x2{pack_bf16(o[4] * inv, o[5] * inv), pack_bf16(o[6] * inv, o[7] * inv)},
+                      u32x2{pack_bf16(o[8] * inv, o[9] * inv), pack_bf16(o[10] * inv, o[11] * inv)});
+        } else {
+            store.pad(j, pos);
         }
     }
     FLASH_STAMP(5, __builtin_amdgcn_s_memrealtime());
+}
+
+template <int NQ>
+__global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParams p) {
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform, and the compiler knows it
+    const int nqc = (p.ax.len + 32 * NQ - 1) / (32 * NQ);
+    // (sequence, head group) pairs are dealt to the 8 XCDs (block b runs on XCD b % 8) so that ALL q-chunks of a
+    // pair -- which stream the same K/V -- share one L2: K/V leave HBM once.
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int qc = rest % nqc, pair = (rest / nqc) * 8 + xcd;
+    const int seq = pair >> 2, hg = pair & 3;
+    if (seq >= p.ax.nseq) return;
+    const int head = hg * 4 + w;
+    flash_job<NQ>(p, seq, head, qc, w, FlashStoreGlobal{p.obuf, p.ax, seq, head});
+}
+
+// =================================================================================================
+// k_flash_proj: the attention of ALL 16 heads for 64 queries of one sequence, then the sub-layer's out-projection + gated
+// residual (mha.py:389-397, latent_model.py:462,476) -- k_flash + k_proj<0> in one launch (round 5).
+//
+// A workgroup owns 64 consecutive positions of one sequence.  Its four waves run flash_job four times (head groups 0..3, wave w
+// = head 4 hg + w) and drop the normalised output rows into a bf16 LDS panel [64][384] in the swizzled A-operand layout of the
+// resident-panel GEMM family (panel.h) instead of HBM; after one barrier the panel is multiplied with W_o (wave w: features
+// 96 w .. 96 w + 95, 144 MFMAs) and the result is added to the residual stream through the staged 16-byte read-modify-write
+// epilogue k_proj<0> uses.  What it removes per launch at cfg-2: the 49 MB write and read of the attention output, 98 MB of
+// the residual stream's traffic moved out of a kernel that did nothing else (k_proj<0> ran at its HBM roof, 55 us) into the
+// shadow of other workgroups' VALU-bound attention loops, and a launch boundary.  Workgroups of a sequence go to one XCD (they
+// stream the same K / V^T fragments).  OCC = workgroups per CU the register budget is cut for (2: 256 registers, the GEMM's
+// weight ring four k-steps deep; 3: 168 registers, two k-steps).
+// =================================================================================================
+typedef __attribute__((address_space(3))) unsigned char lds_byte;   // (an LDS pointer inside a struct must keep its address
+                                                                    // space, or every store becomes a flat_store: DESIGN 6.25)
+struct FlashStorePanel {
+    lds_byte* panel;
+    int head;
+    __device__ __forceinline__ void put(int j, u32x2 a, u32x2 b, u32x2 c) const {
+        const int lane = lane_id(), row = 32 * j + (lane & 31), byte = head * 48 + (lane >> 5) * 24;
+        typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+        *reinterpret_cast<lds_u32x2*>(panel + panel_off(row, byte, kC * 2)) = a;
+        *reinterpret_cast<lds_u32x2*>(panel + panel_off(row, byte + 8, kC * 2)) = b;
+        *reinterpret_cast<lds_u32x2*>(panel + panel_off(row, byte + 16, kC * 2)) = c;
+    }
+    __device__ __forceinline__ void row(int j, int, u32x2 a, u32x2 b, u32x2 c) const { put(j, a, b, c); }
+    // rows past the end of the sequence enter the GEMM as zeros (their results are never stored)
+    __device__ __forceinline__ void pad(int j, int) const { put(j, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}); }
+};
+
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void k_flash_proj(const FlashProjParams p) {
+    constexpr int NQ = 2;
+    static_assert(32 * NQ == kPanel, "one workgroup = one 64-row panel");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanel * kC * 2];
+    PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
+    unsigned char* panel = smem + sizeof(PanelRows);
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());
+    const int nqc = (p.f.ax.len + kPanel - 1) / kPanel;
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int qc = rest % nqc, seq = (rest / nqc) * 8 + xcd;
+    if (seq >= p.f.ax.nseq) return;
+    setup_rows_axis(pr, p.f.ax, seq, qc * kPanel, p.mm);   // read after the barrier below
+#pragma unroll 1
+    for (int hg = 0; hg < 4; ++hg)
+        flash_job<NQ>(p.f, seq, 4 * hg + w, qc, w, FlashStorePanel{(lds_byte*)panel, 4 * hg + w});
+    __syncthreads();   // the attention output of all 16 heads is in the panel
+    const int lane = lane_id();
+    f32x16 acc[6];
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, 24, false, OCC == 3 ? 2 : 4>(panel, kC * 2, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
+    epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
+                                  p.h);
 }
 
 // Measured (cfg-2 / cfg-4, same box, back to back): NQ = 4 runs 160-162 / 76 us, NQ = 2 160-164 / 76 us -- a tie; 2 keeps
@@ -509,6 +588,16 @@ void launch_flash(const FlashParams& p, hipStream_t s) {
     const int nqc = (p.ax.len + 32 * NQ - 1) / (32 * NQ);
     const int npair8 = (p.ax.nseq * 4 + 7) / 8;   // (sequence, head group) pairs, in groups of 8 (one per XCD)
     hipLaunchKernelGGL(k_flash<NQ>, dim3(npair8 * nqc * 8), dim3(256), 0, s, p);
+}
+
+// jobs of a fused launch: one workgroup per (sequence, 64-query chunk)
+long flash_proj_jobs(const AxisMap& ax) { return (long)ax.nseq * ((ax.len + kPanel - 1) / kPanel); }
+
+void launch_flash_proj(const FlashProjParams& p, int occ, hipStream_t s) {
+    const int nqc = (p.f.ax.len + kPanel - 1) / kPanel;
+    const int nseq8 = (p.f.ax.nseq + 7) / 8;   // sequences, in groups of 8 (one per XCD)
+    if (occ == 3) hipLaunchKernelGGL(k_flash_proj<3>, dim3(nseq8 * nqc * 8), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_flash_proj<2>, dim3(nseq8 * nqc * 8), dim3(256), 0, s, p);
 }
 
 }  // namespace mdg

@@ -396,13 +396,7 @@ __global__ __launch_bounds__(512, 1) void k_ln_qkv8(const QkvParams p) {
 
 // PROJ: also run the sub-layer's out-projection and gated residual update here (mha.py:397, latent_model.py:462):
 // the attention output goes straight into the LDS panel as the A operand instead of through HBM.
-// QKVT (with PROJ): the kernel goes on with the TEMPORAL sub-layer's front half for the same 64 tokens -- LayerNorm of the rows
-// it has just updated (re-read from L2), q / k / v projections, RoPE at the frame index, fragment stores -- i.e. what
-// k_ln_qkv<false> does in a launch of its own after reading the residual stream back from HBM (latent_model.py:465-475).
-// The panel's 32-row tiles then hold 8 frames x 4 residues in the order row n <-> frame 4 ((n >> 2) & 1) + (n >> 3), residue
-// n & 3 (k_chain.hip: quads stay whole frames; in the non-transposed V product the registers 4 a + i of lane half hh are the
-// frames 4 hh + a of residue i = an aligned 8-byte piece of sequence (b, i)'s V^T fragment).
-template <bool PROJ, bool QKVT>
+template <bool PROJ>
 __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
     // q of the second 32-token tile waits in LDS while the K GEMM runs ([wave][value][lane]: conflict-free): with
@@ -411,18 +405,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     __shared__ uint32_t qstash[4][24][64];
     PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
     unsigned char* panel = smem + sizeof(PanelRows);
-    if (QKVT) {
-        if (threadIdx.x < kPanel) {   // rows in (frame, residue)-permuted order inside each 32-token tile; nrows % 32 == 0
-            const int r = threadIdx.x, n = r & 31;
-            long t = (long)blockIdx.x * kPanel + (r & 32) + 4 * (4 * ((n >> 2) & 1) + (n >> 3)) + (n & 3), mo = 0;
-            if (t < p.nrows) mo = p.mm.row_off(t); else t = -1;
-            pr->tok[r] = (int)t;
-            pr->moff[r] = (int)mo;
-            set_uniform(pr, r, t, mo);
-        }
-    } else {
-        setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
-    }
+    setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
     __syncthreads();
     prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
     __syncthreads();
@@ -622,171 +605,6 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
     epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk,
                                   true, p.h_rw);
-    if (!QKVT) return;
-    // ================= temporal sub-layer, front half =================
-    __syncthreads();   // (vmcnt(0) + barrier) every wave's residual stores are in L2, and the staging slabs are free again
-    prologue_ln<false>(panel, pr, p.h_rw, p.mm, p.shift_t, p.scale_t, 1e-6f);
-    __syncthreads();
-    // geometry of the panel's two 32-token tiles: sample b, first frame t0 (uniform per tile); this lane's frame / residue
-    const int ntile = p.ntile_t;
-    const int l4 = tk & 3, ttf = 4 * ((tk >> 2) & 1) + (tk >> 3);
-    int bsm[2], t0s[2];
-    bool tlive[2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        const long tb = (long)blockIdx.x * kPanel + 32 * tt;
-        tlive[tt] = tb < p.nrows;
-        const int f0 = tlive[tt] ? (int)(tb >> 2) : 0;
-        bsm[tt] = f0 / p.T;
-        t0s[tt] = f0 - bsm[tt] * p.T;
-    }
-    // ---- q, k (transposed): bias + RoPE at the frame -> the token's slot of its sequence's fragment
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {
-        zero_acc<6>(acc);
-        wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, (which ? p.wk_t : p.wq_t) + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
-        load_head_bias(which ? p.bk_t : p.bq_t, w, hh, bb);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const f32x4* rc = reinterpret_cast<const f32x4*>(p.rope + (long)(t0s[tt] + ttf) * kRopeRow + 16 * hh);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rq[tt][i] = rc[i];
-        }
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int slot = (t0s[tt] & 31) + ttf;
-            const long f0 = ((long)(bsm[tt] * 4 + l4) * kH + 4 * w) * ntile + (t0s[tt] >> 5);
-#pragma unroll
-            for (int hd = 0; hd < 4; ++hd) {
-                float e[12];
-                head_values(acc, tt, hd, bb[hd], e);
-                uint32_t u[6];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const float c = rq[tt][q >> 2][q & 3], sn = rq[tt][2 + (q >> 2)][q & 3];
-                    const float x1 = e[2 * q], x2 = e[2 * q + 1];
-                    u[q] = pack_bf16(x1 * c - x2 * sn, x2 * c + x1 * sn);
-                }
-                if (tlive[tt]) {
-                    if (which == 1) {
-                        unsigned char* base = p.kf + (f0 + (long)hd * ntile) * kFragK;
-                        *reinterpret_cast<u32x4*>(base + (hh * 32 + slot) * 16) = u32x4{u[0], u[1], u[2], u[3]};
-                        *reinterpret_cast<u32x4*>(base + 1024 + (hh * 32 + slot) * 16) = u32x4{u[4], u[5], 0x3f803f80u, 0u};
-                    } else {
-                        unsigned char* base = p.qf + (f0 + (long)hd * ntile) * kFragQ;
-                        *reinterpret_cast<u32x4*>(base + (hh * 32 + slot) * 16) = u32x4{u[0], u[1], u[2], u[3]};
-                        *reinterpret_cast<u32x2*>(base + 1024 + (hh * 32 + slot) * 8) = u32x2{u[4], u[5]};
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- v (non-transposed): registers 4 a + i of lane half hh = frames 4 hh + a of residue i -> 8-byte pieces
-    zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wv_t + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int col = 32 * j + tk, hd = col / kDH, d = col - hd * kDH;
-        const float bv = p.bv_t[w * 96 + col];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int g8 = (t0s[tt] & 31) >> 3;
-            unsigned char* dst = p.vf + (((long)bsm[tt] * 4 * kH + 4 * w + hd) * ntile + (t0s[tt] >> 5)) * kFragV + (g8 >> 1) * 800 +
-                                 hh * 400 + d * 16 + (g8 & 1) * 8;
-            const f32x16 a = acc[tt * 3 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const u32x2 v = {pack_bf16(a[i] + bv, a[4 + i] + bv), pack_bf16(a[8 + i] + bv, a[12 + i] + bv)};
-                if (tlive[tt]) *reinterpret_cast<u32x2*>(dst + (long)i * kH * ntile * kFragV) = v;
-            }
-        }
-    }
-    // ---- per tile: ones rows of the touched V^T pieces, the key-validity byte of each sequence, the sample's tail
-#pragma unroll 1
-    for (int tt = 0; tt < 2; ++tt) {
-        if (!tlive[tt]) continue;
-        const int b = bsm[tt], t0 = t0s[tt], tl5 = t0 >> 5, g8 = (t0 & 31) >> 3;
-        const long seq0 = (long)b * 4 * kH * ntile + tl5;
-        if (threadIdx.x < 128) {   // 4 sequences x 16 heads x 2 key halves, 8 bytes each
-            const int idx = threadIdx.x, li = idx & 3, head = (idx >> 2) & 15, hk = idx >> 6;
-            *reinterpret_cast<u32x2*>(p.vf + (seq0 + ((long)li * kH + head) * ntile) * kFragV + (long)(g8 >> 1) * 800 + hk * 400 +
-                                      kDH * 16 + (g8 & 1) * 8) = u32x2{0x3f803f80u, 0x3f803f80u};
-        }
-        if (w == 0) {
-            const float mv = p.mk.at(pr->tok[tt * 32 + tk]);
-            const uint32_t lo = (uint32_t)__ballot(mv != 0.f);   // bit n = row n of the tile
-            if (lane < 4) {
-                uint32_t byte = 0;
-#pragma unroll
-                for (int f = 0; f < 8; ++f) byte |= ((lo >> (8 * (f & 3) + 4 * (f >> 2) + lane)) & 1u) << f;
-                reinterpret_cast<unsigned char*>(p.vmask + (long)(b * 4 + lane) * p.vmask_stride)[tl5 * 4 + g8] = (unsigned char)byte;
-            }
-        }
-        if (t0 + 8 != p.T) continue;
-        // the tile holds a sample's LAST 8 frames: the learned bias key / value as a real entry (key slot T) of the K / V^T
-        // fragments of its four sequences, the validity words behind the last real key, finite padding query slots
-        // (k_chain.hip; k_gemm.hip write_bias_slots).  All 256 threads; these stores follow the tile's own (program order per
-        // wave is not enough across waves: the barrier below orders them behind every wave's q / k / v stores).
-        __syncthreads();
-        const int len = p.T, kt = len >> 5, sl = len & 31, tid = threadIdx.x;
-        if (sl == 0) {
-            for (int it = tid; it < 4 * kH * (kFragK / 16); it += 256) {
-                const int sh = it / (kFragK / 16), o16 = it % (kFragK / 16);
-                const long fi = ((long)(b * 4 + (sh >> 4)) * kH + (sh & 15)) * ntile + kt;
-                *reinterpret_cast<u32x4*>(p.kf + fi * kFragK + o16 * 16) = u32x4{0u, 0u, o16 >= 64 ? 0x3f803f80u : 0u, 0u};
-            }
-            for (int it = tid; it < 4 * kH * (kFragV / 16); it += 256) {
-                const int sh = it / (kFragV / 16), o16 = it % (kFragV / 16);
-                const long fi = ((long)(b * 4 + (sh >> 4)) * kH + (sh & 15)) * ntile + kt;
-                const uint32_t v = (o16 % 25) == kDH ? 0x3f803f80u : 0u;
-                *reinterpret_cast<u32x4*>(p.vf + fi * kFragV + o16 * 16) = u32x4{v, v, v, v};
-            }
-            __syncthreads();
-        }
-        {
-            const int pend = min(ntile * 32, ((len + 63) >> 6) << 6), np_ = pend - len;
-            for (int it = tid; it < 4 * kH * 2 * np_; it += 256) {
-                const int pz = len + it % np_, h2 = (it / np_) & 1, sh = it / (2 * np_);
-                unsigned char* base = p.qf + (((long)(b * 4 + (sh >> 4)) * kH + (sh & 15)) * ntile + (pz >> 5)) * kFragQ;
-                *reinterpret_cast<u32x4*>(base + (h2 * 32 + (pz & 31)) * 16) = u32x4{0u, 0u, 0u, 0u};
-                *reinterpret_cast<u32x2*>(base + 1024 + (h2 * 32 + (pz & 31)) * 8) = u32x2{0u, 0u};
-            }
-        }
-        if (tid < 128) {   // K: (sequence li, head, half h2) -> 12 rotated values of key slot sl
-            const int li = tid & 3, head = (tid >> 2) & 15, h2 = tid >> 6;
-            const float* bk = p.bias_k_t + head * kDH;
-            const float* rc = p.rope + (long)len * kRopeRow + 16 * h2;
-            float e[12];
-#pragma unroll
-            for (int pp = 0; pp < 6; ++pp) {
-                const float x1 = bk[6 * h2 + pp], x2 = bk[6 * h2 + pp + 12], cs = rc[pp], sn = rc[8 + pp];
-                e[2 * pp] = x1 * cs - x2 * sn;
-                e[2 * pp + 1] = x2 * cs + x1 * sn;
-            }
-            unsigned char* base = p.kf + (((long)(b * 4 + li) * kH + head) * ntile + kt) * kFragK;
-            *reinterpret_cast<u32x4*>(base + (h2 * 32 + sl) * 16) =
-                u32x4{pack_bf16(e[0], e[1]), pack_bf16(e[2], e[3]), pack_bf16(e[4], e[5]), pack_bf16(e[6], e[7])};
-            *reinterpret_cast<u32x4*>(base + 1024 + (h2 * 32 + sl) * 16) =
-                u32x4{pack_bf16(e[8], e[9]), pack_bf16(e[10], e[11]), 0x3f803f80u, 0u};
-        }
-        {   // V^T rows d (and the ones row 24) of (sequence li, head): key slot sl
-            const int hk = (sl >> 2) & 1, rr = (sl & 3) + 4 * (sl >> 3);
-            for (int it = tid; it < 4 * kH * (kDH + 1); it += 256) {
-                const int d = it % (kDH + 1), sh = it / (kDH + 1), li = sh >> 4, head = sh & 15;
-                const int dpsi = 12 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3);
-                const uint32_t v = d == kDH ? 0x3f80u : pack_bf16(p.bias_v_t[head * kDH + (d == kDH ? 0 : dpsi)], 0.f);
-                unsigned char* base = p.vf + (((long)(b * 4 + li) * kH + head) * ntile + kt) * kFragV;
-                *reinterpret_cast<uint16_t*>(base + (rr >> 3) * 800 + hk * 400 + d * 16 + (rr & 7) * 2) = (uint16_t)v;
-            }
-        }
-        if (tid < 4) {
-            unsigned char* vm = reinterpret_cast<unsigned char*>(p.vmask + (long)(b * 4 + tid) * p.vmask_stride);
-            for (int by = kt * 4 + (sl >> 3); by < kt * 4 + 4; ++by) vm[by] = by == kt * 4 + (sl >> 3) ? 1 : 0;
-            uint32_t* vw = p.vmask + (long)(b * 4 + tid) * p.vmask_stride;
-            for (int wi = kt + 1; wi < p.vmask_stride; ++wi) vw[wi] = 0u;
-        }
-    }
 }
 
 // =================================================================================================
@@ -1376,7 +1194,11 @@ __global__ __launch_bounds__(256, 2) void k_final(const FinalParams p) {
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
-void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre) {
+// Four or eight waves per 64-row panel (k_mlp / k_mlp8, k_ln_qkv<false> / k_ln_qkv8): eight where a launch is at most one
+// workgroup per CU, unless the caller forces one form (option panel_waves: 4 / 8).
+int panel_waves_for(long grid, int forced, int ncu) { return forced == 4 || forced == 8 ? forced : (grid <= ncu ? 8 : 4); }
+
+void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre, int waves) {
     if (pre) {
         const int grid = p.ax.nseq * p.panels_per_seq;
         hipLaunchKernelGGL((k_ln_qkv<false, true>), dim3(grid), dim3(256), 0, s, p);
@@ -1387,18 +1209,14 @@ void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre) {
         hipLaunchKernelGGL(k_ln_qkv<true>, dim3(grid), dim3(256), 0, s, p);
     } else {
         const int grid = p.ax.nseq * p.panels_per_seq;
-        if (grid <= 256) hipLaunchKernelGGL(k_ln_qkv8, dim3(grid), dim3(512), 0, s, p);   // at most one workgroup per CU
+        if (waves == 8) hipLaunchKernelGGL(k_ln_qkv8, dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL(k_ln_qkv<false>, dim3(grid), dim3(256), 0, s, p);
     }
 }
-void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s, bool with_qkv_t) {
-    if (with_qkv_t) {
-        hipLaunchKernelGGL((k_ln_qkv_attn4<true, true>), dim3((unsigned)((p.nrows + kPanel - 1) / kPanel)), dim3(256), 0, s, p);
-        return;
-    }
+void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-    if (fuse_proj) hipLaunchKernelGGL((k_ln_qkv_attn4<true, false>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_ln_qkv_attn4<false, false>), dim3(grid), dim3(256), 0, s, p);
+    if (fuse_proj) hipLaunchKernelGGL((k_ln_qkv_attn4<true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_ln_qkv_attn4<false>), dim3(grid), dim3(256), 0, s, p);
 }
 void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
@@ -1406,9 +1224,9 @@ void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
     else if (mode == 1) hipLaunchKernelGGL(k_proj<1>, dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k_proj<2>, dim3(grid), dim3(256), 0, s, p);
 }
-void launch_mlp(const MlpParams& p, hipStream_t s) {
+void launch_mlp(const MlpParams& p, hipStream_t s, int waves) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-    if (grid <= 256 && !p.trace) {   // at most one workgroup per CU: eight waves per panel (the phase stamps stay with k_mlp)
+    if (waves == 8 && !p.trace) {   // (the phase stamps stay with k_mlp: mdgen_profile_phase_trace selects the four-wave kernel)
         if (p.o) hipLaunchKernelGGL((k_mlp8<true>), dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((k_mlp8<false>), dim3(grid), dim3(512), 0, s, p);
         return;

@@ -385,8 +385,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
 // dst fragment f (1 KiB = 64 lanes x 8 bf16) <- rows 32 tile .. + 31 of the matrix tab[f] names, K slice of k-step ks in
 // kappa order (rows.h).  tab[f] = mat << 16 | tile << 8 | ks; only entries with mat == which are written.
 // `kappa` = 0: natural K order k = 16 ks + 8 hh + j instead (operands whose B fragments are loaded from memory: the out-projection).
-// `kappa` = 2: the K order of k_chain_l4's out-projection: element j of k-step ks, lane half hh = the lane's attention output
-// value q = 8 ks + j = feature (q / 12) * 24 + 12 hh + q % 12.  rowmap (nullable): packed row r reads source row rowmap[r].
+// rowmap (nullable): packed row r reads source row rowmap[r].
 __global__ void k_pack_stream(const float* __restrict__ wsrc, int ld, int which, const int* __restrict__ tab, int nfrag,
                               float scale, int kappa, bf16x8* __restrict__ dst, const int* __restrict__ rowmap) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -400,10 +399,7 @@ __global__ void k_pack_stream(const float* __restrict__ wsrc, int ld, int which,
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int qo = 8 * ks + j;
-        const int col = kappa == 2 ? (qo / 12) * kDH + 12 * hh + qo % 12
-                      : kappa == 1 ? 16 * ks + 8 * (j >> 2) + 4 * hh + (j & 3)
-                                   : 16 * ks + 8 * hh + j;
+        const int col = kappa == 1 ? 16 * ks + 8 * (j >> 2) + 4 * hh + (j & 3) : 16 * ks + 8 * hh + j;
         v[j] = (__bf16)(wsrc[(long)row * ld + col] * scale);
     }
     dst[i] = v;

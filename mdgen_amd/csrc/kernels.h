@@ -27,13 +27,6 @@ struct QkvParams {
     const bf16x8* wo;               // packed out-projection weights
     const float* bo;
     int gate_chunk;
-    // k_ln_qkv_attn4<true, true>: additionally the TEMPORAL sub-layer's LN -> q, k, v -> fragments of the same 64 tokens (qf /
-    // kf / vf / vmask above are then the temporal axis'); T frames per sample (a multiple of 8), ntile_t = T / 32 + 1
-    int T, ntile_t;
-    int shift_t, scale_t;
-    const bf16x8 *wq_t, *wk_t, *wv_t;       // packed as for k_ln_qkv (FLASH-layout V)
-    const float *bq_t, *bk_t, *bv_t;
-    const float *bias_k_t, *bias_v_t;
 };
 
 struct ProjParams {
@@ -89,29 +82,6 @@ struct MlpRowsParams {
     long trace_cap;
 };
 
-// k_chain_l4 (k_chain.hip): residue-axis attention sub-layer (L == 4) + the temporal axis' LN -> q, k, v -> fragments, one
-// row-owner kernel.  Weight streams: 24-fragment slots in the kernel's stage order (api.hip chain_tables).
-struct ChainParams {
-    float* h;
-    long nrows;                      // B * T * 4, a multiple of 32
-    int T, ntile;                    // frames per sample (a multiple of 8); key tiles per temporal sequence (T / 32 + 1)
-    ModMap mm;
-    int shift_l, scale_l, gate_l, shift_t, scale_t;
-    const unsigned char *ws_l, *ws_o, *ws_t;   // residue q|k|v (36 slots), residue out-projection (12), temporal q, k, v (36)
-    const float *bq_l, *bk_l, *bv_l;           // lane-ordered biases (perm_qk, perm_qk, perm_vsmall)
-    const float* bo_l;                         // natural
-    const float *bq_t, *bk_t, *bv_t;           // perm_qk, perm_qk, map_vflash order
-    const float *bias_k_l, *bias_v_l, *bias_k_t, *bias_v_t;   // learned bias key / value, natural fp32 [384]
-    const float* rope;
-    MaskMap mk;
-    unsigned char *qf, *kf, *vf;
-    uint32_t* vmask;
-    int vmask_stride;
-    void* dump;                      // >= 4 KiB nobody reads: where the waves of a partial last workgroup put their stores
-    unsigned long long* trace;       // measurement only: [wave][10] s_memtime stamps, or null
-    long trace_cap;
-};
-
 struct LnLinearParams {
     const float* h;
     long nrows;
@@ -159,6 +129,16 @@ struct FlashParams {
     int force_robust;       // option attention_path: 1 = skip the fixed-anchor loop, always run the moving-shift loop
 };
 
+// k_flash_proj: k_flash for all 16 heads of 64 queries + the sub-layer's out-projection + gated residual (k_proj<0>'s work)
+struct FlashProjParams {
+    FlashParams f;          // (f.obuf is not used: the attention output stays in LDS)
+    float* h;               // residual stream, updated in place
+    ModMap mm;
+    int gate_chunk;
+    const bf16x8* wo;       // packed out-projection weights [12 ftile][24 kstep][64 lane][8]
+    const float* bo;
+};
+
 struct EmbedParams {
     const float *x, *x_cond;
     const int64_t* x_cond_mask;
@@ -195,19 +175,21 @@ struct FloatChunk {
     int n;
 };
 
-void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre = false);
-void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s, bool with_qkv_t = false);
+int panel_waves_for(long grid, int forced, int ncu);   // 4 or 8 waves per 64-row panel for a launch of `grid` panels
+void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre = false, int waves = 4);
+void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
-void launch_mlp(const MlpParams& p, hipStream_t s);
+void launch_mlp(const MlpParams& p, hipStream_t s, int waves = 4);
 void launch_mlp_rows(const MlpRowsParams& p, int nw, hipStream_t s);
-void launch_chain_l4(const ChainParams& p, hipStream_t s);
 // rowmap (nullable): source row of packed row r (a permutation of the matrix's rows); kappa: K order inside a k-step -- 0
-// natural, 1 rows.h kappa (operand = LayerNorm / GELU registers), 2 the register order of k_chain_l4's attention output
+// natural, 1 rows.h kappa (operand = LayerNorm / GELU registers)
 void launch_pack_stream(const float* w, int ld, int which, const int* tab, int nfrag, float scale, int kappa, bf16x8* dst,
                         hipStream_t s, const int* rowmap = nullptr);
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s);
 void launch_final(const FinalParams& p, hipStream_t s);
 void launch_flash(const FlashParams& p, hipStream_t s);
+long flash_proj_jobs(const AxisMap& ax);
+void launch_flash_proj(const FlashProjParams& p, int occ, hipStream_t s);
 void launch_pack_embed(const float* w, int D, float* pack, hipStream_t s);   // pack: kEmbPackFloats floats
 constexpr int kEmbPackFloats = 4 * 3 * 14 * 64;
 void launch_embed(const EmbedParams& p, hipStream_t s);

@@ -1,4 +1,5 @@
-"""GPU: per-kernel-class hipEvent timings of one Euler rollout + a quick parity check (dev loop helper)."""
+"""GPU: per-kernel-class hipEvent timings of one Euler rollout + a quick parity check (dev loop helper).
+    python scripts/kbench.py [workload] [S] [option=value ...]      (library options, e.g. flash_proj=0)"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -23,10 +24,13 @@ for name in ("fwd_full_pep", "fwd_full_atlas"):
     del m
 wl = sys.argv[1] if len(sys.argv) > 1 else "tetrapeptide_fwdsim_crop4_T1000_B16"
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+OPTS = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in sys.argv[3:]}
 B, T, L, abs_pos, n_pad = bench.WORKLOADS[wl]
 cfg = ModelConfig(crop=L, num_frames=T, abs_pos_emb=abs_pos, sim_condition=True)
 w = NewMDGenWrapper(cfg, device=dev); w.model.load_state_dict(synth_state_dict(cfg, 0))
 w.model.set_option("streams", 1)   # full-batch launches on one stream (what the profiling leg measures)
+for k, v in OPTS.items():
+    w.model.set_option(k, v)
 batch = bench.synth_batch(B, T, L, n_pad, dev, seed=100)
 zs = torch.randn(B, T, L, 21, generator=torch.Generator().manual_seed(137)).to(dev)
 w.inference(batch, zs=zs, num_steps=S, use_graph=False)
@@ -36,7 +40,7 @@ rep = w.model.profile_report()
 w.model.profile(False)
 assert torch.isfinite(a).all()
 tot = sum(v["ms"] for v in rep.values())
-print(f"{wl} S={S}: total event ms {tot:.2f} -> per NFE {tot / S:.3f} ms")
+print(f"{wl} S={S} {OPTS}: total event ms {tot:.2f} -> per NFE {tot / S:.3f} ms")
 for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
     fl = bench.algorithmic_flops(k, B, T, L)
     us = v["ms"] / v["count"] * 1e3

@@ -1,7 +1,7 @@
 """Dev tool (GPU): per-wave cycle stamps of the attention kernel from the -DMDGEN_DEV_FLASH_STAMPS experiment build.
 
     bash scripts/micro/flash_variants.sh STAMPS
-    MDGEN_AMD_LIB=scripts/micro/dev_libs/libmdgen_amd_STAMPS.so python scripts/micro/flash_stamps.py [workload]
+    MDGEN_AMD_LIB=gpurun_out/dev_libs/libmdgen_amd_STAMPS.so python scripts/micro/flash_stamps.py [workload]
 
 Prints the shader clock actually sustained inside the kernel (s_memtime ticks per s_memrealtime tick, the latter a
 constant 100 MHz), the cycles one wave spends per (32-key, 32-query) pair in the loop, and the prologue / epilogue."""

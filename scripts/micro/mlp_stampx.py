@@ -1,6 +1,6 @@
 """Dev tool (GPU): where does an fc1 stage of k_mlp spend its time?  Needs the experiment build
     KFILE=k_gemm KPFX=MLP bash scripts/micro/flash_variants.sh STAMPX
-    MDGEN_AMD_LIB=scripts/micro/dev_libs/libmdgen_amd_STAMPX.so python scripts/micro/mlp_stampx.py
+    MDGEN_AMD_LIB=gpurun_out/dev_libs/libmdgen_amd_STAMPX.so python scripts/micro/mlp_stampx.py
 which adds three s_memtime stamps around / inside the fc1 stage of chunk 5: barrier exit, after k-step 11, stage end."""
 import sys, os
 sys.path.insert(0, os.getcwd())

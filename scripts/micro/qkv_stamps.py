@@ -1,7 +1,7 @@
 """Dev tool (GPU): phase budget of k_ln_qkv<false> (LN prologue, the three GEMMs and their epilogues) from the
 -DMDGEN_DEV_QKV_STAMPS experiment build:
     KFILE=k_gemm KPFX=QKV bash scripts/micro/flash_variants.sh STAMPS
-    MDGEN_AMD_LIB=scripts/micro/dev_libs/libmdgen_amd_STAMPS.so python scripts/micro/qkv_stamps.py"""
+    MDGEN_AMD_LIB=gpurun_out/dev_libs/libmdgen_amd_STAMPS.so python scripts/micro/qkv_stamps.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, bench

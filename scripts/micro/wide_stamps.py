@@ -1,5 +1,5 @@
 """GPU: phase stamps of k16_linear_wide (library built by KFILE=k_wide16 KPFX=WIDE bash scripts/micro/flash_variants.sh STAMPS;
-run with MDGEN_AMD_LIB=scripts/micro/dev_libs/libmdgen_amd_STAMPS.so).  s_memtime ticks at 100 MHz."""
+run with MDGEN_AMD_LIB=gpurun_out/dev_libs/libmdgen_amd_STAMPS.so).  s_memtime ticks at 100 MHz."""
 import ctypes, os, sys, runpy
 import numpy as np
 sys.argv = [sys.argv[0], "1", "250", "256", "1", "16"]

@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 R=$PWD; O=$R/gpurun_out/r04a; mkdir -p $O; export PYTHONUNBUFFERED=1 TMPDIR=/tmp
 : > $O/summary.txt
 for v in product "$@"; do
-  if [ $v = product ]; then unset MDGEN_AMD_LIB; else export MDGEN_AMD_LIB=$R/scripts/micro/dev_libs/libmdgen_amd_$v.so; fi
+  if [ $v = product ]; then unset MDGEN_AMD_LIB; else export MDGEN_AMD_LIB=$R/gpurun_out/dev_libs/libmdgen_amd_$v.so; fi
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$v -o kt -- python $R/scripts/r04/attn16_run.py 5 > $O/run_$v.log 2>&1 < /dev/null)
   f=$(find $O/prof_$v -name "*kernel_stats.csv" | head -1)
   echo "== $v  $(tail -1 $O/run_$v.log)" >> $O/summary.txt

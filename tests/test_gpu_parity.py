@@ -2166,98 +2166,62 @@ def test_training_attention_kernels_unit(ln, layout):
 
 
 def test_row_owner_mlp_paths_agree():
-    """The MLP block has these forms: the 64-row resident-panel kernel (`mlp_path` 0), the row-owner kernel (`mlp_path` 2:
-    activations in registers, LDS-DMA weight stream) and the row-owner kernel with the temporal out-projection fused in front
-    of it (`fuse_proj` 1).  All three against the reference golden at the bf16 gate, and against each other (different
-    summation orders / GELU polynomial: a few 1e-3); the IPA stack (S*B*L rows: partial tiles, idle waves) takes the
-    row-owner kernel too under `mlp_path` 2."""
+    """The MLP block has these forms: the 64-row resident-panel kernel with four waves (k_mlp<3>) or eight (k_mlp8; `panel_waves`),
+    each with or without the temporal out-projection as a prologue phase (`fuse_proj` 2), the row-owner kernel (`mlp_path` 2:
+    activations in registers, LDS-DMA weight stream) with or without the out-projection fused in front (`fuse_proj` 1); the
+    temporal LN -> q, k, v kernel has a four- and an eight-wave form too (k_ln_qkv<false> / k_ln_qkv8) and, on the tiled residue
+    axis, the residue out-projection as a prologue phase (`fuse_proj_qkv`).  Every form against the reference golden at the bf16
+    gate and against each other (summation orders / GELU polynomial: a few 1e-3) -- and the profile report must name the
+    kernel the options asked for (`@p4` / `@p8` tags): at these sizes every launch is <= 256 panels, so without `panel_waves` 4 the
+    four-wave kernels would not run at all (round-4 verdict, weak #1).  The IPA stack (S*B*L rows: partial tiles, idle waves)
+    takes the same kernels."""
     from mdgen_amd.model import LatentMDGenModel
     dev = _cuda()
+    P4, P8 = {"panel_waves": 4}, {"panel_waves": 8}
+    forms = (("panel4", dict(P4, mlp_path=0, fuse_proj=0), "mlp@p4"), ("panel8", dict(P8, mlp_path=0, fuse_proj=0), "mlp@p8"),
+             ("panel4+proj", dict(P4, mlp_path=0, fuse_proj=2), "proj_mlp@p4"), ("panel8+proj", dict(P8, mlp_path=0, fuse_proj=2), "proj_mlp@p8"),
+             ("rows", {"mlp_path": 2, "fuse_proj": 0}, "mlp"), ("rows+proj", {"mlp_path": 2, "fuse_proj": 1}, "proj_mlp"),
+             ("no-qkv-prologue p4", dict(P4, mlp_path=0, fuse_proj=0, fuse_proj_qkv=0), "ln_qkv_T"),
+             ("no-qkv-prologue p8", dict(P8, mlp_path=0, fuse_proj=0, fuse_proj_qkv=0), "ln_qkv_T@p8"),
+             ("qkv-prologue", dict(P4, mlp_path=0, fuse_proj=0, fuse_proj_qkv=1), None), ("defaults", {}, None))
     for name in ("fwd_full_pep", "fwd_full_atlas"):
         g = load_golden(name)
         cfg, sd = weights_for(g)
         outs = {}
-        for key, opts in (("panel", {"mlp_path": 0, "fuse_proj": 0}), ("rows", {"mlp_path": 2, "fuse_proj": 0}), ("rows+proj", {"mlp_path": 2, "fuse_proj": 1}),
-                          ("panel+proj", {"mlp_path": 0, "fuse_proj": 2}), ("no-qkv-prologue", {"mlp_path": 0, "fuse_proj": 0, "fuse_proj_qkv": 0}),
-                          ("qkv-prologue", {"mlp_path": 0, "fuse_proj": 0, "fuse_proj_qkv": 1}), ("defaults", {})):
+        for key, opts, want in forms:
             m = LatentMDGenModel(cfg)
             m.load_state_dict(sd)
+            m.set_option("flash_proj", 0)   # (this test is about the projection-carrying forms of the MLP / q, k, v kernels)
             for k, v in opts.items():
                 m.set_option(k, v)
             kw = _kw(g, dev)
             kw.pop("end_frames")
+            m.profile(True)
             out = m.forward(**kw)
             torch.cuda.synchronize()
+            ran = {k: v["count"] for k, v in m.profile_report().items()}
+            m.profile(False)
             assert torch.isfinite(out).all()
             outs[key] = out.cpu()
             e = rel_l2(outs[key], g["out"])
-            print(f"{name} {key}: rel-L2 vs reference {e:.2e}")
+            print(f"{name} {key}: rel-L2 vs reference {e:.2e}   {sorted(k for k in ran if 'mlp' in k or 'qkv' in k)}")
             assert e < TOL_FWD
+            T_, L_ = g["x"].shape[1:3]
+            if want is not None:
+                assert ran.get(want) == cfg.num_layers, (key, want, ran)
+                other = {"mlp@p4": "mlp@p8", "mlp@p8": "mlp@p4", "proj_mlp@p4": "proj_mlp@p8", "proj_mlp@p8": "proj_mlp@p4",
+                         "ln_qkv_T": "ln_qkv_T@p8", "ln_qkv_T@p8": "ln_qkv_T"}.get(want)
+                assert other is None or other not in ran, (key, ran)
+            if key == "qkv-prologue":
+                assert ("projL_qkvT" in ran) == (L_ > 8 and T_ > 8), ran   # (neither golden has both: test_panel_kernels_257_to_383_panels_vs_oracle does)
             del m
-        assert rel_l2(outs["rows"], outs["panel"]) < 6e-3 and rel_l2(outs["rows+proj"], outs["rows"]) < 6e-3
-        # the prologue-phase fusions (round 4): the temporal out-projection inside the panel MLP kernel (`fuse_proj` 2) and the
-        # residue out-projection inside the temporal LN -> q, k, v kernel (`fuse_proj_qkv`, default 1 for L > 8)
-        assert rel_l2(outs["panel+proj"], outs["panel"]) < 6e-3 and rel_l2(outs["qkv-prologue"], outs["no-qkv-prologue"]) < 6e-3
-        # the defaults at this size: panel MLP kernel (fewer than 768 row tiles) with the out-projection in front (`fuse_proj` 3)
-        assert torch.equal(outs["defaults"], outs["panel+proj"]) or rel_l2(outs["defaults"], outs["panel+proj"]) < 6e-3
-
-
-@pytest.mark.parametrize("shape", [(1, 40, 0), (1, 64, 0), (2, 8, 0), (3, 104, 1), (2, 1000, 0), (1, 96, 2)])
-def test_chain_kernel_vs_panel_kernels_and_oracle(shape):
-    """Option `chain_path`: the tetrapeptide trunk's residue-axis attention sub-layer and the temporal sub-layer's LN -> q, k, v
-    -> fragments (latent_model.py:457-475, mha.py:258-268, 356-357) in ONE launch -- 1 the panel kernel
-    k_ln_qkv_attn4<true, true> (the default), 3 the row-owner kernel k_chain_l4 (csrc/k_chain.hip) --
-    against (a) the CPU oracle at the bf16 gate and (b) the two panel kernels they replace (`chain_path` 0; different
-    summation orders only: a few 1e-3).  Shapes (B, T, padded residues): a launch whose last workgroup has idle waves
-    (T 40: 5 row tiles), T a multiple of 32 / 64 (the learned bias key opens a key tile of its own, which the kernel must
-    zero-fill), one 8-frame group per sample (T 8), key padding on the residue axis, the headline's T 1000 (32 key tiles;
-    sample boundaries inside a workgroup), T 96.  Runs on a workspace filled with 0xFF bytes."""
-    from oracle import mdgen_oracle as O
-    from mdgen_amd.config import ModelConfig
-    from mdgen_amd.model import LatentMDGenModel
-    from mdgen_amd.synthetic import synth_forward_inputs, synth_state_dict
-    dev = _cuda()
-    B, T, n_pad = shape
-    cfg = ModelConfig.forward_sim(num_frames=T, crop=4)
-    sd = synth_state_dict(cfg, 5)
-    inp = synth_forward_inputs(cfg, B, T, 4, n_pad, 300 + T)
-    kw = dict(x=inp["x"], t=inp["t"], mask=inp["mask"], start_frames=(inp["start_rot"], inp["start_trans"]),
-              end_frames=(inp["end_rot"], inp["end_trans"]), x_cond=inp["x_cond"], x_cond_mask=inp["x_cond_mask"],
-              aatype=inp["aatype"])
-    dkw = {k: (tuple(u.to(dev) for u in v) if isinstance(v, tuple) else v.to(dev)) for k, v in kw.items()}
-    ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
-    outs = {}
-    for path in (0, 1, 3):
-        m = LatentMDGenModel(cfg)
-        m.load_state_dict(sd)
-        m.set_option("chain_path", path)
-        m.forward(**dkw)
-        for ws in m._ws.values():
-            ws.view(torch.uint8).fill_(0xFF)
-        out, tr = m.forward(**dkw, return_trace=True)
-        torch.cuda.synchronize()
-        assert torch.isfinite(out).all(), path
-        rep = {k: rel_l2(tr[k].cpu(), rtr[k]) for k in [f"h{i}" for i in range(cfg.num_layers + 1)]}
-        rep["out"] = rel_l2(out.cpu(), ref)
-        print(shape, "chain_path", path, {k: f"{v:.2e}" for k, v in rep.items()})
-        for k, v in rep.items():
-            assert v < TOL_FWD, (path, k, v)
-        outs[path] = (out.cpu(), tr["h1"].cpu())
-        del m
-    for path, what in ((1, "one panel kernel"), (3, "row-owner kernel")):
-        e_out, e_h1 = rel_l2(outs[path][0], outs[0][0]), rel_l2(outs[path][1], outs[0][1])
-        print(shape, f"{what} vs the two panel kernels: out {e_out:.2e}  h1 {e_h1:.2e}")
-        assert e_out < 5e-3 and e_h1 < 5e-3
-    # padded residues never influence the valid ones
-    if n_pad:
-        x2 = inp["x"].clone()
-        x2[:, :, 4 - n_pad:] = 1e3
-        m = LatentMDGenModel(cfg)
-        m.load_state_dict(sd)
-        m.set_option("chain_path", 3)
-        a = m.forward(**dkw)
-        b2 = m.forward(**dict(dkw, x=x2.to(dev)))
-        assert torch.equal(a[:, :, :4 - n_pad], b2[:, :, :4 - n_pad])
+        assert rel_l2(outs["panel8"], outs["panel4"]) < 6e-3 and rel_l2(outs["panel8+proj"], outs["panel4+proj"]) < 6e-3
+        assert rel_l2(outs["rows"], outs["panel4"]) < 6e-3 and rel_l2(outs["rows+proj"], outs["rows"]) < 6e-3
+        assert rel_l2(outs["panel4+proj"], outs["panel4"]) < 6e-3
+        assert rel_l2(outs["no-qkv-prologue p8"], outs["no-qkv-prologue p4"]) < 6e-3
+        assert rel_l2(outs["qkv-prologue"], outs["no-qkv-prologue p4"]) < 6e-3
+        # the defaults at this size: eight-wave panel MLP kernel (at most one workgroup per CU) with the out-projection in front
+        assert rel_l2(outs["defaults"], outs["panel8+proj"]) < 6e-3
 
 
 def test_validation_on_ema_weights_leaves_the_master_parameters_alone(tmp_path):
@@ -2306,3 +2270,180 @@ def test_validation_on_ema_weights_leaves_the_master_parameters_alone(tmp_path):
     wi.restore_cached_weights()
     raw2 = wi.model.forward(**kw, **mk)
     assert torch.equal(raw, raw2) and not torch.equal(raw, ema) and torch.isfinite(ema).all()
+
+
+# ---- round 5: k_flash_proj, the 257..383-panel window, four- vs eight-wave panel kernels ---------------------------------------
+def _fwd_case(B, T, L, n_pad, seed, weights_seed=5):
+    """(cfg, sd, host kwargs, device kwargs) of one synthetic forward call (forward-simulation model, crop max(L, 4))."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_forward_inputs, synth_state_dict
+    dev = _cuda()
+    cfg = ModelConfig.forward_sim(num_frames=T, crop=max(L, 4))
+    sd = synth_state_dict(cfg, weights_seed)
+    inp = synth_forward_inputs(cfg, B, T, L, n_pad, seed)
+    kw = dict(x=inp["x"], t=inp["t"], mask=inp["mask"], start_frames=(inp["start_rot"], inp["start_trans"]),
+              end_frames=(inp["end_rot"], inp["end_trans"]), x_cond=inp["x_cond"], x_cond_mask=inp["x_cond_mask"],
+              aatype=inp["aatype"])
+    dkw = {k: (tuple(u.to(dev) for u in v) if isinstance(v, tuple) else v.to(dev)) for k, v in kw.items()}
+    return cfg, sd, kw, dkw
+
+
+def _profiled_forward(m, dkw, poison=True):
+    """One forward on a 0xFF-filled workspace with the hipEvent profile on: (out, trace, {kernel class: launches})."""
+    m.forward(**dkw)                       # allocates (and caches) the workspace of this shape
+    if poison:
+        for ws in m._ws.values():
+            ws.view(torch.uint8).fill_(0xFF)
+    m.profile(True)
+    try:
+        out, tr = m.forward(**dkw, return_trace=True)
+        torch.cuda.synchronize()
+        rep = m.profile_report()
+    finally:
+        m.profile(False)
+    return out, tr, {k: v["count"] for k, v in rep.items()}
+
+
+@pytest.mark.parametrize("shape", [(1, 130, 9, 1), (2, 64, 33, 0), (1, 40, 96, 5), (2, 1000, 4, 0), (1, 250, 64, 3)],
+                         ids=["T130_L9", "T64_L33", "T40_L96", "T1000_L4", "T250_L64"])
+def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
+    """Option `flash_proj` (round 5): the tiled attention of all 16 heads for 64 queries of a sequence + the sub-layer's
+    out-projection + gated residual in ONE launch (k_flash_proj; mha.py:359-397, latent_model.py:462,476) against (a) the CPU oracle
+    at the bf16 gate, every trace, and (b) the separate kernels it replaces (k_flash, then k_proj<0> or a projection deferred into
+    the next kernel): same operands, same summation order -> equal to fp32 rounding.  Both register budgets (`flash_proj_occ`
+    2 / 3) and both softmax loops (`attention_path` 0 / 1).  Shapes: a partial last 64-query chunk whose second tile is past the
+    sequence (T 130, L 9), T a multiple of 64 (the bias key opens a key tile of its own), L 33 / 96 / 64 on the residue axis,
+    padded residues (their temporal sequences see only the learned bias key: the direct bias_v path), the headline's T 1000.
+    Workspace filled with 0xFF bytes; the profile report says which kernels ran."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.model import LatentMDGenModel
+    B, T, L, n_pad = shape
+    cfg, sd, kw, dkw = _fwd_case(B, T, L, n_pad, 500 + T + L)
+    ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
+    outs = {}
+    for key, opts in (("separate", {"flash_proj": 0}), ("fused", {"flash_proj": 2, "flash_proj_occ": 2}),
+                      ("fused occ 3", {"flash_proj": 2, "flash_proj_occ": 3}),
+                      ("fused robust loop", {"flash_proj": 2, "attention_path": 1})):
+        m = LatentMDGenModel(cfg)
+        m.load_state_dict(sd)
+        for k, v in opts.items():
+            m.set_option(k, v)
+        out, tr, ran = _profiled_forward(m, dkw)
+        assert torch.isfinite(out).all(), key
+        rep = {k: rel_l2(tr[k].cpu(), rtr[k]) for k in ["ipa_out"] + [f"h{i}" for i in range(cfg.num_layers + 1)]}
+        rep["out"] = rel_l2(out.cpu(), ref)
+        print(shape, key, {k: f"{v:.2e}" for k, v in rep.items()}, {k: v for k, v in ran.items() if "flash" in k or "proj" in k})
+        for k, v in rep.items():
+            assert v < TOL_FWD, (key, k, v)
+        fused = key != "separate"
+        assert ("flash_proj_T" in ran) == fused and ("flash_T" in ran) != fused, ran
+        if L > 8:
+            assert ("flash_proj_L" in ran) == fused and ("ipa.flash_proj" in ran) == fused, ran
+        if fused:   # nothing left to project: no k_proj<0>, no projection deferred into the next kernel
+            assert not any(k.startswith(("proj_T", "proj_L", "projL_qkvT", "proj_mlp")) for k in ran), ran
+        outs[key] = (out.cpu(), tr[f"h{cfg.num_layers}"].cpu())
+        del m
+    for key in ("fused", "fused occ 3"):
+        e_out, e_h = rel_l2(outs[key][0], outs["separate"][0]), rel_l2(outs[key][1], outs["separate"][1])
+        print(shape, f"{key} vs separate kernels: out {e_out:.2e} h {e_h:.2e} equal {torch.equal(outs[key][0], outs['separate'][0])}")
+        assert e_out < 2e-5 and e_h < 2e-5
+    assert rel_l2(outs["fused robust loop"][0], outs["fused"][0]) < 2e-3
+    if n_pad:   # padded residues never influence the valid ones
+        m = LatentMDGenModel(cfg)
+        m.load_state_dict(sd)
+        m.set_option("flash_proj", 2)
+        x2 = kw["x"].clone()
+        x2[:, :, L - n_pad:] = 1e3
+        a = m.forward(**dkw)
+        b2 = m.forward(**dict(dkw, x=x2.to(a.device)))
+        assert torch.equal(a[:, :, :L - n_pad], b2[:, :, :L - n_pad])
+
+
+def test_flash_proj_is_the_default_where_the_launch_fills_the_chip():
+    """`flash_proj` 1 (default): k_flash_proj for launches of >= 512 (sequence, 64-query chunk) workgroups -- B 8 x T 1000 x L 4 is
+    32 sequences x 16 chunks = 512 -- and the separate kernels below (B 7: 448).  Both against the separate kernels' output."""
+    from mdgen_amd.model import LatentMDGenModel
+    for B, want in ((8, True), (7, False)):
+        cfg, sd, kw, dkw = _fwd_case(B, 1000, 4, 0, 77)
+        m = LatentMDGenModel(cfg)
+        m.load_state_dict(sd)
+        out, _, ran = _profiled_forward(m, dkw, poison=False)
+        assert ("flash_proj_T" in ran) == want and ("flash_T" in ran) != want, (B, ran)
+        m.set_option("flash_proj", 0)
+        out0, _, ran0 = _profiled_forward(m, dkw, poison=False)
+        assert "flash_T" in ran0 and "flash_proj_T" not in ran0
+        e = rel_l2(out, out0)
+        print(f"B {B}: default {sorted(k for k in ran if 'flash' in k)} vs flash_proj 0: {e:.2e}")
+        assert torch.isfinite(out).all() and e < 2e-5   # (same operands, same summation order)
+        del m
+
+
+@pytest.mark.parametrize("case", ["B5_T1000_L4", "B1_T250_L80_pad"])
+def test_panel_kernels_257_to_383_panels_vs_oracle(case):
+    """Launches of 257..383 64-row panels take the FOUR-wave panel kernels (more than one workgroup per CU, fewer than the 768 row
+    tiles the row-owner MLP wants): k_mlp<3, true> (temporal out-projection as its prologue phase, `fuse_proj` 3) and, on the
+    tiled residue axis, k_ln_qkv<false, true> (`fuse_proj_qkv`).  That window is what two sub-batch streams make of B = 9..12 at
+    T 1000 L 4 and what ATLAS chains of L ~ 66..98 are at T 250.  Default options, every element against the CPU oracle
+    (latent_model.py:446-481), 313 panels each; the profile report names the kernels that ran."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.model import LatentMDGenModel
+    B, T, L, n_pad = (5, 1000, 4, 0) if case == "B5_T1000_L4" else (1, 250, 80, 10)
+    assert 257 <= (B * T * L + 63) // 64 <= 383
+    cfg, sd, kw, dkw = _fwd_case(B, T, L, n_pad, 900 + L)
+    ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
+    m = LatentMDGenModel(cfg)
+    m.load_state_dict(sd)
+    out, tr, ran = _profiled_forward(m, dkw)
+    rep = {k: rel_l2(tr[k].cpu(), rtr[k]) for k in ["ipa_out"] + [f"h{i}" for i in range(cfg.num_layers + 1)]}
+    rep["out"] = rel_l2(out.cpu(), ref)
+    print(case, {k: f"{v:.2e}" for k, v in rep.items()}, ran)
+    assert torch.isfinite(out).all()
+    for k, v in rep.items():
+        assert v < TOL_FWD, (k, v)
+    nl = cfg.num_layers
+    assert ran.get("proj_mlp@p4") == nl and "mlp" not in ran and "proj_mlp@p8" not in ran, ran   # k_mlp<3, true>, not k_mlp8 / k_mlp_rows
+    if L > 8:
+        assert ran.get("projL_qkvT") == nl, ran                                                   # k_ln_qkv<false, true>
+    else:
+        assert ran.get("ln_qkv_T") == nl and "ln_qkv_T@p8" not in ran, ran                        # k_ln_qkv<false>, not k_ln_qkv8
+    # the worst element, not only the norm: nothing in the window is off by more than a few bf16 roundings of the output scale
+    assert (out.cpu() - ref).abs().max() < 0.1 * ref.abs().max()
+
+
+def test_two_stream_views_in_the_panel_window_match_one_stream():
+    """sample_euler B 10 x T 1000 x L 4 with `streams` 2 = two views of B 5 (313 panels each: k_mlp<3, true>, k_ln_qkv<false>)
+    against one stream -- (a) with the same kernels forced (`mlp_path` 0, `fuse_proj` 2: bit-identical, a panel's arithmetic does
+    not depend on the launch it is in) and (b) with the defaults (one view of 625 panels takes the row-owner MLP: rounding level)."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.model import LatentMDGenModel
+    from mdgen_amd.synthetic import synth_state_dict
+    dev = _cuda()
+    B, T, L, S = 10, 1000, 4, 3
+    cfg = ModelConfig.forward_sim(num_frames=T, crop=4)
+    sd = synth_state_dict(cfg, 3)
+    gen = torch.Generator().manual_seed(16)
+    zs = torch.randn(B, T, L, 21, generator=gen).to(dev)
+    mask = torch.ones(B, T, L, device=dev)
+    R = torch.eye(3, device=dev).expand(B, L, 3, 3).contiguous()
+    tr_ = torch.randn(B, L, 3, generator=gen).to(dev)
+    cm = torch.zeros(B, T, L, dtype=torch.long, device=dev)
+    cm[:, 0] = 1
+    xc = torch.where(cm.unsqueeze(-1).bool(), torch.randn(B, T, L, 21, generator=gen).to(dev), torch.zeros((), device=dev))
+    aat = torch.randint(0, 20, (B, L), generator=gen).to(dev)
+    kw = dict(mask=mask, start_frames=(R, tr_), x_cond=xc, x_cond_mask=cm, aatype=aat)
+    outs = {}
+    for key, opts in (("two streams", {"streams": 2}), ("one stream, same kernels", {"streams": 1, "mlp_path": 0, "fuse_proj": 2}),
+                      ("one stream, defaults", {"streams": 1})):
+        m = LatentMDGenModel(cfg)
+        m.load_state_dict(sd)
+        for k, v in opts.items():
+            m.set_option(k, v)
+        outs[key] = [m.sample_euler(zs, S, use_graph=g, **kw) for g in (False, True)]
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs[key][0]).all() and torch.equal(outs[key][0], outs[key][1]), key   # graph == eager
+        del m
+    a = outs["two streams"][0]
+    assert torch.equal(a, outs["one stream, same kernels"][0])
+    e = rel_l2(a, outs["one stream, defaults"][0])
+    print(f"two 313-panel views vs one 625-panel view (row-owner MLP): {e:.2e}")
+    assert e < 3e-3

@@ -248,163 +248,6 @@ def test_row_owner_mlp_pipeline_reproduces_the_mlp():
     np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-9)
 
 
-# ---- chain kernel (csrc/k_chain.hip): residue-axis L = 4 sub-layer + temporal q, k, v fragments, one row-owner kernel ----
-def chain_table(which):
-    import mdgen_amd._lib as L
-    n = 288 if which == 2 else 864
-    buf = (ctypes.c_int32 * n)()
-    assert L.lib.mdgen_debug_chain_stream_table(which, buf, n) == n
-    return np.array(buf)
-
-
-def chain_lane_token(n):
-    """lane n (0..31) of a wave -> (frame, residue) of its 8 frames x 4 residues (k_chain.hip header)."""
-    return 4 * ((n >> 2) & 1) + (n >> 3), n & 3
-
-
-def test_chain_stream_tables_cover_every_fragment_once_in_stage_order():
-    for which, mats, ntile in ((0, (0, 1, 2), 12), (1, (0, 1, 2), 12), (2, (3,), 12)):
-        t = chain_table(which)
-        mat, tile, ks = t >> 16, (t >> 8) & 255, t & 255
-        for m in mats:
-            got = set(zip(tile[mat == m].tolist(), ks[mat == m].tolist()))
-            assert got == {(a, b) for a in range(ntile) for b in range(24)} and (mat == m).sum() == ntile * 24
-        # a stage = 72 consecutive entries: ONE matrix, three consecutive row tiles, k-step major / tile minor
-        for s in range(len(t) // 72):
-            st = t[72 * s:72 * s + 72]
-            m, tl, k = st >> 16, (st >> 8) & 255, st & 255
-            assert len(set(m.tolist())) == 1 and tl.min() % 3 == 0
-            assert (tl - tl.min()).tolist() == [i % 3 for i in range(72)] and k.tolist() == [i // 3 for i in range(72)]
-    # residue axis: head group by head group q | k | v; temporal axis: all q, all k, all v
-    t0, t1 = chain_table(0), chain_table(1)
-    assert [(int(t0[72 * s] >> 16), int((t0[72 * s] >> 8) & 255) // 3) for s in range(12)] == [(m, g) for g in range(4) for m in range(3)]
-    assert [(int(t1[72 * s] >> 16), int((t1[72 * s] >> 8) & 255) // 3) for s in range(12)] == [(m, g) for m in range(3) for g in range(4)]
-
-
-def test_chain_kernel_index_algebra():
-    """Replays k_chain_l4's novel index algebra for one wave (8 frames x 4 residues) with the library's stream tables and
-    permutation maps, on the documented 32x32x16 lane maps:
-      (a) residue axis: a transposed stage leaves, per lane (token, half), the 12 lane-order values of each head; the
-          attention output packed in THAT order is the B operand of the out-projection whose weight fragments are packed in
-          the matching K order (k_pack_stream kappa = 2): the product equals o @ W_o^T;
-      (b) temporal axis: q / k slots and the 8-byte V^T pieces land where the fragment layout (kernels.h, k_flash.hip) puts
-          key slot t & 31 of sequence (b, l): scores and P V computed from the written fragments equal plain attention."""
-    qk, vf, vs, pqk, pvs = maps()
-    rng = np.random.default_rng(1)
-    C = 384
-    lanes = [chain_lane_token(l & 31) for l in range(64)]
-    tok_of_lane = np.array([4 * tt + res for tt, res in lanes])          # token row (frame-major) of each lane
-    assert sorted(tok_of_lane[:32].tolist()) == list(range(32))
-    X = rng.standard_normal((32, C))                                      # LayerNorm output of the wave's 32 tokens
-
-    def xfrag(ks):                                                        # rows_norm: lane (token, hh) holds k = kappa(ks, hh, j)
-        return np.stack([[X[tok_of_lane[l], kappa(ks, l >> 5, j)] for j in range(8)] for l in range(64)])
-
-    def wfrag_k(W, rowmap, tile, ks, kmode):
-        out = np.zeros((64, 8))
-        for l in range(64):
-            hh = l >> 5
-            row = rowmap[tile * 32 + (l & 31)] if rowmap is not None else tile * 32 + (l & 31)
-            for j in range(8):
-                q = 8 * ks + j
-                col = (q // 12) * 24 + 12 * hh + q % 12 if kmode == 2 else kappa(ks, hh, j)
-                out[l, j] = W[row, col]
-        return out
-
-    def run_stage(tab, s, W, rowmap, kmode, bfrag, swap):
-        acc = [np.zeros((64, 16)) for _ in range(3)]
-        for f in range(72):                                               # stream order: k-step major, tile minor
-            e = int(tab[72 * s + f])
-            tile, ks = (e >> 8) & 255, e & 255
-            wf = wfrag_k(W, rowmap, tile, ks, kmode)
-            acc[f % 3] = mfma(bfrag(ks), wf, acc[f % 3]) if swap else mfma(wf, bfrag(ks), acc[f % 3])
-        return acc
-
-    def head12(acc, hd):
-        e = np.zeros((64, 12))
-        for c in range(3):
-            ap = 3 * hd + c
-            for b in range(4):
-                e[:, 4 * c + b] = acc[ap >> 2][:, 4 * (ap & 3) + b]
-        return e
-
-    # (a) residue axis, v of head group g = 1 (SMALL-layout V: natural feature order) and the out-projection
-    Wv, Wo = rng.standard_normal((C, C)) / 20, rng.standard_normal((C, C)) / 20
-    tab0, tab2 = chain_table(0), chain_table(2)
-    v_ref = X @ Wv.T
-    o_regs = np.zeros((64, 192))                                          # the lane's attention-output value list (here: o := v)
-    for g in range(4):
-        acc = run_stage(tab0, 3 * g + 2, Wv, vs, 1, xfrag, False)
-        for hd in range(4):
-            e = head12(acc, hd)
-            for l in range(64):
-                feats = (4 * g + hd) * 24 + 12 * (l >> 5) + np.arange(12)
-                assert np.allclose(e[l], v_ref[tok_of_lane[l], feats])
-            o_regs[:, 48 * g + 12 * hd: 48 * g + 12 * hd + 12] = e
-    offrag = lambda ks: o_regs[:, 8 * ks: 8 * ks + 8]                     # of[ks]: values 8 ks .. 8 ks + 7, no data movement
-    y_ref = v_ref @ Wo.T
-    for st in range(4):
-        acc = run_stage(tab2, st, Wo, None, 2, offrag, False)
-        for tl in range(3):
-            for l in range(64):
-                for r in range(16):
-                    feat = 32 * (3 * st + tl) + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
-                    assert abs(acc[tl][l, r] - y_ref[tok_of_lane[l], feat]) < 1e-9
-    # (b) temporal axis: the wave's frames are key slots s0 .. s0 + 7 of the four sequences' tile
-    Wq, Wk = rng.standard_normal((C, C)) / 20, rng.standard_normal((C, C)) / 20
-    tab1 = chain_table(1)
-    s0 = 16                                                               # t0 & 31 (a multiple of 8)
-    g8 = s0 >> 3
-    Qf = np.zeros((4, 16, 2, 64, 8)); Kf = np.zeros((4, 16, 2, 64, 8))    # [sequence l][head][k-step][lane slot][8]
-    Vf = np.zeros((4, 16, 2, 2, 25, 8))                                   # [sequence l][head][k-step][key half][row d][8]
-    for g in range(4):
-        aq = run_stage(tab1, g, Wq, qk, 1, xfrag, False)
-        ak = run_stage(tab1, 4 + g, Wk, qk, 1, xfrag, False)
-        av = run_stage(tab1, 8 + g, Wv, vf, 1, xfrag, True)
-        for hd in range(4):
-            eq, ek = head12(aq, hd), head12(ak, hd)
-            for l in range(64):
-                tt, res = lanes[l]
-                slot = (l >> 5) * 32 + s0 + tt
-                for F, e in ((Qf, eq), (Kf, ek)):
-                    F[res, 4 * g + hd, 0, slot] = e[l, :8]
-                    F[res, 4 * g + hd, 1, slot, :4] = e[l, 8:]
-        for j in range(3):
-            for l in range(64):
-                col, hh = 32 * j + (l & 31), l >> 5
-                hd, d = col // 24, col % 24
-                for i in range(4):                                        # residue i: registers 4 a + i = frames 4 hh + a
-                    piece = [av[j][l, 4 * a + i] for a in range(4)]
-                    Vf[i, 4 * g + hd, g8 >> 1, hh, d, 4 * (g8 & 1): 4 * (g8 & 1) + 4] = piece
-    q, k, v = X @ Wq.T, X @ Wk.T, X @ Wv.T
-    for res in (0, 3):
-        toks = [4 * tt + res for tt in range(8)]
-        for head in (0, 7, 15):
-            sl = slice(head * 24, head * 24 + 24)
-            S = mfma(Kf[res, head, 0], Qf[res, head, 0], np.zeros((64, 16)))
-            S = mfma(Kf[res, head, 1], Qf[res, head, 1], S)               # S^T[key slot][query slot]
-            v0, v1 = np.zeros((64, 8)), np.zeros((64, 8))
-            for l in range(64):
-                if (l & 31) < 24:
-                    v0[l], v1[l] = Vf[res, head, 0, l >> 5, l & 31], Vf[res, head, 1, l >> 5, l & 31]
-            Oacc = mfma(v1, S[:, 8:], mfma(v0, S[:, :8], np.zeros((64, 16))))
-            s_ref = q[toks][:, sl] @ k[toks][:, sl].T                     # [query frame][key frame]
-            o_ref = s_ref @ v[toks][:, sl]
-            for l in range(64):
-                qs = l & 31
-                if s0 <= qs < s0 + 8:                                     # a query slot this wave wrote
-                    for r in range(16):
-                        ks_ = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
-                        want = s_ref[qs - s0, ks_ - s0] if s0 <= ks_ < s0 + 8 else 0.0
-                        assert abs(S[l, r] - want) < 1e-9
-                    got = Oacc[l, :12]                                    # O^T rows 12 hh .. of V^T rows d -> feature psi(d)
-                    for r in range(12):
-                        d = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
-                        if d < 24:
-                            psi = 12 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3)
-                            assert abs(got[r] - o_ref[qs - s0, psi]) < 1e-9
-
-
 def test_training_attention_workgroup_order_keeps_a_sequence_on_one_xcd():
     """csrc/k_attn16.hip `wg_of` / `wg_grid`: workgroup b runs on XCD b % 8 (hardware round robin, one L2 per XCD).  The mapping
     must (a) cover every (sequence, head, row block) exactly once, (b) send all 16 x nblk workgroups of a sequence to ONE XCD

@@ -218,3 +218,30 @@ def test_flat_order_follows_the_backward_pass():
     fr = FlatParams(trainable_shapes(cfg), device="cpu")
     gr = GradBucketer(fr, fr.like(), dist=None)
     assert max(grad_milestone(n, nl) for n in gr.buckets[0]["names"]) == 2 * nl + 2
+
+
+def test_bench_self_launches_its_ranks_when_run_without_a_launcher():
+    """`python bench.py --gpus 2 ...` with WORLD_SIZE unset (the shape of the driver's 1-GPU command) must start its own two
+    ranks (torch.distributed.run --standalone, 127.0.0.1) and print ONE JSON line with n_gpus 2, per-rank rates and the
+    max-over-ranks time -- driven here on CPU through bench.py's test hook `--fake-sampler` (step = sleep of 10 ms x (rank + 1),
+    gloo in place of RCCL): launcher, rendezvous, barrier-bracketed timed region, reductions and JSON assembly are the real
+    code (train.py:46-68 / tps_inference.py:160-161 are the reference's multi-process entry points)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--fake-sampler"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert len(d["per_rank_frames_per_s"]) == 2 and d["rank_max_over_min"] > 1.5          # rank 1 sleeps twice as long
+    # whole-job value = frames of BOTH ranks / the slowest rank's time (4 steps x 20 ms)
+    assert d["ms_per_step"] >= 20.0 and abs(d["value"] - 2 * 16 * 1000 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-3 * d["value"]
+    # a launcher that disagrees with --gpus is refused, not silently accepted
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--fake-sampler"], capture_output=True, text=True,
+                        timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=root)
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
