@@ -129,6 +129,10 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      for launches of >= 512 such workgroups (cfg-2, ATLAS), 0 never (k_flash, then k_proj<0> or a projection
  *                      deferred into the next kernel per fuse_proj / fuse_proj_qkv), 2 always.  Same values as the separate
  *                      kernels (same operands, same summation order).
+ *   "flash_rotate"     1 (default) / 0: tiled attention, fixed-anchor loop: the 64-query chunks of a sequence walk its key tiles from
+ *                      different starting tiles (chunk c of n starts at tile c * tiles / n and wraps): chunks that start together then
+ *                      miss on different fragments instead of queueing behind one chain of HBM misses.  A sum over keys: same
+ *                      values to fp32 rounding.
  *   "flash_proj_occ"   2 (default) / 3: workgroups per CU that kernel's register budget is cut for.
  *   "panel_waves"      0 (default) / 4 / 8: the 64-row panel kernels that exist in a four- and an eight-wave form (k_mlp / k_mlp8,
  *                      k_ln_qkv<false> / k_ln_qkv8) take the eight-wave form for launches of at most one workgroup per CU; 4 / 8

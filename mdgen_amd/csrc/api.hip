@@ -138,9 +138,11 @@ struct mdgen_ctx {
     int opt_panel_waves = 0;    // 64-row panel kernels with a four- and an eight-wave form (k_mlp / k_mlp8, k_ln_qkv<false> / k_ln_qkv8): 0 (default)
                                 // eight waves where a launch is at most one workgroup per CU, 4 / 8 force one form (tests, A/B runs)
     int ncu = 256;              // compute units of the device the context was created on (hipDeviceAttributeMultiprocessorCount)
+    int opt_flash_rotate = 1;   // tiled attention: the 64-query chunks of a sequence start their walk over the key tiles at different tiles (k_flash.hip)
     int opt_flash_proj = 1;     // tiled attention + its out-projection + gated residual in ONE launch (k_flash_proj): 0 off (k_flash, then
                                 // k_proj<0> or a deferred projection), 1 (default) when the launch has >= kFlashProjMinJobs workgroups
                                 // of (sequence, 64 queries), 2 always
+    int opt_flash_proj_epi = 1; // ... its residual epilogue: 1 all 64 rows requested up front, 0 in four batches (as k_proj<0>)
     int opt_flash_proj_occ = 2; // ... built for 2 (256 registers) or 3 (168 registers) workgroups per CU
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_train_streams = 2;      // training step: 2 = weight / bias gradients of the linear layers on a second stream (train.inc)
@@ -640,9 +642,15 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "panel_waves") {
         if (value != 0 && value != 4 && value != 8) return fail(-2, "panel_waves must be 0 (by launch size), 4 or 8");
         c->opt_panel_waves = value;
+    } else if (n == "flash_rotate") {
+        if (value != 0 && value != 1) return fail(-2, "flash_rotate must be 0 or 1");
+        c->opt_flash_rotate = value;
     } else if (n == "flash_proj") {
         if (value < 0 || value > 2) return fail(-2, "flash_proj must be 0 (off), 1 (launches that fill the chip) or 2 (always)");
         c->opt_flash_proj = value;
+    } else if (n == "flash_proj_epilogue") {
+        if (value != 0 && value != 1) return fail(-2, "flash_proj_epilogue must be 0 or 1");
+        c->opt_flash_proj_epi = value;
     } else if (n == "flash_proj_occ") {
         if (value != 2 && value != 3) return fail(-2, "flash_proj_occ must be 2 or 3 (workgroups per CU)");
         c->opt_flash_proj_occ = value;
@@ -992,6 +1000,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         f.rope = r.c->rope;
         f.obuf = r.obufp;
         f.force_robust = r.c->opt_attn_path;
+        f.rotate = r.c->opt_flash_rotate;
         f.vmask = q.vmask;
         f.vmask_stride = q.vmask_stride;
         if (flash_proj_on(r.c, ax)) {
@@ -1003,6 +1012,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
             fp.gate_chunk = gate;
             fp.wo = m.wo;
             fp.bo = m.bo;
+            fp.epi_upfront = r.c->opt_flash_proj_epi;
             { ProfScope ps(r.c, !trunk ? "ipa.flash_proj" : residue_axis ? "flash_proj_L" : "flash_proj_T", r.s); launch_flash_proj(fp, r.c->opt_flash_proj_occ, r.s); }
             LAUNCHCHK();
             return 0;
@@ -1502,7 +1512,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | c->opt_flash_proj_occ << 28 | (uint64_t)c->opt_panel_waves << 32), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | c->opt_flash_proj_occ << 28 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_epi << 37), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1562,7 +1572,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | c->opt_flash_proj_occ << 28 | (uint64_t)c->opt_panel_waves << 32),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | c->opt_flash_proj_occ << 28 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_epi << 37),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

@@ -201,8 +201,19 @@ extern "C" int mdgen_dev_flash_stamps(void* host, size_t bytes) {
 }
 #define FLASH_STAMP(slot, v)                                                                          \
     if (lane == 0 && (long)blockIdx.x * 4 + w < 32768) g_flash_stamps[((long)blockIdx.x * 4 + w) * 16 + (slot)] = (v)
+// k_flash_proj: [wave][16]: 0 start, 1..4 after head group 0..3, 5 after the barrier, 6 after the GEMM, 7 end (s_memtime);
+// 8 / 9 s_memrealtime at start / end; 10 HW_ID
+__device__ unsigned long long g_fproj_stamps[8192 * 16];
+extern "C" int mdgen_dev_fproj_stamps(void* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fproj_stamps), bytes);
+}
+#define FPROJ_STAMP(slot, v)                                                                          \
+    if (lane_id() == 0 && (long)blockIdx.x * 4 + w < 8192) g_fproj_stamps[((long)blockIdx.x * 4 + w) * 16 + (slot)] = (v)
+#define FLASH_STAMP_ROW(w, hg) ((w) + 4096 * (hg))   // k_flash_proj: flash_job's own stamps of head group hg go to rows 4096 hg + ...
 #else
 #define FLASH_STAMP(slot, v)
+#define FPROJ_STAMP(slot, v)
+#define FLASH_STAMP_ROW(w, hg) (w)
 #endif
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., so that h[j], q[j], s[j & 1] are constant-indexed and stay
@@ -237,58 +248,87 @@ struct FlashStoreGlobal {
 // k_flash (one job per wave, output rows to HBM) and k_flash_proj (four jobs per wave, output rows into the LDS panel of
 // the out-projection).  `store.row(j, pos, a, b, c)`: the 12 bf16 output features 12 hh .. 12 hh + 11 of this head (three
 // 8-byte pieces) for query tile j, sequence position pos; `store.pad(j, pos)`: a row past the end of the sequence.
+// What a job reads before its loop: requested by flash_prefetch, consumed by flash_job.  k_flash_proj requests the NEXT head's set
+// before it starts the current head's loop, so that a job's two serial memory round trips (Q / first K tile, then the loop's
+// first tiles) shrink to one (ATLAS: 8-tile sequences, where the prologue was ~40 % of a job).
+template <int NQ>
+struct FlashPre {
+    QTile q[NQ];     // Q fragments of q-tiles NQ qc .. NQ qc + NQ - 1 (tiles past the end of the sequence reuse the first one)
+    u32x4 kb0;       // the learned bias key's K slot (len a multiple of 32: it sits alone in the last tile, see flash_job)
+    u32x2 kb1;
+    f32x4 bvl[3];    // this lane half's 12 features of the learned bias value
+    KTile k0t;       // K tile 0 (the anchor)
+    uint32_t vmw;    // key-validity words of tiles 0..63 (lane i = tile i)
+};
+
+__device__ __forceinline__ void* flash_uniform_ptr(const unsigned char* q_) {
+    const unsigned long long a = (unsigned long long)q_;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (void*)(((unsigned long long)hi << 32) | lo);
+}
+
+template <int NQ>
+__device__ __forceinline__ void flash_prefetch(const FlashParams p, const int seq, const int head, const int qc, FlashPre<NQ>& pre) {
+    const int lane = lane_id(), hh = lane >> 5;
+    const int len = p.ax.len, nt = p.ax.ntile();
+    const long ftile = (long)(seq * kH + head) * nt;   // first fragment tile of this (sequence, head)
+    const unsigned char* qb = p.qf + ftile * kFragQ;
+    const int qt0 = NQ * qc;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int qt = (qt0 + j) * 32 < len ? qt0 + j : qt0;
+        pre.q[j].q0 = frag16(qb + (long)qt * kFragQ + lane * 16);
+        pre.q[j].q1 = frag8(qb + (long)qt * kFragQ + 1024 + lane * 8);
+    }
+    // len a multiple of 32: the learned bias key sits ALONE in the last tile and is handled as a rank-1 term; its K slot and
+    // value row are requested here, with Q, so that their round trip is hidden (requested at their use they cost more than
+    // the tile they save)
+    const bool bias_alone = (len & 31) == 0 && len >= 32;
+    const unsigned char* kb = p.kf + (ftile + (bias_alone ? (len >> 5) : 0)) * kFragK + hh * 32 * 16;   // key slot 0 of this lane half
+    pre.kb0 = *reinterpret_cast<const u32x4*>(kb);
+    pre.kb1 = *reinterpret_cast<const u32x2*>(kb + 1024);
+    const f32x4* bv = reinterpret_cast<const f32x4*>(p.bias_v + head * kDH + hh * 12);
+    pre.bvl[0] = bv[0];
+    pre.bvl[1] = bv[1];
+    pre.bvl[2] = bv[2];
+    // K tile 0 is wanted first (the anchor): requested together with Q, so that its round trip overlaps the validity-word read
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(flash_uniform_ptr(p.kf + ftile * kFragK), 0, 0x7fffffff, 0x00020000);
+    pre.k0t.k0 = __builtin_amdgcn_raw_buffer_load_b128(krs, lane * 16, 0, 0);
+    pre.k0t.k1 = __builtin_amdgcn_raw_buffer_load_b128(krs, lane * 16 + 1024, 0, 0);
+    // per-tile key-validity words (key-padding mask; the bias key at position len is always valid; positions > len are
+    // invalid): written by k_ln_qkv, read 64 tiles at a time into ONE register (lane i = tile i of the window) and picked out
+    // with v_readlane.  No LDS, no barrier: the four waves of a workgroup never meet in the loop.
+    pre.vmw = (p.vmask + (long)seq * p.vmask_stride)[lane];
+}
+
 template <int NQ, class Store>
 __device__ __forceinline__ void flash_job(const FlashParams p, const int seq, const int head, const int qc, const int w,
-                                          const Store store) {   // (by value: through a reference hipcc spills 15 registers)
+                                          const FlashPre<NQ> pre, const Store store) {   // (by value: through a reference hipcc spills 15 registers)
     const int lane = lane_id(), hh = lane >> 5, ql = lane & 31;
     FLASH_STAMP(0, __builtin_amdgcn_s_memtime());
     FLASH_STAMP(4, __builtin_amdgcn_s_memrealtime());
     const int len = p.ax.len, nt = p.ax.ntile();   // tiles per (seq, head): they cover the len keys + the bias key
     const long ftile = (long)(seq * kH + head) * nt;   // first fragment tile of this (sequence, head)
-    const unsigned char* qb = p.qf + ftile * kFragQ;
-
-    // ---- Q fragments of q-tiles NQ qc .. NQ qc + NQ - 1 (tiles past the end of the sequence reuse the first one and are
-    //      never stored)
     const int qt0 = NQ * qc;
     QTile q[NQ];
     bool qvalid[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         qvalid[j] = (qt0 + j) * 32 < len;
-        const int qt = qvalid[j] ? qt0 + j : qt0;
-        q[j].q0 = frag16(qb + (long)qt * kFragQ + lane * 16);
-        q[j].q1 = frag8(qb + (long)qt * kFragQ + 1024 + lane * 8);
+        q[j] = pre.q[j];
     }
-
-    // len a multiple of 32: the learned bias key sits ALONE in the last tile and is handled as a rank-1 term (below); its K
-    // slot and value row are requested here, with Q, so that their round trip is hidden (requested at their use they cost
-    // more than the tile they save)
     const bool bias_alone = (len & 31) == 0 && len >= 32;
-    u32x4 kb0 = {0u, 0u, 0u, 0u};
-    u32x2 kb1 = {0u, 0u};
-    f32x4 bvl[3] = {};
-    {
-        const unsigned char* kb = p.kf + (ftile + (bias_alone ? (len >> 5) : 0)) * kFragK + hh * 32 * 16;   // key slot 0 of this lane half
-        kb0 = *reinterpret_cast<const u32x4*>(kb);
-        kb1 = *reinterpret_cast<const u32x2*>(kb + 1024);
-        const f32x4* bv = reinterpret_cast<const f32x4*>(p.bias_v + head * kDH + hh * 12);
-        bvl[0] = bv[0];
-        bvl[1] = bv[1];
-        bvl[2] = bv[2];
-    }
+    const u32x4 kb0 = pre.kb0;
+    const u32x2 kb1 = pre.kb1;
+    const f32x4 bvl[3] = {pre.bvl[0], pre.bvl[1], pre.bvl[2]};
 
     // ---- K / V^T streams: one buffer descriptor each (wave-uniform base = this (sequence, head)'s first tile), a
     // constant per-lane byte offset, and the tile offset as the scalar offset of the load.  V^T: rows d <= 24 are
     // lanes of the fragment (row 24 = ones); the lanes of rows d > 24 point far out of range and read zeros.
     // Loads are UNCONDITIONAL: tiles past the end of this (sequence, head) read whatever follows in the fragment
     // buffer (finite bf16 of the next head, or the tail) and their results are never used.
-    auto uniform_ptr = [](const unsigned char* q_) {
-        const unsigned long long a = (unsigned long long)q_;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-        return (void*)(((unsigned long long)hi << 32) | lo);
-    };
-    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.kf + ftile * kFragK), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.vf + ftile * kFragV), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(flash_uniform_ptr(p.kf + ftile * kFragK), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(flash_uniform_ptr(p.vf + ftile * kFragV), 0, 0x7fffffff, 0x00020000);
     const int koff = lane * 16;
     const int voff = ql <= kDH ? hh * 400 + ql * 16 : (int)0x80000000;
     auto issue_k = [&](KTile& t, int kt) __attribute__((always_inline)) {
@@ -299,16 +339,9 @@ __device__ __forceinline__ void flash_job(const FlashParams p, const int seq, co
         t.v0 = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, kt * kFragV, 0);
         t.v1 = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff + 800, kt * kFragV, 0);
     };
-    // K tile 0 is wanted first (the anchor below): requested here, together with Q, so that its round trip overlaps
-    // the validity-word read
-    KTile k0t;
-    issue_k(k0t, 0);
-
-    // ---- per-tile key-validity words (key-padding mask; the bias key at position len is always valid; positions
-    //      > len are invalid): written by k_ln_qkv, read here 64 tiles at a time into ONE register (lane i = tile i of
-    //      the window) and picked out with v_readlane.  No LDS, no barrier: the four waves of a workgroup never meet.
+    const KTile k0t = pre.k0t;
     const uint32_t* vmrow = p.vmask + (long)seq * p.vmask_stride;
-    uint32_t vmw = vmrow[lane];
+    uint32_t vmw = pre.vmw;
 
     // One key tile = NQ (key tile, query tile) pairs, query tiles 0 .. NQ-1 in turn.  Pipeline: the block of pair i
     // issues the score MFMAs of pair i+1 and the PV MFMAs of pair i-1 beside its own exps.  Two score tuples and two P
@@ -320,8 +353,21 @@ __device__ __forceinline__ void flash_job(const FlashParams p, const int seq, co
     KTile kx, ky;
     VTile vx, vy;
     // (always_inline: a lambda that is NOT inlined keeps everything it captures by reference in scratch memory)
-    auto tile = [&](auto robust, int t, KTile& kc, KTile& kn, VTile& vc, VTile& vprev) __attribute__((always_inline)) {
+    // Walk order: step i of a run over n tiles visits tile phys(i) = (i + rot) mod n.  The fixed-anchor loop starts every 64-query
+    // chunk of a sequence at a different tile (rot = qc n / nqc): the q-chunks of a (sequence, head) start together and stream the
+    // same K / V^T fragments, and in step they all sit behind ONE chain of HBM misses (the leader's, one per tile: the stamps of
+    // k_flash_proj showed the first job of a launch's first round at 1.7x the time of a warm one); staggered, the 16 chunks pull
+    // the whole fragment set into L2 at once and each misses on a sixteenth of it.  A sum over all keys does not care about the
+    // order (the shift is fixed before the loop); the robust loop keeps the natural order (rot = 0), as do sequences of more than
+    // 64 tiles (the validity words arrive in 64-tile windows).
+    int rot = 0, nrun = 1;
+    auto phys = [&](int i) __attribute__((always_inline)) {
+        const int t = i + rot;
+        return t >= nrun ? t - nrun : t;
+    };
+    auto tile = [&](auto robust, int ti, KTile& kc, KTile& kn, VTile& vc, VTile& vprev) __attribute__((always_inline)) {
         constexpr bool kRobust = decltype(robust)::value;
+        const int t = kRobust ? ti : phys(ti);
         const uint32_t vm = __builtin_amdgcn_readlane(vmw, t & 63);
         static_for<NQ>([&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
@@ -335,24 +381,26 @@ __device__ __forceinline__ void flash_job(const FlashParams p, const int seq, co
             else block(kn, q[0], s[0], vc, pt[(j - 1) & 1], h[j - 1].o, s[j & 1], pt[j & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef MDGEN_DEV_FLASH_NOLOAD   // (timing experiments only: scripts/micro/flash_variants.sh)
-            if constexpr (j == 0) issue_v(vprev, t + 1);      // V(t-1) is consumed: refill its slot
-            if constexpr (j == NQ - 2) issue_k(kc, t + 2);    // K(t) has served its last query tile
+            if constexpr (j == 0) issue_v(vprev, kRobust ? ti + 1 : phys(ti + 1));      // V(t-1) is consumed: refill its slot
+            if constexpr (j == NQ - 2) issue_k(kc, kRobust ? ti + 2 : phys(ti + 2));    // K(t) has served its last query tile
             if constexpr (j == 0 || j == NQ - 2) __builtin_amdgcn_sched_barrier(0);
 #endif
         });
     };
     // The whole (head, 32 NQ queries) job over key tiles 0 .. nt - 1; returns with the last pair's PV MFMAs issued.
-    auto run = [&](auto robust, const int nt) __attribute__((always_inline)) {
+    auto run = [&](auto robust, const int nt, const int rot_) __attribute__((always_inline)) {
+        rot = rot_;
+        nrun = nt;
 #pragma unroll
         for (int j = 0; j < NQ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[j].o[r] = opaque_zero();
         pt[(NQ - 1) & 1].p0 = pt[(NQ - 1) & 1].p1 = u32x4{0u, 0u, 0u, 0u};   // "previous pair" of the very first block: P = 0
         if (nt > 64) vmw = vmrow[lane];          // (a re-run after a long fast loop: back to the first window)
-        issue_k(kx, 0);
-        issue_v(vy, 0);    // stands in for "V(-1)": any finite values (its P is zero)
-        issue_k(ky, 1);
-        issue_v(vx, 0);
+        issue_k(kx, phys(0));
+        issue_v(vy, phys(0));    // stands in for "V(-1)": any finite values (its P is zero)
+        issue_k(ky, phys(1));
+        issue_v(vx, phys(0));
         __builtin_amdgcn_sched_barrier(0);
         s[0] = scores(kx, q[0]);   // pair (0, 0)
         // The loop body is a PAIR of tiles with a single exit (an exit between the two makes hipcc keep O in
@@ -442,7 +490,7 @@ __device__ __forceinline__ void flash_job(const FlashParams p, const int seq, co
     FLASH_STAMP(6, (unsigned long long)robust_needed);
     FLASH_STAMP(8, (unsigned long long)__float_as_uint(h[0].m));   // lane 0's fixed anchor (first-tile row max + kAnchor)
     if (!robust_needed) {
-        run(std::false_type{}, nt_fast);
+        run(std::false_type{}, nt_fast, (p.rotate && nt_fast > 2 && nt <= 64) ? (qc * nt_fast) / ((len + 32 * NQ - 1) / (32 * NQ)) : 0);
         if (bias_alone) {
             // the learned bias key as a rank-1 term: P_b = 2^(q . k_b - M), O += P_b v_b, denominator += P_b
 #pragma unroll
@@ -481,7 +529,7 @@ __device__ __forceinline__ void flash_job(const FlashParams p, const int seq, co
             h[j].unanch = ~0ull;
             set_shift(q[j], 0.f, hh);
         }
-        run(std::true_type{}, nt);
+        run(std::true_type{}, nt, 0);
     }
     FLASH_STAMP(3, __builtin_amdgcn_s_memtime());
     FLASH_STAMP(11, (unsigned long long)__float_as_uint(h[0].m));   // lane 0's final shift (robust loop: ~ the true row max)
@@ -518,7 +566,9 @@ __global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParam
     const int seq = pair >> 2, hg = pair & 3;
     if (seq >= p.ax.nseq) return;
     const int head = hg * 4 + w;
-    flash_job<NQ>(p, seq, head, qc, w, FlashStoreGlobal{p.obuf, p.ax, seq, head});
+    FlashPre<NQ> pre;
+    flash_prefetch<NQ>(p, seq, head, qc, pre);
+    flash_job<NQ>(p, seq, head, qc, w, pre, FlashStoreGlobal{p.obuf, p.ax, seq, head});
 }
 
 // =================================================================================================
@@ -552,7 +602,7 @@ struct FlashStorePanel {
     __device__ __forceinline__ void pad(int j, int) const { put(j, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}); }
 };
 
-template <int OCC>
+template <int OCC, bool UPFRONT>
 __global__ __launch_bounds__(256, OCC) void k_flash_proj(const FlashProjParams p) {
     constexpr int NQ = 2;
     static_assert(32 * NQ == kPanel, "one workgroup = one 64-row panel");
@@ -564,18 +614,42 @@ __global__ __launch_bounds__(256, OCC) void k_flash_proj(const FlashProjParams p
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
     const int qc = rest % nqc, seq = (rest / nqc) * 8 + xcd;
     if (seq >= p.f.ax.nseq) return;
+    FPROJ_STAMP(0, __builtin_amdgcn_s_memtime());
+    FPROJ_STAMP(8, __builtin_amdgcn_s_memrealtime());
+    FPROJ_STAMP(10, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));   // HW_REG_HW_ID
     setup_rows_axis(pr, p.f.ax, seq, qc * kPanel, p.mm);   // read after the barrier below
+    FlashPre<NQ> cur;
+    flash_prefetch<NQ>(p.f, seq, w, qc, cur);
 #pragma unroll 1
-    for (int hg = 0; hg < 4; ++hg)
-        flash_job<NQ>(p.f, seq, 4 * hg + w, qc, w, FlashStorePanel{(lds_byte*)panel, 4 * hg + w});
+    for (int hg = 0; hg < 4; ++hg) {
+        if constexpr (OCC == 2) {   // (256 registers: room for the next head's set across the loop)
+            FlashPre<NQ> nxt;
+            flash_prefetch<NQ>(p.f, seq, 4 * (hg < 3 ? hg + 1 : 3) + w, qc, nxt);   // in flight while this head's job runs
+            __builtin_amdgcn_sched_barrier(0);
+            flash_job<NQ>(p.f, seq, 4 * hg + w, qc, FLASH_STAMP_ROW(w, hg), cur, FlashStorePanel{(lds_byte*)panel, 4 * hg + w});
+            cur = nxt;
+        } else {
+            if (hg) flash_prefetch<NQ>(p.f, seq, 4 * hg + w, qc, cur);
+            flash_job<NQ>(p.f, seq, 4 * hg + w, qc, w, cur, FlashStorePanel{(lds_byte*)panel, 4 * hg + w});
+        }
+        FPROJ_STAMP(1 + hg, __builtin_amdgcn_s_memtime());
+    }
     __syncthreads();   // the attention output of all 16 heads is in the panel
+    FPROJ_STAMP(5, __builtin_amdgcn_s_memtime());
     const int lane = lane_id();
     f32x16 acc[6];
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, false, OCC == 3 ? 2 : 4>(panel, kC * 2, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    FPROJ_STAMP(6, __builtin_amdgcn_s_memtime());
     __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
-    epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
-                                  p.h);
+    if constexpr (UPFRONT)
+        epilogue_gate_residual_lds_upfront<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk,
+                                              true, p.h);
+    else
+        epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
+                                      p.h);
+    FPROJ_STAMP(7, __builtin_amdgcn_s_memtime());
+    FPROJ_STAMP(9, __builtin_amdgcn_s_memrealtime());
 }
 
 // Measured (cfg-2 / cfg-4, same box, back to back): NQ = 4 runs 160-162 / 76 us, NQ = 2 160-164 / 76 us -- a tie; 2 keeps
@@ -596,8 +670,10 @@ long flash_proj_jobs(const AxisMap& ax) { return (long)ax.nseq * ((ax.len + kPan
 void launch_flash_proj(const FlashProjParams& p, int occ, hipStream_t s) {
     const int nqc = (p.f.ax.len + kPanel - 1) / kPanel;
     const int nseq8 = (p.f.ax.nseq + 7) / 8;   // sequences, in groups of 8 (one per XCD)
-    if (occ == 3) hipLaunchKernelGGL(k_flash_proj<3>, dim3(nseq8 * nqc * 8), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_flash_proj<2>, dim3(nseq8 * nqc * 8), dim3(256), 0, s, p);
+    const dim3 grid(nseq8 * nqc * 8);
+    if (occ == 3) hipLaunchKernelGGL((k_flash_proj<3, false>), grid, dim3(256), 0, s, p);
+    else if (p.epi_upfront) hipLaunchKernelGGL((k_flash_proj<2, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_flash_proj<2, false>), grid, dim3(256), 0, s, p);
 }
 
 }  // namespace mdg

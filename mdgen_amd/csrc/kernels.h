@@ -127,6 +127,7 @@ struct FlashParams {
     const uint32_t* vmask;  // [seq][vmask_stride]: bit k of word t = key 32 t + k may be attended (written by k_ln_qkv)
     int vmask_stride;
     int force_robust;       // option attention_path: 1 = skip the fixed-anchor loop, always run the moving-shift loop
+    int rotate;             // option flash_rotate: 1 = every 64-query chunk starts its walk over the key tiles at a different tile
 };
 
 // k_flash_proj: k_flash for all 16 heads of 64 queries + the sub-layer's out-projection + gated residual (k_proj<0>'s work)
@@ -137,6 +138,7 @@ struct FlashProjParams {
     int gate_chunk;
     const bf16x8* wo;       // packed out-projection weights [12 ftile][24 kstep][64 lane][8]
     const float* bo;
+    int epi_upfront;        // option flash_proj_epilogue: 1 = all residual rows of the panel requested up front (one HBM round trip)
 };
 
 struct EmbedParams {

