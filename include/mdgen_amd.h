@@ -133,7 +133,6 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      different starting tiles (chunk c of n starts at tile c * tiles / n and wraps): chunks that start together then
  *                      miss on different fragments instead of queueing behind one chain of HBM misses.  A sum over keys: same
  *                      values to fp32 rounding.
- *   "flash_proj_occ"   2 (default) / 3: workgroups per CU that kernel's register budget is cut for.
  *   "panel_waves"      0 (default) / 4 / 8: the 64-row panel kernels that exist in a four- and an eight-wave form (k_mlp / k_mlp8,
  *                      k_ln_qkv<false> / k_ln_qkv8) take the eight-wave form for launches of at most one workgroup per CU; 4 / 8
  *                      force one form whatever the launch size (tests, A/B runs).  mdgen_profile_report tags the class of such

@@ -138,12 +138,12 @@ struct mdgen_ctx {
     int opt_panel_waves = 0;    // 64-row panel kernels with a four- and an eight-wave form (k_mlp / k_mlp8, k_ln_qkv<false> / k_ln_qkv8): 0 (default)
                                 // eight waves where a launch is at most one workgroup per CU, 4 / 8 force one form (tests, A/B runs)
     int ncu = 256;              // compute units of the device the context was created on (hipDeviceAttributeMultiprocessorCount)
+    int opt_mlp_cap = 0;        // experiment: the four-wave panel MLP kernel at one workgroup per CU (profiles/r05_experiments.txt #7)
+    int opt_stream_offset = 0;  // experiment: microseconds by which sub-batch stream i starts after stream i - 1
     int opt_flash_rotate = 1;   // tiled attention: the 64-query chunks of a sequence start their walk over the key tiles at different tiles (k_flash.hip)
     int opt_flash_proj = 1;     // tiled attention + its out-projection + gated residual in ONE launch (k_flash_proj): 0 off (k_flash, then
                                 // k_proj<0> or a deferred projection), 1 (default) when the launch has >= kFlashProjMinJobs workgroups
                                 // of (sequence, 64 queries), 2 always
-    int opt_flash_proj_epi = 1; // ... its residual epilogue: 1 all 64 rows requested up front, 0 in four batches (as k_proj<0>)
-    int opt_flash_proj_occ = 2; // ... built for 2 (256 registers) or 3 (168 registers) workgroups per CU
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_train_streams = 2;      // training step: 2 = weight / bias gradients of the linear layers on a second stream (train.inc)
     hipStream_t train_side = nullptr;   // that stream (created on first use, default priority)
@@ -642,18 +642,18 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "panel_waves") {
         if (value != 0 && value != 4 && value != 8) return fail(-2, "panel_waves must be 0 (by launch size), 4 or 8");
         c->opt_panel_waves = value;
+    } else if (n == "mlp_cap") {
+        if (value != 0 && value != 1) return fail(-2, "mlp_cap must be 0 or 1");
+        c->opt_mlp_cap = value;
+    } else if (n == "stream_offset") {
+        if (value < 0 || value > 100000) return fail(-2, "stream_offset must be 0..100000 microseconds");
+        c->opt_stream_offset = value;
     } else if (n == "flash_rotate") {
         if (value != 0 && value != 1) return fail(-2, "flash_rotate must be 0 or 1");
         c->opt_flash_rotate = value;
     } else if (n == "flash_proj") {
         if (value < 0 || value > 2) return fail(-2, "flash_proj must be 0 (off), 1 (launches that fill the chip) or 2 (always)");
         c->opt_flash_proj = value;
-    } else if (n == "flash_proj_epilogue") {
-        if (value != 0 && value != 1) return fail(-2, "flash_proj_epilogue must be 0 or 1");
-        c->opt_flash_proj_epi = value;
-    } else if (n == "flash_proj_occ") {
-        if (value != 2 && value != 3) return fail(-2, "flash_proj_occ must be 2 or 3 (workgroups per CU)");
-        c->opt_flash_proj_occ = value;
     } else if (n == "mlp_path") {
         if (value < 0 || value > 2) return fail(-2, "mlp_path must be 0 (panel kernel), 1 (row-owner kernel when it fills the chip) or 2 (always)");
         c->opt_mlp_path = value;
@@ -1012,8 +1012,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
             fp.gate_chunk = gate;
             fp.wo = m.wo;
             fp.bo = m.bo;
-            fp.epi_upfront = r.c->opt_flash_proj_epi;
-            { ProfScope ps(r.c, !trunk ? "ipa.flash_proj" : residue_axis ? "flash_proj_L" : "flash_proj_T", r.s); launch_flash_proj(fp, r.c->opt_flash_proj_occ, r.s); }
+            { ProfScope ps(r.c, !trunk ? "ipa.flash_proj" : residue_axis ? "flash_proj_L" : "flash_proj_T", r.s); launch_flash_proj(fp, r.s); }
             LAUNCHCHK();
             return 0;
         }
@@ -1092,7 +1091,7 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
     }
     const int pw = p.trace ? 4 : panel_waves_for((nrows + kPanel - 1) / kPanel, r.c->opt_panel_waves, r.c->ncu);
     const std::string cls = std::string(!trunk ? "ipa.mlp" : p.o ? "proj_mlp" : "mlp") + (pw == 8 ? "@p8" : "@p4");
-    { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_mlp(p, r.s, pw); }
+    { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_mlp(p, r.s, pw, r.c->opt_mlp_cap); }
     LAUNCHCHK();
     return 0;
 }
@@ -1428,7 +1427,10 @@ static int euler_body(const Run& r, const std::vector<float>& tg, float* x) {
     // contiguous sub-batch views, view i on stream i % ns (fork after the shared preparation, join at the end)
     mdgen_ctx* c = r.c;
     if (ns > 1) HIPCHK(hipEventRecord(c->ev_fork, r.s));
-    for (int i = 1; i < ns; ++i) HIPCHK(hipStreamWaitEvent(c->side[i - 1], c->ev_fork, 0));
+    for (int i = 1; i < ns; ++i) {
+        HIPCHK(hipStreamWaitEvent(c->side[i - 1], c->ev_fork, 0));
+        if (c->opt_stream_offset) launch_spin(i * c->opt_stream_offset, c->side[i - 1]);
+    }
     int b0 = 0;
     for (int i = 0; i < nv; ++i) {
         const int Bs = r.B / nv + (i < r.B % nv ? 1 : 0);
@@ -1512,7 +1514,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | c->opt_flash_proj_occ << 28 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_epi << 37), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_mlp_cap << 37), (uint64_t)c->opt_stream_offset, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1572,7 +1574,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | c->opt_flash_proj_occ << 28 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_epi << 37),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_mlp_cap << 37), (uint64_t)c->opt_stream_offset,
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

@@ -582,8 +582,10 @@ __global__ __launch_bounds__(256, NQ == 2 ? 3 : 2) void k_flash(const FlashParam
 // epilogue k_proj<0> uses.  What it removes per launch at cfg-2: the 49 MB write and read of the attention output, 98 MB of
 // the residual stream's traffic moved out of a kernel that did nothing else (k_proj<0> ran at its HBM roof, 55 us) into the
 // shadow of other workgroups' VALU-bound attention loops, and a launch boundary.  Workgroups of a sequence go to one XCD (they
-// stream the same K / V^T fragments).  OCC = workgroups per CU the register budget is cut for (2: 256 registers, the GEMM's
-// weight ring four k-steps deep; 3: 168 registers, two k-steps).
+// stream the same K / V^T fragments).  Two workgroups per CU (227 registers: the next head's Q / first K tile / bias slots are
+// requested before the current head's loop starts).  Measured and dropped (profiles/r05_experiments.txt): a 168-register build for
+// three workgroups per CU (1024 jobs on 768 slots: the second, one-third-full round costs more than the denser loop gains), the
+// residual rows of the whole panel requested up front (epilogue 16.8k -> 23.2k cycles: the HBM queue, not the round trips, paces it).
 // =================================================================================================
 typedef __attribute__((address_space(3))) unsigned char lds_byte;   // (an LDS pointer inside a struct must keep its address
                                                                     // space, or every store becomes a flat_store: DESIGN 6.25)
@@ -602,8 +604,7 @@ struct FlashStorePanel {
     __device__ __forceinline__ void pad(int j, int) const { put(j, u32x2{0u, 0u}, u32x2{0u, 0u}, u32x2{0u, 0u}); }
 };
 
-template <int OCC, bool UPFRONT>
-__global__ __launch_bounds__(256, OCC) void k_flash_proj(const FlashProjParams p) {
+__global__ __launch_bounds__(256, 2) void k_flash_proj(const FlashProjParams p) {
     constexpr int NQ = 2;
     static_assert(32 * NQ == kPanel, "one workgroup = one 64-row panel");
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanel * kC * 2];
@@ -622,16 +623,11 @@ __global__ __launch_bounds__(256, OCC) void k_flash_proj(const FlashProjParams p
     flash_prefetch<NQ>(p.f, seq, w, qc, cur);
 #pragma unroll 1
     for (int hg = 0; hg < 4; ++hg) {
-        if constexpr (OCC == 2) {   // (256 registers: room for the next head's set across the loop)
-            FlashPre<NQ> nxt;
-            flash_prefetch<NQ>(p.f, seq, 4 * (hg < 3 ? hg + 1 : 3) + w, qc, nxt);   // in flight while this head's job runs
-            __builtin_amdgcn_sched_barrier(0);
-            flash_job<NQ>(p.f, seq, 4 * hg + w, qc, FLASH_STAMP_ROW(w, hg), cur, FlashStorePanel{(lds_byte*)panel, 4 * hg + w});
-            cur = nxt;
-        } else {
-            if (hg) flash_prefetch<NQ>(p.f, seq, 4 * hg + w, qc, cur);
-            flash_job<NQ>(p.f, seq, 4 * hg + w, qc, w, cur, FlashStorePanel{(lds_byte*)panel, 4 * hg + w});
-        }
+        FlashPre<NQ> nxt;
+        flash_prefetch<NQ>(p.f, seq, 4 * (hg < 3 ? hg + 1 : 3) + w, qc, nxt);   // in flight while this head's job runs
+        __builtin_amdgcn_sched_barrier(0);
+        flash_job<NQ>(p.f, seq, 4 * hg + w, qc, FLASH_STAMP_ROW(w, hg), cur, FlashStorePanel{(lds_byte*)panel, 4 * hg + w});
+        cur = nxt;
         FPROJ_STAMP(1 + hg, __builtin_amdgcn_s_memtime());
     }
     __syncthreads();   // the attention output of all 16 heads is in the panel
@@ -639,15 +635,11 @@ __global__ __launch_bounds__(256, OCC) void k_flash_proj(const FlashProjParams p
     const int lane = lane_id();
     f32x16 acc[6];
     zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, false, OCC == 3 ? 2 : 4>(panel, kC * 2, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    wave_gemm<2, 3, 24, false>(panel, kC * 2, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     FPROJ_STAMP(6, __builtin_amdgcn_s_memtime());
     __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
-    if constexpr (UPFRONT)
-        epilogue_gate_residual_lds_upfront<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk,
-                                              true, p.h);
-    else
-        epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
-                                      p.h);
+    epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
+                                  p.h);
     FPROJ_STAMP(7, __builtin_amdgcn_s_memtime());
     FPROJ_STAMP(9, __builtin_amdgcn_s_memrealtime());
 }
@@ -667,13 +659,10 @@ void launch_flash(const FlashParams& p, hipStream_t s) {
 // jobs of a fused launch: one workgroup per (sequence, 64-query chunk)
 long flash_proj_jobs(const AxisMap& ax) { return (long)ax.nseq * ((ax.len + kPanel - 1) / kPanel); }
 
-void launch_flash_proj(const FlashProjParams& p, int occ, hipStream_t s) {
+void launch_flash_proj(const FlashProjParams& p, hipStream_t s) {
     const int nqc = (p.f.ax.len + kPanel - 1) / kPanel;
     const int nseq8 = (p.f.ax.nseq + 7) / 8;   // sequences, in groups of 8 (one per XCD)
-    const dim3 grid(nseq8 * nqc * 8);
-    if (occ == 3) hipLaunchKernelGGL((k_flash_proj<3, false>), grid, dim3(256), 0, s, p);
-    else if (p.epi_upfront) hipLaunchKernelGGL((k_flash_proj<2, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_flash_proj<2, false>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_flash_proj, dim3(nseq8 * nqc * 8), dim3(256), 0, s, p);
 }
 
 }  // namespace mdg

@@ -213,8 +213,18 @@ extern "C" int mdgen_dev_qkv_stamps(void* host, size_t bytes) {
 #define QKV_STAMP(slot)                                                                                      \
     if (!SMALL && lane_id() == 0 && (long)blockIdx.x * 4 + wave_id() < 16384)                                  \
     g_qkv_stamps[((long)blockIdx.x * 4 + wave_id()) * 8 + (slot)] = __builtin_amdgcn_s_memtime()
+// k_ln_qkv_attn4: [wave][16]: 0 start, 1 LN prologue, 2 Q GEMM, 3 Q epilogue, 4 K GEMM, 5 K RoPE, 6 scores + softmax, 7 V GEMM, 8 P V +
+// panel, 9 out-projection GEMM, 10 end (scripts/r05/attn4_stamps.py)
+__device__ unsigned long long g_attn4_stamps[8192 * 16];
+extern "C" int mdgen_dev_attn4_stamps(void* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn4_stamps), bytes);
+}
+#define ATTN4_STAMP(slot)                                                                                    \
+    if (lane_id() == 0 && (long)blockIdx.x * 4 + wave_id() < 8192)                                             \
+    g_attn4_stamps[((long)blockIdx.x * 4 + wave_id()) * 16 + (slot)] = __builtin_amdgcn_s_memtime()
 #else
 #define QKV_STAMP(slot)
+#define ATTN4_STAMP(slot)
 #endif
 
 // PRE (FLASH layout only): the panel first runs the PREVIOUS sub-layer's out-projection + gated residual for its 64 tokens
@@ -405,10 +415,12 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     __shared__ uint32_t qstash[4][24][64];
     PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
     unsigned char* panel = smem + sizeof(PanelRows);
+    ATTN4_STAMP(0);
     setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
     __syncthreads();
     prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
     __syncthreads();
+    ATTN4_STAMP(1);
     const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id(), hh = lane >> 5, tk = lane & 31;
     constexpr int L = 4;
     // per-token constants: token id, key validity of the own token; the rotary factors (position = token % 4)
@@ -435,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     // ---- Q (heads 4w..4w+3): RoPE, keep as bf16 pairs (48 registers)
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    ATTN4_STAMP(2);
     load_head_bias(p.bq, w, hh, bb);
     load_rope(rq);
     uint32_t qp[2][4][6];
@@ -455,10 +468,12 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     for (int hd = 0; hd < 4; ++hd)
 #pragma unroll
         for (int q = 0; q < 6; ++q) qstash[w][hd * 6 + q][lane] = qp[1][hd][q];
+    ATTN4_STAMP(3);
     __builtin_amdgcn_sched_barrier(0);
     // ---- K: RoPE in place, then the scores of the 4 keys of the quad + the bias key; softmax -> P (40 registers)
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, true, 2>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);   // shallow ring: q is live
+    ATTN4_STAMP(4);
     load_head_bias(p.bk, w, hh, bb);
     load_rope(rq);
     // pass 1: bias + RoPE IN PLACE in the accumulators (frees the bias / rotary registers before the scores)
@@ -481,6 +496,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
                 }
             }
         }
+    ATTN4_STAMP(5);
     __builtin_amdgcn_sched_barrier(0);
     // pass 2: scores against the 4 keys of the quad + the bias key, softmax -> P (40 registers)
     float P[2][4][5];
@@ -544,6 +560,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
             __builtin_amdgcn_sched_barrier(0);   // one head at a time: keeps the scheduler from overlapping all four
         }
     }
+    ATTN4_STAMP(6);
     // the 40 attention weights of this lane wait in the (now free) q stash as 20 bf16 pairs while the V GEMM runs
     // (bf16 weights: what the streaming kernel feeds its PV MFMA as well)
     {
@@ -555,6 +572,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     // ---- V (transposed as well: a lane holds features 12 hh .. 12 hh + 11 of each head of its token)
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, true, 3>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    ATTN4_STAMP(7);
     load_head_bias(p.bv, w, hh, bb);
     {
         float* Pf = &P[0][0][0];
@@ -600,11 +618,14 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     if (!PROJ) return;
     // ---- out-projection + gated residual, as k_proj<0>
     __syncthreads();   // the whole attention output is in the panel
+    ATTN4_STAMP(8);
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    ATTN4_STAMP(9);
     __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
     epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk,
                                   true, p.h_rw);
+    ATTN4_STAMP(10);
 }
 
 // =================================================================================================
@@ -1224,15 +1245,18 @@ void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
     else if (mode == 1) hipLaunchKernelGGL(k_proj<1>, dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k_proj<2>, dim3(grid), dim3(256), 0, s, p);
 }
-void launch_mlp(const MlpParams& p, hipStream_t s, int waves) {
+void launch_mlp(const MlpParams& p, hipStream_t s, int waves, int cap) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
     if (waves == 8 && !p.trace) {   // (the phase stamps stay with k_mlp: mdgen_profile_phase_trace selects the four-wave kernel)
         if (p.o) hipLaunchKernelGGL((k_mlp8<true>), dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((k_mlp8<false>), dim3(grid), dim3(512), 0, s, p);
         return;
     }
-    if (p.o) hipLaunchKernelGGL((k_mlp<3, true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_mlp<3>), dim3(grid), dim3(256), 0, s, p);
+    // cap: 2 KiB of dynamic LDS nobody uses -- with the kernel's 80 KiB a second workgroup no longer fits a CU's 160 KiB, which
+    // leaves half of the CU's registers to a workgroup of another kernel (the co-scheduling experiment, option mlp_cap)
+    const unsigned dyn = cap ? 2048u : 0u;
+    if (p.o) hipLaunchKernelGGL((k_mlp<3, true>), dim3(grid), dim3(256), dyn, s, p);
+    else hipLaunchKernelGGL((k_mlp<3>), dim3(grid), dim3(256), dyn, s, p);
 }
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);

@@ -138,7 +138,6 @@ struct FlashProjParams {
     int gate_chunk;
     const bf16x8* wo;       // packed out-projection weights [12 ftile][24 kstep][64 lane][8]
     const float* bo;
-    int epi_upfront;        // option flash_proj_epilogue: 1 = all residual rows of the panel requested up front (one HBM round trip)
 };
 
 struct EmbedParams {
@@ -181,7 +180,7 @@ int panel_waves_for(long grid, int forced, int ncu);   // 4 or 8 waves per 64-ro
 void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre = false, int waves = 4);
 void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
-void launch_mlp(const MlpParams& p, hipStream_t s, int waves = 4);
+void launch_mlp(const MlpParams& p, hipStream_t s, int waves = 4, int cap = 0);   // cap: 1 = at most one workgroup per CU (experiment option mlp_cap)
 void launch_mlp_rows(const MlpRowsParams& p, int nw, hipStream_t s);
 // rowmap (nullable): source row of packed row r (a permutation of the matrix's rows); kappa: K order inside a k-step -- 0
 // natural, 1 rows.h kappa (operand = LayerNorm / GELU registers)
@@ -191,7 +190,7 @@ void launch_ln_linear(const LnLinearParams& p, hipStream_t s);
 void launch_final(const FinalParams& p, hipStream_t s);
 void launch_flash(const FlashParams& p, hipStream_t s);
 long flash_proj_jobs(const AxisMap& ax);
-void launch_flash_proj(const FlashProjParams& p, int occ, hipStream_t s);
+void launch_flash_proj(const FlashProjParams& p, hipStream_t s);
 void launch_pack_embed(const float* w, int D, float* pack, hipStream_t s);   // pack: kEmbPackFloats floats
 constexpr int kEmbPackFloats = 4 * 3 * 14 * 64;
 void launch_embed(const EmbedParams& p, hipStream_t s);
@@ -286,6 +285,7 @@ void launch_ipa_init(const float* aa_emb, const int64_t* aatype, const float* re
                      float* h, int ngroups, int B, int L, hipStream_t s);
 void launch_add_inplace(float* dst, const float* src, long n, hipStream_t s);
 void launch_write_floats(const float* host_vals, int n, float* dst, hipStream_t s);
+void launch_spin(int us, hipStream_t s);
 void launch_rel7(const float* r1, const float* t1, const float* r2, const float* t2, float* out7, long n, hipStream_t s);
 
 // SE(3) / pre / post (k_se3.hip)

@@ -367,55 +367,6 @@ __device__ __forceinline__ void epi_rmw(const int t, const PanelRows* pr, const 
     }
 }
 
-// The same update with the residual rows of BOTH 32-row halves requested before anything else (32 16-byte loads per lane in
-// flight, 128 registers): one HBM round trip per workgroup instead of four.  For kernels whose workgroups are NOT in step
-// (k_flash_proj: every workgroup reaches its epilogue at a different time) -- where all workgroups of a launch are in the
-// same phase the deeper burst only lengthens the HBM queue (see prologue_ln).
-template <int FT>
-__device__ __forceinline__ void epilogue_gate_residual_lds_upfront(const f32x16* acc, const PanelRows* pr, float* stage, int col0,
-                                                                   const float* __restrict__ bias, const ModMap mm, int gate_chunk,
-                                                                   bool gated, float* __restrict__ h) {
-    static_assert(FT == 3, "slab is [32][96]");
-    const int lane = lane_id();
-    const int q = lane % 24, r2 = lane / 24;
-    const bool active = lane < 48;
-    const int slot = active ? lane : 0;
-    f32x4 hv[2][16];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int row = active ? t * 32 + 2 * k + r2 : 0;
-            const int tk = active ? pr->tok[row] : -1;
-            hv[t][k] = *reinterpret_cast<const f32x4*>(h + (long)(tk < 0 ? 0 : tk) * kC + col0 + 4 * q);
-        }
-    __builtin_amdgcn_sched_barrier(0);
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + col0 + 4 * q);
-    const f32x4* stage4 = reinterpret_cast<const f32x4*>(stage);
-    const int um = gated ? pr->uniform : -1;
-    const bool per_row = gated && um < 0;
-    f32x4 gu = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (gated && um >= 0) gu = *reinterpret_cast<const f32x4*>(mm.mod + um + gate_chunk * kC + col0 + 4 * q);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        epi_stage(acc + t * FT, stage);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int row = active ? t * 32 + 2 * k + r2 : 0;
-            const int tk = active ? pr->tok[row] : -1;
-            f32x4 g = gu;
-            if (per_row) g = *reinterpret_cast<const f32x4*>(mm.mod + pr->moff[row] + gate_chunk * kC + col0 + 4 * q);
-            const f32x4 v = stage4[k * 48 + slot];
-            f32x4 o = hv[t][k];
-            o[0] += g[0] * (v[0] + b4[0]);
-            o[1] += g[1] * (v[1] + b4[1]);
-            o[2] += g[2] * (v[2] + b4[2]);
-            o[3] += g[3] * (v[3] + b4[3]);
-            if (tk >= 0) *reinterpret_cast<f32x4*>(h + (long)tk * kC + col0 + 4 * q) = o;
-        }
-    }
-}
-
 template <int FT>
 __device__ __forceinline__ void epilogue_gate_residual_lds(const f32x16* acc, const PanelRows* pr, float* stage, int col0,
                                                            const float* __restrict__ bias, const ModMap mm,

@@ -2310,8 +2310,8 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
     """Option `flash_proj` (round 5): the tiled attention of all 16 heads for 64 queries of a sequence + the sub-layer's
     out-projection + gated residual in ONE launch (k_flash_proj; mha.py:359-397, latent_model.py:462,476) against (a) the CPU oracle
     at the bf16 gate, every trace, and (b) the separate kernels it replaces (k_flash, then k_proj<0> or a projection deferred into
-    the next kernel): same operands, same summation order -> equal to fp32 rounding.  Both register budgets (`flash_proj_occ`
-    2 / 3) and both softmax loops (`attention_path` 0 / 1).  Shapes: a partial last 64-query chunk whose second tile is past the
+    the next kernel): same operands, same summation order -> equal to fp32 rounding.  Both key-tile walk orders (`flash_rotate`)
+    and both softmax loops (`attention_path` 0 / 1).  Shapes: a partial last 64-query chunk whose second tile is past the
     sequence (T 130, L 9), T a multiple of 64 (the bias key opens a key tile of its own), L 33 / 96 / 64 on the residue axis,
     padded residues (their temporal sequences see only the learned bias key: the direct bias_v path), the headline's T 1000.
     Workspace filled with 0xFF bytes; the profile report says which kernels ran."""
@@ -2321,8 +2321,7 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
     cfg, sd, kw, dkw = _fwd_case(B, T, L, n_pad, 500 + T + L)
     ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
     outs = {}
-    for key, opts in (("separate", {"flash_proj": 0}), ("fused", {"flash_proj": 2, "flash_proj_occ": 2}),
-                      ("fused occ 3", {"flash_proj": 2, "flash_proj_occ": 3}),
+    for key, opts in (("separate", {"flash_proj": 0}), ("fused", {"flash_proj": 2}), ("fused, natural tile order", {"flash_proj": 2, "flash_rotate": 0}),
                       ("fused robust loop", {"flash_proj": 2, "attention_path": 1})):
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
@@ -2343,10 +2342,12 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
             assert not any(k.startswith(("proj_T", "proj_L", "projL_qkvT", "proj_mlp")) for k in ran), ran
         outs[key] = (out.cpu(), tr[f"h{cfg.num_layers}"].cpu())
         del m
-    for key in ("fused", "fused occ 3"):
+    for key in ("fused", "fused, natural tile order"):
         e_out, e_h = rel_l2(outs[key][0], outs["separate"][0]), rel_l2(outs[key][1], outs["separate"][1])
         print(shape, f"{key} vs separate kernels: out {e_out:.2e} h {e_h:.2e} equal {torch.equal(outs[key][0], outs['separate'][0])}")
-        assert e_out < 2e-5 and e_h < 2e-5
+        # (`flash_rotate` changes the order in which a query's keys are summed: fp32 rounding, now and then one bf16 step of an
+        # attention output; the default walks the tiles in the same rotated order in both kernels)
+        assert (e_out < 2e-5 and e_h < 2e-5) if key == "fused" else (e_out < 2e-3 and e_h < 2e-3)
     assert rel_l2(outs["fused robust loop"][0], outs["fused"][0]) < 6e-3   # (P rounded to bf16 around a different shift)
     if n_pad:   # padded residues never influence the valid ones
         m = LatentMDGenModel(cfg)
