@@ -138,8 +138,6 @@ struct mdgen_ctx {
     int opt_panel_waves = 0;    // 64-row panel kernels with a four- and an eight-wave form (k_mlp / k_mlp8, k_ln_qkv<false> / k_ln_qkv8): 0 (default)
                                 // eight waves where a launch is at most one workgroup per CU, 4 / 8 force one form (tests, A/B runs)
     int ncu = 256;              // compute units of the device the context was created on (hipDeviceAttributeMultiprocessorCount)
-    int opt_mlp_cap = 0;        // experiment: the four-wave panel MLP kernel at one workgroup per CU (profiles/r05_experiments.txt #7)
-    int opt_stream_offset = 0;  // experiment: microseconds by which sub-batch stream i starts after stream i - 1
     int opt_flash_rotate = 1;   // tiled attention: the 64-query chunks of a sequence start their walk over the key tiles at different tiles (k_flash.hip)
     int opt_flash_proj = 1;     // tiled attention + its out-projection + gated residual in ONE launch (k_flash_proj): 0 off (k_flash, then
                                 // k_proj<0> or a deferred projection), 1 (default) when the launch has >= kFlashProjMinJobs workgroups
@@ -642,12 +640,6 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "panel_waves") {
         if (value != 0 && value != 4 && value != 8) return fail(-2, "panel_waves must be 0 (by launch size), 4 or 8");
         c->opt_panel_waves = value;
-    } else if (n == "mlp_cap") {
-        if (value != 0 && value != 1) return fail(-2, "mlp_cap must be 0 or 1");
-        c->opt_mlp_cap = value;
-    } else if (n == "stream_offset") {
-        if (value < 0 || value > 100000) return fail(-2, "stream_offset must be 0..100000 microseconds");
-        c->opt_stream_offset = value;
     } else if (n == "flash_rotate") {
         if (value != 0 && value != 1) return fail(-2, "flash_rotate must be 0 or 1");
         c->opt_flash_rotate = value;
@@ -1091,7 +1083,7 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
     }
     const int pw = p.trace ? 4 : panel_waves_for((nrows + kPanel - 1) / kPanel, r.c->opt_panel_waves, r.c->ncu);
     const std::string cls = std::string(!trunk ? "ipa.mlp" : p.o ? "proj_mlp" : "mlp") + (pw == 8 ? "@p8" : "@p4");
-    { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_mlp(p, r.s, pw, r.c->opt_mlp_cap); }
+    { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_mlp(p, r.s, pw); }
     LAUNCHCHK();
     return 0;
 }
@@ -1427,10 +1419,7 @@ static int euler_body(const Run& r, const std::vector<float>& tg, float* x) {
     // contiguous sub-batch views, view i on stream i % ns (fork after the shared preparation, join at the end)
     mdgen_ctx* c = r.c;
     if (ns > 1) HIPCHK(hipEventRecord(c->ev_fork, r.s));
-    for (int i = 1; i < ns; ++i) {
-        HIPCHK(hipStreamWaitEvent(c->side[i - 1], c->ev_fork, 0));
-        if (c->opt_stream_offset) launch_spin(i * c->opt_stream_offset, c->side[i - 1]);
-    }
+    for (int i = 1; i < ns; ++i) HIPCHK(hipStreamWaitEvent(c->side[i - 1], c->ev_fork, 0));
     int b0 = 0;
     for (int i = 0; i < nv; ++i) {
         const int Bs = r.B / nv + (i < r.B % nv ? 1 : 0);
@@ -1514,7 +1503,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_mlp_cap << 37), (uint64_t)c->opt_stream_offset, (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1574,7 +1563,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_mlp_cap << 37), (uint64_t)c->opt_stream_offset,
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

@@ -1245,18 +1245,15 @@ void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
     else if (mode == 1) hipLaunchKernelGGL(k_proj<1>, dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k_proj<2>, dim3(grid), dim3(256), 0, s, p);
 }
-void launch_mlp(const MlpParams& p, hipStream_t s, int waves, int cap) {
+void launch_mlp(const MlpParams& p, hipStream_t s, int waves) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
     if (waves == 8 && !p.trace) {   // (the phase stamps stay with k_mlp: mdgen_profile_phase_trace selects the four-wave kernel)
         if (p.o) hipLaunchKernelGGL((k_mlp8<true>), dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((k_mlp8<false>), dim3(grid), dim3(512), 0, s, p);
         return;
     }
-    // cap: 2 KiB of dynamic LDS nobody uses -- with the kernel's 80 KiB a second workgroup no longer fits a CU's 160 KiB, which
-    // leaves half of the CU's registers to a workgroup of another kernel (the co-scheduling experiment, option mlp_cap)
-    const unsigned dyn = cap ? 2048u : 0u;
-    if (p.o) hipLaunchKernelGGL((k_mlp<3, true>), dim3(grid), dim3(256), dyn, s, p);
-    else hipLaunchKernelGGL((k_mlp<3>), dim3(grid), dim3(256), dyn, s, p);
+    if (p.o) hipLaunchKernelGGL((k_mlp<3, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_mlp<3>), dim3(grid), dim3(256), 0, s, p);
 }
 void launch_ln_linear(const LnLinearParams& p, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);

@@ -756,14 +756,6 @@ void launch_ipa_init(const float* aa_emb, const int64_t* aatype, const float* re
     hipLaunchKernelGGL(k_ipa_init, dim3((unsigned)((long)ngroups * L)), dim3(384), 0, s, aa_emb, aatype, rel7, w7, b7, h,
                        B, L);
 }
-// One wave that does nothing for `us` microseconds (s_memrealtime ticks at 100 MHz): the experiment option stream_offset delays a
-// sub-batch stream by this much so that the two streams run different kernel types side by side.
-__global__ void k_spin(int us) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(32);
-}
-void launch_spin(int us, hipStream_t s) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, us); }
-
 void launch_write_floats(const float* host_vals, int n, float* dst, hipStream_t s) {
     for (int o = 0; o < n; o += 128) {
         FloatChunk c;

@@ -180,7 +180,7 @@ int panel_waves_for(long grid, int forced, int ncu);   // 4 or 8 waves per 64-ro
 void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre = false, int waves = 4);
 void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
-void launch_mlp(const MlpParams& p, hipStream_t s, int waves = 4, int cap = 0);   // cap: 1 = at most one workgroup per CU (experiment option mlp_cap)
+void launch_mlp(const MlpParams& p, hipStream_t s, int waves = 4);
 void launch_mlp_rows(const MlpRowsParams& p, int nw, hipStream_t s);
 // rowmap (nullable): source row of packed row r (a permutation of the matrix's rows); kappa: K order inside a k-step -- 0
 // natural, 1 rows.h kappa (operand = LayerNorm / GELU registers)
@@ -285,7 +285,6 @@ void launch_ipa_init(const float* aa_emb, const int64_t* aatype, const float* re
                      float* h, int ngroups, int B, int L, hipStream_t s);
 void launch_add_inplace(float* dst, const float* src, long n, hipStream_t s);
 void launch_write_floats(const float* host_vals, int n, float* dst, hipStream_t s);
-void launch_spin(int us, hipStream_t s);
 void launch_rel7(const float* r1, const float* t1, const float* r2, const float* t2, float* out7, long n, hipStream_t s);
 
 // SE(3) / pre / post (k_se3.hip)
