@@ -233,11 +233,15 @@ int32_t mdgen_rollout_euler(mdgen_ctx* ctx, const mdgen_shape* shape, int32_t n_
  * Per-kernel-class timing with hipEvents recorded on the launch stream (bench.py's roofline leg).
  * While enabled, launches are bracketed by event pairs and hipGraph capture/replay is bypassed.
  * `mdgen_profile_report` synchronises `stream`, writes a JSON object
- *   {"<class>": {"count": n, "ms": total_ms}, ...}   into buf (NUL-terminated) and resets the log. */
+ *   {"<class>": {"count": n, "ms": total_ms}, ...}   into buf (NUL-terminated) and resets the log.  Classes of the 64-row panel
+ * kernels that exist in two forms carry "@p4" / "@p8" (four / eight waves per panel; option panel_waves). */
 int32_t mdgen_profile_enable(mdgen_ctx* ctx, int32_t on);
 /* Measurement only: the NEXT trunk MLP launch (the dominant kernel) writes per-wave s_memtime phase stamps into
  * dev_buf ([workgroup*4 + wave][32] uint64; slot meaning: csrc/k_gemm.hip `stamp`).  One-shot; pass NULL to cancel.
- * Only meaningful with profiling enabled or use_graph == 0 (a captured graph would replay the pointer). */
+ * Only meaningful with profiling enabled or use_graph == 0 (a captured graph would replay the pointer).
+ * Which kernel is traced: the row-owner kernel (k_mlp_rows) where the launch takes it, else the FOUR-wave panel kernel k_mlp<3> --
+ * also for launches that would otherwise take the eight-wave k_mlp8 (at most one workgroup per CU), which carries no stamps: a
+ * trace of such a launch measures k_mlp<3>, not the product's kernel for that size. */
 int32_t mdgen_profile_phase_trace(mdgen_ctx* ctx, uint64_t* dev_buf, int64_t capacity_words);
 int32_t mdgen_profile_report(mdgen_ctx* ctx, void* stream, char* buf, size_t buflen);
 

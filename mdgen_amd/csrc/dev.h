@@ -5,10 +5,10 @@
 // correctness path off (MDGEN_DEV_FLASH_NOFALLBACK) or produce wrong values (MDGEN_DEV_ROWS_COALESCED) in a product
 // library, and mdgen_dev_switches() (api.hip) lets a loader see what a given .so was built with.
 //
-//   MDGEN_DEV_FLASH_STAMPS      k_flash: per-wave s_memtime stamps            (scripts/micro/flash_stamps.py)
+//   MDGEN_DEV_FLASH_STAMPS      k_flash / k_flash_proj: per-wave s_memtime stamps (scripts/micro/flash_stamps.py, scripts/r05/fproj_stamps.py)
 //   MDGEN_DEV_FLASH_NOLOAD      k_flash: K / V loads left out, timing only
 //   MDGEN_DEV_FLASH_NOFALLBACK  k_flash: no re-run with the robust loop: shows what the fixed anchor alone does
-//   MDGEN_DEV_QKV_STAMPS        k_ln_qkv: phase stamps                         (scripts/micro/qkv_stamps.py)
+//   MDGEN_DEV_QKV_STAMPS        k_ln_qkv / k_ln_qkv_attn4: phase stamps         (scripts/micro/qkv_stamps.py, scripts/r05/attn4_stamps.py)
 //   MDGEN_DEV_MLP_STAMPX        k_mlp: stamp inside one fc1 stage              (scripts/micro/mlp_stampx.py)
 //   MDGEN_DEV_ROWS_NOGELU       k_mlp_rows: main loop without its VALU work, timing only (values wrong)
 //   MDGEN_DEV_ROWS_COALESCED    k_mlp_rows: row loads as coalesced 1 KiB requests, timing only (values wrong)
@@ -18,7 +18,7 @@
 #pragma once
 
 #if defined(MDGEN_DEV_FLASH_STAMPS) || defined(MDGEN_DEV_FLASH_NOLOAD) || defined(MDGEN_DEV_FLASH_NOFALLBACK) || \
-    defined(MDGEN_DEV_QKV_STAMPS) || defined(MDGEN_DEV_MLP_STAMPX) || defined(MDGEN_DEV_ROWS_NOGELU) ||           \
+    defined(MDGEN_DEV_QKV_STAMPS) ||  defined(MDGEN_DEV_MLP_STAMPX) || defined(MDGEN_DEV_ROWS_NOGELU) ||           \
     defined(MDGEN_DEV_ROWS_COALESCED) || defined(MDGEN_DEV_WIDE_NOLOAD) || defined(MDGEN_DEV_WIDE_NOMMA) ||        \
     defined(MDGEN_DEV_WIDE_NOSTORE) || defined(MDGEN_DEV_WIDE_STAMPS) || \
     defined(MDGEN_DEV_ATTN16_NOEXP) || defined(MDGEN_DEV_ATTN16_NOSTAGE) ||         \

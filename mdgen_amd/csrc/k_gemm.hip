@@ -406,6 +406,10 @@ __global__ __launch_bounds__(512, 1) void k_ln_qkv8(const QkvParams p) {
 
 // PROJ: also run the sub-layer's out-projection and gated residual update here (mha.py:397, latent_model.py:462):
 // the attention output goes straight into the LDS panel as the A operand instead of through HBM.
+// Weight-ring depth (k-steps in flight) of the K and V GEMMs, which run with q / P live.  Deeper rings compile without further
+// spills (3 / 4) or with 8 more spilled dwords (4 / 4) and change nothing: 129.4-132.8 us per launch at cfg-2 for all four
+// combinations on one box (profiles/r05_experiments.txt #9).
+constexpr int kAttn4KPF = 2, kAttn4VPF = 3;
 template <bool PROJ>
 __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     __builtin_amdgcn_sched_barrier(0);
     // ---- K: RoPE in place, then the scores of the 4 keys of the quad + the bias key; softmax -> P (40 registers)
     zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, true, 2>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);   // shallow ring: q is live
+    wave_gemm<2, 3, 24, true, kAttn4KPF>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);   // (q is live)
     ATTN4_STAMP(4);
     load_head_bias(p.bk, w, hh, bb);
     load_rope(rq);
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     __builtin_amdgcn_sched_barrier(0);
     // ---- V (transposed as well: a lane holds features 12 hh .. 12 hh + 11 of each head of its token)
     zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, true, 3>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    wave_gemm<2, 3, 24, true, kAttn4VPF>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     ATTN4_STAMP(7);
     load_head_bias(p.bv, w, hh, bb);
     {

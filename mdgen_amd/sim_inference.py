@@ -14,12 +14,15 @@
 The rollout (sim_inference.py:61-98) stays on the device: each block's last frame becomes the next block's
 conditioning frame through `mdgen_atom14_to_cond` (no D->H->D round trip).  Output, as the reference
 (sim_inference.py:117-119): `{out_dir}/{name}.pdb`, a multi-model PDB of all sampled frames written by
-`mdgen_amd.pdb.atom14_to_pdb` (byte-compatible with `mdgen.utils.atom14_to_pdb`).  `--xtc` needs mdtraj and
-`--no_frames` / `--tps` select other models: accepted and rejected loudly.
+`mdgen_amd.pdb.atom14_to_pdb` (byte-compatible with `mdgen.utils.atom14_to_pdb`).  `--xtc` (sim_inference.py:121-125, and part of
+the README's own forward-simulation command, README.md:72) is accepted: the PDB is always written; where `mdtraj` imports, the
+reference's four lines run as they stand (superposed trajectory -> `{name}.xtc`, the PDB cut to its first frame), where it does not
+(this image) a warning says so and the multi-model PDB stays.  `--no_frames` / `--tps` select other models: rejected loudly.
 """
 from __future__ import annotations
 
 import argparse
+import sys
 import os
 import time
 from typing import Dict, List, Sequence
@@ -105,6 +108,29 @@ def sample_group(model, batch, args):
     return torch.cat(out, 1)
 
 
+_XTC_WARNED = False
+
+
+def write_xtc(pdb_path, xtc_path):
+    """`--xtc` (sim_inference.py:121-125): superpose the sampled trajectory on its first frame, save it as XTC and cut the PDB to
+    that frame.  mdtraj is the reference's dependency for this and is not part of the hot path; without it the multi-model PDB
+    (which holds every frame) is left as written and a warning is printed once.  Returns True if the XTC was written."""
+    global _XTC_WARNED
+    try:
+        import mdtraj
+    except ImportError:
+        if not _XTC_WARNED:
+            print("warning: --xtc needs mdtraj, which is not installed: keeping the multi-model PDB (all frames) and writing no .xtc",
+                  file=sys.stderr)
+            _XTC_WARNED = True
+        return False
+    traj = mdtraj.load(pdb_path)
+    traj.superpose(traj)
+    traj.save(xtc_path)
+    traj[0].save(pdb_path)
+    return True
+
+
 def run(args, model, device, names_seqres, rank=0, world=1, batch_fn=make_group_batch, sync=None, dist=None):
     """The driver proper (sim_inference.py:100-128), given a loaded model: select this process's peptides
     (chunk, rank shard, --pdb_id), group them into batches of equal length, sample every group, write
@@ -136,6 +162,8 @@ def run(args, model, device, names_seqres, rank=0, world=1, batch_fn=make_group_
         for i, n in enumerate(group):
             aat = np.array([restype_order[c] for c in seqres[n]])
             atom14_to_pdb(host[i], aat, os.path.join(args.out_dir, f"{n}.pdb"))
+            if getattr(args, "xtc", False):
+                write_xtc(os.path.join(args.out_dir, f"{n}.pdb"), os.path.join(args.out_dir, f"{n}.xtc"))
             if args.npy:
                 np.save(os.path.join(args.out_dir, f"{n}.npy"), host[i])
     job_s = max_over_ranks(total_s, dist)
@@ -178,8 +206,8 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    if args.no_frames or args.tps or args.xtc:
-        raise SystemExit("--no_frames / --tps / --xtc are outside this build's scope (see DESIGN.md)")
+    if args.no_frames or args.tps:
+        raise SystemExit("--no_frames / --tps are outside this build's scope (see DESIGN.md)")
     import pandas as pd
     from .config import ModelConfig
     from .synthetic import synth_state_dict

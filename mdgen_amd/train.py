@@ -10,6 +10,7 @@ one (the bf16 MFMA kernels of the sampler have no backward counterparts); see DE
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from collections import OrderedDict
 from typing import Optional
 
@@ -164,9 +165,11 @@ class TrainableModel:
         require_cuda(xt, t, target, loss_mask, mask, sr, st, x_cond, x_cond_mask, aatype)
         ws = m._workspace(B, T, L_, 1, False)
         sh = L.Shape(B, T, L_)
-        if self._tape_key != (B, T, L_):
-            nbytes = C.c_size_t()
-            check(lib.mdgen_train_workspace_bytes(m._ctx, C.byref(sh), C.byref(nbytes)))
+        # (the tape's size also depends on the option train_streams: ask every call -- a host-side sum -- and grow when needed)
+        nbytes = C.c_size_t()
+        check(lib.mdgen_train_workspace_bytes(m._ctx, C.byref(sh), C.byref(nbytes)))
+        if self._tape is None or self._tape.numel() < nbytes.value or self._tape_key != (B, T, L_):
+            self._tape = None
             self._tape = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
             self._tape_key = (B, T, L_)
         loss = torch.empty(B, device=self.device)
@@ -192,7 +195,9 @@ class Trainer:
     def __init__(self, wrapper, lr: float = 1e-4, adamw: bool = False, grad_clip: Optional[float] = 1.0,
                  ema_decay: Optional[float] = None, dist=None, state_dict=None):
         self.wrapper = wrapper                    # a NewMDGenWrapper whose .model is replaced by the trainable model's
-        wrapper.trainer = self                    # (load_ema_weights caches the trainer's CURRENT weights, not the loaded ones)
+        # (load_ema_weights caches the trainer's CURRENT weights, not the loaded ones.  A weak reference: wrapper -> trainer ->
+        # wrapper would be a cycle, and `__del__` -> `close()`, which detaches the milestone events, would run only at a cyclic GC)
+        wrapper.trainer = weakref.ref(self)
         sd = state_dict if state_dict is not None else getattr(wrapper, "model_state_dict", None)
         if sd is None:
             raise L.MdgenError("Trainer needs the model's state dict: load the wrapper with load_model_state_dict() / "
@@ -231,7 +236,8 @@ class Trainer:
         if ctx is not None and getattr(ctx, "_ctx", None) and getattr(self, "_events", None):
             lib.mdgen_train_set_milestone_events(ctx._ctx, None, 0)
         self._events = []
-        if getattr(getattr(self, "wrapper", None), "trainer", None) is self:
+        ref = getattr(getattr(self, "wrapper", None), "trainer", None)
+        if ref is not None and ref() in (self, None):
             self.wrapper.trainer = None
 
     def __del__(self):
@@ -293,7 +299,9 @@ class Trainer:
         sd = self.tm.state_dict()
         ckpt = {"state_dict": OrderedDict(("model." + k, v.detach().cpu().clone()) for k, v in sd.items()),
                 "hyper_parameters": {"args": self.wrapper.args},
-                # torch.optim.Adam's own layout (what Lightning stores and the reference's trainer can resume from)
+                # torch.optim.Adam's own layout (what Lightning stores under this key).  NOT a complete Lightning checkpoint: a
+                # Lightning `Trainer.fit(ckpt_path=...)` resume also wants `epoch`, `lr_schedulers`, `loops` and
+                # `pytorch-lightning_version`; this file is for `load_from_checkpoint` (inference) and `Trainer.load_checkpoint`
                 "optimizer_states": [adam_state_to_torch(self.opt.state_dict(), list(trainable_shapes(self.wrapper.cfg)))],
                 "global_step": self.global_step}
         if self.ema is not None:

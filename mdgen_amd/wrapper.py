@@ -81,6 +81,7 @@ class NewMDGenWrapper:
             raise L.MdgenError("load_ema_weights needs the raw weights to restore later: use load_model_state_dict()")
         # the weights to restore are the CURRENT ones: a Trainer attached to this wrapper has moved on from what was loaded
         tr = getattr(self, "trainer", None)
+        tr = tr() if tr is not None else None          # (`Trainer` leaves a weak reference here)
         self.cached_weights = ({k: v.detach().clone() for k, v in tr.tm.state_dict().items()} if tr is not None
                                else self.model_state_dict)
         self.model.load_state_dict({k: v for k, v in ema_params.items()})

@@ -245,3 +245,32 @@ def test_bench_self_launches_its_ranks_when_run_without_a_launcher():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--fake-sampler"], capture_output=True, text=True,
                         timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=root)
     assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
+
+
+def test_cli_accepts_the_readme_flags_incl_xtc(tmp_path, capsys):
+    """The reference README's forward-simulation command line (README.md:72: `--num_rollouts 10 --num_frames 1000 --xtc`) must
+    run in the drop-in CLI: `--xtc` is accepted, the multi-model PDB is written, and the XTC (sim_inference.py:121-125, mdtraj)
+    is written where mdtraj imports -- here it does not, so a warning is printed once and the PDB keeps every frame."""
+    import numpy as np
+    from mdgen_amd import sim_inference as cli
+    from mdgen_amd.geometry import restype_order
+    data = tmp_path / "data"
+    data.mkdir()
+    np.save(data / "pA.npy", np.zeros((2, 4, 14, 3), np.float16))
+    out = tmp_path / "out"
+    args = cli.build_parser().parse_args(["--data_dir", str(data), "--out_dir", str(out), "--num_frames", "3", "--num_rollouts", "2",
+                                          "--xtc", "--suffix", ""])
+    assert args.xtc
+
+    def batch_fn(names, arrs, seqres, device):
+        return {"seqres": torch.tensor([[restype_order[c] for c in seqres[n]] for n in names]),
+                "tag": torch.tensor([float(ord(n[1])) for n in names])}
+    res = cli.run(args, _FakeSampler(), "cpu", {"pA": "FLRH"}, batch_fn=batch_fn)
+    assert res["frames"] == 6
+    pdb = open(out / "pA.pdb").read()
+    try:
+        import mdtraj  # noqa: F401
+        assert (out / "pA.xtc").exists() and pdb.count("MODEL") <= 1
+    except ImportError:
+        assert pdb.count("MODEL") == 6 and not (out / "pA.xtc").exists()
+        assert "mdtraj" in capsys.readouterr().err
