@@ -17,17 +17,6 @@ constexpr int kPanelBytes = kPanel * kRowB;
 // holds, for its token, 12 features of each head = six rotary pairs (i, i+12): RoPE is lane-local
 // and the accumulators ARE the attention MFMA fragments (DESIGN.md "fragment layout").
 // =================================================================================================
-// Experiment (profiles/r05_experiments.txt #10): the two workgroups that share a CU run the same phases in step -- both in a GEMM
-// (half the matrix pipe each), both in the HBM phases (matrix pipe idle).  Delaying one of them by about one phase would let the
-// GEMM of one overlap the prologue / epilogue of the other.  pattern 0: odd workgroups, 1: the second 256 of every 512.
-__device__ __forceinline__ void stagger_start(int cycles, int pattern) {
-    if (cycles <= 0) return;
-    const bool late = pattern == 0 ? (blockIdx.x & 1) : ((blockIdx.x >> 8) & 1);
-    if (!late) return;
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)cycles) __builtin_amdgcn_s_sleep(16);
-}
-
 template <bool ROPE>
 __device__ __forceinline__ void epilogue_heads_T(const f32x16* acc /*[3 ft][2 tt]*/, const PanelRows* pr, int w,
                                                  const float* __restrict__ bias_perm, const float* __restrict__ rope,
@@ -274,7 +263,6 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv(const QkvParams p) {
         }
     }
     QKV_STAMP(0);
-    if (!SMALL && !PRE) stagger_start(p.stagger, p.stagger_pattern);
     __syncthreads();
     const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id();
     f32x16 acc[6];
@@ -432,7 +420,6 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
     unsigned char* panel = smem + sizeof(PanelRows);
     ATTN4_STAMP(0);
-    stagger_start(p.stagger, p.stagger_pattern);
     setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
     __syncthreads();
     prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);

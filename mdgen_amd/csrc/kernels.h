@@ -18,7 +18,6 @@ struct QkvParams {
     int panels_per_seq;
     uint32_t* vmask;       // FLASH layout: key-validity words [seq][vmask_stride], one per 32-key tile (see flash_vmask)
     int vmask_stride;
-    int stagger, stagger_pattern;   // experiment (options stagger / stagger_pattern): start delay in shader cycles of every second workgroup
     // k_ln_qkv_attn4 only (residue axis, L == 4: attention inside the QKV kernel)
     const float *bias_k, *bias_v;   // learned bias key / value [384]
     MaskMap mk;                     // key-padding mask
