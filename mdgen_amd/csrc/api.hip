@@ -139,11 +139,6 @@ struct mdgen_ctx {
                                 // eight waves where a launch is at most one workgroup per CU, 4 / 8 force one form (tests, A/B runs)
     int ncu = 256;              // compute units of the device the context was created on (hipDeviceAttributeMultiprocessorCount)
     int opt_flash_rotate = 1;   // tiled attention: the 64-query chunks of a sequence start their walk over the key tiles at different tiles (k_flash.hip)
-    int opt_flash_proj_form = 1; // ... which fused form: 1 (default) k_flash_la -- k_flash's job grain (4 heads x 64 queries, three workgroups per CU), the
-                                // projection done by the last of a panel's four workgroups to arrive; 0 k_flash_proj -- one workgroup owns a panel for all 16 heads
-    unsigned* flash_counters = nullptr;   // k_flash_la's arrival counters: one per (sequence, 64-query chunk), indexed from token / 4 of a view
-    size_t flash_counters_cap = 0;        // (entries)
-    bool xcd_round_robin = false;         // placement probe: workgroups with equal blockIdx % 8 share an XCD (k_flash_la relies on it)
     int opt_flash_proj = 1;     // tiled attention + its out-projection + gated residual in ONE launch (k_flash_proj): 0 off (k_flash, then
                                 // k_proj<0> or a deferred projection), 1 (default) when the launch has >= kFlashProjMinJobs workgroups
                                 // of (sequence, 64 queries), 2 always
@@ -407,19 +402,6 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0)
             c->ncu = ncu;
     }
-    {   // placement probe for k_flash_la: do workgroups with the same blockIdx % 8 run on the same XCD?
-        int* d = nullptr;
-        int h[64];
-        if (hipMalloc((void**)&d, sizeof(h)) == hipSuccess) {
-            launch_xcc_probe(d, 64, nullptr);
-            if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-                bool ok = true;
-                for (int i = 8; i < 64; ++i) ok = ok && h[i] == h[i & 7];
-                c->xcd_round_robin = ok;
-            }
-            (void)hipFree(d);
-        }
-    }
     c->d = *d;
     c->nl = d->num_layers;
     c->D = d->latent_dim;
@@ -572,7 +554,6 @@ extern "C" int32_t mdgen_ctx_destroy(mdgen_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (hipEvent_t e : c->train_ev) (void)hipEventDestroy(e);
     if (c->train_side) (void)hipStreamDestroy(c->train_side);
-    if (c->flash_counters) (void)hipFree(c->flash_counters);
     for (int i = 0; i < mdgen_ctx::kMaxSide; ++i) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
@@ -662,9 +643,6 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "flash_rotate") {
         if (value != 0 && value != 1) return fail(-2, "flash_rotate must be 0 or 1");
         c->opt_flash_rotate = value;
-    } else if (n == "flash_proj_form") {
-        if (value != 0 && value != 1) return fail(-2, "flash_proj_form must be 0 (k_flash_proj) or 1 (k_flash_la)");
-        c->opt_flash_proj_form = value;
     } else if (n == "flash_proj") {
         if (value < 0 || value > 2) return fail(-2, "flash_proj must be 0 (off), 1 (launches that fill the chip) or 2 (always)");
         c->opt_flash_proj = value;
@@ -799,7 +777,6 @@ struct Run {
     float* modp;                 // adaLN table row of (step 0, first batch element of this view)
     const float* ipa_out_p;      // IPA table of (step 0, first batch element of this view)
     long ipa_step_stride;        // floats between consecutive steps of the IPA table
-    long tok0 = 0;               // first token of this view within the whole call (k_flash_la's counters are indexed from it)
     float* h() const { return hp; }
     float* mod() const { return modp; }
 };
@@ -830,7 +807,6 @@ static Run sub_run(const Run& r, int b0, int Bs, hipStream_t stream) {
     v.vfp = r.vfp + (size_t)b0 * per_b_kv;
     v.modp = r.modp + (long)b0 * r.mod_group_stride;
     v.ipa_out_p = r.ipa_out_p + (long)b0 * r.L * kC;
-    v.tok0 = r.tok0 + (long)b0 * tl;
     return v;
 }
 
@@ -1028,11 +1004,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
             fp.gate_chunk = gate;
             fp.wo = m.wo;
             fp.bo = m.bo;
-            // the last-arriver form: trunk launches only (the IPA stack's views share no token range with them), and only where
-            // the placement probe has confirmed that a panel's four workgroups meet in one L2
-            if (trunk && r.c->opt_flash_proj_form == 1 && r.c->xcd_round_robin && r.c->flash_counters)
-                fp.counters = r.c->flash_counters + r.tok0 / 4;
-            { ProfScope ps(r.c, !trunk ? "ipa.flash_proj" : fp.counters ? (residue_axis ? "flash_la_L" : "flash_la_T") : residue_axis ? "flash_proj_L" : "flash_proj_T", r.s); launch_flash_proj(fp, r.s); }
+            { ProfScope ps(r.c, !trunk ? "ipa.flash_proj" : residue_axis ? "flash_proj_L" : "flash_proj_T", r.s); launch_flash_proj(fp, r.s); }
             LAUNCHCHK();
             return 0;
         }
@@ -1208,8 +1180,6 @@ static int prepare(const Run& r, const float* t_dev, const float* t_host) {
     // K/V fragment regions: key slots past a sequence's end are never written by k_ln_qkv but are read (and
     // masked to P = 0) by k_flash, so they must hold FINITE values: zero them once per call.
     HIPCHK(hipMemsetAsync(r.ws + r.lay.kf, 0, r.lay.obuf - r.lay.kf, r.s));
-    // (the last arriver of a panel leaves its counter at zero; a call that was cut short must not leave the next one a count)
-    if (c->flash_counters) HIPCHK(hipMemsetAsync(c->flash_counters, 0, (size_t)(r.N / 4 + 256) * sizeof(unsigned), r.s));
     if (t_dev) {
         if (r.t_shared && r.B > 1) return fail(-2, "device t rows require t_shared == 0 or B == 1");
         launch_temb(t_dev, R, c->d.time_multiplier, c->t_w0, c->t_b0, c->t_w2, c->t_b2, silu, r.s);
@@ -1371,17 +1341,6 @@ static int make_run(Run* r, mdgen_ctx* c, const mdgen_shape* sh, int S, int t_sh
     r->modp = (float*)(r->ws + r->lay.mod);
     r->ipa_out_p = (const float*)(r->ws + r->lay.ipa_out);
     r->ipa_step_stride = (long)sh->B * sh->L * kC;
-    {   // arrival counters of k_flash_la: (sequence, 64-query chunk) pairs of a view number < its tokens / 4 (sequences of > 8 positions)
-        const size_t want = (size_t)(r->N / 4 + 256);
-        if (c->flash_counters_cap < want) {
-            if (c->flash_counters) (void)hipFree(c->flash_counters);
-            c->flash_counters = nullptr;
-            c->flash_counters_cap = 0;
-            HIPCHK(hipMalloc((void**)&c->flash_counters, want * sizeof(unsigned)));
-            HIPCHK(hipMemset(c->flash_counters, 0, want * sizeof(unsigned)));
-            c->flash_counters_cap = want;
-        }
-    }
     return 0;
 }
 
@@ -1544,7 +1503,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 37), (uint64_t)c->flash_counters, (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1604,7 +1563,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 37), (uint64_t)c->flash_counters,
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

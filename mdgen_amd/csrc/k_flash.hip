@@ -644,72 +644,6 @@ __global__ __launch_bounds__(256, 2) void k_flash_proj(const FlashProjParams p) 
     FPROJ_STAMP(9, __builtin_amdgcn_s_memrealtime());
 }
 
-// =================================================================================================
-// k_flash_la: k_flash (one workgroup = 4 heads x 64 queries, three workgroups per CU: the finer job grain and the third wave per
-// SIMD the attention loop wants) + the out-projection + gated residual done by the LAST ARRIVER of the four workgroups that share a
-// (sequence, 64-query chunk).  Each workgroup writes its heads' bf16 output rows to the attention-output buffer as k_flash does,
-// waits for its stores to reach L2, and bumps the panel's counter; the one that finds 3 there reads the whole 64 x 384 panel back
-// (from L2: the other three wrote it moments ago), and runs k_proj<0>'s GEMM + staged residual epilogue in 48 KB of LDS.  Nobody
-// waits for anybody (no spinning, no deadlock), and the projection is computed by ONE workgroup from the complete panel in a
-// fixed order: bitwise the values of k_flash + k_proj<0>, whichever workgroup happens to be last.
-//
-// Memory ordering.  The four workgroups of a panel are placed on ONE XCD (block b runs on XCD b % 8: the same residue), so the
-// panel's bytes meet in that XCD's L2 -- the L2s of different XCDs are not coherent inside a kernel, and an agent-scope release
-// would have to write the whole L2 back.  Producer: s_waitcnt vmcnt(0) (stores are acknowledged by L2), workgroup barrier, then an
-// agent-scope atomic add by one thread.  Consumer: agent-scope acquire fence (invalidates this CU's vector cache, which may still
-// hold the panel's lines from the previous layer), then ordinary loads.  The residue -> XCD assumption is verified once per
-// context (mdgen_ctx_create: a probe kernel reads HW_REG_XCC_ID per workgroup); where it does not hold the launcher refuses this
-// kernel and the caller falls back to k_flash_proj.
-// =================================================================================================
-__global__ __launch_bounds__(256, 3) void k_flash_la(const FlashProjParams p) {
-    constexpr int NQ = 2;
-    static_assert(32 * NQ == kPanel, "one workgroup = one 64-row panel");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanel * kC * 2];
-    __shared__ int s_last;
-    const int w = __builtin_amdgcn_readfirstlane(wave_id());
-    const int nqc = (p.f.ax.len + kPanel - 1) / kPanel;
-    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int qc = rest % nqc, r2 = rest / nqc;
-    const int hg = r2 & 3, seq = (r2 >> 2) * 8 + xcd;   // the four head groups of a (sequence, chunk): same XCD
-    if (seq >= p.f.ax.nseq) return;
-    const int head = 4 * hg + w;
-    {
-        FlashPre<NQ> pre;
-        flash_prefetch<NQ>(p.f, seq, head, qc, pre);
-        flash_job<NQ>(p.f, seq, head, qc, w, pre, FlashStoreGlobal{p.f.obuf, p.f.ax, seq, head});
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's output rows have been acknowledged by L2
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned* c = p.counters + (long)seq * nqc + qc;
-        const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old == 3u;
-        if (old == 3u) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // no stale copy of the panel in this CU's vector cache
-    PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
-    unsigned char* panel = smem + sizeof(PanelRows);
-    setup_rows_axis(pr, p.f.ax, seq, qc * kPanel, p.mm);
-    __syncthreads();
-    prologue_bf16<kC>(panel, pr, p.f.obuf);
-    __syncthreads();
-    const int lane = lane_id();
-    f32x16 acc[6];
-    zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, false, 2>(panel, kC * 2, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
-    __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
-    epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
-                                  p.h);
-}
-
-// which XCC (XCD) a workgroup runs on: out[blockIdx.x] = HW_REG_XCC_ID[3:0] (mdgen_ctx_create's placement probe)
-__global__ void k_xcc_probe(int* out) {
-    if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);   // 4 bits at offset 0 of register 20
-}
-void launch_xcc_probe(int* out, int nblocks, hipStream_t s) { hipLaunchKernelGGL(k_xcc_probe, dim3(nblocks), dim3(64), 0, s, out); }
-
 // Measured (cfg-2 / cfg-4, same box, back to back): NQ = 4 runs 160-162 / 76 us, NQ = 2 160-164 / 76 us -- a tie; 2 keeps
 // three waves per SIMD and is faster on short sequences (IPA stack: 10 vs 14 us).
 #ifndef MDGEN_FLASH_NQ
@@ -728,8 +662,7 @@ long flash_proj_jobs(const AxisMap& ax) { return (long)ax.nseq * ((ax.len + kPan
 void launch_flash_proj(const FlashProjParams& p, hipStream_t s) {
     const int nqc = (p.f.ax.len + kPanel - 1) / kPanel;
     const int nseq8 = (p.f.ax.nseq + 7) / 8;   // sequences, in groups of 8 (one per XCD)
-    if (p.counters) hipLaunchKernelGGL(k_flash_la, dim3(nseq8 * nqc * 4 * 8), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_flash_proj, dim3(nseq8 * nqc * 8), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_flash_proj, dim3(nseq8 * nqc * 8), dim3(256), 0, s, p);
 }
 
 }  // namespace mdg

@@ -138,7 +138,6 @@ struct FlashProjParams {
     int gate_chunk;
     const bf16x8* wo;       // packed out-projection weights [12 ftile][24 kstep][64 lane][8]
     const float* bo;
-    unsigned* counters;     // k_flash_la: one arrival counter per (sequence, 64-query chunk), zero before the launch; null: k_flash_proj
 };
 
 struct EmbedParams {
@@ -191,8 +190,7 @@ void launch_ln_linear(const LnLinearParams& p, hipStream_t s);
 void launch_final(const FinalParams& p, hipStream_t s);
 void launch_flash(const FlashParams& p, hipStream_t s);
 long flash_proj_jobs(const AxisMap& ax);
-void launch_flash_proj(const FlashProjParams& p, hipStream_t s);   // p.counters != null: the last-arriver form (k_flash_la)
-void launch_xcc_probe(int* out, int nblocks, hipStream_t s);
+void launch_flash_proj(const FlashProjParams& p, hipStream_t s);
 void launch_pack_embed(const float* w, int D, float* pack, hipStream_t s);   // pack: kEmbPackFloats floats
 constexpr int kEmbPackFloats = 4 * 3 * 14 * 64;
 void launch_embed(const EmbedParams& p, hipStream_t s);

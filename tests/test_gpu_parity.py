@@ -2307,10 +2307,8 @@ def _profiled_forward(m, dkw, poison=True):
 @pytest.mark.parametrize("shape", [(1, 130, 9, 1), (2, 64, 33, 0), (1, 40, 96, 5), (2, 1000, 4, 0), (1, 250, 64, 3)],
                          ids=["T130_L9", "T64_L33", "T40_L96", "T1000_L4", "T250_L64"])
 def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
-    """Option `flash_proj` (round 5): the tiled attention + the sub-layer's out-projection + gated residual in ONE launch
-    (mha.py:359-397, latent_model.py:462,476) -- `flash_proj_form` 1 (default) k_flash_la: k_flash's workgroups (4 heads x 64
-    queries), the projection of a 64-query panel done by the last of its four workgroups to arrive; 0 k_flash_proj: one
-    workgroup owns the panel for all 16 heads -- against (a) the CPU oracle
+    """Option `flash_proj` (round 5): the tiled attention of all 16 heads for 64 queries of a sequence + the sub-layer's
+    out-projection + gated residual in ONE launch (k_flash_proj; mha.py:359-397, latent_model.py:462,476) against (a) the CPU oracle
     at the bf16 gate, every trace, and (b) the separate kernels it replaces (k_flash, then k_proj<0> or a projection deferred into
     the next kernel): same operands, same summation order -> equal to fp32 rounding.  Both key-tile walk orders (`flash_rotate`)
     and both softmax loops (`attention_path` 0 / 1).  Shapes: a partial last 64-query chunk whose second tile is past the
@@ -2323,11 +2321,8 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
     cfg, sd, kw, dkw = _fwd_case(B, T, L, n_pad, 500 + T + L)
     ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
     outs = {}
-    for key, opts in (("separate", {"flash_proj": 0}), ("last arriver", {"flash_proj": 2, "flash_proj_form": 1}),
-                      ("one owner", {"flash_proj": 2, "flash_proj_form": 0}),
-                      ("last arriver, natural tile order", {"flash_proj": 2, "flash_rotate": 0}),
-                      ("last arriver, robust loop", {"flash_proj": 2, "attention_path": 1}),
-                      ("one owner, robust loop", {"flash_proj": 2, "flash_proj_form": 0, "attention_path": 1})):
+    for key, opts in (("separate", {"flash_proj": 0}), ("fused", {"flash_proj": 2}), ("fused, natural tile order", {"flash_proj": 2, "flash_rotate": 0}),
+                      ("fused, robust loop", {"flash_proj": 2, "attention_path": 1})):
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
         for k, v in opts.items():
@@ -2340,27 +2335,21 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
         for k, v in rep.items():
             assert v < TOL_FWD, (key, k, v)
         fused = key != "separate"
-        la = key.startswith("last arriver")
-        assert ("flash_la_T" in ran) == la and ("flash_proj_T" in ran) == (fused and not la) and ("flash_T" in ran) != fused, ran
+        assert ("flash_proj_T" in ran) == fused and ("flash_T" in ran) != fused, ran
         if L > 8:
-            assert ("flash_la_L" in ran) == la and ("flash_proj_L" in ran) == (fused and not la), ran
-            assert ("ipa.flash_proj" in ran) == fused, ran   # (the IPA stack's launches take the one-owner form: no counters there)
+            assert ("flash_proj_L" in ran) == fused and ("ipa.flash_proj" in ran) == fused, ran
         if fused:   # nothing left to project: no k_proj<0>, no projection deferred into the next kernel
             assert not any(k.startswith(("proj_T", "proj_L", "projL_qkvT", "proj_mlp")) for k in ran), ran
         outs[key] = (out.cpu(), tr[f"h{cfg.num_layers}"].cpu())
-        # the last-arriver form leaves every arrival counter at zero (the next launch, and the next call, count from there), and a
-        # second call on the same context gives the same bits
-        out_again = m.forward(**dkw)
-        assert torch.equal(out_again, out), key
+        assert torch.equal(m.forward(**dkw), out), key   # a second call on the same context: the same bits
         del m
-    for key in ("last arriver", "one owner", "last arriver, natural tile order"):
+    for key in ("fused", "fused, natural tile order"):
         e_out, e_h = rel_l2(outs[key][0], outs["separate"][0]), rel_l2(outs[key][1], outs["separate"][1])
         print(shape, f"{key} vs separate kernels: out {e_out:.2e} h {e_h:.2e} equal {torch.equal(outs[key][0], outs['separate'][0])}")
         # (`flash_rotate` changes the order in which a query's keys are summed: fp32 rounding, now and then one bf16 step of an
-        # attention output; the default walks the tiles in the same rotated order in all three kernels)
-        assert (e_out < 2e-5 and e_h < 2e-5) if "natural" not in key else (e_out < 2e-3 and e_h < 2e-3)
-    assert rel_l2(outs["last arriver, robust loop"][0], outs["last arriver"][0]) < 6e-3   # (P rounded to bf16 around a different shift)
-    assert torch.equal(outs["one owner, robust loop"][0], outs["last arriver, robust loop"][0])
+        # attention output; the default walks the tiles in the same rotated order in both kernels)
+        assert (e_out < 2e-5 and e_h < 2e-5) if key == "fused" else (e_out < 2e-3 and e_h < 2e-3)
+    assert rel_l2(outs["fused, robust loop"][0], outs["fused"][0]) < 6e-3   # (P rounded to bf16 around a different shift)
     if n_pad:   # padded residues never influence the valid ones
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
@@ -2381,10 +2370,10 @@ def test_flash_proj_is_the_default_where_the_launch_fills_the_chip():
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
         out, _, ran = _profiled_forward(m, dkw, poison=False)
-        assert ("flash_la_T" in ran) == want and ("flash_T" in ran) != want, (B, ran)
+        assert ("flash_proj_T" in ran) == want and ("flash_T" in ran) != want, (B, ran)
         m.set_option("flash_proj", 0)
         out0, _, ran0 = _profiled_forward(m, dkw, poison=False)
-        assert "flash_T" in ran0 and "flash_la_T" not in ran0 and "flash_proj_T" not in ran0
+        assert "flash_T" in ran0 and "flash_proj_T" not in ran0
         e = rel_l2(out, out0)
         print(f"B {B}: default {sorted(k for k in ran if 'flash' in k)} vs flash_proj 0: {e:.2e}")
         assert torch.isfinite(out).all() and e < 2e-5   # (same operands, same summation order)
@@ -2460,50 +2449,3 @@ def test_two_stream_views_in_the_panel_window_match_one_stream():
     e = rel_l2(a, outs["one stream, defaults"][0])
     print(f"two 313-panel views vs one 625-panel view (row-owner MLP): {e:.2e}")
     assert e < 3e-3
-
-
-def test_last_arriver_projection_is_race_free_at_full_size():
-    """k_flash_la hands a panel's attention output from three workgroups to a fourth through L2 (arrival counter, no spinning).
-    A stale or missing row would change bits: at the headline size (B 16 x T 1000 x L 4, two sub-batch streams, graph replay,
-    S = 4) and at ATLAS's (B 1 x T 250 x L 256, both axes tiled) the rollout must equal, bit for bit, the one-owner form's
-    (`flash_proj_form` 0: no cross-workgroup traffic) on every one of several repeats -- and the placement probe the kernel relies
-    on (workgroups with equal blockIdx % 8 share an XCD) must have passed on this device, or the library would not use it."""
-    from mdgen_amd.config import ModelConfig
-    from mdgen_amd.model import LatentMDGenModel
-    from mdgen_amd.synthetic import synth_state_dict
-    dev = _cuda()
-    for B, T, L, n_pad in ((16, 1000, 4, 0), (1, 250, 256, 16)):
-        cfg = ModelConfig.forward_sim(num_frames=T, crop=max(L, 4))
-        sd = synth_state_dict(cfg, 2)
-        gen = torch.Generator().manual_seed(31 + L)
-        zs = torch.randn(B, T, L, 21, generator=gen).to(dev)
-        mask = torch.ones(B, T, L)
-        if n_pad:
-            mask[:, :, L - n_pad:] = 0
-        mask = mask.to(dev)
-        q = torch.randn(B, L, 4, generator=gen)
-        from mdgen_amd.rigid_utils import Rotation
-        R = Rotation(quats=(q / q.norm(dim=-1, keepdim=True)).to(dev)).get_rot_mats()
-        tr_ = torch.cumsum(2.2 * torch.randn(B, L, 3, generator=gen), 1).to(dev)
-        cm = torch.zeros(B, T, L, dtype=torch.long, device=dev)
-        cm[:, 0] = 1
-        xc = torch.where(cm.unsqueeze(-1).bool(), torch.randn(B, T, L, 21, generator=gen).to(dev), torch.zeros((), device=dev))
-        aat = torch.randint(0, 20, (B, L), generator=gen).to(dev)
-        kw = dict(mask=mask, start_frames=(R, tr_), x_cond=xc, x_cond_mask=cm, aatype=aat)
-        outs = {}
-        for form in (0, 1):
-            m = LatentMDGenModel(cfg)
-            m.load_state_dict(sd)
-            m.set_option("flash_proj_form", form)
-            m.profile(True)
-            m.sample_euler(zs, 1, use_graph=False, **kw)
-            ran = set(m.profile_report())
-            m.profile(False)
-            assert ("flash_la_T" in ran) == (form == 1) and ("flash_proj_T" in ran) == (form == 0), ran
-            outs[form] = [m.sample_euler(zs, 4, use_graph=True, **kw) for _ in range(4)]
-            torch.cuda.synchronize()
-            del m
-        ref = outs[0][0]
-        assert torch.isfinite(ref).all()
-        for rep in outs[0][1:] + outs[1]:
-            assert torch.equal(rep, ref), (B, T, L)
