@@ -129,12 +129,6 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      for launches of >= 512 such workgroups (cfg-2, ATLAS), 0 never (k_flash, then k_proj<0> or a projection
  *                      deferred into the next kernel per fuse_proj / fuse_proj_qkv), 2 always.  Same values as the separate
  *                      kernels (same operands, same summation order).
- *   "split_sample"     1 (default) / 0: Euler rollouts of ONE sample (B == 1: what the reference's ATLAS command runs, README.md:87)
- *                      whose halves still fill the chip run as two views inside the sample on two streams -- frame halves for the
- *                      embedding, the residue-axis sub-layer, the MLP and the final layer, residue halves for the temporal sub-layer
- *                      (no phase couples tokens across its own cut), with a stream barrier before and after the temporal sub-layer
- *                      of every layer.  Same kernels on the same panels: bit-identical to the one-stream run.  Needs L, T > 8 and
- *                      even, "streams" >= 2, "flash_proj" != 0.
  *   "flash_rotate"     1 (default) / 0: tiled attention, fixed-anchor loop: the 64-query chunks of a sequence walk its key tiles from
  *                      different starting tiles (chunk c of n starts at tile c * tiles / n and wraps): chunks that start together then
  *                      miss on different fragments instead of queueing behind one chain of HBM misses.  A sum over keys: same
@@ -264,10 +258,6 @@ int32_t mdgen_debug_view_plan(const mdgen_shape* shape, int32_t streams, int32_t
  *   perm_qk[((w*2+h)*4+hd)*12+e], perm_vsmall[...] = source feature of lane-ordered bias slot. */
 int32_t mdgen_debug_layout_maps(int32_t* map_qk, int32_t* map_vflash, int32_t* map_vsmall,
                                 int32_t* perm_qk, int32_t* perm_vsmall);
-
-/* 1 if an Euler rollout (mdgen_sample_euler / mdgen_rollout_euler) of this shape would run as two views INSIDE the sample with the
- * context's current options (B == 1, both axes on the tiled-attention path, halves that fill the chip: option split_sample), else 0. */
-int32_t mdgen_debug_split_sample(mdgen_ctx* ctx, const mdgen_shape* shape);
 
 /* Host-only (no GPU): the weight-fragment stream of the row-owner MLP kernel (csrc/k_rows.hip), for layout tests.
  * out[f] = mat << 16 | row_tile << 8 | k_step for fragment f (2304 of them); mat 0 = fc1 (layers.py:77-84 `fc1`), 1 = fc2.

@@ -15,7 +15,7 @@ ABI_VERSION = 5   # include/mdgen_amd.h MDGEN_ABI_VERSION
 EXPORTS = [
     "mdgen_last_error", "mdgen_abi_version", "mdgen_dev_build", "mdgen_ctx_create", "mdgen_ctx_destroy", "mdgen_ctx_set_weight",
     "mdgen_ctx_finalize", "mdgen_ctx_set_option", "mdgen_debug_view_plan", "mdgen_ctx_num_weights", "mdgen_ctx_weight_name", "mdgen_workspace_layout",
-    "mdgen_denoiser_forward", "mdgen_sample_euler", "mdgen_rollout_euler", "mdgen_profile_enable", "mdgen_profile_report", "mdgen_profile_phase_trace", "mdgen_debug_layout_maps", "mdgen_debug_mlp_stream_table", "mdgen_debug_split_sample", "mdgen_debug_train_linear", "mdgen_debug_train_dw", "mdgen_debug_train_attention",
+    "mdgen_denoiser_forward", "mdgen_sample_euler", "mdgen_rollout_euler", "mdgen_profile_enable", "mdgen_profile_report", "mdgen_profile_phase_trace", "mdgen_debug_layout_maps", "mdgen_debug_mlp_stream_table", "mdgen_debug_train_linear", "mdgen_debug_train_dw", "mdgen_debug_train_attention",
     "mdgen_rigid_compose", "mdgen_rigid_invert",
     "mdgen_rigid_apply", "mdgen_quat_to_rot", "mdgen_rot_to_quat", "mdgen_prep_latents",
     "mdgen_samples_to_atom14", "mdgen_atom14_to_cond", "mdgen_path_plan", "mdgen_masked_mse", "mdgen_from_3_points",
@@ -75,7 +75,6 @@ def _load():
     lib.mdgen_profile_report.argtypes = [vp, vp, C.c_char_p, sz]
     lib.mdgen_debug_layout_maps.argtypes = [vp] * 5
     lib.mdgen_debug_mlp_stream_table.argtypes = [vp, i32]
-    lib.mdgen_debug_split_sample.argtypes = [vp, C.POINTER(Shape)]
     lib.mdgen_debug_train_linear.argtypes = [i32, vp, i32, vp, i32, vp, i64, i32, i32, vp, i32, vp, vp]
     lib.mdgen_debug_train_dw.argtypes = [i32, vp, i32, vp, i32, i64, i32, i32, vp, vp, vp, i64, vp]
     lib.mdgen_debug_train_attention.argtypes = [i32, vp, i64, i32, i32, i32, i32, i32, i32] + [vp] * 11

@@ -139,8 +139,6 @@ struct mdgen_ctx {
                                 // eight waves where a launch is at most one workgroup per CU, 4 / 8 force one form (tests, A/B runs)
     int ncu = 256;              // compute units of the device the context was created on (hipDeviceAttributeMultiprocessorCount)
     int opt_flash_rotate = 1;   // tiled attention: the 64-query chunks of a sequence start their walk over the key tiles at different tiles (k_flash.hip)
-    int opt_split_sample = 1;   // B == 1 rollouts whose sample fills the chip twice over (ATLAS): the sample itself is cut in two views on two
-                                // streams -- frame halves for the residue axis / MLP, residue halves for the temporal axis (euler_steps_split)
     int opt_flash_proj = 1;     // tiled attention + its out-projection + gated residual in ONE launch (k_flash_proj): 0 off (k_flash, then
                                 // k_proj<0> or a deferred projection), 1 (default) when the launch has >= kFlashProjMinJobs workgroups
                                 // of (sequence, 64 queries), 2 always
@@ -645,9 +643,6 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "flash_rotate") {
         if (value != 0 && value != 1) return fail(-2, "flash_rotate must be 0 or 1");
         c->opt_flash_rotate = value;
-    } else if (n == "split_sample") {
-        if (value != 0 && value != 1) return fail(-2, "split_sample must be 0 or 1");
-        c->opt_split_sample = value;
     } else if (n == "flash_proj") {
         if (value < 0 || value > 2) return fail(-2, "flash_proj must be 0 (off), 1 (launches that fill the chip) or 2 (always)");
         c->opt_flash_proj = value;
@@ -782,7 +777,6 @@ struct Run {
     float* modp;                 // adaLN table row of (step 0, first batch element of this view)
     const float* ipa_out_p;      // IPA table of (step 0, first batch element of this view)
     long ipa_step_stride;        // floats between consecutive steps of the IPA table
-    bool half_view = false;      // one of the two intra-sample views of euler_steps_split: half the jobs of a launch, the other half beside it
     float* h() const { return hp; }
     float* mod() const { return modp; }
 };
@@ -888,10 +882,8 @@ static int check_launch_rows(long nrows) {
 // workgroups.  It pays where those still fill the chip (cfg-2: 1024 per launch, ATLAS: 1000 / 1024); small launches (B = 1: 64,
 // the IPA stack) keep the finer-grained k_flash + projection.
 constexpr long kFlashProjMinJobs = 512;
-static bool flash_proj_on(const Run& r, const AxisMap& ax) {
-    const mdgen_ctx* c = r.c;
-    const long jobs = flash_proj_jobs(ax) * (r.half_view ? 2 : 1);   // (a half view runs beside its other half)
-    return c->opt_precision == 16 && (c->opt_flash_proj == 2 || (c->opt_flash_proj == 1 && jobs >= kFlashProjMinJobs));
+static bool flash_proj_on(const mdgen_ctx* c, const AxisMap& ax) {
+    return c->opt_precision == 16 && (c->opt_flash_proj == 2 || (c->opt_flash_proj == 1 && flash_proj_jobs(ax) >= kFlashProjMinJobs));
 }
 
 // `defer`: when non-null and the sub-layer takes the tiled-attention path, its out-projection is NOT launched; *defer receives
@@ -1003,7 +995,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         f.rotate = r.c->opt_flash_rotate;
         f.vmask = q.vmask;
         f.vmask_stride = q.vmask_stride;
-        if (flash_proj_on(r, ax)) {
+        if (flash_proj_on(r.c, ax)) {
             // attention of all heads + out-projection + gated residual in one launch: nothing is deferred, no k_proj<0>
             FlashProjParams fp{};
             fp.f = f;
@@ -1418,177 +1410,13 @@ static int euler_steps(const Run& v, const std::vector<float>& tg, float* x) {
 }
 
 
-// ---- B == 1: two views INSIDE the sample (round 5) -------------------------------------------------------------------------
-// The reference's ATLAS command samples one protein at a time (README.md:87: B = 1), so there is no second sub-batch to run
-// beside the first -- and one stream of 1000-workgroup launches leaves the tails and HBM phases of every kernel uncovered (cfg-2:
-// one stream 108.6k, two 118.3k frames/s).  But nothing in a trunk layer couples all tokens at once: the residue-axis sub-layer
-// couples the residues of ONE frame, the temporal sub-layer the frames of ONE residue, the MLP / embedding / final layer nothing.
-// So the sample is cut in two along the axis a phase does not couple:
-//     frames [0, T/2) | [T/2, T)      embedding, residue-axis sub-layer, MLP, final layer     (contiguous token ranges)
-//     residues [0, L/2) | [L/2, L)    temporal sub-layer                                         (token stride L, base shifted)
-// each half on its own stream, and the two streams meet only where the cut changes direction: before and after the temporal
-// sub-layer of every layer (2 x nl barriers per step; MLP -> next layer's residue sub-layer -> ... -> next step's embedding stay
-// on one stream).  Same kernels on the same panels: bit-identical to the one-stream run.  Needs the tiled-attention path on both
-// axes (L, T > 8) with the fused out-projection (nothing deferred across the cut), even T and L, frame halves of whole 128-row
-// blocks, and halves that still fill the chip.
-static bool split_ok(const Run& r) {
-    const mdgen_ctx* c = r.c;
-    if (!c->opt_split_sample || c->opt_precision != 16 || c->prof_on || c->opt_flash_proj == 0 || c->opt_streams < 2) return false;
-    if (r.B != 1 || r.L <= 8 || r.T <= 8 || (r.T & 1) || (r.L & 1)) return false;
-    const long half = (long)(r.T / 2) * r.L;
-    return half % 128 == 0 && half >= (long)c->ncu * kPanel;
-}
-// frames [t0, t0 + Th) of a B == 1 run: a contiguous token range; residue-axis fragments are per frame
-static Run view_frames(const Run& r, int t0, int Th, hipStream_t s) {
-    Run v = r;
-    const long tok = (long)t0 * r.L;
-    v.T = Th;
-    v.N = (long)Th * r.L;
-    v.s = s;
-    v.half_view = true;
-    v.mask = r.mask + tok;
-    v.x_cond = r.x_cond + tok * r.D;
-    v.x_cond_mask = r.x_cond_mask + tok;
-    v.hp = r.hp + tok * kC;
-    v.obufp = r.obufp + tok * kC;
-    const size_t per_seq = (size_t)kH * (r.L / 32 + 1) * kFragBytes;
-    v.qfp = r.qfp + (size_t)t0 * per_seq;
-    v.kfp = r.kfp + (size_t)t0 * per_seq;
-    v.vfp = r.vfp + (size_t)t0 * per_seq;
-    return v;
-}
-// residues [l0, l0 + Lh) of a B == 1 run, for the TEMPORAL axis: token = pos * L + l, so the view is a base shift of l0 tokens
-// with the full L as position stride (the caller builds the axis map); temporal fragments are per residue
-static Run view_residues(const Run& r, int l0, hipStream_t s) {
-    Run v = r;
-    v.s = s;
-    v.half_view = true;
-    v.mask = r.mask + l0;
-    v.hp = r.hp + (long)l0 * kC;
-    v.obufp = r.obufp + (long)l0 * kC;
-    const size_t per_seq = (size_t)kH * (r.T / 32 + 1) * kFragBytes;
-    v.qfp = r.qfp + (size_t)l0 * per_seq;
-    v.kfp = r.kfp + (size_t)l0 * per_seq;
-    v.vfp = r.vfp + (size_t)l0 * per_seq;
-    return v;
-}
-// both streams wait for everything the other one has been given so far
-static int cross_streams(mdgen_ctx* c, hipStream_t a, hipStream_t b) {
-    HIPCHK(hipEventRecord(c->ev_fork, a));
-    HIPCHK(hipEventRecord(c->ev_join[0], b));
-    HIPCHK(hipStreamWaitEvent(a, c->ev_join[0], 0));
-    HIPCHK(hipStreamWaitEvent(b, c->ev_fork, 0));
-    return 0;
-}
-static int embed_part(const Run& r, int step, const float* x) {
-    mdgen_ctx* c = r.c;
-    EmbedParams e{};
-    e.x = x;
-    e.x_cond = r.x_cond;
-    e.x_cond_mask = r.x_cond_mask;
-    e.wl = c->wl;
-    e.wl_pack = c->wl_pack;
-    e.wc_pack = c->wc_pack;
-    e.bl = c->bl;
-    e.wc = c->wc;
-    e.bc = c->bc;
-    e.mask_emb = c->mask_emb;
-    e.pos_embed = c->d.abs_pos_emb ? c->pos_embed : nullptr;
-    e.ipa_out = r.ipa_out_p + (long)step * r.ipa_step_stride;
-    e.h = r.h();
-    e.N = r.N;
-    e.T = r.T;
-    e.L = r.L;
-    e.D = r.D;
-    { ProfScope ps(c, "embed", r.s); launch_embed(e, r.s); }
-    LAUNCHCHK();
-    return 0;
-}
-static int final_part(const Run& r, const float* modstep, float* x, float* out, int euler, float dt) {
-    mdgen_ctx* c = r.c;
-    FinalParams f{};
-    f.h = r.h();
-    f.nrows = r.N;
-    f.mm = ModMap{modstep + c->final_off(), r.T * r.L, r.B, 0, r.mod_group_stride};
-    f.shift_chunk = 0;
-    f.scale_chunk = 1;
-    f.w = c->wfin;
-    f.bias = c->bfin;
-    f.D = r.D;
-    f.euler = euler;
-    f.dt = dt;
-    f.x = x;
-    f.out = out;
-    { ProfScope ps(c, "final_euler", r.s); launch_final(f, r.s); }
-    LAUNCHCHK();
-    return 0;
-}
-static int euler_steps_split(const Run& r, const std::vector<float>& tg, float* x) {
-    mdgen_ctx* c = r.c;
-    hipStream_t st[2] = {r.s, c->side[0]};
-    const int Th = r.T / 2, Lh = r.L / 2;
-    const Run vf[2] = {view_frames(r, 0, Th, st[0]), view_frames(r, Th, r.T - Th, st[1])};
-    const Run vr[2] = {view_residues(r, 0, st[0]), view_residues(r, Lh, st[1])};
-    float* xs[2] = {x, x + (long)Th * r.L * r.D};
-    const long span = (long)r.T * r.L;
-    HIPCHK(hipEventRecord(c->ev_fork, r.s));                     // the second stream joins behind the shared preparation
-    HIPCHK(hipStreamWaitEvent(st[1], c->ev_fork, 0));
-    for (int i = 0; i < r.S; ++i) {
-        const float dt = tg[i + 1] - tg[i];
-        const float* modstep = r.mod() + (long)i * r.mod_step_stride;
-        for (int k = 0; k < 2; ++k)
-            if (int e = embed_part(vf[k], i, xs[k])) return e;
-        for (int ly = 0; ly < c->nl; ++ly) {
-            const TrunkW& w = c->trunk[ly];
-            const float* ml = modstep + c->trunk_off(ly);
-            for (int k = 0; k < 2; ++k) {   // residue axis: frame halves
-                const Run& v = vf[k];
-                const AxisMap axL{v.T, v.L, v.T, 0, v.L, 1};
-                const ModMap mm{ml, v.T * v.L, 1, 0, r.mod_group_stride};
-                if (int e = attn_sublayer(v, w.mha_l, v.h(), v.N, axL, mm, 0, 1, 2, MaskMap{v.mask, 0}, true, true)) return e;
-            }
-            if (int e = cross_streams(c, st[0], st[1])) return e;
-            for (int k = 0; k < 2; ++k) {   // temporal axis: residue halves
-                const Run& v = vr[k];
-                const int nl_ = k ? r.L - Lh : Lh;
-                const AxisMap axT{nl_, r.T, nl_, r.T * r.L, 1, r.L};
-                const ModMap mm{ml, r.T * r.L, 1, 0, r.mod_group_stride};
-                if (int e = attn_sublayer(v, w.mha_t, v.h(), span, axT, mm, 3, 4, 5, MaskMap{v.mask, 0}, false, true)) return e;
-            }
-            if (int e = cross_streams(c, st[0], st[1])) return e;
-            for (int k = 0; k < 2; ++k) {   // MLP: frame halves again (and on into the next layer / step without a barrier)
-                const Run& v = vf[k];
-                const ModMap mm{ml, v.T * v.L, 1, 0, r.mod_group_stride};
-                if (int e = mlp_sublayer(v, w.ffn, v.h(), v.N, mm, 6, 7, 8, true)) return e;
-            }
-        }
-        for (int k = 0; k < 2; ++k)
-            if (int e = final_part(vf[k], modstep, xs[k], nullptr, 1, dt)) return e;
-    }
-    HIPCHK(hipEventRecord(c->ev_join[0], st[1]));                // join
-    HIPCHK(hipStreamWaitEvent(r.s, c->ev_join[0], 0));
-    return 0;
-}
-
-// 1 if an Euler rollout of this shape runs as two intra-sample views (euler_steps_split) with the context's current options
-extern "C" int32_t mdgen_debug_split_sample(mdgen_ctx* c, const mdgen_shape* sh) {
-    if (!c || !sh) return fail(-1, "null argument");
-    Run r{};
-    r.c = c;
-    r.B = sh->B;
-    r.T = sh->T;
-    r.L = sh->L;
-    r.N = (long)sh->B * sh->T * sh->L;
-    return n_streams(r) == 1 && plan_views(r.B, r.T, r.L, 1) == 1 && split_ok(r) ? 1 : 0;
-}
-
 static int euler_body(const Run& r, const std::vector<float>& tg, float* x) {
     if (int e = prepare(r, nullptr, tg.data())) return e;
     const int ns = n_streams(r);
     // >= ns views; more when a view would exceed kMaxViewTokens (the fp32 kernels index with 64 bits: one view)
     const int nv = r.c->opt_precision == 32 ? 1 : plan_views(r.B, r.T, r.L, ns);
     if (nv == 0) return fail(-2, "sample too large for one launch");
-    if (nv == 1) return split_ok(r) ? euler_steps_split(r, tg, x) : euler_steps(r, tg, x);
+    if (nv == 1) return euler_steps(r, tg, x);
     // contiguous sub-batch views, view i on stream i % ns (fork after the shared preparation, join at the end)
     mdgen_ctx* c = r.c;
     if (ns > 1) HIPCHK(hipEventRecord(c->ev_fork, r.s));
@@ -1676,7 +1504,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_split_sample << 37), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1736,7 +1564,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_split_sample << 37),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

@@ -2449,53 +2449,3 @@ def test_two_stream_views_in_the_panel_window_match_one_stream():
     e = rel_l2(a, outs["one stream, defaults"][0])
     print(f"two 313-panel views vs one 625-panel view (row-owner MLP): {e:.2e}")
     assert e < 3e-3
-
-
-@pytest.mark.parametrize("shape", [(250, 256, 16), (128, 256, 0), (256, 128, 5)], ids=["T250_L256", "T128_L256", "T256_L128"])
-def test_intra_sample_split_matches_one_stream(shape):
-    """Option `split_sample` (round 5): a B = 1 rollout whose halves still fill the chip (what the reference's ATLAS command
-    runs: sim_inference.py:100-113 with README.md:87's `--num_frames 250`, one protein at a time) is cut in two INSIDE the sample
-    -- frame halves for the embedding / residue-axis sub-layer / MLP / final layer, residue halves for the temporal sub-layer --
-    on two streams that meet before and after every temporal sub-layer.  Same kernels on the same panels: the result must be
-    bit-identical to the one-stream run, eager and graph-replayed, incl. key padding on the residue axis; and the library must
-    say that it really split (mdgen_debug_split_sample), or not (B = 2, an odd T, the option off)."""
-    import ctypes as C
-    import mdgen_amd._lib as Lb
-    from mdgen_amd.config import ModelConfig
-    from mdgen_amd.model import LatentMDGenModel
-    from mdgen_amd.rigid_utils import Rotation
-    from mdgen_amd.synthetic import synth_state_dict
-    dev = _cuda()
-    T, L, n_pad = shape
-    B, S = 1, 3
-    cfg = ModelConfig.forward_sim(num_frames=T, crop=L)
-    sd = synth_state_dict(cfg, 4)
-    gen = torch.Generator().manual_seed(91 + T)
-    zs = torch.randn(B, T, L, 21, generator=gen).to(dev)
-    mask = torch.ones(B, T, L)
-    if n_pad:
-        mask[:, :, L - n_pad:] = 0
-    mask = mask.to(dev)
-    q = torch.randn(B, L, 4, generator=gen)
-    R = Rotation(quats=(q / q.norm(dim=-1, keepdim=True)).to(dev)).get_rot_mats()
-    tr_ = torch.cumsum(2.2 * torch.randn(B, L, 3, generator=gen), 1).to(dev)
-    cm = torch.zeros(B, T, L, dtype=torch.long, device=dev)
-    cm[:, 0] = 1
-    xc = torch.where(cm.unsqueeze(-1).bool(), torch.randn(B, T, L, 21, generator=gen).to(dev), torch.zeros((), device=dev))
-    aat = torch.randint(0, 20, (B, L), generator=gen).to(dev)
-    kw = dict(mask=mask, start_frames=(R, tr_), x_cond=xc, x_cond_mask=cm, aatype=aat)
-    outs = {}
-    for split in (0, 1):
-        m = LatentMDGenModel(cfg)
-        m.load_state_dict(sd)
-        m.set_option("split_sample", split)
-        says = lambda b, t, l: Lb.lib.mdgen_debug_split_sample(m._ctx, C.byref(Lb.Shape(b, t, l)))
-        assert says(B, T, L) == split
-        assert says(2, T, L) == 0 and says(1, T + 1, L) == 0 and says(1, 40, 40) == 0
-        outs[split] = [m.sample_euler(zs, S, use_graph=g, **kw) for g in (False, True, True)]
-        torch.cuda.synchronize()
-        del m
-    ref = outs[0][0]
-    assert torch.isfinite(ref).all()
-    for o in outs[0][1:] + outs[1]:
-        assert torch.equal(o, ref)
