@@ -133,6 +133,10 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      different starting tiles (chunk c of n starts at tile c * tiles / n and wraps): chunks that start together then
  *                      miss on different fragments instead of queueing behind one chain of HBM misses.  A sum over keys: same
  *                      values to fp32 rounding.
+ *   "flash_proj_form"  0 (default) / 4 / 8: which fused kernel: k_flash_proj (four waves, a 64-query panel, two workgroups per CU) or
+ *                      k_flash_proj8 (eight waves, a 128-query panel, four query tiles per wave, one workgroup per CU).  0: the
+ *                      128-query form for sequences of >= 512 positions whose launch gives every CU a workgroup, else the 64-query
+ *                      form.  Same values up to the order in which a query's keys are summed (fp32 rounding).
  *   "panel_waves"      0 (default) / 4 / 8: the 64-row panel kernels that exist in a four- and an eight-wave form (k_mlp / k_mlp8,
  *                      k_ln_qkv<false> / k_ln_qkv8) take the eight-wave form for launches of at most one workgroup per CU; 4 / 8
  *                      force one form whatever the launch size (tests, A/B runs).  mdgen_profile_report tags the class of such

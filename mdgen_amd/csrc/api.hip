@@ -139,6 +139,9 @@ struct mdgen_ctx {
                                 // eight waves where a launch is at most one workgroup per CU, 4 / 8 force one form (tests, A/B runs)
     int ncu = 256;              // compute units of the device the context was created on (hipDeviceAttributeMultiprocessorCount)
     int opt_flash_rotate = 1;   // tiled attention: the 64-query chunks of a sequence start their walk over the key tiles at different tiles (k_flash.hip)
+    int opt_flash_proj_form = 0;   // ... 0 (default): k_flash_proj8 (eight waves, 128-row panel, four query tiles per wave) for sequences of >= 512
+                                   // positions whose launch gives every CU such a workgroup (cfg-2), else k_flash_proj (four waves, 64-row
+                                   // panel; ATLAS); 4 / 8: one form always
     int opt_flash_proj = 1;     // tiled attention + its out-projection + gated residual in ONE launch (k_flash_proj): 0 off (k_flash, then
                                 // k_proj<0> or a deferred projection), 1 (default) when the launch has >= kFlashProjMinJobs workgroups
                                 // of (sequence, 64 queries), 2 always
@@ -643,6 +646,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "flash_rotate") {
         if (value != 0 && value != 1) return fail(-2, "flash_rotate must be 0 or 1");
         c->opt_flash_rotate = value;
+    } else if (n == "flash_proj_form") {
+        if (value != 0 && value != 4 && value != 8) return fail(-2, "flash_proj_form must be 0 (by shape), 4 or 8");
+        c->opt_flash_proj_form = value;
     } else if (n == "flash_proj") {
         if (value < 0 || value > 2) return fail(-2, "flash_proj must be 0 (off), 1 (launches that fill the chip) or 2 (always)");
         c->opt_flash_proj = value;
@@ -1004,7 +1010,10 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
             fp.gate_chunk = gate;
             fp.wo = m.wo;
             fp.bo = m.bo;
-            { ProfScope ps(r.c, !trunk ? "ipa.flash_proj" : residue_axis ? "flash_proj_L" : "flash_proj_T", r.s); launch_flash_proj(fp, r.s); }
+            // the 128-row form where it still gives every CU a workgroup (cfg-2: 256 per sub-batch stream)
+            const long jobs8 = (long)ax.nseq * ((ax.len + 2 * kPanel - 1) / (2 * kPanel));
+            const int form = r.c->opt_flash_proj_form ? r.c->opt_flash_proj_form : (ax.len >= 512 && jobs8 >= r.c->ncu) ? 8 : 4;
+            { ProfScope ps(r.c, !trunk ? "ipa.flash_proj" : residue_axis ? "flash_proj_L" : "flash_proj_T", r.s); launch_flash_proj(fp, form, r.s); }
             LAUNCHCHK();
             return 0;
         }
@@ -1504,7 +1513,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1564,7 +1573,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

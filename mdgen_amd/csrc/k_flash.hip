@@ -644,6 +644,56 @@ __global__ __launch_bounds__(256, 2) void k_flash_proj(const FlashProjParams p) 
     FPROJ_STAMP(9, __builtin_amdgcn_s_memrealtime());
 }
 
+// =================================================================================================
+// k_flash_proj8: the same fusion with the attention loop at k_flash<4>'s density.  k_flash_proj's loop runs two waves of two query
+// tiles per SIMD -- 260-290 cycles per (32-key, 32-query) pair per SIMD where three such waves (k_flash) or two waves of FOUR tiles
+// (k_flash<4>, a measured tie) run at 200 -- because a 64-row panel per workgroup at two workgroups per CU is all the LDS allows.
+// Here ONE workgroup of EIGHT waves owns 128 consecutive positions of a sequence: every wave runs flash_job<4> (128 queries of one
+// head: the K / V^T fragment loads and the prologue serve twice the pairs) for head 8 pass + wave, two passes; the output rows go
+// into a bf16 LDS panel [128][384] (96 KB: one workgroup per CU, which the 256-register budget of two waves per SIMD implies anyway);
+// then the eight waves run the out-projection as a 2 x 4 grid of k_proj<0>'s wave tiles (wave (g, w): rows 64 g .. 64 g + 63,
+// features 96 w .. 96 w + 95) and the staged residual epilogue over eight 12 KiB slabs.  cfg-2: 64 sequences x 8 chunks = 512
+// workgroups = exactly two rounds of 256 (one round per sub-batch stream); ATLAS 512 / 500.
+// =================================================================================================
+__global__ __launch_bounds__(512, 1) void k_flash_proj8(const FlashProjParams p) {
+    constexpr int NQ = 4, kRows = 32 * NQ;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * sizeof(PanelRows) + kRows * kC * 2];
+    PanelRows* pr = reinterpret_cast<PanelRows*>(smem);   // [2]: one row table per 64-row half
+    unsigned char* panel = smem + 2 * sizeof(PanelRows);
+    const int w8 = __builtin_amdgcn_readfirstlane(wave_id()), g = w8 >> 2, w = w8 & 3;
+    const int nqc = (p.f.ax.len + kRows - 1) / kRows;
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int qc = rest % nqc, seq = (rest / nqc) * 8 + xcd;
+    if (seq >= p.f.ax.nseq) return;
+    if (threadIdx.x < kRows) {   // waves 0 and 1 fill the two row tables (read after the barrier below)
+        const int hf = threadIdx.x >> 6, i = threadIdx.x & 63;
+        const int pos = qc * kRows + hf * kPanel + i;
+        long tk = -1, mo = 0;
+        if (pos < p.f.ax.len) {
+            tk = p.f.ax.token(seq, pos);
+            mo = p.mm.row_off(tk);
+        }
+        pr[hf].tok[i] = (int)tk;
+        pr[hf].moff[i] = (int)mo;
+        set_uniform(&pr[hf], i, tk, mo);
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const int head = 8 * pass + w8;
+        FlashPre<NQ> pre;
+        flash_prefetch<NQ>(p.f, seq, head, qc, pre);
+        flash_job<NQ>(p.f, seq, head, qc, w8, pre, FlashStorePanel{(lds_byte*)panel, head});
+    }
+    __syncthreads();   // the attention output of all 16 heads is in the panel
+    const int lane = lane_id();
+    f32x16 acc[6];
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, 24, false>(panel, kC * 2, 2 * g, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    __syncthreads();   // every wave is done reading the panel: reuse it as eight 12 KiB staging slabs
+    epilogue_gate_residual_lds<3>(acc, &pr[g], reinterpret_cast<float*>(panel) + w8 * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
+                                  p.h);
+}
+
 // Measured (cfg-2 / cfg-4, same box, back to back): NQ = 4 runs 160-162 / 76 us, NQ = 2 160-164 / 76 us -- a tie; 2 keeps
 // three waves per SIMD and is faster on short sequences (IPA stack: 10 vs 14 us).
 #ifndef MDGEN_FLASH_NQ
@@ -659,9 +709,14 @@ void launch_flash(const FlashParams& p, hipStream_t s) {
 // jobs of a fused launch: one workgroup per (sequence, 64-query chunk)
 long flash_proj_jobs(const AxisMap& ax) { return (long)ax.nseq * ((ax.len + kPanel - 1) / kPanel); }
 
-void launch_flash_proj(const FlashProjParams& p, hipStream_t s) {
-    const int nqc = (p.f.ax.len + kPanel - 1) / kPanel;
+void launch_flash_proj(const FlashProjParams& p, int form, hipStream_t s) {
     const int nseq8 = (p.f.ax.nseq + 7) / 8;   // sequences, in groups of 8 (one per XCD)
+    if (form == 8) {
+        const int nqc = (p.f.ax.len + 2 * kPanel - 1) / (2 * kPanel);
+        hipLaunchKernelGGL(k_flash_proj8, dim3(nseq8 * nqc * 8), dim3(512), 0, s, p);
+        return;
+    }
+    const int nqc = (p.f.ax.len + kPanel - 1) / kPanel;
     hipLaunchKernelGGL(k_flash_proj, dim3(nseq8 * nqc * 8), dim3(256), 0, s, p);
 }
 

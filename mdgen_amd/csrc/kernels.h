@@ -190,7 +190,7 @@ void launch_ln_linear(const LnLinearParams& p, hipStream_t s);
 void launch_final(const FinalParams& p, hipStream_t s);
 void launch_flash(const FlashParams& p, hipStream_t s);
 long flash_proj_jobs(const AxisMap& ax);
-void launch_flash_proj(const FlashProjParams& p, hipStream_t s);
+void launch_flash_proj(const FlashProjParams& p, int form, hipStream_t s);   // form 4: k_flash_proj (64-row panels), 8: k_flash_proj8 (128-row)
 void launch_pack_embed(const float* w, int D, float* pack, hipStream_t s);   // pack: kEmbPackFloats floats
 constexpr int kEmbPackFloats = 4 * 3 * 14 * 64;
 void launch_embed(const EmbedParams& p, hipStream_t s);

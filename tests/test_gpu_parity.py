@@ -2321,8 +2321,11 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
     cfg, sd, kw, dkw = _fwd_case(B, T, L, n_pad, 500 + T + L)
     ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
     outs = {}
-    for key, opts in (("separate", {"flash_proj": 0}), ("fused", {"flash_proj": 2}), ("fused, natural tile order", {"flash_proj": 2, "flash_rotate": 0}),
-                      ("fused, robust loop", {"flash_proj": 2, "attention_path": 1})):
+    F4, F8 = {"flash_proj": 2, "flash_proj_form": 4}, {"flash_proj": 2, "flash_proj_form": 8}
+    for key, opts in (("separate", {"flash_proj": 0}), ("fused", F4), ("fused, natural tile order", dict(F4, flash_rotate=0)),
+                      ("fused, robust loop", dict(F4, attention_path=1)), ("fused 128", F8),
+                      ("fused 128, natural tile order", dict(F8, flash_rotate=0)), ("fused 128, robust loop", dict(F8, attention_path=1)),
+                      ("separate, natural tile order", {"flash_proj": 0, "flash_rotate": 0})):
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
         for k, v in opts.items():
@@ -2334,7 +2337,7 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
         print(shape, key, {k: f"{v:.2e}" for k, v in rep.items()}, {k: v for k, v in ran.items() if "flash" in k or "proj" in k})
         for k, v in rep.items():
             assert v < TOL_FWD, (key, k, v)
-        fused = key != "separate"
+        fused = not key.startswith("separate")
         assert ("flash_proj_T" in ran) == fused and ("flash_T" in ran) != fused, ran
         if L > 8:
             assert ("flash_proj_L" in ran) == fused and ("ipa.flash_proj" in ran) == fused, ran
@@ -2343,17 +2346,25 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
         outs[key] = (out.cpu(), tr[f"h{cfg.num_layers}"].cpu())
         assert torch.equal(m.forward(**dkw), out), key   # a second call on the same context: the same bits
         del m
-    for key in ("fused", "fused, natural tile order"):
+    for key in ("fused", "fused, natural tile order", "fused 128"):
         e_out, e_h = rel_l2(outs[key][0], outs["separate"][0]), rel_l2(outs[key][1], outs["separate"][1])
         print(shape, f"{key} vs separate kernels: out {e_out:.2e} h {e_h:.2e} equal {torch.equal(outs[key][0], outs['separate'][0])}")
         # (`flash_rotate` changes the order in which a query's keys are summed: fp32 rounding, now and then one bf16 step of an
-        # attention output; the default walks the tiles in the same rotated order in both kernels)
+        # attention output; k_flash and k_flash_proj walk the tiles in the same rotated order, the 128-row form rotates by
+        # 128-query chunks)
         assert (e_out < 2e-5 and e_h < 2e-5) if key == "fused" else (e_out < 2e-3 and e_h < 2e-3)
+    # in natural tile order all three forms sum every query's keys in the same order: the same bits
+    assert torch.equal(outs["fused, natural tile order"][0], outs["separate, natural tile order"][0])
+    e8 = rel_l2(outs["fused 128, natural tile order"][0], outs["separate, natural tile order"][0])
+    print(shape, f"128-row form vs separate kernels, natural tile order: {e8:.2e}")
+    assert e8 < 2e-5
     assert rel_l2(outs["fused, robust loop"][0], outs["fused"][0]) < 6e-3   # (P rounded to bf16 around a different shift)
+    assert rel_l2(outs["fused 128, robust loop"][0], outs["fused 128"][0]) < 6e-3
     if n_pad:   # padded residues never influence the valid ones
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
         m.set_option("flash_proj", 2)
+        m.set_option("flash_proj_form", 8)
         x2 = kw["x"].clone()
         x2[:, :, L - n_pad:] = 1e3
         a = m.forward(**dkw)
@@ -2362,8 +2373,9 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
 
 
 def test_flash_proj_is_the_default_where_the_launch_fills_the_chip():
-    """`flash_proj` 1 (default): k_flash_proj for launches of >= 512 (sequence, 64-query chunk) workgroups -- B 8 x T 1000 x L 4 is
-    32 sequences x 16 chunks = 512 -- and the separate kernels below (B 7: 448).  Both against the separate kernels' output."""
+    """`flash_proj` 1 (default): the fused kernel for launches of >= 512 (sequence, 64-query chunk) workgroups -- B 8 x T 1000 x L 4 is
+    32 sequences x 16 chunks = 512 (and 32 x 8 = 256 128-query chunks: one per CU, so `flash_proj_form` 0 picks the 128-row form
+    k_flash_proj8 there) -- and the separate kernels below (B 7: 448).  Both against the separate kernels' output."""
     from mdgen_amd.model import LatentMDGenModel
     for B, want in ((8, True), (7, False)):
         cfg, sd, kw, dkw = _fwd_case(B, 1000, 4, 0, 77)
@@ -2376,7 +2388,7 @@ def test_flash_proj_is_the_default_where_the_launch_fills_the_chip():
         assert "flash_T" in ran0 and "flash_proj_T" not in ran0
         e = rel_l2(out, out0)
         print(f"B {B}: default {sorted(k for k in ran if 'flash' in k)} vs flash_proj 0: {e:.2e}")
-        assert torch.isfinite(out).all() and e < 2e-5   # (same operands, same summation order)
+        assert torch.isfinite(out).all() and e < 2e-3   # (the 128-row form rotates its key-tile walk by 128-query chunks: fp32 rounding)
         del m
 
 
