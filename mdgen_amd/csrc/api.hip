@@ -647,7 +647,7 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
         if (value != 0 && value != 1) return fail(-2, "flash_rotate must be 0 or 1");
         c->opt_flash_rotate = value;
     } else if (n == "flash_proj_form") {
-        if (value != 0 && value != 4 && value != 8 && value != 12) return fail(-2, "flash_proj_form must be 0 (by shape), 4, 8 or 12");
+        if (value != 0 && value != 4 && value != 8) return fail(-2, "flash_proj_form must be 0 (by shape), 4 or 8");
         c->opt_flash_proj_form = value;
     } else if (n == "flash_proj") {
         if (value < 0 || value > 2) return fail(-2, "flash_proj must be 0 (off), 1 (launches that fill the chip) or 2 (always)");

@@ -210,10 +210,7 @@ extern "C" int mdgen_dev_fproj_stamps(void* host, size_t bytes) {
 #define FPROJ_STAMP(slot, v)                                                                          \
     if (lane_id() == 0 && (long)blockIdx.x * 4 + w < 8192) g_fproj_stamps[((long)blockIdx.x * 4 + w) * 16 + (slot)] = (v)
 #define FLASH_STAMP_ROW(w, hg) ((w) + 4096 * (hg))   // k_flash_proj: flash_job's own stamps of head group hg go to rows 4096 hg + ...
-#define FPROJ12_STAMP(slot, v)   /* k_flash_proj12: rows of twelve waves; 1..3 after pass 0..2 */                      \
-    if (lane_id() == 0 && (long)blockIdx.x * 12 + w < 8192) g_fproj_stamps[((long)blockIdx.x * 12 + w) * 16 + (slot)] = (v)
 #else
-#define FPROJ12_STAMP(slot, v)
 #define FLASH_STAMP(slot, v)
 #define FPROJ_STAMP(slot, v)
 #define FLASH_STAMP_ROW(w, hg) (w)
@@ -271,9 +268,8 @@ __device__ __forceinline__ void* flash_uniform_ptr(const unsigned char* q_) {
 }
 
 template <int NQ>
-__device__ __forceinline__ void flash_prefetch(const FlashParams p, const int seq, const int head, const int qc, FlashPre<NQ>& pre,
-                                               const int lane = lane_id()) {
-    const int hh = lane >> 5;
+__device__ __forceinline__ void flash_prefetch(const FlashParams p, const int seq, const int head, const int qc, FlashPre<NQ>& pre) {
+    const int lane = lane_id(), hh = lane >> 5;
     const int len = p.ax.len, nt = p.ax.ntile();
     const long ftile = (long)(seq * kH + head) * nt;   // first fragment tile of this (sequence, head)
     const unsigned char* qb = p.qf + ftile * kFragQ;
@@ -307,9 +303,8 @@ __device__ __forceinline__ void flash_prefetch(const FlashParams p, const int se
 
 template <int NQ, class Store>
 __device__ __forceinline__ void flash_job(const FlashParams p, const int seq, const int head, const int qc, const int w,
-                                          const FlashPre<NQ> pre, const Store store,   // (by value: through a reference hipcc spills 15 registers)
-                                          const int lane = lane_id()) {
-    const int hh = lane >> 5, ql = lane & 31;
+                                          const FlashPre<NQ> pre, const Store store) {   // (by value: through a reference hipcc spills 15 registers)
+    const int lane = lane_id(), hh = lane >> 5, ql = lane & 31;
     FLASH_STAMP(0, __builtin_amdgcn_s_memtime());
     FLASH_STAMP(4, __builtin_amdgcn_s_memrealtime());
     const int len = p.ax.len, nt = p.ax.ntile();   // tiles per (seq, head): they cover the len keys + the bias key
@@ -659,6 +654,9 @@ __global__ __launch_bounds__(256, 2) void k_flash_proj(const FlashProjParams p) 
 // then the eight waves run the out-projection as a 2 x 4 grid of k_proj<0>'s wave tiles (wave (g, w): rows 64 g .. 64 g + 63,
 // features 96 w .. 96 w + 95) and the staged residual epilogue over eight 12 KiB slabs.  cfg-2: 64 sequences x 8 chunks = 512
 // workgroups = exactly two rounds of 256 (one round per sub-batch stream); ATLAS 512 / 500.
+// Measured and dropped (profiles/r05_experiments.txt 17): the same kernel at THREE waves per SIMD -- six-wave workgroups (the
+// dispatcher keeps only one per CU at 168 registers: scripts/micro/occ_probe.hip) and twelve-wave workgroups with 32 (head, half)
+// flash_job<2> jobs (a tie: the loop is bound by the VALU issue port, 16 quarter-rate exponentials per pair, at any occupancy).
 // =================================================================================================
 __global__ __launch_bounds__(512, 1) void k_flash_proj8(const FlashProjParams p) {
     constexpr int NQ = 4, kRows = 32 * NQ;
@@ -699,84 +697,6 @@ __global__ __launch_bounds__(512, 1) void k_flash_proj8(const FlashProjParams p)
                                   p.h);
 }
 
-// =================================================================================================
-// k_flash_proj12: the same fusion at THREE waves per SIMD.  The issue-rate table of round 2 (profiles/r02_issue_rate.txt: the loop's
-// mix costs 409 cycles per SIMD-iteration with two waves per SIMD, 290 with three -- the transcendental path alternates badly between
-// exactly two waves) says the two forms above sit in the worst regime.  Ways to three waves per SIMD that do NOT work: 4-wave
-// workgroups at three per CU (768 slots do not divide cfg-2's 1024 jobs: experiment 2); 6-wave workgroups at two per CU (the
-// dispatcher reserves ceil(6 / 4) = 2 wave slots on EVERY SIMD per workgroup, so at 168 registers only one fits: occ_probe.hip,
-// experiment 17).  TWELVE waves in one workgroup per CU do: three per SIMD by construction, 168 registers (flash_job<2> needs 165),
-// a 128-row panel (96 KB) like k_flash_proj8's, the same two-rounds grid.  The 16 heads x two 64-row halves = 32 flash_job<2>
-// jobs go to the waves as job = 12 pass + wave, (head, half) = (job / 2, job % 2): waves 2 h and 2 h + 1 stream the same K / V^T
-// fragments at the same time; three passes (12, 12, 8: waves 8..11 sit out the last, 4 of 36 wave-passes idle).  The out-projection
-// is a 2 x 6 grid of wave tiles (wave (g, c): rows 64 g .., features 64 c .. 64 c + 63, wave_gemm<2, 2>) and the staged epilogue
-// uses twelve 8 KiB slabs (epi_rmw64).
-// =================================================================================================
-__global__ __launch_bounds__(768, 3) void k_flash_proj12(const FlashProjParams p) {
-    constexpr int NQ = 2, kRows = 2 * kPanel;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * sizeof(PanelRows) + kRows * kC * 2];
-    PanelRows* pr = reinterpret_cast<PanelRows*>(smem);   // [2]: one row table per 64-row half
-    unsigned char* panel = smem + 2 * sizeof(PanelRows);
-    const int w = __builtin_amdgcn_readfirstlane(wave_id());   // 0..11
-    const int nqc = (p.f.ax.len + kRows - 1) / kRows;
-    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int qc = rest % nqc, seq = (rest / nqc) * 8 + xcd;
-    if (seq >= p.f.ax.nseq) return;
-    FPROJ12_STAMP(0, __builtin_amdgcn_s_memtime());
-    FPROJ12_STAMP(8, __builtin_amdgcn_s_memrealtime());
-    FPROJ12_STAMP(10, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));   // HW_REG_HW_ID
-    if (threadIdx.x < kRows) {   // waves 0 and 1 fill the two row tables (read after the barrier below)
-        const int hf = threadIdx.x >> 6, i = threadIdx.x & 63;
-        const int pos = qc * kRows + hf * kPanel + i;
-        long tk = -1, mo = 0;
-        if (pos < p.f.ax.len) {
-            tk = p.f.ax.token(seq, pos);
-            mo = p.mm.row_off(tk);
-        }
-        pr[hf].tok[i] = (int)tk;
-        pr[hf].moff[i] = (int)mo;
-        set_uniform(&pr[hf], i, tk, mo);
-    }
-#pragma unroll 1
-    for (int pass = 0; pass < 3; ++pass) {
-        const int job = 12 * pass + w, head = job >> 1, half = job & 1;
-        if (job < 2 * kH) {
-            const int qc64 = 2 * qc + half;   // the job's 64-query chunk of the sequence
-            const FlashStorePanel store{(lds_byte*)panel + half * (kPanel * kC * 2), head};
-            if (qc64 * kPanel < p.f.ax.len) {
-                // (the lane index is made opaque per pass: hipcc otherwise hoists every lane-derived offset of the job out of this
-                // loop and, at 168 registers, parks them in scratch)
-                int lane_o = lane_id();
-                asm volatile("" : "+v"(lane_o));
-                FlashPre<NQ> pre;
-                flash_prefetch<NQ>(p.f, seq, head, qc64, pre, lane_o);
-                flash_job<NQ>(p.f, seq, head, qc64, 8191 * 4, pre, store, lane_o);
-            } else {   // the whole half lies past the end of the sequence: zeros into the GEMM, nothing stored
-                store.pad(0, 0);
-                store.pad(1, 0);
-            }
-        }
-        FPROJ12_STAMP(1 + pass, __builtin_amdgcn_s_memtime());
-    }
-    __syncthreads();   // the attention output of all 16 heads is in the panel
-    FPROJ12_STAMP(5, __builtin_amdgcn_s_memtime());
-    const int lane = lane_id();
-    const int g = w >= 6 ? 1 : 0, c = w - 6 * g;
-    f32x16 acc[4];
-    zero_acc<4>(acc);
-    wave_gemm<2, 2, 24, false>(panel, kC * 2, 2 * g, 0, p.wo + (size_t)(2 * c) * 24 * 64 + lane, 24 * 64, acc);
-    FPROJ12_STAMP(6, __builtin_amdgcn_s_memtime());
-    __syncthreads();   // every wave is done reading the panel: reuse it as twelve 8 KiB staging slabs
-    float* slab = reinterpret_cast<float*>(panel) + w * (32 * 64);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        epi_stage64(acc + 2 * t, slab);
-        epi_rmw64<8>(t, &pr[g], slab, 64 * c, p.bo, p.mm, p.gate_chunk, true, p.h);
-    }
-    FPROJ12_STAMP(7, __builtin_amdgcn_s_memtime());
-    FPROJ12_STAMP(9, __builtin_amdgcn_s_memrealtime());
-}
-
 // Measured (cfg-2 / cfg-4, same box, back to back): NQ = 4 runs 160-162 / 76 us, NQ = 2 160-164 / 76 us -- a tie; 2 keeps
 // three waves per SIMD and is faster on short sequences (IPA stack: 10 vs 14 us).
 #ifndef MDGEN_FLASH_NQ
@@ -794,10 +714,9 @@ long flash_proj_jobs(const AxisMap& ax) { return (long)ax.nseq * ((ax.len + kPan
 
 void launch_flash_proj(const FlashProjParams& p, int form, hipStream_t s) {
     const int nseq8 = (p.f.ax.nseq + 7) / 8;   // sequences, in groups of 8 (one per XCD)
-    if (form == 8 || form == 12) {
+    if (form == 8) {
         const int nqc = (p.f.ax.len + 2 * kPanel - 1) / (2 * kPanel);
-        if (form == 12) hipLaunchKernelGGL(k_flash_proj12, dim3(nseq8 * nqc * 8), dim3(768), 0, s, p);
-        else hipLaunchKernelGGL(k_flash_proj8, dim3(nseq8 * nqc * 8), dim3(512), 0, s, p);
+        hipLaunchKernelGGL(k_flash_proj8, dim3(nseq8 * nqc * 8), dim3(512), 0, s, p);
         return;
     }
     const int nqc = (p.f.ax.len + kPanel - 1) / kPanel;

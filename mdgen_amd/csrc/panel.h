@@ -379,54 +379,4 @@ __device__ __forceinline__ void epilogue_gate_residual_lds(const f32x16* acc, co
     }
 }
 
-// The 64-column form (k_flash_proj12: a 2 x 6 grid of waves, 64 output columns each): slab [32 rows][64 cols] fp32 (8 KiB per wave),
-// 16 lanes x float4 = FOUR rows per step, all 64 lanes busy.
-__device__ __forceinline__ void epi_stage64(const f32x16* acc2, float* stage) {
-    const int lane = lane_id();
-    const int hh = lane >> 5, n = lane & 31;
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) stage[mfma_row(r, hh) * 64 + f * 32 + n] = acc2[f][r];
-}
-
-template <int BR>
-__device__ __forceinline__ void epi_rmw64(const int t, const PanelRows* pr, const float* stage, int col0,
-                                          const float* __restrict__ bias, const ModMap mm, int gate_chunk, bool gated,
-                                          float* __restrict__ h) {
-    static_assert(8 % BR == 0, "batches of row quads");
-    const int lane = lane_id();
-    const int q = lane & 15, r4 = lane >> 4;
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + col0 + 4 * q);
-    const f32x4* stage4 = reinterpret_cast<const f32x4*>(stage);
-    const int um = gated ? pr->uniform : -1;
-    const bool per_row = gated && um < 0;
-    f32x4 gu = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (gated && um >= 0) gu = *reinterpret_cast<const f32x4*>(mm.mod + um + gate_chunk * kC + col0 + 4 * q);
-#pragma unroll
-    for (int b = 0; b < 8 / BR; ++b) {
-        f32x4 hv[BR], g[BR];
-        int tk[BR];
-#pragma unroll
-        for (int k = 0; k < BR; ++k) {
-            const int row = t * 32 + 4 * (BR * b + k) + r4;
-            tk[k] = pr->tok[row];
-            const long tc = tk[k] < 0 ? 0 : tk[k];
-            hv[k] = *reinterpret_cast<const f32x4*>(h + tc * kC + col0 + 4 * q);
-            g[k] = gu;
-            if (per_row) g[k] = *reinterpret_cast<const f32x4*>(mm.mod + pr->moff[row] + gate_chunk * kC + col0 + 4 * q);
-        }
-#pragma unroll
-        for (int k = 0; k < BR; ++k) {
-            const f32x4 v = stage4[(BR * b + k) * 64 + lane];
-            f32x4 o = hv[k];
-            o[0] += g[k][0] * (v[0] + b4[0]);
-            o[1] += g[k][1] * (v[1] + b4[1]);
-            o[2] += g[k][2] * (v[2] + b4[2]);
-            o[3] += g[k][3] * (v[3] + b4[3]);
-            if (tk[k] >= 0) *reinterpret_cast<f32x4*>(h + (long)tk[k] * kC + col0 + 4 * q) = o;
-        }
-    }
-}
-
 }  // namespace mdg

@@ -2322,11 +2322,9 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
     ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
     outs = {}
     F4, F8 = {"flash_proj": 2, "flash_proj_form": 4}, {"flash_proj": 2, "flash_proj_form": 8}
-    F12 = {"flash_proj": 2, "flash_proj_form": 12}
     for key, opts in (("separate", {"flash_proj": 0}), ("fused", F4), ("fused, natural tile order", dict(F4, flash_rotate=0)),
                       ("fused, robust loop", dict(F4, attention_path=1)), ("fused 128", F8),
                       ("fused 128, natural tile order", dict(F8, flash_rotate=0)), ("fused 128, robust loop", dict(F8, attention_path=1)),
-                      ("fused 12 waves", F12), ("fused 12 waves, robust loop", dict(F12, attention_path=1)),
                       ("separate, natural tile order", {"flash_proj": 0, "flash_rotate": 0})):
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
@@ -2362,10 +2360,6 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
     assert e8 < 2e-5
     assert rel_l2(outs["fused, robust loop"][0], outs["fused"][0]) < 6e-3   # (P rounded to bf16 around a different shift)
     assert rel_l2(outs["fused 128, robust loop"][0], outs["fused 128"][0]) < 6e-3
-    # the twelve-wave form (128-row panel, 32 (head, 64-query half) jobs in three passes, a 2 x 6 grid of output tiles) runs the same
-    # flash_job<2> jobs and sums every output element in the same order as the four-wave form: the same bits
-    assert torch.equal(outs["fused 12 waves"][0], outs["fused"][0]) and torch.equal(outs["fused 12 waves"][1], outs["fused"][1])
-    assert torch.equal(outs["fused 12 waves, robust loop"][0], outs["fused, robust loop"][0])
     if n_pad:   # padded residues never influence the valid ones
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
