@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 /* Bumped whenever a public struct or signature changes; mdgen_amd/_lib.py refuses a library whose version differs. */
-#define MDGEN_ABI_VERSION 5
+#define MDGEN_ABI_VERSION 6   /* 6: mdgen_ws_layout.split */
 
 typedef struct mdgen_ctx mdgen_ctx;
 
@@ -77,6 +77,8 @@ typedef struct mdgen_ws_layout {
     size_t tgrid;      /* fp32 per-step times         [S][B]                           */
     size_t f32_scratch;/* fp32 path: LN out | q,k,v | attention out | MLP hidden | IPA features (0 bytes unless the
                           context keeps fp32 weights)                                            */
+    size_t split;      /* scratch of the split-panel MLP kernel (option "small_split"): arrival counters (1 KiB) | fp32 partials |
+                          private residual rows, [panels <= 96][3][64][384] each                 */
 } mdgen_ws_layout;
 
 const char* mdgen_last_error(void);

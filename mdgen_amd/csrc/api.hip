@@ -138,6 +138,11 @@ struct mdgen_ctx {
     int opt_panel_waves = 0;    // 64-row panel kernels with a four- and an eight-wave form (k_mlp / k_mlp8, k_ln_qkv<false> / k_ln_qkv8): 0 (default)
                                 // eight waves where a launch is at most one workgroup per CU, 4 / 8 force one form (tests, A/B runs)
     int ncu = 256;              // compute units of the device the context was created on (hipDeviceAttributeMultiprocessorCount)
+    int opt_small_split = 1;    // launches far below one workgroup per CU (B = 1, the IPA stack): a panel's work over several workgroups --
+                                // k_mlp8<., kMlpSplit> (hidden chunks over 3 workgroups, last arriver finishes; panels <= ncu / 3) and
+                                // k_ln_qkv8<true> (q, k | v over 2 workgroups; panels <= ncu / 2).  0 off, 1 (default) on
+    bool xcd_round_robin = false;   // placement probe: workgroups with equal blockIdx % 8 share an XCD (k_mlp8's split form relies on it)
+    int live_streams = 1;       // sub-batch streams of the call being recorded / run (the workspace's split scratch serves one launch at a time)
     int opt_flash_rotate = 1;   // tiled attention: the 64-query chunks of a sequence start their walk over the key tiles at different tiles (k_flash.hip)
     int opt_flash_proj_form = 0;   // ... 0 (default): k_flash_proj8 (eight waves, 128-row panel, four query tiles per wave) for sequences of >= 512
                                    // positions whose launch gives every CU such a workgroup (cfg-2), else k_flash_proj (four waves, 64-row
@@ -405,6 +410,19 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0)
             c->ncu = ncu;
     }
+    {   // placement probe for k_mlp8's split form: do workgroups with the same blockIdx % 8 run on the same XCD?
+        int* dp = nullptr;
+        int hx[64];
+        if (hipMalloc((void**)&dp, sizeof(hx)) == hipSuccess) {
+            launch_xcc_probe(dp, 64, nullptr);
+            if (hipMemcpy(hx, dp, sizeof(hx), hipMemcpyDeviceToHost) == hipSuccess) {
+                bool ok = true;
+                for (int i = 8; i < 64; ++i) ok = ok && hx[i] == hx[i & 7];
+                c->xcd_round_robin = ok;
+            }
+            (void)hipFree(dp);
+        }
+    }
     c->d = *d;
     c->nl = d->num_layers;
     c->D = d->latent_dim;
@@ -640,6 +658,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "fuse_proj_qkv") {
         if (value != 0 && value != 1) return fail(-2, "fuse_proj_qkv must be 0 or 1");
         c->opt_fuse_proj_qkv = value;
+    } else if (n == "small_split") {
+        if (value != 0 && value != 1) return fail(-2, "small_split must be 0 or 1");
+        c->opt_small_split = value;
     } else if (n == "panel_waves") {
         if (value != 0 && value != 4 && value != 8) return fail(-2, "panel_waves must be 0 (by launch size), 4 or 8");
         c->opt_panel_waves = value;
@@ -674,6 +695,15 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
 // workspace
 // ---------------------------------------------------------------------------------------------
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// panels the split scratch of a call covers, and its bytes (counters first: make_run zeroes them in every call)
+static long split_panels(long maxrows) {
+    const long pn = (maxrows + kPanel - 1) / kPanel;
+    return pn < kMlpSplitMaxPanels ? pn : kMlpSplitMaxPanels;
+}
+constexpr size_t kSplitCounterBytes = 1024;   // kMlpSplitMaxPanels counters, padded
+static_assert(kMlpSplitMaxPanels * sizeof(unsigned) <= kSplitCounterBytes, "counter block");
+static size_t split_bytes(long panels) { return kSplitCounterBytes + 2 * (size_t)panels * kMlpSplit * kPanel * kC * 4; }
 
 static size_t frag_bytes(long nseq, int len) { return (size_t)nseq * kH * (len / 32 + 1) * kFragBytes; }
 
@@ -757,6 +787,9 @@ extern "C" int32_t mdgen_workspace_layout(const mdgen_ctx* c, const mdgen_shape*
     // fp32 path scratch: LN output [rows][384] | q,k,v [rows][1152] | attention output [rows][384] | MLP hidden
     // [rows][1536] | IPA features [Mp][256]   (only when the context keeps fp32 weights)
     o->f32_scratch = take(c->opt_keep_fp32 ? (size_t)maxrows * (kC + 3 * kC + kC + kF) * 4 + (size_t)Mp * kIpaFeat * 4 : 0);
+    // k_mlp8's split form (launches of <= ncu / kMlpSplit panels): counters [kMlpSplitMaxPanels] | fc2 partials | private residual rows,
+    // the latter two [panels][kMlpSplit][64][384] fp32 each
+    o->split = take(split_bytes(split_panels(maxrows)));
     o->total_bytes = off;
     return 0;
 }
@@ -783,6 +816,10 @@ struct Run {
     float* modp;                 // adaLN table row of (step 0, first batch element of this view)
     const float* ipa_out_p;      // IPA table of (step 0, first batch element of this view)
     long ipa_step_stride;        // floats between consecutive steps of the IPA table
+    // split scratch (layout.split): arrival counters, fc2 partials, private residual rows; split_cap panels
+    unsigned* split_counters;
+    float *split_part, *split_hupd;
+    long split_cap;
     float* h() const { return hp; }
     float* mod() const { return modp; }
 };
@@ -983,8 +1020,9 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         } else {
             // (profile class "...@p8": the eight-wave form ran -- tests assert which kernel a launch took)
             const int pw = panel_waves_for((long)ax.nseq * q.panels_per_seq, r.c->opt_panel_waves, r.c->ncu);
-            const std::string cls = std::string(c_qkv) + (pw == 8 ? "@p8" : "");
-            { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_ln_qkv(q, false, r.s, false, pw); }
+            const bool split = pw == 8 && r.c->opt_small_split && 2L * ax.nseq * q.panels_per_seq <= r.c->ncu;
+            const std::string cls = std::string(c_qkv) + (split ? "@p8x2" : pw == 8 ? "@p8" : "");
+            { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_ln_qkv(q, false, r.s, false, pw, split); }
             LAUNCHCHK();
         }
         FlashParams f{};
@@ -1090,8 +1128,17 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
         p.trace_cap = r.c->phase_trace_cap;
         r.c->phase_trace = nullptr;
     }
-    const int pw = p.trace ? 4 : panel_waves_for((nrows + kPanel - 1) / kPanel, r.c->opt_panel_waves, r.c->ncu);
-    const std::string cls = std::string(!trunk ? "ipa.mlp" : p.o ? "proj_mlp" : "mlp") + (pw == 8 ? "@p8" : "@p4");
+    const long panels = (nrows + kPanel - 1) / kPanel;
+    const int pw = p.trace ? 4 : panel_waves_for(panels, r.c->opt_panel_waves, r.c->ncu);
+    // the split form: the context's scratch serves one launch at a time (one stream), and its workgroups must meet in one L2
+    const bool split = pw == 8 && r.c->opt_small_split && r.c->xcd_round_robin && r.c->live_streams <= 1 &&
+                       panels * kMlpSplit <= r.c->ncu && panels <= r.split_cap;
+    if (split) {
+        p.part = r.split_part;
+        p.hupd = r.split_hupd;
+        p.counters = r.split_counters;
+    }
+    const std::string cls = std::string(!trunk ? "ipa.mlp" : p.o ? "proj_mlp" : "mlp") + (split ? "@p8x3" : pw == 8 ? "@p8" : "@p4");
     { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_mlp(p, r.s, pw); }
     LAUNCHCHK();
     return 0;
@@ -1350,6 +1397,16 @@ static int make_run(Run* r, mdgen_ctx* c, const mdgen_shape* sh, int S, int t_sh
     r->modp = (float*)(r->ws + r->lay.mod);
     r->ipa_out_p = (const float*)(r->ws + r->lay.ipa_out);
     r->ipa_step_stride = (long)sh->B * sh->L * kC;
+    {
+        const long maxrows = r->N > r->Mp ? r->N : r->Mp;
+        r->split_cap = split_panels(maxrows);
+        r->split_counters = (unsigned*)(r->ws + r->lay.split);
+        r->split_part = (float*)(r->ws + r->lay.split + kSplitCounterBytes);
+        r->split_hupd = r->split_part + (size_t)r->split_cap * kMlpSplit * kPanel * kC;
+        // the counters must be zero when a launch starts (every launch leaves them so); the caller's workspace holds anything.
+        // Eagerly on the call's stream, ahead of the (possibly replayed) graph.
+        HIPCHK(hipMemsetAsync(r->split_counters, 0, kSplitCounterBytes, r->s));
+    }
     return 0;
 }
 
@@ -1425,7 +1482,13 @@ static int euler_body(const Run& r, const std::vector<float>& tg, float* x) {
     // >= ns views; more when a view would exceed kMaxViewTokens (the fp32 kernels index with 64 bits: one view)
     const int nv = r.c->opt_precision == 32 ? 1 : plan_views(r.B, r.T, r.L, ns);
     if (nv == 0) return fail(-2, "sample too large for one launch");
+    r.c->live_streams = 1;
     if (nv == 1) return euler_steps(r, tg, x);
+    struct Live {   // the views below run on ns streams at once: kernels that use context-owned scratch stay off meanwhile
+        mdgen_ctx* c;
+        ~Live() { c->live_streams = 1; }
+    } live{r.c};
+    r.c->live_streams = ns;
     // contiguous sub-batch views, view i on stream i % ns (fork after the shared preparation, join at the end)
     mdgen_ctx* c = r.c;
     if (ns > 1) HIPCHK(hipEventRecord(c->ev_fork, r.s));
@@ -1513,7 +1576,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1573,7 +1636,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

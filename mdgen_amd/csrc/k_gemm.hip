@@ -353,15 +353,22 @@ __device__ __forceinline__ void load_head_bias(const float* bias_perm, int w, in
 // (see k_mlp8.)  The split keeps 64 rows per wave -- with one row tile per wave every weight fragment feeds one MFMA instead of two and
 // the launch gets slower (profiles/r04_experiments.txt #17) -- and divides the three products instead: waves 0..3 compute q and k,
 // waves 4..7 compute v (and its all-ones row); the LayerNorm prologue is split by row batches.
+//
+// SPLIT (launches of at most half a workgroup per CU: B = 1): a panel's three products go to TWO workgroups -- blockIdx 2 n: waves
+// 0..3 q, waves 4..7 k (and the key-validity words); blockIdx 2 n + 1: waves 0..3 v, waves 4..7 leave after their share of the
+// LayerNorm prologue (which both workgroups run in full) -- so the longest chain of a launch is one product instead of two.  The
+// two workgroups write disjoint fragments; nothing is exchanged.
+template <bool SPLIT>
 __global__ __launch_bounds__(512, 1) void k_ln_qkv8(const QkvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
     PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
     unsigned char* panel = smem + sizeof(PanelRows);
-    const int seq = blockIdx.x / p.panels_per_seq;
-    const int pn = blockIdx.x - seq * p.panels_per_seq;
+    const int blk = SPLIT ? blockIdx.x >> 1 : blockIdx.x, half = SPLIT ? blockIdx.x & 1 : 0;
+    const int seq = blk / p.panels_per_seq;
+    const int pn = blk - seq * p.panels_per_seq;
     const int pos0 = pn * kPanel, tile0 = pn * 2;
     setup_rows_axis(pr, p.ax, seq, pos0, p.mm);
-    if (wave_id() == 0) {   // key-validity words of this panel's two tiles (as k_ln_qkv<false>)
+    if (wave_id() == 0 && half == 0) {   // key-validity words of this panel's two tiles (as k_ln_qkv<false>)
         const int lane = lane_id(), len = p.ax.len, pos = pos0 + lane;
         const float mv = p.mk.at(p.ax.token(seq, pos < len ? pos : len - 1));
         const unsigned long long bal = __ballot(pos == len || (pos < len && mv != 0.f));
@@ -381,11 +388,16 @@ __global__ __launch_bounds__(512, 1) void k_ln_qkv8(const QkvParams p) {
     const int ntile = p.ax.ntile(), len = p.ax.len;
     const bool last = pn == p.panels_per_seq - 1;
     f32x16 acc[6];
-    if (g == 0) {
+    // which products this wave group computes: q and k (do_q, do_k) or v
+    const bool do_q = SPLIT ? half == 0 && g == 0 : g == 0, do_k = SPLIT ? half == 0 && g == 1 : g == 0;
+    const bool do_v = SPLIT ? half == 1 && g == 0 : g == 1;
+    if (do_q) {
         zero_acc<6>(acc);
         wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
         epilogue_heads_T<true>(acc, pr, w, p.bq, p.rope, false, pos0, len, seq, ntile, tile0, p.qf, p.qkv_small, 0);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (do_k) {
         zero_acc<6>(acc);
         wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
         epilogue_heads_T<true>(acc, pr, w, p.bk, p.rope, false, pos0, len, seq, ntile, tile0, p.kf, p.qkv_small, 1);
@@ -393,7 +405,8 @@ __global__ __launch_bounds__(512, 1) void k_ln_qkv8(const QkvParams p) {
             __builtin_amdgcn_sched_barrier(0);
             write_bias_slots(p, seq, w, true, false);
         }
-    } else {
+    }
+    if (do_v) {
         zero_acc<6>(acc);
         wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
         epilogue_v_flash(acc, w, p.bv, seq, ntile, tile0, p.vf);
@@ -1042,10 +1055,24 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
 // the two partial fc2 sums meet in LDS: group g hands the other group its partial of row tile 1 - g and finishes row tile g
 // (bias, gate, residual).  The LayerNorm prologue is split by row batches, the out-projection prologue phase (PRE) by row tiles.
 // Summation order differs from k_mlp's (two six-chunk partials instead of twelve chunks in sequence): fp32 rounding only.
-template <bool PRE>
+//
+// S > 1 (launches of at most a third of a workgroup per CU: B = 1, the IPA stack): the twelve hidden chunks are also divided over S
+// WORKGROUPS (workgroup s, group g: chunks NC (2 s + g) .., NC = 12 / (2 S)), so that the chip's idle CUs take two thirds of the
+// weight stream and of the MFMAs of a panel.  Each workgroup runs the prologue phases in full (out-projection: redundantly, into a
+// PRIVATE copy p.hupd of the panel's updated residual rows -- nobody writes h while another workgroup may still read it), writes its
+// fp32 partial of the fc2 product to p.part and bumps the panel's counter; the LAST ARRIVER adds the S partials in the order of s
+// (the same bits whoever is last) and runs the gated residual epilogue from its private rows into h.
+// Nobody waits for anybody.  Memory ordering as measured for the attention kernels in round 5 (profiles/r05_experiments.txt 4): the
+// S workgroups of a panel are placed on ONE XCD (equal blockIdx % 8: their partials meet in that XCD's L2; the context's placement
+// probe has checked the residue -> XCD rule, else the launcher never picks this form); producer: s_waitcnt vmcnt(0), barrier,
+// agent-scope atomic add; consumer: agent-scope acquire fence (drops stale lines of its vector cache), ordinary loads.
+template <bool PRE, int S = 1>
 __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
+    static_assert(kNChunk % (2 * S) == 0, "whole chunks per group");
     __shared__ __attribute__((aligned(16))) unsigned char smem[kPanelBytes + 4 * kPanel * kHRowB];
     __shared__ PanelRows prs;
+    __shared__ PanelRows prs2;   // S > 1: the same rows in this workgroup's private copy (p.hupd) of the updated residual rows
+    __shared__ int s_last;
     unsigned char* panel = smem;
     PanelRows* pr = &prs;
     const int w8 = __builtin_amdgcn_readfirstlane(wave_id());
@@ -1054,7 +1081,20 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
     unsigned char* hb0 = smem + kPanelBytes + (2 * g) * (kPanel * kHRowB);
     unsigned char* hb1 = hb0 + kPanel * kHRowB;
     float* slab = reinterpret_cast<float*>(smem) + w8 * (32 * 96);   // eight 12 KiB staging slabs over panel + hidden buffers
-    setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
+    int pn = blockIdx.x, sp = 0;
+    if (S > 1) {
+        const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+        sp = rest % S;
+        pn = (rest / S) * 8 + xcd;
+        if ((long)pn * kPanel >= p.nrows) return;
+    }
+    const int slot = pn * S + sp;   // this workgroup's slot in p.part / p.hupd
+    setup_rows_linear(pr, (long)pn * kPanel, p.nrows, p.mm);
+    constexpr bool PRIV = PRE && S > 1;   // residual rows come from / go to the private copy
+    if (PRIV) {
+        setup_rows_linear(&prs2, (long)pn * kPanel, p.nrows, p.mm);
+        if (threadIdx.x < kPanel && prs2.tok[threadIdx.x] >= 0) prs2.tok[threadIdx.x] = slot * kPanel + threadIdx.x;   // (same thread wrote it)
+    }
     __syncthreads();
     if (PRE) {
         if (threadIdx.x < 256) prologue_bf16<kC>(panel, pr, p.o);
@@ -1064,18 +1104,21 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
         wave_gemm<1, 3, 24, false>(panel, kRowB, g, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
         __syncthreads();   // every wave is done reading the panel
         epi_stage(acc, slab);
-        epi_rmw<8>(g, pr, slab, 96 * w, p.bo, p.mm, p.gate_chunk_o, true, p.h);
+        if (PRIV) epi_rmw<8>(g, pr, slab, 96 * w, p.bo, p.mm, p.gate_chunk_o, true, p.h, &prs2, p.hupd);
+        else epi_rmw<8>(g, pr, slab, 96 * w, p.bo, p.mm, p.gate_chunk_o, true, p.h);
         __syncthreads();   // (vmcnt(0) + barrier) the updated rows are in L2; the slabs are free
     }
-    if (g == 0) prologue_ln<false, 0, 2>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
-    else prologue_ln<false, 2, 4>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
+    const PanelRows* prx = PRIV ? &prs2 : pr;          // where the MLP's input rows (and the residual of its epilogue) are read
+    const float* hx = PRIV ? p.hupd : p.h;
+    if (g == 0) prologue_ln<false, 0, 2>(panel, prx, hx, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
+    else prologue_ln<false, 2, 4>(panel, prx, hx, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
     __syncthreads();
     const bf16x8* w1l = p.w1 + (size_t)w * 24 * 64 + lane;
     const bf16x8* w2l = p.w2 + (size_t)(3 * w) * 96 * 64 + lane;
     const float* b1l = p.b1 + 32 * w + 4 * hh;
     constexpr size_t W1C = (size_t)4 * 24 * 64;
-    constexpr int NC = kNChunk / 2;
-    const int c0 = NC * g;
+    constexpr int NC = kNChunk / (2 * S);
+    const int c0 = NC * (2 * sp + g);
     f32x16 y[6];
     zero_acc<6>(y);
     f32x16 a1[2];
@@ -1136,9 +1179,45 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
                 z[f][r] = lo + hi;
             }
     }
-    __syncthreads();   // exchange area read: the slabs may overwrite it
+    if (S > 1) {
+        // this workgroup's partial: [slot][wave][3 tiles x 16 registers][lane] -- 256-byte runs per store
+        float* mine = p.part + ((size_t)slot * 8 + w8) * (3 * 16 * 64) + lane;
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(f * 16 + r) * 64] = z[f][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // acknowledged by L2
+        __syncthreads();                                    // (also: exchange area read)
+        if (threadIdx.x == 0) {
+            unsigned* c = p.counters + pn;
+            const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (unsigned)(S - 1);
+            if (old == (unsigned)(S - 1)) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // no stale copy of the others' partials in this CU's vector cache
+        f32x16 zt[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zt[f][r] = 0.f;
+#pragma unroll
+        for (int o = 0; o < S; ++o) {   // fixed order (its own partial is read back like the others): the same bits whichever workgroup is last
+            const float* src = p.part + ((size_t)(pn * S + o) * 8 + w8) * (3 * 16 * 64) + lane;
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zt[f][r] += src[(f * 16 + r) * 64];
+        }
+#pragma unroll
+        for (int f = 0; f < 3; ++f) z[f] = zt[f];
+    } else {
+        __syncthreads();   // exchange area read: the slabs may overwrite it
+    }
     epi_stage(z, slab);
-    epi_rmw<8>(g, pr, slab, 96 * w, p.b2, p.mm, p.gate_chunk, true, p.h);
+    if (PRIV) epi_rmw<8>(g, &prs2, slab, 96 * w, p.b2, p.mm, p.gate_chunk, true, p.hupd, pr, p.h);
+    else epi_rmw<8>(g, pr, slab, 96 * w, p.b2, p.mm, p.gate_chunk, true, p.h);
 }
 
 // =================================================================================================
@@ -1223,7 +1302,7 @@ __global__ __launch_bounds__(256, 2) void k_final(const FinalParams p) {
 // workgroup per CU, unless the caller forces one form (option panel_waves: 4 / 8).
 int panel_waves_for(long grid, int forced, int ncu) { return forced == 4 || forced == 8 ? forced : (grid <= ncu ? 8 : 4); }
 
-void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre, int waves) {
+void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre, int waves, bool split) {
     if (pre) {
         const int grid = p.ax.nseq * p.panels_per_seq;
         hipLaunchKernelGGL((k_ln_qkv<false, true>), dim3(grid), dim3(256), 0, s, p);
@@ -1234,10 +1313,17 @@ void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre, int 
         hipLaunchKernelGGL(k_ln_qkv<true>, dim3(grid), dim3(256), 0, s, p);
     } else {
         const int grid = p.ax.nseq * p.panels_per_seq;
-        if (waves == 8) hipLaunchKernelGGL(k_ln_qkv8, dim3(grid), dim3(512), 0, s, p);
+        if (waves == 8 && split) hipLaunchKernelGGL(k_ln_qkv8<true>, dim3(2 * grid), dim3(512), 0, s, p);
+        else if (waves == 8) hipLaunchKernelGGL(k_ln_qkv8<false>, dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL(k_ln_qkv<false>, dim3(grid), dim3(256), 0, s, p);
     }
 }
+// placement probe (mdgen_ctx_create): the XCD each of `nblocks` workgroups ran on (HW_REG_XCC_ID, 4 bits)
+__global__ void k_xcc_probe(int* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);
+}
+void launch_xcc_probe(int* out, int nblocks, hipStream_t s) { hipLaunchKernelGGL(k_xcc_probe, dim3(nblocks), dim3(64), 0, s, out); }
+
 void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
     if (fuse_proj) hipLaunchKernelGGL((k_ln_qkv_attn4<true>), dim3(grid), dim3(256), 0, s, p);
@@ -1251,6 +1337,12 @@ void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
 }
 void launch_mlp(const MlpParams& p, hipStream_t s, int waves) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
+    if (waves == 8 && !p.trace && p.part) {   // hidden chunks over kMlpSplit workgroups per panel (same XCD), last arriver finishes
+        const int g3 = (grid + 7) / 8 * 8 * kMlpSplit;
+        if (p.o) hipLaunchKernelGGL((k_mlp8<true, kMlpSplit>), dim3(g3), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((k_mlp8<false, kMlpSplit>), dim3(g3), dim3(512), 0, s, p);
+        return;
+    }
     if (waves == 8 && !p.trace) {   // (the phase stamps stay with k_mlp: mdgen_profile_phase_trace selects the four-wave kernel)
         if (p.o) hipLaunchKernelGGL((k_mlp8<true>), dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((k_mlp8<false>), dim3(grid), dim3(512), 0, s, p);

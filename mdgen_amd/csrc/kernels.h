@@ -61,7 +61,15 @@ struct MlpParams {
     const bf16x8* wo;
     const float* bo;
     int gate_chunk_o;
+    // k_mlp8<PRE, kMlpSplit> (part != null): the hidden chunks of a panel over kMlpSplit workgroups.  part: fp32 partials of the fc2
+    // product [panel][kMlpSplit][64][384]; hupd: each workgroup's private copy of the panel's residual rows after the fused
+    // out-projection (same shape; PRE only); counters: one per panel, zero before the first launch (the last arriver resets it)
+    float* part;
+    float* hupd;
+    unsigned* counters;
 };
+constexpr int kMlpSplit = 3;            // workgroups per panel in the split form
+constexpr int kMlpSplitMaxPanels = 96;  // panels the context's split scratch covers (the form is for launches of <= ncu / 3 panels)
 
 // k_mlp_rows (k_rows.hip): the MLP block in row-owner form; `wstream` = both weight matrices as one fragment stream in
 // consumption order (api.hip mlp_stream_table)
@@ -177,7 +185,8 @@ struct FloatChunk {
 };
 
 int panel_waves_for(long grid, int forced, int ncu);   // 4 or 8 waves per 64-row panel for a launch of `grid` panels
-void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre = false, int waves = 4);
+void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre = false, int waves = 4, bool split = false);
+void launch_xcc_probe(int* out, int nblocks, hipStream_t s);
 void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
 void launch_mlp(const MlpParams& p, hipStream_t s, int waves = 4);

@@ -325,10 +325,12 @@ __device__ __forceinline__ void epi_stage(const f32x16* acc3, float* stage) {
 // The loads of BR row pairs at a time are UNCONDITIONAL (padding rows and idle lanes read token 0) and issued
 // back to back; only the stores are predicated.  With a load under `if (tk >= 0)` every row paid its own HBM
 // round trip, 32 in sequence per wave.
+// prd / hd (optional): the updated rows go to hd[prd->tok[row]] instead of back to h[pr->tok[row]] (k_mlp8's split form: rows read
+// from / written to a workgroup-private copy of the panel's residual rows); prd marks the same rows valid as pr.
 template <int BR>
 __device__ __forceinline__ void epi_rmw(const int t, const PanelRows* pr, const float* stage, int col0,
                                         const float* __restrict__ bias, const ModMap mm, int gate_chunk, bool gated,
-                                        float* __restrict__ h) {
+                                        float* __restrict__ h, const PanelRows* prd = nullptr, float* hd = nullptr) {
     static_assert(16 % BR == 0, "batches of row pairs");
     const int lane = lane_id();
     const int q = lane % 24, r2 = lane / 24;
@@ -344,11 +346,12 @@ __device__ __forceinline__ void epi_rmw(const int t, const PanelRows* pr, const 
 #pragma unroll
     for (int b = 0; b < 16 / BR; ++b) {
         f32x4 hv[BR], g[BR];
-        int tk[BR];
+        int tk[BR], td[BR];
 #pragma unroll
         for (int k = 0; k < BR; ++k) {
             const int row = active ? t * 32 + 2 * (BR * b + k) + r2 : 0;
             tk[k] = active ? pr->tok[row] : -1;
+            td[k] = prd ? prd->tok[row] : tk[k];
             const long tc = tk[k] < 0 ? 0 : tk[k];
             hv[k] = *reinterpret_cast<const f32x4*>(h + tc * kC + col0 + 4 * q);
             g[k] = gu;
@@ -362,7 +365,7 @@ __device__ __forceinline__ void epi_rmw(const int t, const PanelRows* pr, const 
             o[1] += g[k][1] * (v[1] + b4[1]);
             o[2] += g[k][2] * (v[2] + b4[2]);
             o[3] += g[k][3] * (v[3] + b4[3]);
-            if (tk[k] >= 0) *reinterpret_cast<f32x4*>(h + (long)tk[k] * kC + col0 + 4 * q) = o;
+            if (tk[k] >= 0) *reinterpret_cast<f32x4*>((hd ? hd : h) + (long)td[k] * kC + col0 + 4 * q) = o;
         }
     }
 }

@@ -2177,12 +2177,15 @@ def test_row_owner_mlp_paths_agree():
     takes the same kernels."""
     from mdgen_amd.model import LatentMDGenModel
     dev = _cuda()
-    P4, P8 = {"panel_waves": 4}, {"panel_waves": 8}
+    P4, P8 = {"panel_waves": 4}, {"panel_waves": 8, "small_split": 0}
+    X8 = {"panel_waves": 8, "small_split": 1}   # (round 5) a panel's work over several workgroups: k_mlp8<., 3>, k_ln_qkv8<true>
     forms = (("panel4", dict(P4, mlp_path=0, fuse_proj=0), "mlp@p4"), ("panel8", dict(P8, mlp_path=0, fuse_proj=0), "mlp@p8"),
              ("panel4+proj", dict(P4, mlp_path=0, fuse_proj=2), "proj_mlp@p4"), ("panel8+proj", dict(P8, mlp_path=0, fuse_proj=2), "proj_mlp@p8"),
+             ("panel8 split", dict(X8, mlp_path=0, fuse_proj=0), "mlp@p8x3"), ("panel8+proj split", dict(X8, mlp_path=0, fuse_proj=2), "proj_mlp@p8x3"),
              ("rows", {"mlp_path": 2, "fuse_proj": 0}, "mlp"), ("rows+proj", {"mlp_path": 2, "fuse_proj": 1}, "proj_mlp"),
              ("no-qkv-prologue p4", dict(P4, mlp_path=0, fuse_proj=0, fuse_proj_qkv=0), "ln_qkv_T"),
              ("no-qkv-prologue p8", dict(P8, mlp_path=0, fuse_proj=0, fuse_proj_qkv=0), "ln_qkv_T@p8"),
+             ("no-qkv-prologue p8 split", dict(X8, mlp_path=0, fuse_proj=0, fuse_proj_qkv=0), "ln_qkv_T@p8x2"),
              ("qkv-prologue", dict(P4, mlp_path=0, fuse_proj=0, fuse_proj_qkv=1), None), ("defaults", {}, None))
     for name in ("fwd_full_pep", "fwd_full_atlas"):
         g = load_golden(name)
@@ -2209,9 +2212,10 @@ def test_row_owner_mlp_paths_agree():
             T_, L_ = g["x"].shape[1:3]
             if want is not None:
                 assert ran.get(want) == cfg.num_layers, (key, want, ran)
-                other = {"mlp@p4": "mlp@p8", "mlp@p8": "mlp@p4", "proj_mlp@p4": "proj_mlp@p8", "proj_mlp@p8": "proj_mlp@p4",
-                         "ln_qkv_T": "ln_qkv_T@p8", "ln_qkv_T@p8": "ln_qkv_T"}.get(want)
-                assert other is None or other not in ran, (key, ran)
+                family = [k for k in ran if k.split("@")[0] == want.split("@")[0] and k != want]   # no other form of the same kernel ran
+                assert not family, (key, want, ran)
+                if "split" in key:   # the IPA stack's MLP (S B L rows: one panel here) takes the split form too
+                    assert any(k == "ipa.mlp@p8x3" for k in ran), ran
             if key == "qkv-prologue":
                 assert ("projL_qkvT" in ran) == (L_ > 8 and T_ > 8), ran   # (neither golden has both: test_panel_kernels_257_to_383_panels_vs_oracle does)
             del m
@@ -2219,9 +2223,15 @@ def test_row_owner_mlp_paths_agree():
         assert rel_l2(outs["rows"], outs["panel4"]) < 6e-3 and rel_l2(outs["rows+proj"], outs["rows"]) < 6e-3
         assert rel_l2(outs["panel4+proj"], outs["panel4"]) < 6e-3
         assert rel_l2(outs["no-qkv-prologue p8"], outs["no-qkv-prologue p4"]) < 6e-3
+        # the split forms: k_ln_qkv8<true> computes the same products with the same operands (same bits as k_ln_qkv8<false>);
+        # k_mlp8<., 3> adds three partial fc2 sums instead of two (fp32 rounding)
+        assert torch.equal(outs["no-qkv-prologue p8 split"], outs["no-qkv-prologue p8"]) or \
+            rel_l2(outs["no-qkv-prologue p8 split"], outs["no-qkv-prologue p8"]) < 2e-3   # (its MLP is the split form too)
+        assert rel_l2(outs["panel8 split"], outs["panel8"]) < 2e-3 and rel_l2(outs["panel8+proj split"], outs["panel8+proj"]) < 2e-3
         assert rel_l2(outs["qkv-prologue"], outs["no-qkv-prologue p4"]) < 6e-3
-        # the defaults at this size: eight-wave panel MLP kernel (at most one workgroup per CU) with the out-projection in front
-        assert rel_l2(outs["defaults"], outs["panel8+proj"]) < 6e-3
+        # the defaults at this size: eight-wave panel MLP kernel (at most one workgroup per CU), split over three workgroups, with
+        # the out-projection in front
+        assert rel_l2(outs["defaults"], outs["panel8+proj split"]) < 6e-3
 
 
 def test_validation_on_ema_weights_leaves_the_master_parameters_alone(tmp_path):
@@ -2390,6 +2400,86 @@ def test_flash_proj_is_the_default_where_the_launch_fills_the_chip():
         print(f"B {B}: default {sorted(k for k in ran if 'flash' in k)} vs flash_proj 0: {e:.2e}")
         assert torch.isfinite(out).all() and e < 2e-3   # (the 128-row form rotates its key-tile walk by 128-query chunks: fp32 rounding)
         del m
+
+
+@pytest.mark.parametrize("shape", [(1, 1000, 4, 0), (1, 130, 4, 0), (1, 40, 96, 5), (2, 100, 9, 1)],
+                         ids=["B1_T1000_L4", "B1_T130_L4", "B1_T40_L96_pad", "B2_T100_L9_pad"])
+def test_small_launches_split_a_panel_over_workgroups_vs_oracle(shape):
+    """Option `small_split` (round 5, default on): launches far below one workgroup per CU -- the CLI's B = 1 (sim_inference.py:100-113),
+    the IPA stack -- give a 64-row panel to SEVERAL workgroups: k_mlp8<., 3> (latent_model.py:477-481: the twelve hidden chunks over
+    three workgroups on one XCD; fp32 partials of the fc2 product meet in L2 and the last arriver runs the gated residual epilogue;
+    with the temporal out-projection fused in front each workgroup keeps a private copy of the updated rows) and k_ln_qkv8<true>
+    (q, k | v over two workgroups).  Against the CPU oracle at the bf16 gate (every trace), against the unsplit kernels (fp32
+    rounding of a three-term instead of a two-term sum), bit-reproducible over repeated calls on a 0xFF-filled workspace (the arrival
+    counters are re-zeroed per call; a race between the workgroups of a panel would show as differing bits), and through a replayed
+    hipGraph rollout.  Shapes: 63 panels (B 1 x T 1000 x L 4: the headline model at B = 1), 9 panels with a partial last one and a
+    grid padded to whole XCD groups (T 130), the tiled residue axis with padded residues (L 96), L 9."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.model import LatentMDGenModel
+    B, T, L, n_pad = shape
+    cfg, sd, kw, dkw = _fwd_case(B, T, L, n_pad, 1200 + T + L)
+    ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
+    outs = {}
+    for key, opts in (("split", {}), ("unsplit", {"small_split": 0})):
+        m = LatentMDGenModel(cfg)
+        m.load_state_dict(sd)
+        for k, v in opts.items():
+            m.set_option(k, v)
+        out, tr, ran = _profiled_forward(m, dkw)
+        rep = {k: rel_l2(tr[k].cpu(), rtr[k]) for k in ["ipa_out"] + [f"h{i}" for i in range(cfg.num_layers + 1)]}
+        rep["out"] = rel_l2(out.cpu(), ref)
+        print(shape, key, {k: f"{v:.2e}" for k, v in rep.items()}, {k: v for k, v in ran.items() if "mlp" in k or "qkv" in k})
+        assert torch.isfinite(out).all()
+        for k, v in rep.items():
+            assert v < TOL_FWD, (key, k, v)
+        split = key == "split"
+        nl = cfg.num_layers
+        assert (ran.get("proj_mlp@p8x3", 0) + ran.get("mlp@p8x3", 0) == nl) == split, ran
+        assert ("ipa.mlp@p8x3" in ran) == split, ran
+        qkv = [k for k in ran if k.startswith("ln_qkv_T")]   # (none on the tiled residue axis: projL_qkvT carries the projection)
+        assert all((k == "ln_qkv_T@p8x2") == split for k in qkv) and (qkv or L > 8), ran
+        if split:   # repeated calls, each on a poisoned workspace: the same bits (profile off: the product's launch path)
+            for rep_i in range(6):
+                for ws in m._ws.values():
+                    ws.view(torch.uint8).fill_(0xFF)
+                again = m.forward(**dkw)
+                assert torch.equal(again, out), (shape, rep_i, rel_l2(again.cpu(), out.cpu()))
+        outs[key] = out.cpu()
+        del m
+    e = rel_l2(outs["split"], outs["unsplit"])
+    print(shape, f"split vs unsplit kernels: {e:.2e}")
+    assert e < 2e-3
+
+
+def test_small_split_in_a_replayed_graph_rollout():
+    """The split kernels inside the hipGraph Euler rollout (B 1 x T 1000 x L 4, 3 steps): replays give the same bits (counters zeroed
+    ahead of every launch of the graph, partial sums added in a fixed order) and the trajectory matches the unsplit kernels'."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict
+    from mdgen_amd.wrapper import NewMDGenWrapper
+    import bench
+    dev = _cuda()
+    B, T, L, abs_pos, n_pad = bench.WORKLOADS["tetrapeptide_fwdsim_crop4_T1000_B1"]
+    cfg = ModelConfig(crop=L, num_frames=T, abs_pos_emb=abs_pos, sim_condition=True)
+    sd = synth_state_dict(cfg, 0)
+    batch = bench.synth_batch(B, T, L, n_pad, dev, seed=100)
+    zs = torch.randn(1, 1000, 4, 21, generator=torch.Generator().manual_seed(137)).to(dev)
+    res = {}
+    for key, v in (("split", 1), ("unsplit", 0)):
+        w = NewMDGenWrapper(cfg, device=dev)
+        w.model.load_state_dict(sd)
+        w.model.set_option("small_split", v)
+        a, _ = w.inference(batch, zs=zs, num_steps=3, use_graph=True)
+        for _ in range(3):
+            b, _ = w.inference(batch, zs=zs, num_steps=3, use_graph=True)   # replays
+            assert torch.equal(a, b), key
+        e, _ = w.inference(batch, zs=zs, num_steps=3, use_graph=False)
+        assert torch.equal(a, e), key                                        # eager launches: the same kernels, the same bits
+        res[key] = a.cpu()
+        del w
+    d = rel_l2(res["split"], res["unsplit"])
+    print(f"rollout, split vs unsplit kernels: {d:.2e}")
+    assert torch.isfinite(res["split"]).all() and d < 5e-3
 
 
 @pytest.mark.parametrize("case", ["B5_T1000_L4", "B1_T250_L80_pad"])
