@@ -143,6 +143,13 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      k_ln_qkv<false> / k_ln_qkv8) take the eight-wave form for launches of at most one workgroup per CU; 4 / 8
  *                      force one form whatever the launch size (tests, A/B runs).  mdgen_profile_report tags the class of such
  *                      a launch with "@p4" / "@p8".
+ *   "small_split"      1 (default) / 0: launches far below one workgroup per CU (B = 1: sim_inference.py runs one trajectory; the IPA
+ *                      stack) give a 64-row panel to several workgroups: the MLP block's twelve hidden chunks go to three workgroups
+ *                      on one XCD (k_mlp8<., 3>, launches of <= CUs / 3 panels; fp32 partials of the second product meet in L2, the
+ *                      last arriver adds them in a fixed order and runs the gated residual epilogue -- bit-reproducible, nobody
+ *                      waits) and q, k | v of the temporal LN -> q, k, v kernel to two (k_ln_qkv8<true>, <= CUs / 2 panels).
+ *                      Scratch: mdgen_ws_layout.split.  Same values to fp32 rounding (a three-term instead of a two-term sum);
+ *                      the report tags such launches "@p8x3" / "@p8x2".  Off while a call runs sub-batch streams.
  *   "train_precision"  operands of the matrix products of mdgen_train_forward_backward (linear layers, weight gradients,
  *                      the attention's q k^T / p v and their backward): 32 (default) fp32, the exact mode; 16 rounded to
  *                      bf16 on the MFMA, fp32 accumulation, fp32 master weights and activations (train.py:13
