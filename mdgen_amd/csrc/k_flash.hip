@@ -645,9 +645,10 @@ __global__ __launch_bounds__(256, 2) void k_flash_proj(const FlashProjParams p) 
 }
 
 // =================================================================================================
-// k_flash_proj8: the same fusion with the attention loop at k_flash<4>'s density.  k_flash_proj's loop runs two waves of two query
-// tiles per SIMD -- 260-290 cycles per (32-key, 32-query) pair per SIMD where three such waves (k_flash) or two waves of FOUR tiles
-// (k_flash<4>, a measured tie) run at 200 -- because a 64-row panel per workgroup at two workgroups per CU is all the LDS allows.
+// k_flash_proj8: the same fusion with four query tiles per wave.  The loop of either form runs at 260-290 cycles per (32-key,
+// 32-query) pair per SIMD -- its bound is the VALU issue port (16 quarter-rate exponentials + 8 conversions per pair: ~200 cycles
+// per SIMD at any occupancy, profiles/r05_experiments.txt 17), not the number of waves -- so what this form buys is elsewhere: the
+// K / V^T fragment loads and the prologue of a job serve twice the pairs, and the launch has no second, partly filled round.
 // Here ONE workgroup of EIGHT waves owns 128 consecutive positions of a sequence: every wave runs flash_job<4> (128 queries of one
 // head: the K / V^T fragment loads and the prologue serve twice the pairs) for head 8 pass + wave, two passes; the output rows go
 // into a bf16 LDS panel [128][384] (96 KB: one workgroup per CU, which the 256-register budget of two waves per SIMD implies anyway);
