@@ -30,6 +30,25 @@ def test_library_exports_every_declared_symbol():
     assert L.lib.mdgen_abi_version() == L.ABI_VERSION == 6   # include/mdgen_amd.h MDGEN_ABI_VERSION; _lib refuses a mismatch
 
 
+def test_public_struct_layouts_agree_between_header_python_mirror_and_the_integration_stub():
+    """mdgen_ws_layout is written by the library into caller memory: the header's field list, `_lib.WsLayout` and the ctypes stub a
+    maintainer would copy from INTEGRATION.md must have the same number of size_t fields (a shorter buffer is a heap overrun: the
+    round-5 `split` field crashed the stub's GPU test before this check existed), and the stub must pin the ABI version."""
+    import re
+    import mdgen_amd._lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "mdgen_amd.h")).read()
+    body = re.search(r"typedef struct mdgen_ws_layout \{(.*?)\} mdgen_ws_layout;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [n.strip() for decl in re.findall(r"size_t\s+([^;]+);", body) for n in decl.split(",")]
+    assert fields == [n for n, _ in L.WsLayout._fields_], (fields, L.WsLayout._fields_)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    n_stub = int(re.search(r"lay = \(C\.c_size_t \* (\d+)\)\(\)", doc).group(1))
+    assert n_stub == len(fields)
+    v = int(re.search(r"#define MDGEN_ABI_VERSION (\d+)", hdr).group(1))
+    assert v == L.ABI_VERSION and f"assert lib.mdgen_abi_version() == {v}" in doc
+
+
 def test_argument_validation_without_gpu():
     import mdgen_amd._lib as L
     assert L.lib.mdgen_rigid_compose(4, None, None, None, None, None, None, None) == -1
