@@ -279,3 +279,44 @@ def test_training_attention_workgroup_order_keeps_a_sequence_on_one_xcd():
             load[b & 7] += 1
         assert len(seen) == nseq * kH * nblk
         assert max(load) - min(load) <= kH * nblk          # at most one sequence of difference between XCDs
+
+
+def test_small_split_block_mapping_covers_every_panel_and_chunk_once():
+    """csrc/k_gemm.hip `k_mlp8<PRE, S>` (option `small_split`) and `k_ln_qkv8<true>`, index algebra replayed in Python.
+    k_mlp8: block b -> (xcd = b & 7, s = (b >> 3) % S, panel = ((b >> 3) / S) * 8 + xcd); grid = ceil(panels / 8) * 8 * S.  The S
+    workgroups of a panel must (a) share `b % 8` (= one XCD, one L2: their fp32 partials meet there), (b) cover the twelve hidden
+    chunks exactly once between their 2 S wave groups (group g of workgroup s: chunks NC (2 s + g) .. + NC - 1, NC = 12 / (2 S)),
+    (c) own disjoint slots of the partial / private-row scratch (slot = panel * S + s, < panels * S), and padding blocks (panel >=
+    panels) must be whole workgroups that exit.  k_ln_qkv8<true>: block b -> (panel = b >> 1, half = b & 1): q and k on half 0
+    (wave groups 0 / 1), v on half 1 (group 0), each product exactly once per panel."""
+    kNChunk, S = 12, 3
+    NC = kNChunk // (2 * S)
+    for panels in (1, 2, 7, 8, 9, 63, 85, 96):
+        grid = (panels + 7) // 8 * 8 * S
+        seen, xcd_of_panel, slots = {}, {}, set()
+        for b in range(grid):
+            xcd, rest = b & 7, b >> 3
+            s, pn = rest % S, (rest // S) * 8 + xcd
+            if pn >= panels:
+                continue                                   # padding: the whole workgroup returns before its first barrier
+            assert xcd_of_panel.setdefault(pn, xcd) == xcd
+            slot = pn * S + s
+            assert slot not in slots and slot < panels * S
+            slots.add(slot)
+            for g in range(2):
+                c0 = NC * (2 * s + g)
+                for c in range(c0, c0 + NC):
+                    assert (pn, c) not in seen
+                    seen[(pn, c)] = (s, g)
+        assert len(seen) == panels * kNChunk and len(slots) == panels * S
+    for panels in (1, 5, 63, 128):
+        done = {}
+        for b in range(2 * panels):
+            pn, half = b >> 1, b & 1
+            for g in range(2):
+                do_q, do_k, do_v = half == 0 and g == 0, half == 0 and g == 1, half == 1 and g == 0
+                for name, on in (("q", do_q), ("k", do_k), ("v", do_v)):
+                    if on:
+                        assert (pn, name) not in done
+                        done[(pn, name)] = (half, g)
+        assert len(done) == 3 * panels
