@@ -126,7 +126,13 @@ def cpu_baseline(cfg, sd, B, T, L, S, n_pad, budget_s=20.0):
 _KERNEL_OF_CLASS = {"mlp": "k_mlp", "proj_mlp": "k_mlp_rows", "flash_T": "k_flash<", "flash_L": "k_flash<", "ln_qkv_T": "k_ln_qkv<false",
                     "ln_qkv_L": "k_ln_qkv<true", "proj_T": "k_proj<0>", "proj_L": "k_proj<2>",
                     "attn_L_fused": "k_ln_qkv_attn4<true>", "flash_proj_T": "k_flash_proj", "flash_proj_L": "k_flash_proj",
-                    "projL_qkvT": "k_ln_qkv<false, true>"}
+                    "projL_qkvT": "k_ln_qkv<false, true>",
+                    # tagged classes name ONE kernel form (looked up before the untagged base class)
+                    "mlp@fold": "k_mlp_rows<4, false, true, true>", "mlp@p4": "k_mlp<3, false>", "mlp@p8": "k_mlp8<false>",
+                    "mlp@p8x3": "k_mlp8<false, 3>", "proj_mlp@p4": "k_mlp<3, true>", "proj_mlp@p8": "k_mlp8<true>",
+                    "proj_mlp@p8x3": "k_mlp8<true, 3>", "ln_qkv_T@p8": "k_ln_qkv8<false>", "ln_qkv_T@p8x2": "k_ln_qkv8<true>",
+                    "flash_proj_T@q128": "k_flash_proj8", "flash_proj_T@q64": "k_flash_proj(", "flash_proj_L@q64": "k_flash_proj(",
+                    "flash_proj_L@q128": "k_flash_proj8"}
 
 
 def pmc_traffic(kernel_class, workload):
@@ -140,7 +146,7 @@ def pmc_traffic(kernel_class, workload):
             m = json.load(f)
     except (OSError, ValueError):
         return None, None
-    sub = _KERNEL_OF_CLASS.get(kernel_class.split("@")[0])
+    sub = _KERNEL_OF_CLASS.get(kernel_class) or _KERNEL_OF_CLASS.get(kernel_class.split("@")[0])
     kern = m.get("workloads", {}).get(workload, {}).get("kernels")
     if kern is None and m.get("workload") == workload:   # (round-1 layout of the file: one workload)
         kern = m.get("kernels")

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 /* Bumped whenever a public struct or signature changes; mdgen_amd/_lib.py refuses a library whose version differs. */
-#define MDGEN_ABI_VERSION 6   /* 6: mdgen_ws_layout.split */
+#define MDGEN_ABI_VERSION 7   /* 6: mdgen_ws_layout.split; 7: mdgen_ws_layout.fold */
 
 typedef struct mdgen_ctx mdgen_ctx;
 
@@ -79,6 +79,9 @@ typedef struct mdgen_ws_layout {
                           context keeps fp32 weights)                                            */
     size_t split;      /* scratch of the split-panel MLP kernel (option "small_split"): arrival counters (1 KiB) | fp32 partials |
                           private residual rows, [panels <= 96][3][64][384] each                 */
+    size_t fold;       /* option "mlp_fold": per (step, trunk layer) the MLP weight stream with that step's gate folded into fc2
+                          [S][layers][2304 KiB bf16 fragments] | gate * fc2.bias [S][layers][384] fp32 (0 bytes unless t_shared and
+                          the trunk's MLP launches take the row-owner kernel)                    */
 } mdgen_ws_layout;
 
 const char* mdgen_last_error(void);
@@ -117,6 +120,12 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      (csrc/k_gemm.hip k_mlp); 1 (default) the row-owner kernel (csrc/k_rows.hip k_mlp_rows: a wave owns 32
  *                      rows, activations in registers, weights as one LDS-DMA stream) for launches of >= 768 row tiles,
  *                      which fill the chip, and the panel kernel below that; 2 the row-owner kernel always.
+ *   "mlp_fold"         1 (default) / 0: calls whose batch shares t (mdgen_sample_euler / mdgen_rollout_euler; integrators.py:99) have ONE
+ *                      MLP gate vector per (step, layer): it is folded into the weights once per call -- W2' = diag(gate) W2 rounded to
+ *                      bf16 once from the fp32 weight, b2' = gate * b2 -- so that h + gate * (W2 u + b2) (latent_model.py:481) becomes
+ *                      "accumulators start at h + b2', accumulate W2' u, store": the row-owner kernel reads the residual rows once
+ *                      instead of twice.  Same values to the bf16 rounding of gate * w instead of w.  Workspace: mdgen_ws_layout.fold
+ *                      (S x layers x 2.36 MB); the report tags such launches "mlp@fold".
  *   "fuse_proj"        the temporal attention's out-projection + gated residual (mha.py:397, latent_model.py:476) inside the
  *                      MLP kernel, ahead of the MLP: 0 off / 1 inside the row-owner kernel / 2 as a prologue phase of the
  *                      64-row panel kernel (k_mlp<3, true>; selects the panel kernel) / 3 (default) as 2 where the launch
@@ -247,7 +256,11 @@ int32_t mdgen_rollout_euler(mdgen_ctx* ctx, const mdgen_shape* shape, int32_t n_
  * While enabled, launches are bracketed by event pairs and hipGraph capture/replay is bypassed.
  * `mdgen_profile_report` synchronises `stream`, writes a JSON object
  *   {"<class>": {"count": n, "ms": total_ms}, ...}   into buf (NUL-terminated) and resets the log.  Classes of the 64-row panel
- * kernels that exist in two forms carry "@p4" / "@p8" (four / eight waves per panel; option panel_waves). */
+ * kernels that exist in two forms carry "@p4" / "@p8" (four / eight waves per panel; option panel_waves), "@p8x3" / "@p8x2" the split
+ * forms, the fused attention "@q64" / "@q128" (k_flash_proj / k_flash_proj8), the gate-folded row-owner MLP "mlp@fold".  One entry is
+ * not a kernel class: "@context": {"count": split-form MLP launches since the last report, "xcd_round_robin": 0/1 (the placement
+ * probe of mdgen_ctx_create: workgroups with equal blockIdx % 8 share an XCD -- where it fails the split MLP form is never picked),
+ * "ncu": compute units}. */
 int32_t mdgen_profile_enable(mdgen_ctx* ctx, int32_t on);
 /* Measurement only: the NEXT trunk MLP launch (the dominant kernel) writes per-wave s_memtime phase stamps into
  * dev_buf ([workgroup*4 + wave][32] uint64; slot meaning: csrc/k_gemm.hip `stamp`).  One-shot; pass NULL to cancel.

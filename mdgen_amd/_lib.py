@@ -10,7 +10,7 @@ import torch  # noqa: F401  -- must be imported first: provides the process-wide
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDGEN_AMD_LIB", os.path.join(_HERE, "libmdgen_amd.so"))   # override: debugging builds only
 
-ABI_VERSION = 6   # include/mdgen_amd.h MDGEN_ABI_VERSION
+ABI_VERSION = 7   # include/mdgen_amd.h MDGEN_ABI_VERSION
 
 EXPORTS = [
     "mdgen_last_error", "mdgen_abi_version", "mdgen_dev_build", "mdgen_ctx_create", "mdgen_ctx_destroy", "mdgen_ctx_set_weight",
@@ -39,7 +39,7 @@ class Shape(C.Structure):
 class WsLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "h", "qf", "kf", "vf", "obuf", "mod", "silu_t", "ipa_out", "h_ipa", "ipa_proj",
-        "ipa_feat", "mask_bl", "rel7", "tgrid", "f32_scratch", "split")]
+        "ipa_feat", "mask_bl", "rel7", "tgrid", "f32_scratch", "split", "fold")]
 
 
 class ResidueTables(C.Structure):

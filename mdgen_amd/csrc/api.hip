@@ -68,6 +68,7 @@ struct FfnW {
     bf16x8 *w1 = nullptr, *w2 = nullptr;
     float *b1 = nullptr, *b2 = nullptr;
     bf16x8* wstream = nullptr;   // both matrices as ONE fragment stream in the consumption order of k_mlp_rows (mlp_stream_table)
+    float* w2f = nullptr;        // trunk layers: fp32 fc2.weight [384][1536], the source of the per-step gate-folded streams (option mlp_fold)
 };
 struct TrunkW {
     MhaW mha_l, mha_t;
@@ -142,6 +143,7 @@ struct mdgen_ctx {
                                 // k_mlp8<., kMlpSplit> (hidden chunks over 3 workgroups, last arriver finishes; panels <= ncu / 3) and
                                 // k_ln_qkv8<true> (q, k | v over 2 workgroups; panels <= ncu / 2).  0 off, 1 (default) on
     bool xcd_round_robin = false;   // placement probe: workgroups with equal blockIdx % 8 share an XCD (k_mlp8's split form relies on it)
+    long n_split_launches = 0;  // k_mlp8<., kMlpSplit> launches enqueued (or captured) since the last mdgen_profile_report
     int live_streams = 1;       // sub-batch streams of the call being recorded / run (the workspace's split scratch serves one launch at a time)
     int opt_flash_rotate = 1;   // tiled attention: the 64-query chunks of a sequence start their walk over the key tiles at different tiles (k_flash.hip)
     int opt_flash_proj_form = 0;   // ... 0 (default): k_flash_proj8 (eight waves, 128-row panel, four query tiles per wave) for sequences of >= 512
@@ -155,6 +157,8 @@ struct mdgen_ctx {
     hipStream_t train_side = nullptr;   // that stream (created on first use, default priority)
     std::vector<hipEvent_t> train_ev;   // event pool of that fork / join traffic (created on first use, round-robin)
     size_t train_ev_next = 0;
+    int opt_mlp_fold = 1;       // sampling (t shared by the batch): the MLP gate folded into per-(step, layer) fc2 streams, k_mlp_rows starts its
+                                // accumulators from the residual rows and only stores (one HBM read of the rows instead of two)
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
     std::vector<void*> milestone_events;          // mdgen_train_set_milestone_events (hipEvent_t handles, caller-owned)
     unsigned long long* phase_trace = nullptr;   // mdgen_profile_phase_trace target (device), consumed by one launch
@@ -371,7 +375,9 @@ static int register_mha(mdgen_ctx* c, const std::string& pre, MhaW* m) {
     return 0;
 }
 
-static int register_ffn(mdgen_ctx* c, const std::string& pre, FfnW* f) {
+static int register_ffn(mdgen_ctx* c, const std::string& pre, FfnW* f, bool trunk) {
+    if (trunk)
+        if (int r = c->dalloc(&f->w2f, (size_t)kC * kF)) return r;
     if (int r = c->dalloc(&f->w1, (size_t)48 * kKS * 64)) return r;
     if (int r = c->dalloc(&f->w2, (size_t)12 * 96 * 64)) return r;
     if (int r = c->dalloc(&f->b1, (size_t)kF)) return r;
@@ -387,6 +393,8 @@ static int register_ffn(mdgen_ctx* c, const std::string& pre, FfnW* f) {
         WANT(kC, kF);
         launch_pack_rows(data, kF, c->map_nat, 12, 96, 1.f, f->w2, s);
         launch_pack_stream(data, kF, 1, c->mlp_tab, kMlpFrags, 1.f, 1, f->wstream, s);
+        if (f->w2f)
+            if (int r = copy_f32(f->w2f, data, (size_t)kC * kF, s)) return r;
     });
     SETTER(pre + "fc2.bias", { WANT(kC); if (int r = copy_f32(f->b2, data, kC, s)) return r; });
     return 0;
@@ -411,17 +419,26 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
             c->ncu = ncu;
     }
     {   // placement probe for k_mlp8's split form: do workgroups with the same blockIdx % 8 run on the same XCD?
+        // (a performance hint since round 6: the hand-over is a release / acquire pair at agent scope.)  Private non-blocking stream,
+        // no legacy-stream launch; any error is consumed here and reads as "rule does not hold".
         int* dp = nullptr;
         int hx[64];
-        if (hipMalloc((void**)&dp, sizeof(hx)) == hipSuccess) {
-            launch_xcc_probe(dp, 64, nullptr);
-            if (hipMemcpy(hx, dp, sizeof(hx), hipMemcpyDeviceToHost) == hipSuccess) {
-                bool ok = true;
-                for (int i = 8; i < 64; ++i) ok = ok && hx[i] == hx[i & 7];
-                c->xcd_round_robin = ok;
+        hipStream_t ps = nullptr;
+        if (hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) == hipSuccess) {
+            if (hipMalloc((void**)&dp, sizeof(hx)) == hipSuccess) {
+                launch_xcc_probe(dp, 64, ps);
+                if (hipGetLastError() == hipSuccess &&
+                    hipMemcpyAsync(hx, dp, sizeof(hx), hipMemcpyDeviceToHost, ps) == hipSuccess &&
+                    hipStreamSynchronize(ps) == hipSuccess) {
+                    bool ok = true;
+                    for (int i = 8; i < 64; ++i) ok = ok && hx[i] == hx[i & 7];
+                    c->xcd_round_robin = ok;
+                }
+                (void)hipFree(dp);
             }
-            (void)hipFree(dp);
+            (void)hipStreamDestroy(ps);
         }
+        (void)hipGetLastError();   // nothing sticky is left for the next LAUNCHCHK
     }
     c->d = *d;
     c->nl = d->num_layers;
@@ -524,7 +541,7 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
                { WANT(9 * kC); if (int r = copy_f32(c->ada_b + c->trunk_off(i), data, 9 * kC, s)) return r; });
         TRY(register_mha(c, p + "mha_t.attn.", &t->mha_t));
         TRY(register_mha(c, p + "mha_l.attn.", &t->mha_l));
-        TRY(register_ffn(c, p, &t->ffn));
+        TRY(register_ffn(c, p, &t->ffn, true));
     }
     for (int i = 0; i < nl; ++i) {
         const std::string p = "ipa_layers." + std::to_string(i) + ".";
@@ -559,7 +576,7 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
                { WANT(kC, kIpaFeat); launch_pack_rows(data, kIpaFeat, c->map_nat, 12, 16, 1.f, w->wout, s); });
         SETTER(p + "ipa.linear_out.bias", { WANT(kC); if (int r = copy_f32(w->bout, data, kC, s)) return r; });
         TRY(register_mha(c, p + "mha_l.attn.", &w->mha_l));
-        TRY(register_ffn(c, p, &w->ffn));
+        TRY(register_ffn(c, p, &w->ffn, false));
     }
 #undef TRY
     *out = c;
@@ -682,6 +699,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "train_streams") {
         if (value != 1 && value != 2) return fail(-2, "train_streams must be 1 (one stream) or 2 (weight gradients on a second stream)");
         c->opt_train_streams = value;
+    } else if (n == "mlp_fold") {
+        if (value != 0 && value != 1) return fail(-2, "mlp_fold must be 0 or 1");
+        c->opt_mlp_fold = value;
     } else if (n == "residue_l4_path") {
         if (value < 0 || value > 2) return fail(-2, "residue_l4_path must be 0, 1 or 2");
         c->opt_residue_l4 = value;
@@ -704,6 +724,15 @@ static long split_panels(long maxrows) {
 constexpr size_t kSplitCounterBytes = 1024;   // kMlpSplitMaxPanels counters, padded
 static_assert(kMlpSplitMaxPanels * sizeof(unsigned) <= kSplitCounterBytes, "counter block");
 static size_t split_bytes(long panels) { return kSplitCounterBytes + 2 * (size_t)panels * kMlpSplit * kPanel * kC * 4; }
+
+// Gate fold (option mlp_fold): per (step, trunk layer) one MLP weight stream with that step's gate folded into fc2, and b2' = gate * b2.
+// Carved when the call shares t across the batch and its trunk launches can take the row-owner kernel.
+static bool mlp_uses_rows(const mdgen_ctx* c, long nrows);
+static bool fold_on(const mdgen_ctx* c, long N, int t_shared) {
+    return t_shared && c->opt_mlp_fold && c->opt_precision == 16 && mlp_uses_rows(c, N);
+}
+constexpr size_t kFoldStreamBytes = (size_t)kMlpFrags * 1024;
+static size_t fold_bytes(const mdgen_ctx* c, int S) { return (size_t)S * c->nl * (kFoldStreamBytes + (size_t)kC * 4); }
 
 static size_t frag_bytes(long nseq, int len) { return (size_t)nseq * kH * (len / 32 + 1) * kFragBytes; }
 
@@ -790,6 +819,8 @@ extern "C" int32_t mdgen_workspace_layout(const mdgen_ctx* c, const mdgen_shape*
     // k_mlp8's split form (launches of <= ncu / kMlpSplit panels): counters [kMlpSplitMaxPanels] | fc2 partials | private residual rows,
     // the latter two [panels][kMlpSplit][64][384] fp32 each
     o->split = take(split_bytes(split_panels(maxrows)));
+    // per-(step, layer) gate-folded MLP streams [S][nl][2304 KiB] | b2' [S][nl][384] fp32 (0 bytes unless fold_on)
+    o->fold = take(fold_on(c, N, t_shared) ? fold_bytes(c, S) : 0);
     o->total_bytes = off;
     return 0;
 }
@@ -820,6 +851,9 @@ struct Run {
     unsigned* split_counters;
     float *split_part, *split_hupd;
     long split_cap;
+    // gate fold: streams [S][nl][kFoldStreamBytes], then b2' [S][nl][384]; null when off for this call
+    unsigned char* fold_streams;
+    float* fold_b2g;
     float* h() const { return hp; }
     float* mod() const { return modp; }
 };
@@ -1051,7 +1085,9 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
             // the 128-row form where it still gives every CU a workgroup (cfg-2: 256 per sub-batch stream)
             const long jobs8 = (long)ax.nseq * ((ax.len + 2 * kPanel - 1) / (2 * kPanel));
             const int form = r.c->opt_flash_proj_form ? r.c->opt_flash_proj_form : (ax.len >= 512 && jobs8 >= r.c->ncu) ? 8 : 4;
-            { ProfScope ps(r.c, !trunk ? "ipa.flash_proj" : residue_axis ? "flash_proj_L" : "flash_proj_T", r.s); launch_flash_proj(fp, form, r.s); }
+            // (class "...@q64" / "@q128": which fused form ran -- k_flash_proj / k_flash_proj8; tests assert it)
+            const std::string cls = std::string(!trunk ? "ipa.flash_proj" : residue_axis ? "flash_proj_L" : "flash_proj_T") + (form == 8 ? "@q128" : "@q64");
+            { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_flash_proj(fp, form, r.s); }
             LAUNCHCHK();
             return 0;
         }
@@ -1076,8 +1112,9 @@ static bool mlp_uses_rows(const mdgen_ctx* c, long nrows) {
 }
 
 // `proj`: a deferred out-projection (attn_sublayer) to run inside the MLP kernel, ahead of the MLP
+// `fold_sl` >= 0 (trunk, gate fold active): index step * nl + layer of the folded stream / b2' of this launch
 static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const ModMap& mm, int shift, int scale,
-                        int gate, bool trunk, const ProjParams* proj = nullptr, const bf16x8* wo_stream = nullptr) {
+                        int gate, bool trunk, const ProjParams* proj = nullptr, const bf16x8* wo_stream = nullptr, long fold_sl = -1) {
     if (int e = check_launch_rows(nrows)) return e;
     const bool panel_fused = proj && proj->a_bf16 && r.c->opt_fuse_proj >= 2;   // (3: only handed a projection when the panel kernel runs anyway)
     if (!panel_fused && mlp_uses_rows(r.c, nrows)) {
@@ -1096,13 +1133,17 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
             q.wo_stream = (const unsigned char*)wo_stream;
             q.bo = proj->bias;
             q.gate_chunk_o = proj->gate_chunk;
+        } else if (fold_sl >= 0 && r.fold_streams && mm.group_stride == 0 && mm.step_stride == 0) {
+            q.wstream = r.fold_streams + (size_t)fold_sl * kFoldStreamBytes;
+            q.b2g = r.fold_b2g + (size_t)fold_sl * kC;
         }
         if (trunk && r.c->phase_trace) {
             q.trace = r.c->phase_trace;
             q.trace_cap = r.c->phase_trace_cap;
             r.c->phase_trace = nullptr;
         }
-        { ProfScope ps(r.c, !trunk ? "ipa.mlp" : q.o ? "proj_mlp" : "mlp", r.s); launch_mlp_rows(q, 4, r.s); }
+        // (class "mlp@fold": the folded form ran -- tests assert it)
+        { ProfScope ps(r.c, !trunk ? "ipa.mlp" : q.o ? "proj_mlp" : q.b2g ? "mlp@fold" : "mlp", r.s); launch_mlp_rows(q, 4, r.s); }
         LAUNCHCHK();
         return 0;
     }
@@ -1134,6 +1175,7 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
     const bool split = pw == 8 && r.c->opt_small_split && r.c->xcd_round_robin && r.c->live_streams <= 1 &&
                        panels * kMlpSplit <= r.c->ncu && panels <= r.split_cap;
     if (split) {
+        ++r.c->n_split_launches;
         p.part = r.split_part;
         p.hupd = r.split_hupd;
         p.counters = r.split_counters;
@@ -1250,6 +1292,19 @@ static int prepare(const Run& r, const float* t_dev, const float* t_host) {
     }
     { ProfScope ps(c, "adaln_table", r.s); launch_adaln(silu, R, c->ada_w, c->ada_b, c->modrow, r.mod(), r.s); }
     LAUNCHCHK();
+    if (r.fold_streams) {   // the steps' MLP gates folded into per-(step, layer) fc2 streams (t_shared: R == S rows)
+        int goff[8];
+        const float *w2[8], *b2[8];
+        const bf16x8* base[8];
+        for (int i = 0; i < c->nl; ++i) {
+            goff[i] = c->trunk_off(i) + 8 * kC;
+            w2[i] = c->trunk[i].ffn.w2f;
+            b2[i] = c->trunk[i].ffn.b2;
+            base[i] = c->trunk[i].ffn.wstream;
+        }
+        { ProfScope ps(c, "fold_pack", r.s); launch_pack_fold(r.mod(), r.mod_step_stride, r.S, c->nl, goff, w2, b2, base, c->mlp_tab, (bf16x8*)r.fold_streams, r.fold_b2g, r.s); }
+        LAUNCHCHK();
+    }
     // mask_bl[b][l] = mask[b][0][l]  (latent_model.py:246 passes mask[:,0])
     HIPCHK(hipMemcpy2DAsync(r.ws + r.lay.mask_bl, (size_t)r.L * 4, r.mask, (size_t)r.T * r.L * 4, (size_t)r.L * 4, r.B,
                             hipMemcpyDeviceToDevice, r.s));
@@ -1345,7 +1400,7 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
         if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true, fuse ? &deferred : nullptr,
                                    def_l.a_bf16 ? &def_l : nullptr))
             return er;
-        if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true, &deferred, w.mha_t.wo_stream)) return er;
+        if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true, &deferred, w.mha_t.wo_stream, (long)step * c->nl + i)) return er;
         if (trace_h) HIPCHK(hipMemcpyAsync(trace_h + (size_t)(i + 1) * r.N * kC, h, hbytes, hipMemcpyDeviceToDevice, r.s));
     }
     FinalParams f{};
@@ -1406,6 +1461,12 @@ static int make_run(Run* r, mdgen_ctx* c, const mdgen_shape* sh, int S, int t_sh
         // the counters must be zero when a launch starts (every launch leaves them so); the caller's workspace holds anything.
         // Eagerly on the call's stream, ahead of the (possibly replayed) graph.
         HIPCHK(hipMemsetAsync(r->split_counters, 0, kSplitCounterBytes, r->s));
+    }
+    r->fold_streams = nullptr;
+    r->fold_b2g = nullptr;
+    if (fold_on(c, r->N, t_shared)) {
+        r->fold_streams = r->ws + r->lay.fold;
+        r->fold_b2g = (float*)(r->fold_streams + (size_t)S * c->nl * kFoldStreamBytes);
     }
     return 0;
 }
@@ -1576,7 +1637,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1636,7 +1697,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);
@@ -1681,6 +1742,13 @@ extern "C" int32_t mdgen_profile_report(mdgen_ctx* c, void* stream, char* buf, s
                  kv.second.first, kv.second.second);
         js += tmp;
         first = false;
+    }
+    {   // not a kernel class: the context's placement-probe result and the split-form launches since the last report
+        char tmp[200];
+        snprintf(tmp, sizeof(tmp), "%s\"@context\": {\"count\": %ld, \"ms\": 0.0, \"xcd_round_robin\": %d, \"ncu\": %d}", first ? "" : ", ",
+                 c->n_split_launches, c->xcd_round_robin ? 1 : 0, c->ncu);
+        js += tmp;
+        c->n_split_launches = 0;
     }
     js += "}";
     if (js.size() + 1 > buflen) return fail(-7, "profile buffer too small");

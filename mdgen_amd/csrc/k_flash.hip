@@ -147,8 +147,14 @@ __device__ __forceinline__ void block(const KTile& kn, const QTile& qn, f32x16& 
     for (int j = 0; j < 16; ++j) e[j] = __builtin_amdgcn_exp2f(s[j]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+#ifdef MDGEN_DEV_FLASH_TRUNC   // (experiment) P truncated to bf16 by one v_perm_b32 per pair instead of v_cvt_pk_bf16_f32: the softmax
+                               // denominator is the sum of the SAME truncated P (ones row of V^T), so the -1/2 ulp bias cancels to first order
+        pc.p0[j] = __builtin_amdgcn_perm(__float_as_uint(e[2 * j + 1]), __float_as_uint(e[2 * j]), 0x07060302u);
+        pc.p1[j] = __builtin_amdgcn_perm(__float_as_uint(e[9 + 2 * j]), __float_as_uint(e[8 + 2 * j]), 0x07060302u);
+#else
         pc.p0[j] = pack_bf16(e[2 * j], e[2 * j + 1]);
         pc.p1[j] = pack_bf16(e[8 + 2 * j], e[9 + 2 * j]);
+#endif
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -681,21 +687,41 @@ __global__ __launch_bounds__(512, 1) void k_flash_proj8(const FlashProjParams p)
         pr[hf].moff[i] = (int)mo;
         set_uniform(&pr[hf], i, tk, mo);
     }
+#if defined(MDGEN_DEV_FLASH_PRIO1)   // (experiment) static priority for the second-dispatched half (MI355X_MICROARCH "two waves per SIMD" 4)
+    if (w8 >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
+#if defined(MDGEN_DEV_FLASH_PRIO2)   // (experiment) the two waves of a SIMD take turns: the younger one first
+        if ((w8 >= 4) == (pass == 0)) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+#endif
         const int head = 8 * pass + w8;
         FlashPre<NQ> pre;
         flash_prefetch<NQ>(p.f, seq, head, qc, pre);
         flash_job<NQ>(p.f, seq, head, qc, w8, pre, FlashStorePanel{(lds_byte*)panel, head});
     }
+#if defined(MDGEN_DEV_FLASH_PRIO1) || defined(MDGEN_DEV_FLASH_PRIO2)
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();   // the attention output of all 16 heads is in the panel
     const int lane = lane_id();
     f32x16 acc[6];
+#ifdef MDGEN_DEV_FLASH_EARLY   // (experiment) the residual rows of the epilogue's first batch are requested BEFORE the out-projection GEMM
+    EpiPre<8> ep;
+    epi_rmw_request<8>(0, 0, &pr[g], 96 * w, p.h, ep);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, false>(panel, kC * 2, 2 * g, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     __syncthreads();   // every wave is done reading the panel: reuse it as eight 12 KiB staging slabs
+#ifdef MDGEN_DEV_FLASH_EARLY
+    epilogue_gate_residual_lds_pre<3>(acc, &pr[g], reinterpret_cast<float*>(panel) + w8 * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
+                                      p.h, ep);
+#else
     epilogue_gate_residual_lds<3>(acc, &pr[g], reinterpret_cast<float*>(panel) + w8 * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
                                   p.h);
+#endif
 }
 
 // Measured (cfg-2 / cfg-4, same box, back to back): NQ = 4 runs 160-162 / 76 us, NQ = 2 160-164 / 76 us -- a tie; 2 keeps

@@ -1062,10 +1062,11 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
 // PRIVATE copy p.hupd of the panel's updated residual rows -- nobody writes h while another workgroup may still read it), writes its
 // fp32 partial of the fc2 product to p.part and bumps the panel's counter; the LAST ARRIVER adds the S partials in the order of s
 // (the same bits whoever is last) and runs the gated residual epilogue from its private rows into h.
-// Nobody waits for anybody.  Memory ordering as measured for the attention kernels in round 5 (profiles/r05_experiments.txt 4): the
-// S workgroups of a panel are placed on ONE XCD (equal blockIdx % 8: their partials meet in that XCD's L2; the context's placement
-// probe has checked the residue -> XCD rule, else the launcher never picks this form); producer: s_waitcnt vmcnt(0), barrier,
-// agent-scope atomic add; consumer: agent-scope acquire fence (drops stale lines of its vector cache), ordinary loads.
+// Nobody waits for anybody.  Memory ordering: producer: s_waitcnt vmcnt(0), barrier, agent-scope RELEASE atomic add (L2 write-back);
+// consumer: agent-scope acquire fence (drops stale lines of its vector cache and of its L2), ordinary loads -- a release / acquire
+// pair at agent scope, correct for any placement.  The S workgroups of a panel are nevertheless placed on ONE XCD (equal
+// blockIdx % 8; the context's placement probe checks the residue -> XCD rule and the launcher only picks the form where it holds):
+// that is where the form pays -- the partials then meet in one L2.
 template <bool PRE, int S = 1>
 __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
     static_assert(kNChunk % (2 * S) == 0, "whole chunks per group");
@@ -1186,11 +1187,16 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
         for (int f = 0; f < 3; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mine[(f * 16 + r) * 64] = z[f][r];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // acknowledged by L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's partial stores are acknowledged by this XCD's L2
         __syncthreads();                                    // (also: exchange area read)
         if (threadIdx.x == 0) {
             unsigned* c = p.counters + pn;
-            const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // RELEASE at agent scope (round 6): the arrival writes this XCD's dirty L2 lines back (buffer_wbl2) before the counter
+            // moves, so the hand-over is correct under the HIP memory model wherever the S workgroups of a panel run; the
+            // placement rule (one XCD per panel) is a performance hint only -- the partials then never leave that L2's reach.
+            // The stores of the OTHER waves are covered: they were acknowledged (vmcnt(0)) before the barrier above, and the
+            // write-back is of the whole L2, not of this wave's lines.
+            const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             s_last = old == (unsigned)(S - 1);
             if (old == (unsigned)(S - 1)) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }

@@ -229,8 +229,12 @@ __device__ __forceinline__ void proj_blocks(MlpPipe& m, const bf16x8 (&xf)[24], 
 // launch boundary (k_proj<0> was an HBM-bound 58 us kernel of its own).
 // MODLDS: every 32-row tile of the launch lies inside one modulation group (launch_mlp_rows checks the ModMap): the wave's
 // scale / shift / gate chunks are DMA'd into LDS once and read from there (rows_norm_lds, rows_gate_residual_lds).
-template <int NW, bool PROJ, bool MODLDS>
+// FOLD (round 6; MODLDS, no PROJ): the launch's gate is one vector and is folded into the stream's W2 fragments and into b2'
+// (p.b2g; k_pack_fold, once per call): the fc2 accumulators start from the residual rows + b2' (rows_norm_lds_fold) and the
+// epilogue only stores -- one HBM read of the rows instead of two (98 MB of 332 per launch at cfg-2).
+template <int NW, bool PROJ, bool MODLDS, bool FOLD = false>
 __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) {
+    static_assert(!FOLD || (MODLDS && !PROJ), "the folded form: one modulation group per launch, no fused out-projection");
     // ring | fc1 bias | slack: the last re-arm reads the (non-existent) chunk 24 | per wave: scale, shift, gate chunks (2 KiB slots)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kRingBytes + 8192 + NW * 6144];
     constexpr int NPRE = PROJ ? 12 : 0;   // ring slots of the out-projection ahead of the MLP stream
@@ -259,8 +263,10 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
             const int chunk[3] = {p.scale_chunk, p.shift_chunk, p.gate_chunk};
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                dma_frag<0, true>(mb + (long)chunk[c] * (kC * 4), (unsigned)lane * 16u, lds_addr(modl) + c * 2048);
-                dma_frag<1024, false>(mb + (long)chunk[c] * (kC * 4), (unsigned)lane * 16u, lds_addr(modl) + c * 2048);
+                // (FOLD: the third slot holds b2' = gate * b2 instead of the gate)
+                const unsigned char* src = FOLD && c == 2 ? reinterpret_cast<const unsigned char*>(p.b2g) : mb + (long)chunk[c] * (kC * 4);
+                dma_frag<0, true>(src, (unsigned)lane * 16u, lds_addr(modl) + c * 2048);
+                dma_frag<1024, false>(src, (unsigned)lane * 16u, lds_addr(modl) + c * 2048);
             }
         }
     }
@@ -291,12 +297,13 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
         rows_load(p.h, tok, v);
         // the row loads AND this wave's modulation DMAs have landed (the asm keeps hipcc from lifting the LDS reads above it)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        rows_norm_lds(v, tok, modl, modl + 512, 1e-6f, xf);
+        if (FOLD) rows_norm_lds_fold(v, tok, modl, modl + 512, modl + 1024, 1e-6f, xf, m.y);
+        else rows_norm_lds(v, tok, modl, modl + 512, 1e-6f, xf);
     } else {
         rows_ln(p.h, tok, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, xf);
     }
     ROWS_STAMP(1);
-    rows_acc_init(m.y, p.b2);
+    if (!FOLD) rows_acc_init(m.y, p.b2);
     const float* b1l = b1s + 4 * hh;   // LDS bias row of chunk c: + 64 c (this lane half's four units of every group of 8)
     // ---- P0: X(0).  Barrier 0 certifies slots 0 and 1 (only the FPW DMAs of slot 2 may be in flight) and the LDS copy of b1.
     ring_barrier<FPW>();
@@ -364,7 +371,9 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
     pipe_block<NW, 84, 1, 3, -1, false, -1, false, 12 - kWPF>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, NPRE + 0);
     ROWS_STAMP(4);
     // ---- gated residual
-    if (MODLDS) {
+    if (FOLD) {
+        rows_store<0, 12>(m.y, tok, p.h);
+    } else if (MODLDS) {
         rows_gate_residual_lds<0, 6>(m.y, tok, modl + 1024, p.h);
         rows_gate_residual_lds<6, 12>(m.y, tok, modl + 1024, p.h);
     } else {
@@ -405,6 +414,65 @@ __global__ void k_pack_stream(const float* __restrict__ wsrc, int ld, int which,
     dst[i] = v;
 }
 
+// Gate fold (round 6): the MLP stream of (step s, layer l) with the step's gate folded into fc2, one workgroup row per (s, l):
+//   fc1 fragments: copied from the layer's base stream;  fc2 fragment (feature tile, k-step): bf16(gate[row] * W2[row][kappa cols]),
+//   rounded ONCE from the fp32 weight;  b2g[s][l][f] = gate[f] * b2[f].
+// mod: adaLN table (row of step s at s * mod_step_stride); the layer's MLP gate chunk at goff[l] floats into the row.
+struct PackFoldParams {
+    const float* mod;
+    long mod_step_stride;
+    int nl;
+    int goff[8];
+    const float* w2[8];          // fp32 fc2.weight [384][1536] per layer
+    const float* b2[8];
+    const bf16x8* base[8];       // the layer's unfolded stream (fc1 fragments are copied from it)
+    const int* tab;
+    bf16x8* dst;                 // [S * nl][kMlpFrags * 64]
+    float* b2g;                  // [S * nl][384]
+};
+__global__ __launch_bounds__(256) void k_pack_fold(const PackFoldParams p) {
+    const int sl = blockIdx.y, s = sl / p.nl, l = sl % p.nl;
+    const int i = blockIdx.x * 256 + threadIdx.x;            // < 2304 * 64
+    const int lane = i & 63, f = i >> 6;
+    const float* gate = p.mod + (long)s * p.mod_step_stride + p.goff[l];
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < kC; c += 256) p.b2g[(size_t)sl * kC + c] = gate[c] * p.b2[l][c];
+    const int e = p.tab[f];
+    bf16x8 v;
+    if ((e >> 16) == 0) {
+        v = p.base[l][i];
+    } else {
+        const int tile = (e >> 8) & 255, ks = e & 255, hh = lane >> 5;
+        const int row = tile * 32 + (lane & 31);
+        const float g = gate[row];
+        const float* wr = p.w2[l] + (size_t)row * kF + 16 * ks + 4 * hh;   // kappa: cols 16 ks + 8 (j >> 2) + 4 hh + (j & 3)
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wr), b = *reinterpret_cast<const f32x4*>(wr + 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = (__bf16)(a[j] * g);
+            v[4 + j] = (__bf16)(b[j] * g);
+        }
+    }
+    p.dst[(size_t)sl * (2304 * 64) + i] = v;
+}
+void launch_pack_fold(const float* mod, long mod_step_stride, int S, int nl, const int* goff, const float* const* w2,
+                      const float* const* b2, const bf16x8* const* base, const int* tab, bf16x8* dst, float* b2g, hipStream_t s) {
+    PackFoldParams p{};
+    p.mod = mod;
+    p.mod_step_stride = mod_step_stride;
+    p.nl = nl;
+    for (int l = 0; l < nl; ++l) {
+        p.goff[l] = goff[l];
+        p.w2[l] = w2[l];
+        p.b2[l] = b2[l];
+        p.base[l] = base[l];
+    }
+    p.tab = tab;
+    p.dst = dst;
+    p.b2g = b2g;
+    hipLaunchKernelGGL(k_pack_fold, dim3(2304 * 64 / 256, (unsigned)(S * nl)), dim3(256), 0, s, p);
+}
+
 void launch_pack_stream(const float* w, int ld, int which, const int* tab, int nfrag, float scale, int kappa, bf16x8* dst,
                         hipStream_t s, const int* rowmap) {
     const long total = (long)nfrag * 64;
@@ -422,7 +490,8 @@ static void launch_mlp_rows_nw(const MlpRowsParams& p, long tiles, hipStream_t s
         if (uni) hipLaunchKernelGGL((k_mlp_rows<NW, true, true>), g, b, 0, s, p);
         else hipLaunchKernelGGL((k_mlp_rows<NW, true, false>), g, b, 0, s, p);
     } else {
-        if (uni) hipLaunchKernelGGL((k_mlp_rows<NW, false, true>), g, b, 0, s, p);
+        if (p.b2g) hipLaunchKernelGGL((k_mlp_rows<NW, false, true, true>), g, b, 0, s, p);   // (the caller has checked: one modulation group)
+        else if (uni) hipLaunchKernelGGL((k_mlp_rows<NW, false, true>), g, b, 0, s, p);
         else hipLaunchKernelGGL((k_mlp_rows<NW, false, false>), g, b, 0, s, p);
     }
 }

@@ -88,6 +88,9 @@ struct MlpRowsParams {
     int gate_chunk_o;
     unsigned long long* trace;      // measurement only: [wave][8] s_memtime stamps, or null
     long trace_cap;
+    // gate fold (non-null; o == null, every row of the launch shares the modulation row): `wstream` is the (step, layer) stream with
+    // the gate folded into fc2 and b2g = gate * b2 (launch_pack_fold): accumulators start from the residual rows, store-only epilogue
+    const float* b2g;
 };
 
 struct LnLinearParams {
@@ -191,6 +194,10 @@ void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s);
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
 void launch_mlp(const MlpParams& p, hipStream_t s, int waves = 4);
 void launch_mlp_rows(const MlpRowsParams& p, int nw, hipStream_t s);
+constexpr int kMlpStreamFrags = 2304;   // 1 KiB fragments of one MLP weight stream (api.hip mlp_stream_table)
+// per-(step, layer) MLP streams with the step's gate folded into fc2 (+ b2g = gate * b2); S * nl streams, nl <= 8
+void launch_pack_fold(const float* mod, long mod_step_stride, int S, int nl, const int* goff, const float* const* w2,
+                      const float* const* b2, const bf16x8* const* base, const int* tab, bf16x8* dst, float* b2g, hipStream_t s);
 // rowmap (nullable): source row of packed row r (a permutation of the matrix's rows); kappa: K order inside a k-step -- 0
 // natural, 1 rows.h kappa (operand = LayerNorm / GELU registers)
 void launch_pack_stream(const float* w, int ld, int which, const int* tab, int nfrag, float scale, int kappa, bf16x8* dst,

@@ -370,6 +370,82 @@ __device__ __forceinline__ void epi_rmw(const int t, const PanelRows* pr, const 
     }
 }
 
+// The same read-modify-write with the residual rows of a batch requested AHEAD of their use (epi_rmw_request before a GEMM or
+// before the previous batch's stores, epi_rmw_finish afterwards): the rows do not depend on the GEMM.
+template <int BR>
+struct EpiPre {
+    f32x4 hv[BR];
+    int tk[BR];
+};
+template <int BR>
+__device__ __forceinline__ void epi_rmw_request(const int t, const int b, const PanelRows* pr, int col0, const float* __restrict__ h,
+                                                EpiPre<BR>& e) {
+    const int lane = lane_id();
+    const int q = lane % 24, r2 = lane / 24;
+    const bool active = lane < 48;
+#pragma unroll
+    for (int k = 0; k < BR; ++k) {
+        const int row = active ? t * 32 + 2 * (BR * b + k) + r2 : 0;
+        e.tk[k] = active ? pr->tok[row] : -1;
+        const long tc = e.tk[k] < 0 ? 0 : e.tk[k];
+        e.hv[k] = *reinterpret_cast<const f32x4*>(h + tc * kC + col0 + 4 * q);
+    }
+}
+template <int BR>
+__device__ __forceinline__ void epi_rmw_finish(const int b, const float* stage, int col0, const f32x4 b4, const f32x4 gu,
+                                               float* __restrict__ h, const EpiPre<BR>& e) {
+    const int lane = lane_id();
+    const int q = lane % 24;
+    const int slot = lane < 48 ? lane : 0;
+    const f32x4* stage4 = reinterpret_cast<const f32x4*>(stage);
+#pragma unroll
+    for (int k = 0; k < BR; ++k) {
+        const f32x4 v = stage4[(BR * b + k) * 48 + slot];
+        f32x4 o = e.hv[k];
+        o[0] += gu[0] * (v[0] + b4[0]);
+        o[1] += gu[1] * (v[1] + b4[1]);
+        o[2] += gu[2] * (v[2] + b4[2]);
+        o[3] += gu[3] * (v[3] + b4[3]);
+        if (e.tk[k] >= 0) *reinterpret_cast<f32x4*>(h + (long)e.tk[k] * kC + col0 + 4 * q) = o;
+    }
+}
+// (uniform-gate panels only: the caller's launch shares one modulation row -- else falls back to the plain form)
+template <int FT>
+__device__ __forceinline__ void epilogue_gate_residual_lds_pre(const f32x16* acc, const PanelRows* pr, float* stage, int col0,
+                                                               const float* __restrict__ bias, const ModMap mm, int gate_chunk,
+                                                               bool gated, float* __restrict__ h, EpiPre<8>& e0) {
+    static_assert(FT == 3, "slab is [32][96]");
+    const int um = gated ? pr->uniform : -1;
+    if (um < 0) {   // per-row gates: the plain path (the early request is dropped)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            epi_stage(acc + t * FT, stage);
+            epi_rmw<8>(t, pr, stage, col0, bias, mm, gate_chunk, gated, h);
+        }
+        return;
+    }
+    const int q = lane_id() % 24;
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + col0 + 4 * q);
+    const f32x4 gu = *reinterpret_cast<const f32x4*>(mm.mod + um + gate_chunk * kC + col0 + 4 * q);
+    EpiPre<8> e1;
+    // batches (t, b): (0,0) requested by the caller; each batch's successor is requested before its own stores
+    epi_stage(acc, stage);
+    epi_rmw_request<8>(0, 1, pr, col0, h, e1);
+    __builtin_amdgcn_sched_barrier(0);
+    epi_rmw_finish<8>(0, stage, col0, b4, gu, h, e0);
+    __builtin_amdgcn_sched_barrier(0);
+    epi_rmw_request<8>(1, 0, pr, col0, h, e0);
+    __builtin_amdgcn_sched_barrier(0);
+    epi_rmw_finish<8>(1, stage, col0, b4, gu, h, e1);
+    __builtin_amdgcn_sched_barrier(0);
+    epi_stage(acc + FT, stage);
+    epi_rmw_request<8>(1, 1, pr, col0, h, e1);
+    __builtin_amdgcn_sched_barrier(0);
+    epi_rmw_finish<8>(0, stage, col0, b4, gu, h, e0);
+    __builtin_amdgcn_sched_barrier(0);
+    epi_rmw_finish<8>(1, stage, col0, b4, gu, h, e1);
+}
+
 template <int FT>
 __device__ __forceinline__ void epilogue_gate_residual_lds(const f32x16* acc, const PanelRows* pr, float* stage, int col0,
                                                            const float* __restrict__ bias, const ModMap mm,

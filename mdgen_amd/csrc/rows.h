@@ -237,6 +237,73 @@ __device__ __forceinline__ void rows_norm_lds(const f32x4 (&v)[48], int tok, con
     }
 }
 
+// rows_norm_lds that ALSO starts the fc2 accumulators from the residual rows (round 6, "gate fold"): sampling shares t across the
+// batch (integrators.py:99), so the MLP's gate is one vector per (layer, step) and is folded into the weights once per call --
+// W2' = diag(gate) W2, b2' = gate * b2 (k_pack_fold) -- which turns  h + gate * (W2 u + b2)  (latent_model.py:481) into
+// y0 = h + b2',  y += W2' u:  the accumulator registers 4 a + j of tile ft start as v[4 ft + a][j] + b2'[..] (the row image IS
+// the accumulator image, see rows_load) and the epilogue is a plain store -- the rows are read from HBM once, not twice.
+// `b2g`: b2' in LDS (384 floats, shared by the wave's rows).
+__device__ __forceinline__ void rows_norm_lds_fold(const f32x4 (&v)[48], int tok, const float* sc, const float* sh, const float* b2g,
+                                                   float eps, bf16x8 (&xf)[24], f32x16 (&y)[12]) {
+    const int hh = lane_id() >> 5;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 48; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = half_sum2(s) * (1.0f / kC);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[i][j] - mean;
+            q += d * d;
+        }
+    }
+    const float rstd = tok < 0 ? 0.f : 1.0f / sqrtf(half_sum2(q) * (1.0f / kC) + eps);
+    const float live = tok < 0 ? 0.f : 1.f;
+    float mean2 = mean;
+    asm volatile("" : "+v"(mean2));   // (see rows_norm)
+    const f32x4* scp = reinterpret_cast<const f32x4*>(sc + 4 * hh);
+    const f32x4* shp = reinterpret_cast<const f32x4*>(sh + 4 * hh);
+    const f32x4* bgp = reinterpret_cast<const f32x4*>(b2g + 4 * hh);
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) {
+        uint32_t u[4];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int i = 2 * ks + h2;
+            const f32x4 c = scp[2 * i], d = shp[2 * i], b = bgp[2 * i];   // features 16 ks + 8 h2 + 4 hh ..
+            const f32x4 a = v[i];
+            const float y0 = (a[0] - mean2) * (rstd * c[0] + rstd) + live * d[0];
+            const float y1 = (a[1] - mean2) * (rstd * c[1] + rstd) + live * d[1];
+            const float y2 = (a[2] - mean2) * (rstd * c[2] + rstd) + live * d[2];
+            const float y3 = (a[3] - mean2) * (rstd * c[3] + rstd) + live * d[3];
+            u[2 * h2] = pack_bf16(y0, y1);
+            u[2 * h2 + 1] = pack_bf16(y2, y3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[i >> 2][4 * (i & 3) + j] = a[j] + b[j];
+        }
+        xf[ks] = __builtin_bit_cast(bf16x8, u32x4{u[0], u[1], u[2], u[3]});
+    }
+}
+
+// ... and its epilogue: h[tok][32 ft + 8 a + 4 hh + j] = y[ft][4 a + j], stores only
+template <int FT0, int FT1>
+__device__ __forceinline__ void rows_store(const f32x16 (&y)[12], int tok, float* __restrict__ h) {
+    const int hh = lane_id() >> 5;
+    const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
+    unsigned char* hb = reinterpret_cast<unsigned char*>(h);
+    const unsigned off = tokc * (unsigned)(kC * 4) + (unsigned)hh * 16u;
+    if (tok >= 0) {
+#pragma unroll
+        for (int i = FT0 * 4; i < FT1 * 4; ++i) {
+            const int ft = i >> 2, a = i & 3;
+            const f32x4 o = {y[ft][4 * a], y[ft][4 * a + 1], y[ft][4 * a + 2], y[ft][4 * a + 3]};
+            *reinterpret_cast<f32x4*>(hb + off + 32u * (unsigned)i) = o;
+        }
+    }
+}
+
 __device__ __forceinline__ void rows_ln(const float* __restrict__ x, int tok, const ModMap mm, int shift_chunk,
                                         int scale_chunk, float eps, bf16x8 (&xf)[24]) {
     f32x4 v[48];

@@ -145,7 +145,11 @@ class LatentMDGenModel:
         buf = C.create_string_buffer(1 << 16)
         with torch.cuda.device(self.device):
             check(lib.mdgen_profile_report(self._ctx, L.stream_ptr(), buf, len(buf)))
-        return json.loads(buf.value.decode())
+        rep = json.loads(buf.value.decode())
+        # "@context" is not a kernel class: the placement-probe result (xcd_round_robin), the CU count and the number of
+        # split-panel launches (k_mlp8<., 3>) since the last report
+        self.context_info = rep.pop("@context", None)
+        return rep
 
     # ---- workspace --------------------------------------------------------------------------
     def workspace_layout(self, B, T, L_, S, t_shared):
@@ -157,8 +161,11 @@ class LatentMDGenModel:
     def _workspace(self, B, T, L_, S, t_shared):
         key = (B, T, L_, S, int(t_shared))
         ws = self._ws.get(key)
+        lay = self.workspace_layout(B, T, L_, S, t_shared)   # (options may have changed what the call needs: mlp_fold, precision)
+        if ws is not None and ws.numel() < lay.total_bytes:
+            del self._ws[key]
+            ws = None
         if ws is None:
-            lay = self.workspace_layout(B, T, L_, S, t_shared)
             while len(self._ws) >= self.max_cached_shapes:
                 self._ws.popitem(last=False)                  # least recently used
             ws = torch.empty(lay.total_bytes, dtype=torch.uint8, device=self.device)

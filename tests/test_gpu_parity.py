@@ -657,9 +657,21 @@ def test_forward_headline_regime_vs_reference_and_oracle(name):
     ht, hl = (int(v) for v in g["sub_h"])
     nl = cfg.num_layers
     ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
-    for prec, tol in (("bf16", TOL_FWD), ("fp32", 1e-5)):
-        m = LatentMDGenModel(cfg, precision=prec)
+    # third pass (round 6): the reference's own T = 1000 golden through the HEADLINE's kernels, forced -- by shape this B 2 call takes
+    # k_flash + the eight-wave panel kernels; the bench line's B 8 views take k_flash_proj8 / k_mlp_rows / k_ln_qkv<false, false>
+    forced = {"flash_proj": 2, "flash_proj_form": 8, "mlp_path": 2, "panel_waves": 4}
+    for prec, tol in (("bf16", TOL_FWD), ("fp32", 1e-5), ("bf16 headline kernels", TOL_FWD)):
+        hk = prec == "bf16 headline kernels"
+        if hk and T < 512:
+            continue
+        m = LatentMDGenModel(cfg, precision="bf16" if hk else prec)
         m.load_state_dict(sd)
+        if hk:
+            for k, v in forced.items():
+                m.set_option(k, v)
+            _, _, ran = _profiled_forward(m, dkw)
+            for k in ("flash_proj_T@q128", "mlp", "ln_qkv_T", "attn_L_fused"):
+                assert ran.get(k) == nl, (k, ran)
         out, tr = m.forward(**dkw, return_trace=True)
         torch.cuda.synchronize()
         out = out.cpu()
@@ -2188,7 +2200,9 @@ def test_row_owner_mlp_paths_agree():
     forms = (("panel4", dict(P4, mlp_path=0, fuse_proj=0), "mlp@p4"), ("panel8", dict(P8, mlp_path=0, fuse_proj=0), "mlp@p8"),
              ("panel4+proj", dict(P4, mlp_path=0, fuse_proj=2), "proj_mlp@p4"), ("panel8+proj", dict(P8, mlp_path=0, fuse_proj=2), "proj_mlp@p8"),
              ("panel8 split", dict(X8, mlp_path=0, fuse_proj=0), "mlp@p8x3"), ("panel8+proj split", dict(X8, mlp_path=0, fuse_proj=2), "proj_mlp@p8x3"),
-             ("rows", {"mlp_path": 2, "fuse_proj": 0}, "mlp"), ("rows+proj", {"mlp_path": 2, "fuse_proj": 1}, "proj_mlp"),
+             ("rows", {"mlp_path": 2, "fuse_proj": 0, "mlp_fold": 0}, "mlp"), ("rows+proj", {"mlp_path": 2, "fuse_proj": 1}, "proj_mlp"),
+             # (round 6) a forward of B = 1 shares t: the gate-folded form of the row-owner kernel (option mlp_fold, default on)
+             ("rows fold", {"mlp_path": 2, "fuse_proj": 0}, "mlp@fold|mlp"),
              ("no-qkv-prologue p4", dict(P4, mlp_path=0, fuse_proj=0, fuse_proj_qkv=0), "ln_qkv_T"),
              ("no-qkv-prologue p8", dict(P8, mlp_path=0, fuse_proj=0, fuse_proj_qkv=0), "ln_qkv_T@p8"),
              ("no-qkv-prologue p8 split", dict(X8, mlp_path=0, fuse_proj=0, fuse_proj_qkv=0), "ln_qkv_T@p8x2"),
@@ -2217,6 +2231,8 @@ def test_row_owner_mlp_paths_agree():
             assert e < TOL_FWD
             T_, L_ = g["x"].shape[1:3]
             if want is not None:
+                if "|" in want:   # by batch size: B = 1 -> the first name, else the second
+                    want = want.split("|")[0 if g["x"].shape[0] == 1 else 1]
                 assert ran.get(want) == cfg.num_layers, (key, want, ran)
                 family = [k for k in ran if k.split("@")[0] == want.split("@")[0] and k != want]   # no other form of the same kernel ran
                 assert not family, (key, want, ran)
@@ -2227,6 +2243,7 @@ def test_row_owner_mlp_paths_agree():
             del m
         assert rel_l2(outs["panel8"], outs["panel4"]) < 6e-3 and rel_l2(outs["panel8+proj"], outs["panel4+proj"]) < 6e-3
         assert rel_l2(outs["rows"], outs["panel4"]) < 6e-3 and rel_l2(outs["rows+proj"], outs["rows"]) < 6e-3
+        assert rel_l2(outs["rows fold"], outs["rows"]) < 3e-3
         assert rel_l2(outs["panel4+proj"], outs["panel4"]) < 6e-3
         assert rel_l2(outs["no-qkv-prologue p8"], outs["no-qkv-prologue p4"]) < 6e-3
         # the split forms: k_ln_qkv8<true> computes the same products with the same operands (same bits as k_ln_qkv8<false>);
@@ -2354,9 +2371,11 @@ def test_flash_proj_kernel_vs_separate_kernels_and_oracle(shape):
         for k, v in rep.items():
             assert v < TOL_FWD, (key, k, v)
         fused = not key.startswith("separate")
-        assert ("flash_proj_T" in ran) == fused and ("flash_T" in ran) != fused, ran
+        tag = "@q128" if "128" in key else "@q64"      # the report names the fused form: k_flash_proj8 / k_flash_proj
+        assert ("flash_proj_T" + tag in ran) == fused and ("flash_T" in ran) != fused, ran
+        assert not any(k.startswith("flash_proj") and not k.endswith(tag) for k in ran), ran
         if L > 8:
-            assert ("flash_proj_L" in ran) == fused and ("ipa.flash_proj" in ran) == fused, ran
+            assert ("flash_proj_L" + tag in ran) == fused and ("ipa.flash_proj" + tag in ran) == fused, ran
         if fused:   # nothing left to project: no k_proj<0>, no projection deferred into the next kernel
             assert not any(k.startswith(("proj_T", "proj_L", "projL_qkvT", "proj_mlp")) for k in ran), ran
         outs[key] = (out.cpu(), tr[f"h{cfg.num_layers}"].cpu())
@@ -2398,10 +2417,10 @@ def test_flash_proj_is_the_default_where_the_launch_fills_the_chip():
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
         out, _, ran = _profiled_forward(m, dkw, poison=False)
-        assert ("flash_proj_T" in ran) == want and ("flash_T" in ran) != want, (B, ran)
+        assert ("flash_proj_T@q128" in ran) == want and ("flash_T" in ran) != want, (B, ran)
         m.set_option("flash_proj", 0)
         out0, _, ran0 = _profiled_forward(m, dkw, poison=False)
-        assert "flash_T" in ran0 and "flash_proj_T" not in ran0
+        assert "flash_T" in ran0 and not any(k.startswith("flash_proj") for k in ran0)
         e = rel_l2(out, out0)
         print(f"B {B}: default {sorted(k for k in ran if 'flash' in k)} vs flash_proj 0: {e:.2e}")
         assert torch.isfinite(out).all() and e < 2e-3   # (the 128-row form rotates its key-tile walk by 128-query chunks: fp32 rounding)
@@ -2560,3 +2579,144 @@ def test_two_stream_views_in_the_panel_window_match_one_stream():
     e = rel_l2(a, outs["one stream, defaults"][0])
     print(f"two 313-panel views vs one 625-panel view (row-owner MLP): {e:.2e}")
     assert e < 3e-3
+
+
+# ---- round 6: the gate-folded row-owner MLP, the headline's own kernel mix against the oracle ------------------------------------
+def _euler_kw(dkw):
+    return {k: v for k, v in dkw.items() if k not in ("x", "t", "end_frames")}
+
+
+@pytest.mark.parametrize("shape", [(1, 250, 64, 3), (1, 1000, 4, 0), (1, 70, 9, 1)], ids=["T250_L64_pad", "T1000_L4", "T70_L9_pad"])
+def test_mlp_gate_fold_vs_unfolded_kernel_and_oracle(shape):
+    """Option `mlp_fold` (round 6, default on): where a call shares t across the batch (sampling, integrators.py:99; a forward of
+    B = 1) the MLP block's gate (latent_model.py:481) is ONE vector per (step, layer): k_pack_fold folds it into per-(step, layer)
+    fc2 fragments (rounded to bf16 once, from the fp32 weight) and into b2' = gate * b2; k_mlp_rows<., FOLD> starts its fc2
+    accumulators from the residual rows + b2' and its epilogue only stores.  Against the CPU oracle (every trace, 0xFF workspace),
+    against the unfolded kernel (the product gate * w is rounded instead of w: same order of error), the same bits on a second
+    call, and the report must say which form ran.  `mlp_path` 2 forces the row-owner kernel at these sizes (partial last tiles
+    and padded residues included)."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.model import LatentMDGenModel
+    B, T, L, n_pad = shape
+    cfg, sd, kw, dkw = _fwd_case(B, T, L, n_pad, 1600 + T + L)
+    ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
+    nl = cfg.num_layers
+    outs = {}
+    for key, fold in (("fold", 1), ("unfolded", 0)):
+        m = LatentMDGenModel(cfg)
+        m.load_state_dict(sd)
+        for k, v in (("mlp_path", 2), ("fuse_proj", 0), ("mlp_fold", fold)):
+            m.set_option(k, v)
+        out, tr, ran = _profiled_forward(m, dkw)
+        rep = {k: rel_l2(tr[k].cpu(), rtr[k]) for k in ["ipa_out"] + [f"h{i}" for i in range(nl + 1)]}
+        rep["out"] = rel_l2(out.cpu(), ref)
+        print(shape, key, {k: f"{v:.2e}" for k, v in rep.items()}, {k: v for k, v in ran.items() if "mlp" in k or "fold" in k})
+        assert torch.isfinite(out).all()
+        for k, v in rep.items():
+            assert v < TOL_FWD, (key, k, v)
+        assert (ran.get("mlp@fold") == nl and "mlp" not in ran and ran.get("fold_pack") == 1) if fold else \
+            (ran.get("mlp") == nl and "mlp@fold" not in ran and "fold_pack" not in ran), ran
+        assert torch.equal(m.forward(**dkw), out), key
+        outs[key] = (out.cpu(), tr[f"h{nl}"].cpu())
+        del m
+    e_out, e_h = rel_l2(outs["fold"][0], outs["unfolded"][0]), rel_l2(outs["fold"][1], outs["unfolded"][1])
+    print(shape, f"folded vs unfolded kernel: out {e_out:.2e} h {e_h:.2e}")
+    assert e_out < 3e-3 and e_h < 3e-3
+
+
+def test_mlp_gate_fold_in_the_euler_rollout():
+    """The folded form through `sample_euler` (S = 3 distinct gates per layer; B 3 x T 300 x L 4, `mlp_path` 2): graph replay ==
+    eager launches bit for bit, two sub-batch streams == one stream (a panel's arithmetic does not depend on its launch), and
+    the trajectory matches the unfolded kernel's to rounding."""
+    from mdgen_amd.model import LatentMDGenModel
+    cfg, sd, kw, dkw = _fwd_case(3, 300, 4, 0, 1777)
+    ekw = _euler_kw(dkw)
+    res = {}
+    for key, opts in (("fold", {}), ("fold, one stream", {"streams": 1}), ("unfolded", {"mlp_fold": 0})):
+        m = LatentMDGenModel(cfg)
+        m.load_state_dict(sd)
+        for k, v in dict({"mlp_path": 2, "fuse_proj": 0, "streams": 2}, **opts).items():
+            m.set_option(k, v)
+        a = m.sample_euler(dkw["x"], 3, use_graph=False, **ekw)
+        b = m.sample_euler(dkw["x"], 3, use_graph=True, **ekw)
+        c = m.sample_euler(dkw["x"], 3, use_graph=True, **ekw)
+        assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(b, c), key
+        m.profile(True)
+        m.sample_euler(dkw["x"], 3, use_graph=False, **ekw)
+        ran = {k: v["count"] for k, v in m.profile_report().items()}
+        m.profile(False)
+        assert (ran.get("mlp@fold") == 3 * cfg.num_layers) == (key != "unfolded"), ran
+        res[key] = a.cpu()
+        del m
+    assert torch.equal(res["fold"], res["fold, one stream"])
+    e = rel_l2(res["fold"], res["unfolded"])
+    print(f"3 Euler steps, folded vs unfolded MLP kernel: {e:.2e}")
+    assert e < 3e-3
+
+
+def test_headline_kernel_mix_at_B8_T1000_vs_oracle():
+    """One view of the headline (BASELINE.json configs[1]: B 16 = two sub-batch views of B 8 x T 1000 x L 4: 500 panels, 512 fused
+    attention jobs) with DEFAULT options, every element and every trace against the CPU oracle (latent_model.py:446-483), asserting
+    from the profile report that the launches took the headline's own kernels: k_flash_proj8 (`flash_proj_T@q128`), k_mlp_rows
+    (`mlp` / `mlp@fold`), k_ln_qkv<false, false> (`ln_qkv_T`), k_ln_qkv_attn4<true> (`attn_L_fused`).  (a) `forward` (per-sample t
+    path: the unfolded row-owner MLP) at t = 0; (b) ONE Euler step of size 1 through `sample_euler` -- x1 - x0 = v(x0, t = 0), the
+    shared-t path: the gate-folded MLP -- against the same oracle evaluation."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd.model import LatentMDGenModel
+    B, T, L = 8, 1000, 4
+    cfg, sd, kw, dkw = _fwd_case(B, T, L, 0, 4242, weights_seed=0)
+    kw["t"] = torch.zeros(B)
+    dkw["t"] = kw["t"].to(dkw["x"].device)
+    ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
+    nl = cfg.num_layers
+    m = LatentMDGenModel(cfg)
+    m.load_state_dict(sd)
+    out, tr, ran = _profiled_forward(m, dkw)
+    rep = {k: rel_l2(tr[k].cpu(), rtr[k]) for k in ["ipa_out"] + [f"h{i}" for i in range(nl + 1)]}
+    rep["out"] = rel_l2(out.cpu(), ref)
+    print("B8 T1000 L4 forward, default dispatch:", {k: f"{v:.2e}" for k, v in rep.items()}, ran)
+    assert torch.isfinite(out).all()
+    for k, v in rep.items():
+        assert v < TOL_FWD, (k, v)
+    want = {"flash_proj_T@q128": nl, "mlp": nl, "ln_qkv_T": nl, "attn_L_fused": nl, "embed": 1, "final_euler": 1}
+    for k, n in want.items():
+        assert ran.get(k) == n, (k, ran)
+    assert not any(k.split("@")[0] in ("flash_T", "proj_T", "proj_mlp", "projL_qkvT") for k in ran), ran
+    assert (out.cpu() - ref).abs().max() < 0.1 * ref.abs().max()
+    # (b) the sampler's path (t shared): eager with the profile on to read the classes, then the product's graph path
+    ekw = _euler_kw(dkw)
+    m.profile(True)
+    x1 = m.sample_euler(dkw["x"], 1, use_graph=False, **ekw)
+    ran = {k: v["count"] for k, v in m.profile_report().items()}
+    m.profile(False)
+    want = {"flash_proj_T@q128": nl, "mlp@fold": nl, "ln_qkv_T": nl, "attn_L_fused": nl, "fold_pack": 1}
+    for k, n in want.items():
+        assert ran.get(k) == n, (k, ran)
+    assert "mlp" not in ran, ran
+    xg = m.sample_euler(dkw["x"], 1, use_graph=True, **ekw)
+    assert torch.equal(x1, xg)
+    v = (xg - dkw["x"]).cpu()
+    e = rel_l2(v, ref)
+    per_t = ((v - ref).double().pow(2).sum((0, 2, 3)) / ref.double().pow(2).sum((0, 2, 3))).sqrt()
+    print(f"B8 T1000 L4 one Euler step (folded MLP): velocity vs oracle {e:.2e}, worst frame {float(per_t.max()):.2e}")
+    assert e < TOL_FWD and float(per_t.max()) < 3 * TOL_FWD
+
+
+def test_sample_euler_B16_graph_eager_and_stream_counts_agree():
+    """The bench line's own call shape: `sample_euler` B 16 x T 1000 x L 4, 3 steps, `streams` 2 (two views of B 8: the kernels of
+    test_headline_kernel_mix_at_B8_T1000_vs_oracle) -- graph replay == eager launches == one stream of B 16 bit for bit (both
+    launch sizes select the same kernel forms and a workgroup's arithmetic does not depend on the launch it is in)."""
+    from mdgen_amd.model import LatentMDGenModel
+    cfg, sd, kw, dkw = _fwd_case(16, 1000, 4, 0, 99, weights_seed=0)
+    ekw = _euler_kw(dkw)
+    m = LatentMDGenModel(cfg)
+    m.load_state_dict(sd)
+    res = {}
+    for ns in (2, 1):
+        m.set_option("streams", ns)
+        a = m.sample_euler(dkw["x"], 3, use_graph=False, **ekw)
+        b = m.sample_euler(dkw["x"], 3, use_graph=True, **ekw)
+        c = m.sample_euler(dkw["x"], 3, use_graph=True, **ekw)
+        assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(b, c), ns
+        res[ns] = a
+    assert torch.equal(res[1], res[2])

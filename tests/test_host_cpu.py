@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(L.EXPORTS) == set(names)
-    assert L.lib.mdgen_abi_version() == L.ABI_VERSION == 6   # include/mdgen_amd.h MDGEN_ABI_VERSION; _lib refuses a mismatch
+    assert L.lib.mdgen_abi_version() == L.ABI_VERSION == 7   # include/mdgen_amd.h MDGEN_ABI_VERSION; _lib refuses a mismatch
 
 
 def test_public_struct_layouts_agree_between_header_python_mirror_and_the_integration_stub():
