@@ -126,6 +126,11 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      "accumulators start at h + b2', accumulate W2' u, store": the row-owner kernel reads the residual rows once
  *                      instead of twice.  Same values to the bf16 rounding of gate * w instead of w.  Workspace: mdgen_ws_layout.fold
  *                      (S x layers x 2.36 MB); the report tags such launches "mlp@fold".
+ *   "mlp_tail"         1 (default) / 0: with mlp_fold, the FinalLayer (layers.py:57-74: LN + modulate, Linear C -> D) and the Euler update of x
+ *                      (integrators.py:106) run inside the LAST trunk layer's folded MLP kernel, on the updated rows while they are in
+ *                      registers; that kernel then does not store its rows (nothing reads the residual stream after the last layer) and
+ *                      there is no k_final launch: 196 MB less HBM traffic per network evaluation.  Not with trace_h.  Same values to
+ *                      fp32 summation order; the report tags the launch "mlp@fold+final".
  *   "fuse_proj"        the temporal attention's out-projection + gated residual (mha.py:397, latent_model.py:476) inside the
  *                      MLP kernel, ahead of the MLP: 0 off / 1 inside the row-owner kernel / 2 as a prologue phase of the
  *                      64-row panel kernel (k_mlp<3, true>; selects the panel kernel) / 3 (default) as 2 where the launch
@@ -270,6 +275,17 @@ int32_t mdgen_profile_enable(mdgen_ctx* ctx, int32_t on);
  * trace of such a launch measures k_mlp<3>, not the product's kernel for that size. */
 int32_t mdgen_profile_phase_trace(mdgen_ctx* ctx, uint64_t* dev_buf, int64_t capacity_words);
 int32_t mdgen_profile_report(mdgen_ctx* ctx, void* stream, char* buf, size_t buflen);
+/* Host only (no device, no context): which kernel classes a call of this shape launches and how often -- the library's own
+ * orchestration code (the code path of latent_model.py:212-260 / transport.py:408-451's replacements above) run in a plan mode
+ * that skips every HIP call.  mode 0: mdgen_sample_euler as the product runs it (sub-batch streams); 1: mdgen_denoiser_forward;
+ * 2: mdgen_sample_euler as it runs under mdgen_profile_enable (one stream); 3: mdgen_denoiser_forward with trace_h.  options: "name=value,..." with mdgen_ctx_set_option's
+ * names (bf16 path only).  ncu / xcd_round_robin: the two device facts mdgen_ctx_create would have probed (see "@context" of
+ * mdgen_profile_report).  Writes {"streams": n, "prepare": {"<class>": launches, ...} (the step-invariant part: adaLN table, IPA stack, fold pack),
+ * "views": [{"B": samples of the sub-batch view, "classes": {...}}, ...]} with the class names of mdgen_profile_report.  tests/test_dispatch_cpu.py sweeps shapes with it and fails when a combination of
+ * kernel forms has no oracle-backed GPU test registered. */
+int32_t mdgen_debug_dispatch_plan(const mdgen_shape* shape, int32_t n_steps, int32_t mode, int32_t tps_condition,
+                                  int32_t num_layers, int32_t ncu, int32_t xcd_round_robin, const char* options,
+                                  char* buf, size_t buflen);
 
 /* Host-only (no GPU): how a call of `shape` is cut into contiguous sub-batch launch views.  One launch addresses
  * the residual stream with 32-bit byte offsets (token * 1536), i.e. at most 2 796 202 token rows; larger batches

@@ -15,7 +15,7 @@ ABI_VERSION = 7   # include/mdgen_amd.h MDGEN_ABI_VERSION
 EXPORTS = [
     "mdgen_last_error", "mdgen_abi_version", "mdgen_dev_build", "mdgen_ctx_create", "mdgen_ctx_destroy", "mdgen_ctx_set_weight",
     "mdgen_ctx_finalize", "mdgen_ctx_set_option", "mdgen_debug_view_plan", "mdgen_ctx_num_weights", "mdgen_ctx_weight_name", "mdgen_workspace_layout",
-    "mdgen_denoiser_forward", "mdgen_sample_euler", "mdgen_rollout_euler", "mdgen_profile_enable", "mdgen_profile_report", "mdgen_profile_phase_trace", "mdgen_debug_layout_maps", "mdgen_debug_mlp_stream_table", "mdgen_debug_train_linear", "mdgen_debug_train_dw", "mdgen_debug_train_attention",
+    "mdgen_denoiser_forward", "mdgen_sample_euler", "mdgen_rollout_euler", "mdgen_profile_enable", "mdgen_profile_report", "mdgen_profile_phase_trace", "mdgen_debug_dispatch_plan", "mdgen_debug_layout_maps", "mdgen_debug_mlp_stream_table", "mdgen_debug_train_linear", "mdgen_debug_train_dw", "mdgen_debug_train_attention",
     "mdgen_rigid_compose", "mdgen_rigid_invert",
     "mdgen_rigid_apply", "mdgen_quat_to_rot", "mdgen_rot_to_quat", "mdgen_prep_latents",
     "mdgen_samples_to_atom14", "mdgen_atom14_to_cond", "mdgen_path_plan", "mdgen_masked_mse", "mdgen_from_3_points",
@@ -73,6 +73,7 @@ def _load():
     lib.mdgen_profile_enable.argtypes = [vp, i32]
     lib.mdgen_profile_phase_trace.argtypes = [vp, vp, i64]
     lib.mdgen_profile_report.argtypes = [vp, vp, C.c_char_p, sz]
+    lib.mdgen_debug_dispatch_plan.argtypes = [C.POINTER(Shape), i32, i32, i32, i32, i32, i32, C.c_char_p, C.c_char_p, sz]
     lib.mdgen_debug_layout_maps.argtypes = [vp] * 5
     lib.mdgen_debug_mlp_stream_table.argtypes = [vp, i32]
     lib.mdgen_debug_train_linear.argtypes = [i32, vp, i32, vp, i32, vp, i64, i32, i32, vp, i32, vp, vp]
@@ -156,3 +157,14 @@ def launch(fn, like, *args):
     the call and the launch goes on ITS current stream (centralised device guard)."""
     with torch.cuda.device(like.device):
         check(fn(*args, stream_ptr()))
+
+
+def dispatch_plan(B, T, L_, n_steps=1, mode=0, tps=False, num_layers=5, ncu=256, xcd_round_robin=True, options=None):
+    """`mdgen_debug_dispatch_plan` (host only): {"streams", "prepare": {kernel class: launches}, "views": [{"B", "classes"}]} of a call of this shape.
+    mode 0: sample_euler (product path), 1: forward, 2: sample_euler under the profiler (one stream)."""
+    import json
+    buf = C.create_string_buffer(1 << 14)
+    sh = Shape(B, T, L_)
+    opts = ",".join(f"{k}={int(v)}" for k, v in (options or {}).items()).encode()
+    check(lib.mdgen_debug_dispatch_plan(C.byref(sh), n_steps, mode, int(tps), num_layers, ncu, int(xcd_round_robin), opts, buf, len(buf)))
+    return json.loads(buf.value.decode())

@@ -28,13 +28,19 @@ static int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+// Plan mode (mdgen_debug_dispatch_plan): the orchestration code below runs on the host ONLY -- every HIP call and every launch is
+// skipped, and each launch site's profile class is appended to *g_dry instead.  The plan is therefore the product's own dispatch
+// logic, not a restatement of it.
+static thread_local std::vector<std::string>* g_dry = nullptr;
 #define HIPCHK(expr)                                                                           \
     do {                                                                                       \
+        if (g_dry) break;                                                                      \
         hipError_t e_ = (expr);                                                                \
         if (e_ != hipSuccess) return fail((int)e_, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 #define LAUNCHCHK()                                                                            \
     do {                                                                                       \
+        if (g_dry) break;                                                                      \
         hipError_t e_ = hipGetLastError();                                                     \
         if (e_ != hipSuccess) return fail((int)e_, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
         if (const char* m_ = k32_take_launch_error()) return fail(-7, "internal: %s (%s:%d)", m_, __FILE__, __LINE__); \
@@ -112,6 +118,7 @@ struct mdgen_ctx {
     float *ada_w = nullptr, *ada_b = nullptr;
     float *inv_freq = nullptr, *rope = nullptr;
     bf16x8* wfin = nullptr;
+    bf16x8* wfin_k = nullptr;   // the same tile with the K dimension in rows.h's kappa order (k_mlp_rows<., TAIL>)
     float* bfin = nullptr;
     std::vector<TrunkW> trunk;
     std::vector<IpaW> ipa;
@@ -159,6 +166,8 @@ struct mdgen_ctx {
     size_t train_ev_next = 0;
     int opt_mlp_fold = 1;       // sampling (t shared by the batch): the MLP gate folded into per-(step, layer) fc2 streams, k_mlp_rows starts its
                                 // accumulators from the residual rows and only stores (one HBM read of the rows instead of two)
+    int opt_mlp_tail = 1;       // ... and the FinalLayer + Euler update run inside the last layer's (folded) MLP kernel, which then does not store
+                                // its rows: no k_final launch, 196 MB less traffic per network evaluation
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
     std::vector<void*> milestone_events;          // mdgen_train_set_milestone_events (hipEvent_t handles, caller-owned)
     unsigned long long* phase_trace = nullptr;   // mdgen_profile_phase_trace target (device), consumed by one launch
@@ -191,6 +200,11 @@ struct ProfScope {
     ProfRec r;
     bool on;
     ProfScope(mdgen_ctx* c_, const char* cls, hipStream_t s_) : c(c_), s(s_), on(c_->prof_on) {
+        if (g_dry) {   // plan mode: the class is the record
+            g_dry->push_back(cls);
+            on = false;
+            return;
+        }
         if (on) {
             r.cls = cls;
             on = hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess &&
@@ -491,6 +505,7 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     }
     TRYHIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     TRY(c->dalloc(&c->wfin, (size_t)kKS * 64));
+    TRY(c->dalloc(&c->wfin_k, (size_t)kKS * 64));
     TRY(c->dalloc(&c->bfin, (size_t)32));
     TRYHIP(hipMemset(c->bfin, 0, 32 * sizeof(float)));
 #undef TRYHIP
@@ -520,7 +535,7 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
         SETTER("latent_to_emb_r.bias", { WANT(kC); if (int r = copy_f32(c->br7, data, kC, s)) return r; });
     }
     SETTER("emb_to_latent.linear.weight",
-           { WANT(c->D, kC); launch_pack_rows(data, kC, c->map_fin, 1, kKS, 1.f, c->wfin, s); });
+           { WANT(c->D, kC); launch_pack_rows(data, kC, c->map_fin, 1, kKS, 1.f, c->wfin, s); launch_pack_rows(data, kC, c->map_fin, 1, kKS, 1.f, c->wfin_k, s, 1); });
     SETTER("emb_to_latent.linear.bias", { WANT(c->D); if (int r = copy_f32(c->bfin, data, c->D, s)) return r; });
     SETTER("emb_to_latent.adaLN_modulation.1.weight", {
         WANT(2 * kC, kC);
@@ -702,6 +717,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "mlp_fold") {
         if (value != 0 && value != 1) return fail(-2, "mlp_fold must be 0 or 1");
         c->opt_mlp_fold = value;
+    } else if (n == "mlp_tail") {
+        if (value != 0 && value != 1) return fail(-2, "mlp_tail must be 0 or 1");
+        c->opt_mlp_tail = value;
     } else if (n == "residue_l4_path") {
         if (value < 0 || value > 2) return fail(-2, "residue_l4_path must be 0, 1 or 2");
         c->opt_residue_l4 = value;
@@ -854,6 +872,7 @@ struct Run {
     // gate fold: streams [S][nl][kFoldStreamBytes], then b2' [S][nl][384]; null when off for this call
     unsigned char* fold_streams;
     float* fold_b2g;
+    bool fold_ready;   // prepare() has packed them for this call (its views' MLP launches take the row-owner kernel)
     float* h() const { return hp; }
     float* mod() const { return modp; }
 };
@@ -1011,19 +1030,19 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
             q.wo = m.wo;
             q.bo = m.bo;
             q.gate_chunk = gate;
-            { ProfScope ps(r.c, residue_axis && trunk ? "attn_L_fused" : c_qkv, r.s); launch_ln_qkv_attn4(q, true, r.s); }
+            { ProfScope ps(r.c, residue_axis && trunk ? "attn_L_fused" : c_qkv, r.s); if (!g_dry) launch_ln_qkv_attn4(q, true, r.s); }
             LAUNCHCHK();
         } else {
-            { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv_attn4(q, false, r.s); }
+            { ProfScope ps(r.c, c_qkv, r.s); if (!g_dry) launch_ln_qkv_attn4(q, false, r.s); }
             LAUNCHCHK();
             p.a_bf16 = r.obufp;
-            { ProfScope ps(r.c, c_prj, r.s); launch_proj(p, 0, r.s); }
+            { ProfScope ps(r.c, c_prj, r.s); if (!g_dry) launch_proj(p, 0, r.s); }
             LAUNCHCHK();
         }
     } else if (small) {
         q.wv = m.wv_small;
         q.bv = m.bv_small;
-        { ProfScope ps(r.c, c_qkv, r.s); launch_ln_qkv(q, true, r.s); }
+        { ProfScope ps(r.c, c_qkv, r.s); if (!g_dry) launch_ln_qkv(q, true, r.s); }
         LAUNCHCHK();
         p.qkv_small = q.qkv_small;
         p.ax = ax;
@@ -1031,7 +1050,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
         p.bias_k = m.bias_k;
         p.bias_v = m.bias_v;
         p.rope = r.c->rope;
-        { ProfScope ps(r.c, c_prj, r.s); launch_proj(p, 2, r.s); }
+        { ProfScope ps(r.c, c_prj, r.s); if (!g_dry) launch_proj(p, 2, r.s); }
         LAUNCHCHK();
     } else {
         q.wv = m.wv_flash;
@@ -1049,14 +1068,14 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
             q.bo = pre->bias;
             q.gate_chunk = pre->gate_chunk;
             q.h_rw = h;
-            { ProfScope ps(r.c, "projL_qkvT", r.s); launch_ln_qkv(q, false, r.s, true); }
+            { ProfScope ps(r.c, "projL_qkvT", r.s); if (!g_dry) launch_ln_qkv(q, false, r.s, true); }
             LAUNCHCHK();
         } else {
             // (profile class "...@p8": the eight-wave form ran -- tests assert which kernel a launch took)
             const int pw = panel_waves_for((long)ax.nseq * q.panels_per_seq, r.c->opt_panel_waves, r.c->ncu);
             const bool split = pw == 8 && r.c->opt_small_split && 2L * ax.nseq * q.panels_per_seq <= r.c->ncu;
             const std::string cls = std::string(c_qkv) + (split ? "@p8x2" : pw == 8 ? "@p8" : "");
-            { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_ln_qkv(q, false, r.s, false, pw, split); }
+            { ProfScope ps(r.c, r.c->intern(cls), r.s); if (!g_dry) launch_ln_qkv(q, false, r.s, false, pw, split); }
             LAUNCHCHK();
         }
         FlashParams f{};
@@ -1087,18 +1106,18 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
             const int form = r.c->opt_flash_proj_form ? r.c->opt_flash_proj_form : (ax.len >= 512 && jobs8 >= r.c->ncu) ? 8 : 4;
             // (class "...@q64" / "@q128": which fused form ran -- k_flash_proj / k_flash_proj8; tests assert it)
             const std::string cls = std::string(!trunk ? "ipa.flash_proj" : residue_axis ? "flash_proj_L" : "flash_proj_T") + (form == 8 ? "@q128" : "@q64");
-            { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_flash_proj(fp, form, r.s); }
+            { ProfScope ps(r.c, r.c->intern(cls), r.s); if (!g_dry) launch_flash_proj(fp, form, r.s); }
             LAUNCHCHK();
             return 0;
         }
-        { ProfScope ps(r.c, c_att, r.s); launch_flash(f, r.s); }
+        { ProfScope ps(r.c, c_att, r.s); if (!g_dry) launch_flash(f, r.s); }
         LAUNCHCHK();
         p.a_bf16 = f.obuf;
         if (defer) {
             *defer = p;
             return 0;
         }
-        { ProfScope ps(r.c, c_prj, r.s); launch_proj(p, 0, r.s); }
+        { ProfScope ps(r.c, c_prj, r.s); if (!g_dry) launch_proj(p, 0, r.s); }
         LAUNCHCHK();
     }
     return 0;
@@ -1113,12 +1132,15 @@ static bool mlp_uses_rows(const mdgen_ctx* c, long nrows) {
 
 // `proj`: a deferred out-projection (attn_sublayer) to run inside the MLP kernel, ahead of the MLP
 // `fold_sl` >= 0 (trunk, gate fold active): index step * nl + layer of the folded stream / b2' of this launch
+// `tail` (last trunk layer; nullable): the FinalLayer's parameters; *tail_done = true when the launch ran it (folded row-owner form only)
 static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const ModMap& mm, int shift, int scale,
-                        int gate, bool trunk, const ProjParams* proj = nullptr, const bf16x8* wo_stream = nullptr, long fold_sl = -1) {
+                        int gate, bool trunk, const ProjParams* proj = nullptr, const bf16x8* wo_stream = nullptr, long fold_sl = -1,
+                        const FinalParams* tail = nullptr, bool* tail_done = nullptr) {
     if (int e = check_launch_rows(nrows)) return e;
     const bool panel_fused = proj && proj->a_bf16 && r.c->opt_fuse_proj >= 2;   // (3: only handed a projection when the panel kernel runs anyway)
     if (!panel_fused && mlp_uses_rows(r.c, nrows)) {
         MlpRowsParams q{};
+        bool tail_on = false;
         q.h = h;
         q.nrows = nrows;
         q.mm = mm;
@@ -1133,9 +1155,21 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
             q.wo_stream = (const unsigned char*)wo_stream;
             q.bo = proj->bias;
             q.gate_chunk_o = proj->gate_chunk;
-        } else if (fold_sl >= 0 && r.fold_streams && mm.group_stride == 0 && mm.step_stride == 0) {
+        } else if (fold_sl >= 0 && r.fold_ready && mm.group_stride == 0 && mm.step_stride == 0) {
             q.wstream = r.fold_streams + (size_t)fold_sl * kFoldStreamBytes;
             q.b2g = r.fold_b2g + (size_t)fold_sl * kC;
+            if (tail && tail_done && r.c->opt_mlp_tail && tail->mm.group_stride == 0 && tail->mm.step_stride == 0) {
+                tail_on = true;
+                q.tail_w = r.c->wfin_k;
+                q.tail_b = tail->bias;
+                q.tail_mod = tail->mm.mod;
+                q.tail_D = tail->D;
+                q.tail_euler = tail->euler;
+                q.tail_dt = tail->dt;
+                q.tail_x = tail->x;
+                q.tail_out = tail->out;
+                *tail_done = true;
+            }
         }
         if (trunk && r.c->phase_trace) {
             q.trace = r.c->phase_trace;
@@ -1143,7 +1177,8 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
             r.c->phase_trace = nullptr;
         }
         // (class "mlp@fold": the folded form ran -- tests assert it)
-        { ProfScope ps(r.c, !trunk ? "ipa.mlp" : q.o ? "proj_mlp" : q.b2g ? "mlp@fold" : "mlp", r.s); launch_mlp_rows(q, 4, r.s); }
+        // ("mlp@fold+final": ... with the FinalLayer + Euler update as its tail)
+        { ProfScope ps(r.c, !trunk ? "ipa.mlp" : q.o ? "proj_mlp" : tail_on ? "mlp@fold+final" : q.b2g ? "mlp@fold" : "mlp", r.s); if (!g_dry) launch_mlp_rows(q, 4, r.s); }
         LAUNCHCHK();
         return 0;
     }
@@ -1181,7 +1216,7 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
         p.counters = r.split_counters;
     }
     const std::string cls = std::string(!trunk ? "ipa.mlp" : p.o ? "proj_mlp" : "mlp") + (split ? "@p8x3" : pw == 8 ? "@p8" : "@p4");
-    { ProfScope ps(r.c, r.c->intern(cls), r.s); launch_mlp(p, r.s, pw); }
+    { ProfScope ps(r.c, r.c->intern(cls), r.s); if (!g_dry) launch_mlp(p, r.s, pw); }
     LAUNCHCHK();
     return 0;
 }
@@ -1191,7 +1226,7 @@ static int ipa_stack(const Run& r, float* hbuf, const float* rel7, const float* 
                      const float* trans) {
     mdgen_ctx* c = r.c;
     const int G = r.S * r.B;
-    launch_ipa_init(c->aa_emb, r.aatype, rel7, w7, b7, hbuf, G, r.B, r.L, r.s);
+    if (!g_dry) launch_ipa_init(c->aa_emb, r.aatype, rel7, w7, b7, hbuf, G, r.B, r.L, r.s);
     LAUNCHCHK();
     AxisMap ax{G, r.L, G, 0, r.L, 1};
     MaskMap mk{(const float*)(r.ws + r.lay.mask_bl), (long)r.B * r.L};
@@ -1239,7 +1274,7 @@ static int ipa_stack(const Run& r, float* hbuf, const float* rel7, const float* 
         lp.bias = w.bproj;
         lp.out = (float*)(r.ws + r.lay.ipa_proj);
         lp.nout = kIpaProj;
-        { ProfScope ps(c, "ipa.ln_linear", r.s); launch_ln_linear(lp, r.s); }
+        { ProfScope ps(c, "ipa.ln_linear", r.s); if (!g_dry) launch_ln_linear(lp, r.s); }
         LAUNCHCHK();
         IpaAttnParams ap{};
         ap.proj = lp.out;
@@ -1251,7 +1286,7 @@ static int ipa_stack(const Run& r, float* hbuf, const float* rel7, const float* 
         ap.ngroups = G;
         ap.B = r.B;
         ap.L = r.L;
-        { ProfScope ps(c, "ipa.point_attn", r.s); launch_ipa_attn(ap, r.s); }
+        { ProfScope ps(c, "ipa.point_attn", r.s); if (!g_dry) launch_ipa_attn(ap, r.s); }
         LAUNCHCHK();
         ProjParams pp{};
         pp.h = hbuf;
@@ -1261,7 +1296,7 @@ static int ipa_stack(const Run& r, float* hbuf, const float* rel7, const float* 
         pp.w = w.wout;
         pp.bias = w.bout;
         pp.a_bf16 = ap.feat;
-        { ProfScope ps(c, "ipa.linear_out", r.s); launch_proj(pp, 1, r.s); }
+        { ProfScope ps(c, "ipa.linear_out", r.s); if (!g_dry) launch_proj(pp, 1, r.s); }
         LAUNCHCHK();
         if (int e = attn_sublayer(r, w.mha_l, hbuf, r.Mp, ax, mm, 0, 1, 2, mk, true, false)) return e;
         if (int e = mlp_sublayer(r, w.ffn, hbuf, r.Mp, mm, 3, 4, 5, false)) return e;
@@ -1271,7 +1306,8 @@ static int ipa_stack(const Run& r, float* hbuf, const float* rel7, const float* 
 
 // Step-invariant work: adaLN table for every prepared time row, compact mask, IPA table.
 // t values: t_dev (device, [S][B]) when non-null, else t_host[step] baked into the launch.
-static int prepare(const Run& r, const float* t_dev, const float* t_host) {
+// view_rows: token rows of the call's largest trunk launch (a sub-batch view)
+static int prepare(Run& r, const float* t_dev, const float* t_host, long view_rows) {
     mdgen_ctx* c = r.c;
     float* silu = (float*)(r.ws + r.lay.silu_t);
     const int R = r.t_shared ? r.S : r.S * r.B;
@@ -1280,19 +1316,20 @@ static int prepare(const Run& r, const float* t_dev, const float* t_host) {
     HIPCHK(hipMemsetAsync(r.ws + r.lay.kf, 0, r.lay.obuf - r.lay.kf, r.s));
     if (t_dev) {
         if (r.t_shared && r.B > 1) return fail(-2, "device t rows require t_shared == 0 or B == 1");
-        launch_temb(t_dev, R, c->d.time_multiplier, c->t_w0, c->t_b0, c->t_w2, c->t_b2, silu, r.s);
+        if (!g_dry) launch_temb(t_dev, R, c->d.time_multiplier, c->t_w0, c->t_b0, c->t_w2, c->t_b2, silu, r.s);
         LAUNCHCHK();
     } else {
         // the (tiny) host time grid travels as kernel arguments: capturable, no host buffer lifetime issue
         float* tg = (float*)(r.ws + r.lay.tgrid);
-        launch_write_floats(t_host, r.S, tg, r.s);
+        if (!g_dry) launch_write_floats(t_host, r.S, tg, r.s);
         LAUNCHCHK();
-        launch_temb(tg, r.S, c->d.time_multiplier, c->t_w0, c->t_b0, c->t_w2, c->t_b2, silu, r.s);
+        if (!g_dry) launch_temb(tg, r.S, c->d.time_multiplier, c->t_w0, c->t_b0, c->t_w2, c->t_b2, silu, r.s);
         LAUNCHCHK();
     }
-    { ProfScope ps(c, "adaln_table", r.s); launch_adaln(silu, R, c->ada_w, c->ada_b, c->modrow, r.mod(), r.s); }
+    { ProfScope ps(c, "adaln_table", r.s); if (!g_dry) launch_adaln(silu, R, c->ada_w, c->ada_b, c->modrow, r.mod(), r.s); }
     LAUNCHCHK();
-    if (r.fold_streams) {   // the steps' MLP gates folded into per-(step, layer) fc2 streams (t_shared: R == S rows)
+    r.fold_ready = r.fold_streams && mlp_uses_rows(c, view_rows);
+    if (r.fold_ready) {   // the steps' MLP gates folded into per-(step, layer) fc2 streams (t_shared: R == S rows)
         int goff[8];
         const float *w2[8], *b2[8];
         const bf16x8* base[8];
@@ -1302,7 +1339,7 @@ static int prepare(const Run& r, const float* t_dev, const float* t_host) {
             b2[i] = c->trunk[i].ffn.b2;
             base[i] = c->trunk[i].ffn.wstream;
         }
-        { ProfScope ps(c, "fold_pack", r.s); launch_pack_fold(r.mod(), r.mod_step_stride, r.S, c->nl, goff, w2, b2, base, c->mlp_tab, (bf16x8*)r.fold_streams, r.fold_b2g, r.s); }
+        { ProfScope ps(c, "fold_pack", r.s); if (!g_dry) launch_pack_fold(r.mod(), r.mod_step_stride, r.S, c->nl, goff, w2, b2, base, c->mlp_tab, (bf16x8*)r.fold_streams, r.fold_b2g, r.s); }
         LAUNCHCHK();
     }
     // mask_bl[b][l] = mask[b][0][l]  (latent_model.py:246 passes mask[:,0])
@@ -1322,15 +1359,15 @@ static int prepare(const Run& r, const float* t_dev, const float* t_host) {
         if (r.rel7_in) {
             HIPCHK(hipMemcpyAsync(rel, r.rel7_in, (size_t)2 * BL * 7 * 4, hipMemcpyDeviceToDevice, r.s));
         } else {
-            launch_rel7(r.start_rot, r.start_trans, r.end_rot, r.end_trans, rel, BL, r.s);
-            launch_rel7(r.end_rot, r.end_trans, r.start_rot, r.start_trans, rel + BL * 7, BL, r.s);
+            if (!g_dry) launch_rel7(r.start_rot, r.start_trans, r.end_rot, r.end_trans, rel, BL, r.s);
+            if (!g_dry) launch_rel7(r.end_rot, r.end_trans, r.start_rot, r.start_trans, rel + BL * 7, BL, r.s);
             LAUNCHCHK();
         }
         float* h2 = (float*)(r.ws + r.lay.h_ipa);
         // x_r stream runs on the start frames, x_f stream on the end frames (latent_model.py:203-205)
         if (int e = ipa_stack(r, ipa_out, rel + BL * 7, c->wr7, c->br7, r.start_rot, r.start_trans)) return e;
         if (int e = ipa_stack(r, h2, rel, c->wf7, c->bf7, r.end_rot, r.end_trans)) return e;
-        launch_add_inplace(ipa_out, h2, r.Mp * kC, r.s);
+        if (!g_dry) launch_add_inplace(ipa_out, h2, r.Mp * kC, r.s);
         LAUNCHCHK();
     }
     return 0;
@@ -1358,7 +1395,7 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
     e.T = r.T;
     e.L = r.L;
     e.D = r.D;
-    { ProfScope ps(c, "embed", r.s); launch_embed(e, r.s); }
+    { ProfScope ps(c, "embed", r.s); if (!g_dry) launch_embed(e, r.s); }
     LAUNCHCHK();
     const size_t hbytes = (size_t)r.N * kC * 4;
     if (trace_h) HIPCHK(hipMemcpyAsync(trace_h, h, hbytes, hipMemcpyDeviceToDevice, r.s));
@@ -1385,6 +1422,20 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
         LAUNCHCHK();
         return 0;
     }
+    FinalParams f{};
+    f.h = h;
+    f.nrows = r.N;
+    f.mm = ModMap{modstep + c->final_off(), r.T * r.L, r.B, 0, r.mod_group_stride};
+    f.shift_chunk = 0;
+    f.scale_chunk = 1;
+    f.w = c->wfin;
+    f.bias = c->bfin;
+    f.D = r.D;
+    f.euler = euler;
+    f.dt = dt;
+    f.x = x;
+    f.out = out;
+    bool tail_done = false;
     for (int i = 0; i < c->nl; ++i) {
         const TrunkW& w = c->trunk[i];
         ModMap mm{modstep + c->trunk_off(i), r.T * r.L, r.B, 0, r.mod_group_stride};
@@ -1400,23 +1451,15 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
         if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true, fuse ? &deferred : nullptr,
                                    def_l.a_bf16 ? &def_l : nullptr))
             return er;
-        if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true, &deferred, w.mha_t.wo_stream, (long)step * c->nl + i)) return er;
+        // the last layer's MLP may run the FinalLayer as its tail (then h is NOT written: not with a residual-stream trace)
+        const bool last = i == c->nl - 1 && !trace_h;
+        if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true, &deferred, w.mha_t.wo_stream, (long)step * c->nl + i,
+                                  last ? &f : nullptr, last ? &tail_done : nullptr))
+            return er;
         if (trace_h) HIPCHK(hipMemcpyAsync(trace_h + (size_t)(i + 1) * r.N * kC, h, hbytes, hipMemcpyDeviceToDevice, r.s));
     }
-    FinalParams f{};
-    f.h = h;
-    f.nrows = r.N;
-    f.mm = ModMap{modstep + c->final_off(), r.T * r.L, r.B, 0, r.mod_group_stride};
-    f.shift_chunk = 0;
-    f.scale_chunk = 1;
-    f.w = c->wfin;
-    f.bias = c->bfin;
-    f.D = r.D;
-    f.euler = euler;
-    f.dt = dt;
-    f.x = x;
-    f.out = out;
-    { ProfScope ps(c, "final_euler", r.s); launch_final(f, r.s); }
+    if (tail_done) return 0;
+    { ProfScope ps(c, "final_euler", r.s); if (!g_dry) launch_final(f, r.s); }
     LAUNCHCHK();
     return 0;
 }
@@ -1431,6 +1474,7 @@ static int make_run(Run* r, mdgen_ctx* c, const mdgen_shape* sh, int S, int t_sh
         return fail(-7, "workspace too small: %zu < %zu bytes", ws_bytes, r->lay.total_bytes);
     if (((uintptr_t)ws & 255) != 0) return fail(-7, "workspace must be 256-byte aligned");
     if (c->opt_precision == 32 && !c->opt_keep_fp32) return fail(-6, "precision 32 requires option keep_fp32_weights");
+    if (g_dry && c->opt_precision == 32) return fail(-2, "the dispatch plan covers the bf16 path");
     r->c = c;
     r->B = sh->B;
     r->T = sh->T;
@@ -1464,6 +1508,7 @@ static int make_run(Run* r, mdgen_ctx* c, const mdgen_shape* sh, int S, int t_sh
     }
     r->fold_streams = nullptr;
     r->fold_b2g = nullptr;
+    r->fold_ready = false;
     if (fold_on(c, r->N, t_shared)) {
         r->fold_streams = r->ws + r->lay.fold;
         r->fold_b2g = (float*)(r->fold_streams + (size_t)S * c->nl * kFoldStreamBytes);
@@ -1490,10 +1535,10 @@ extern "C" int32_t mdgen_denoiser_forward(mdgen_ctx* c, const mdgen_shape* sh, c
     r.x_cond = x_cond;
     r.x_cond_mask = x_cond_mask;
     r.aatype = aatype;
-    if (int e = prepare(r, t, nullptr)) return e;
+    const int nv = c->opt_precision == 32 ? 1 : plan_views(r.B, r.T, r.L, 1);
+    if (int e = prepare(r, t, nullptr, nv > 0 ? (long)((r.B + nv - 1) / nv) * r.T * r.L : r.N)) return e;
     if (trace_ipa)
         HIPCHK(hipMemcpyAsync(trace_ipa, r.ws + r.lay.ipa_out, (size_t)r.B * r.L * kC * 4, hipMemcpyDeviceToDevice, r.s));
-    const int nv = c->opt_precision == 32 ? 1 : plan_views(r.B, r.T, r.L, 1);
     if (nv <= 1) return denoise_step(r, 0, const_cast<float*>(x), out, 0, 0.f, trace_h);
     if (trace_h) return fail(-2, "trace_h is not available when the batch needs more than one launch view");
     int b0 = 0;
@@ -1529,6 +1574,7 @@ static int n_streams(const Run& r) {
 }
 
 static int euler_steps(const Run& v, const std::vector<float>& tg, float* x) {
+    if (g_dry) g_dry->push_back("@view");   // plan mode: a sub-batch view's launches start here
     for (int i = 0; i < v.S; ++i) {
         const float dt = tg[i + 1] - tg[i];
         if (int e = denoise_step(v, i, x, nullptr, 1, dt, nullptr)) return e;
@@ -1537,12 +1583,13 @@ static int euler_steps(const Run& v, const std::vector<float>& tg, float* x) {
 }
 
 
-static int euler_body(const Run& r, const std::vector<float>& tg, float* x) {
-    if (int e = prepare(r, nullptr, tg.data())) return e;
+static int euler_body(const Run& r_in, const std::vector<float>& tg, float* x) {
+    Run r = r_in;
     const int ns = n_streams(r);
     // >= ns views; more when a view would exceed kMaxViewTokens (the fp32 kernels index with 64 bits: one view)
     const int nv = r.c->opt_precision == 32 ? 1 : plan_views(r.B, r.T, r.L, ns);
     if (nv == 0) return fail(-2, "sample too large for one launch");
+    if (int e = prepare(r, nullptr, tg.data(), (long)((r.B + nv - 1) / nv) * r.T * r.L)) return e;
     r.c->live_streams = 1;
     if (nv == 1) return euler_steps(r, tg, x);
     struct Live {   // the views below run on ns streams at once: kernels that use context-owned scratch stay off meanwhile
@@ -1637,7 +1684,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45 | (uint64_t)c->opt_mlp_tail << 46), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1697,10 +1744,104 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45 | (uint64_t)c->opt_mlp_tail << 46),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dispatch plan (host only)
+// ---------------------------------------------------------------------------------------------
+// Which kernel classes a call of this shape launches, and how often: the sampler's orchestration code above, run in plan mode
+// (g_dry) on a context that owns no device memory.  mode 0: mdgen_sample_euler as the product runs it (sub-batch streams);
+// 1: mdgen_denoiser_forward; 2: mdgen_sample_euler as mdgen_profile_enable sees it (one stream); 3: mdgen_denoiser_forward with trace_h.  options: "name=value,..."
+// (mdgen_ctx_set_option names).  ncu / xcd_round_robin: what mdgen_ctx_create would have found on the device.
+// Output: {"streams": n, "prepare": {"<class>": launches, ...}, "views": [{"B": samples of the view, "classes": {...}}, ...]}.
+extern "C" int32_t mdgen_debug_dispatch_plan(const mdgen_shape* sh, int32_t n_steps, int32_t mode, int32_t tps_condition,
+                                             int32_t num_layers, int32_t ncu, int32_t xcd_round_robin, const char* options,
+                                             char* buf, size_t buflen) {
+    if (!sh || !buf || buflen < 64) return fail(-1, "null argument");
+    if (mode < 0 || mode > 3) return fail(-2, "mode: 0 sample_euler, 1 forward, 2 sample_euler under the profiler, 3 forward with trace_h");
+    if (num_layers < 1 || num_layers > 8 || ncu < 1) return fail(-2, "num_layers in 1..8, ncu >= 1");
+    mdgen_ctx ctx;   // no device memory, no streams: plan mode never touches them
+    mdgen_ctx* c = &ctx;
+    c->nl = num_layers;
+    c->D = tps_condition ? 28 : 21;
+    c->d.num_layers = num_layers;
+    c->d.latent_dim = c->D;
+    c->d.tps_condition = tps_condition;
+    c->d.abs_pos_emb = 0;
+    c->modrow = (15 * c->nl + 2) * kC;
+    c->trunk.resize(c->nl);
+    c->ipa.resize(c->nl);
+    c->finalized = true;
+    c->ncu = ncu;
+    c->xcd_round_robin = xcd_round_robin != 0;
+    c->prof_on = mode == 2;
+    for (std::string rest = options ? options : ""; !rest.empty();) {
+        const size_t comma = rest.find(',');
+        const std::string kv = rest.substr(0, comma);
+        rest = comma == std::string::npos ? "" : rest.substr(comma + 1);
+        const size_t eq = kv.find('=');
+        if (eq == std::string::npos) return fail(-2, "options: name=value[,name=value...]");
+        if (int e = mdgen_ctx_set_option(c, kv.substr(0, eq).c_str(), std::atoi(kv.c_str() + eq + 1))) return e;
+    }
+    std::vector<std::string> plan;
+    struct Dry {
+        Dry(std::vector<std::string>* p) { g_dry = p; }
+        ~Dry() { g_dry = nullptr; }
+    } dry(&plan);
+    const bool fwd = mode == 1 || mode == 3;
+    const int S = fwd ? 1 : n_steps;
+    const int t_shared = fwd ? (sh->B == 1 ? 1 : 0) : 1;
+    Run r{};
+    if (int e = make_run(&r, c, sh, S, t_shared, (void*)4096, (size_t)1 << 60, nullptr)) return e;
+    float* fake = (float*)4096;   // never dereferenced: plan mode launches nothing
+    r.mask = r.start_rot = r.start_trans = r.end_rot = r.end_trans = r.x_cond = fake;
+    r.x_cond_mask = r.aatype = (const int64_t*)fake;
+    int ns = 1, nv = 1;
+    if (fwd) {
+        nv = plan_views(r.B, r.T, r.L, 1);
+        if (int e = prepare(r, fake, nullptr, (long)((r.B + nv - 1) / nv) * r.T * r.L)) return e;
+        int b0 = 0;
+        for (int i = 0; i < nv; ++i) {
+            const int Bs = r.B / nv + (i < r.B % nv ? 1 : 0);
+            const Run v = nv > 1 ? sub_run(r, b0, Bs, r.s) : r;
+            plan.push_back("@view");
+            if (int e = denoise_step(v, 0, fake, fake, 0, 0.f, mode == 3 ? fake : nullptr)) return e;
+            b0 += Bs;
+        }
+    } else {
+        std::vector<float> tg;
+        linspace01(S + 1, &tg);
+        ns = n_streams(r);
+        nv = plan_views(r.B, r.T, r.L, ns);
+        if (int e = euler_body(r, tg, fake)) return e;
+    }
+    // {"streams": n, "prepare": {class: launches}, "views": [{"B": samples, "classes": {class: launches}}, ...]}
+    auto dump = [](const std::map<std::string, long>& agg) {
+        std::string o = "{";
+        bool first = true;
+        for (const auto& kv : agg) {
+            o += std::string(first ? "" : ", ") + "\"" + kv.first + "\": " + std::to_string(kv.second);
+            first = false;
+        }
+        return o + "}";
+    };
+    std::vector<std::map<std::string, long>> parts(1);
+    for (const auto& k : plan) {
+        if (k == "@view") parts.emplace_back();
+        else ++parts.back()[k];
+    }
+    if ((int)parts.size() != nv + 1) return fail(-7, "internal: %d views planned, %d recorded", nv, (int)parts.size() - 1);
+    std::string js = "{\"streams\": " + std::to_string(ns) + ", \"prepare\": " + dump(parts[0]) + ", \"views\": [";
+    for (int i = 0; i < nv; ++i)
+        js += std::string(i ? ", " : "") + "{\"B\": " + std::to_string(r.B / nv + (i < r.B % nv ? 1 : 0)) + ", \"classes\": " + dump(parts[i + 1]) + "}";
+    js += "]}";
+    if (js.size() + 1 > buflen) return fail(-7, "plan buffer too small");
+    std::memcpy(buf, js.c_str(), js.size() + 1);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -627,8 +627,15 @@ __global__ __launch_bounds__(256, 2) void k_flash_proj(const FlashProjParams p) 
     setup_rows_axis(pr, p.f.ax, seq, qc * kPanel, p.mm);   // read after the barrier below
     FlashPre<NQ> cur;
     flash_prefetch<NQ>(p.f, seq, w, qc, cur);
+#ifdef MDGEN_DEV_FLASH_HWPRIO   // (experiment) the two co-resident workgroups' waves of a SIMD take turns by hardware wave slot parity
+    const int slot = (int)(__builtin_amdgcn_s_getreg((4 << 11) | 4) & 1u);   // HW_REG_HW_ID bits 3:0 = wave slot of the SIMD
+#endif
 #pragma unroll 1
     for (int hg = 0; hg < 4; ++hg) {
+#ifdef MDGEN_DEV_FLASH_HWPRIO
+        if ((hg & 1) ^ slot) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+#endif
         FlashPre<NQ> nxt;
         flash_prefetch<NQ>(p.f, seq, 4 * (hg < 3 ? hg + 1 : 3) + w, qc, nxt);   // in flight while this head's job runs
         __builtin_amdgcn_sched_barrier(0);
@@ -636,16 +643,29 @@ __global__ __launch_bounds__(256, 2) void k_flash_proj(const FlashProjParams p) 
         cur = nxt;
         FPROJ_STAMP(1 + hg, __builtin_amdgcn_s_memtime());
     }
+#ifdef MDGEN_DEV_FLASH_HWPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();   // the attention output of all 16 heads is in the panel
     FPROJ_STAMP(5, __builtin_amdgcn_s_memtime());
     const int lane = lane_id();
     f32x16 acc[6];
+#ifdef MDGEN_DEV_FLASH_EARLY64   // (experiment) as k_flash_proj8: the first batch of residual rows requested ahead of the GEMM
+    EpiPre<8> ep;
+    epi_rmw_request<8>(0, 0, pr, 96 * w, p.h, ep);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, false>(panel, kC * 2, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     FPROJ_STAMP(6, __builtin_amdgcn_s_memtime());
     __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
+#ifdef MDGEN_DEV_FLASH_EARLY64
+    epilogue_gate_residual_lds_pre<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
+                                      p.h, ep);
+#else
     epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
                                   p.h);
+#endif
     FPROJ_STAMP(7, __builtin_amdgcn_s_memtime());
     FPROJ_STAMP(9, __builtin_amdgcn_s_memrealtime());
 }
@@ -687,12 +707,13 @@ __global__ __launch_bounds__(512, 1) void k_flash_proj8(const FlashProjParams p)
         pr[hf].moff[i] = (int)mo;
         set_uniform(&pr[hf], i, tk, mo);
     }
-#if defined(MDGEN_DEV_FLASH_PRIO1)   // (experiment) static priority for the second-dispatched half (MI355X_MICROARCH "two waves per SIMD" 4)
-    if (w8 >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-#if defined(MDGEN_DEV_FLASH_PRIO2)   // (experiment) the two waves of a SIMD take turns: the younger one first
+#ifndef MDGEN_DEV_FLASH_NOPRIO
+        // The two waves of a SIMD (w8, w8 + 4) take turns at static priority, the second-dispatched one first: the arbiter otherwise serves
+        // the older wave on every conflict (MI355X_MICROARCH "two waves per SIMD"), both waves walk their jobs in step and each one's
+        // prologue / anchor / store phases meet the other's.  One flip per job, none inside the loop.  k_flash_proj8 204.3 / 205.8 ->
+        // 195.4 / 196.3 us per launch at cfg-2 (profiles/r06_experiments.txt #2); a fixed priority for waves 4..7 alone: no change.
         if ((w8 >= 4) == (pass == 0)) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
 #endif
@@ -701,13 +722,15 @@ __global__ __launch_bounds__(512, 1) void k_flash_proj8(const FlashProjParams p)
         flash_prefetch<NQ>(p.f, seq, head, qc, pre);
         flash_job<NQ>(p.f, seq, head, qc, w8, pre, FlashStorePanel{(lds_byte*)panel, head});
     }
-#if defined(MDGEN_DEV_FLASH_PRIO1) || defined(MDGEN_DEV_FLASH_PRIO2)
+#ifndef MDGEN_DEV_FLASH_NOPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
     __syncthreads();   // the attention output of all 16 heads is in the panel
     const int lane = lane_id();
     f32x16 acc[6];
-#ifdef MDGEN_DEV_FLASH_EARLY   // (experiment) the residual rows of the epilogue's first batch are requested BEFORE the out-projection GEMM
+#ifndef MDGEN_DEV_FLASH_NOEARLY
+    // the residual rows of the epilogue's first batch are requested BEFORE the out-projection GEMM (they do not depend on it), and every
+    // later batch before the stores of the one ahead of it: 204 -> 200-201 us per launch at cfg-2 (profiles/r06_experiments.txt #2)
     EpiPre<8> ep;
     epi_rmw_request<8>(0, 0, &pr[g], 96 * w, p.h, ep);
     __builtin_amdgcn_sched_barrier(0);
@@ -715,7 +738,7 @@ __global__ __launch_bounds__(512, 1) void k_flash_proj8(const FlashProjParams p)
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, false>(panel, kC * 2, 2 * g, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     __syncthreads();   // every wave is done reading the panel: reuse it as eight 12 KiB staging slabs
-#ifdef MDGEN_DEV_FLASH_EARLY
+#ifndef MDGEN_DEV_FLASH_NOEARLY
     epilogue_gate_residual_lds_pre<3>(acc, &pr[g], reinterpret_cast<float*>(panel) + w8 * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
                                       p.h, ep);
 #else

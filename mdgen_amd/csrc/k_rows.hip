@@ -232,11 +232,16 @@ __device__ __forceinline__ void proj_blocks(MlpPipe& m, const bf16x8 (&xf)[24], 
 // FOLD (round 6; MODLDS, no PROJ): the launch's gate is one vector and is folded into the stream's W2 fragments and into b2'
 // (p.b2g; k_pack_fold, once per call): the fc2 accumulators start from the residual rows + b2' (rows_norm_lds_fold) and the
 // epilogue only stores -- one HBM read of the rows instead of two (98 MB of 332 per launch at cfg-2).
-template <int NW, bool PROJ, bool MODLDS, bool FOLD = false>
+// TAIL (with FOLD; the trunk's last layer in a sampling call): the FinalLayer -- LN + modulate, Linear C -> D, Euler update of x
+// (layers.py:57-74, integrators.py:106; k_final's work) -- runs on the updated rows straight from the accumulators (the row image is
+// the LayerNorm image) and the rows are never stored.
+template <int NW, bool PROJ, bool MODLDS, bool FOLD = false, bool TAIL = false>
 __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) {
     static_assert(!FOLD || (MODLDS && !PROJ), "the folded form: one modulation group per launch, no fused out-projection");
+    static_assert(!TAIL || FOLD, "the tail runs on the folded form's accumulators");
     // ring | fc1 bias | slack: the last re-arm reads the (non-existent) chunk 24 | per wave: scale, shift, gate chunks (2 KiB slots)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[kRingBytes + 8192 + NW * 6144];
+    // | TAIL: the final layer's shift, scale chunks (2 KiB slots, shared by the waves)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kRingBytes + 8192 + NW * 6144 + (TAIL ? 4096 : 0)];
     constexpr int NPRE = PROJ ? 12 : 0;   // ring slots of the out-projection ahead of the MLP stream
     using WS = WStream<NW, NPRE>;
     constexpr int FPW = WS::FPW;
@@ -251,6 +256,15 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
         if (i % NW == w)
             dma_frag<0, true>(reinterpret_cast<const unsigned char*>(p.b1) + i * 1024, (unsigned)lane * 16u,
                               lds_addr(smem) + kRingBytes + i * 1024);
+    if (TAIL) {   // final adaLN chunks 0 (shift), 1 (scale) -> LDS: wave c % NW brings chunk c (two 1 KiB DMAs, upper half into the slot's slack)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (c % NW == w) {
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(p.tail_mod) + c * (kC * 4);
+                dma_frag<0, true>(src, (unsigned)lane * 16u, lds_addr(smem) + kRingBytes + 8192 + NW * 6144 + c * 2048);
+                dma_frag<1024, false>(src, (unsigned)lane * 16u, lds_addr(smem) + kRingBytes + 8192 + NW * 6144 + c * 2048);
+            }
+    }
     const long t = ((long)blockIdx.x * NW + w) * 32 + n;
     const int tok = t < p.nrows ? (int)t : -1;
     // The wave's modulation vectors (scale, shift, gate: 1536 B each) by DMA into LDS when all its rows share them (always,
@@ -371,7 +385,10 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
     pipe_block<NW, 84, 1, 3, -1, false, -1, false, 12 - kWPF>(m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], b1l, ring_lane, ws, NPRE + 0);
     ROWS_STAMP(4);
     // ---- gated residual
-    if (FOLD) {
+    if (TAIL) {
+        const float* fmod = reinterpret_cast<const float*>(smem + kRingBytes + 8192 + NW * 6144);   // [shift 512 floats | scale 512]
+        rows_final_tail(m.y, tok, fmod + 512, fmod, p.tail_w, p.tail_b, p.tail_D, p.tail_euler, p.tail_dt, p.tail_x, p.tail_out, xf);
+    } else if (FOLD) {
         rows_store<0, 12>(m.y, tok, p.h);
     } else if (MODLDS) {
         rows_gate_residual_lds<0, 6>(m.y, tok, modl + 1024, p.h);
@@ -490,7 +507,8 @@ static void launch_mlp_rows_nw(const MlpRowsParams& p, long tiles, hipStream_t s
         if (uni) hipLaunchKernelGGL((k_mlp_rows<NW, true, true>), g, b, 0, s, p);
         else hipLaunchKernelGGL((k_mlp_rows<NW, true, false>), g, b, 0, s, p);
     } else {
-        if (p.b2g) hipLaunchKernelGGL((k_mlp_rows<NW, false, true, true>), g, b, 0, s, p);   // (the caller has checked: one modulation group)
+        if (p.b2g && p.tail_w) hipLaunchKernelGGL((k_mlp_rows<NW, false, true, true, true>), g, b, 0, s, p);
+        else if (p.b2g) hipLaunchKernelGGL((k_mlp_rows<NW, false, true, true>), g, b, 0, s, p);   // (the caller has checked: one modulation group)
         else if (uni) hipLaunchKernelGGL((k_mlp_rows<NW, false, true>), g, b, 0, s, p);
         else hipLaunchKernelGGL((k_mlp_rows<NW, false, false>), g, b, 0, s, p);
     }

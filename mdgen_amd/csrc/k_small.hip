@@ -81,8 +81,10 @@ __global__ void k_gather_f32(const float* __restrict__ src, const int* __restric
 
 // Weight re-pack into MFMA fragment order: dst[(ft*ksteps + ks)*64 + lane] = 8 bf16 of
 // W[rowmap[ft*32 + (lane&31)]][ks*16 + (lane>>5)*8 .. +7] * scale   (rowmap < 0 -> zeros)
+// kappa == 1: the K slice of a k-step in rows.h's kappa order, k = 16 ks + 8 (j >> 2) + 4 hh + (j & 3) (operands whose B fragments are
+// LayerNorm registers of the row-owner kernels); 0: natural, k = 16 ks + 8 hh + j
 __global__ void k_pack_rows(const float* __restrict__ w, int ld, const int* __restrict__ rowmap, int nft, int ksteps,
-                            float scale, bf16x8* __restrict__ dst) {
+                            float scale, bf16x8* __restrict__ dst, int kappa) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)nft * ksteps * 64;
     if (i >= total) return;
@@ -90,10 +92,13 @@ __global__ void k_pack_rows(const float* __restrict__ w, int ld, const int* __re
     const long fk = i >> 6;
     const int ks = (int)(fk % ksteps), ft = (int)(fk / ksteps);
     const int row = rowmap[ft * 32 + (lane & 31)];
-    const int k0 = ks * 16 + (lane >> 5) * 8;
+    const int hh = lane >> 5;
     bf16x8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (__bf16)(row >= 0 && k0 + j < ld ? w[(long)row * ld + k0 + j] * scale : 0.f);
+    for (int j = 0; j < 8; ++j) {
+        const int k = kappa ? ks * 16 + 8 * (j >> 2) + 4 * hh + (j & 3) : ks * 16 + hh * 8 + j;
+        v[j] = (__bf16)(row >= 0 && k < ld ? w[(long)row * ld + k] * scale : 0.f);
+    }
     dst[i] = v;
 }
 
@@ -652,10 +657,10 @@ void launch_gather_f32(const float* src, const int* idx, float scale, float* dst
     hipLaunchKernelGGL(k_gather_f32, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, scale, dst, n);
 }
 void launch_pack_rows(const float* w, int ld, const int* rowmap, int nft, int ksteps, float scale, bf16x8* dst,
-                      hipStream_t s) {
+                      hipStream_t s, int kappa) {
     const long total = (long)nft * ksteps * 64;
     hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, ld, rowmap, nft, ksteps,
-                       scale, dst);
+                       scale, dst, kappa);
 }
 void launch_path_plan(const float* t, const float* x0, const float* x1, float* xt, float* ut, long per_sample, long B,
                       int gvp, hipStream_t s) {

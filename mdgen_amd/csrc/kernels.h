@@ -91,6 +91,17 @@ struct MlpRowsParams {
     // gate fold (non-null; o == null, every row of the launch shares the modulation row): `wstream` is the (step, layer) stream with
     // the gate folded into fc2 and b2g = gate * b2 (launch_pack_fold): accumulators start from the residual rows, store-only epilogue
     const float* b2g;
+    // tail (with b2g, the trunk's LAST layer): FinalLayer + Euler update (layers.py:57-74, integrators.py:106) run on the updated rows while
+    // they are still in registers, and the rows are NOT stored (nothing reads the residual stream after the last layer): k_final's
+    // launch, its 98 MB read and this kernel's 98 MB write are gone.  tail_w: emb_to_latent.linear.weight as 24 fragments in kappa
+    // order (rows >= D zero), tail_b [32], tail_mod: the step's final adaLN row (shift chunk 0, scale chunk 1).
+    const bf16x8* tail_w;
+    const float* tail_b;
+    const float* tail_mod;
+    int tail_D, tail_euler;
+    float tail_dt;
+    float* tail_x;      // euler: state updated in place
+    float* tail_out;    // !euler: velocity
 };
 
 struct LnLinearParams {
@@ -296,7 +307,7 @@ void launch_adaln(const float* st, int nrows, const float* w, const float* b, in
 void launch_rope_table(float* rope, const float* inv_freq, int npos, hipStream_t s);
 void launch_gather_f32(const float* src, const int* idx, float scale, float* dst, int n, hipStream_t s);
 void launch_pack_rows(const float* w, int ld, const int* rowmap, int nft, int ksteps, float scale, bf16x8* dst,
-                      hipStream_t s);
+                      hipStream_t s, int kappa = 0);
 void launch_ipa_init(const float* aa_emb, const int64_t* aatype, const float* rel7, const float* w7, const float* b7,
                      float* h, int ngroups, int B, int L, hipStream_t s);
 void launch_add_inplace(float* dst, const float* src, long n, hipStream_t s);

@@ -304,6 +304,50 @@ __device__ __forceinline__ void rows_store(const f32x16 (&y)[12], int tok, float
     }
 }
 
+// FinalLayer on the wave's 32 rows, from the fc2 accumulators (k_mlp_rows<., TAIL>): v = W (LN(h)(1 + scale) + shift) + b,
+// x += dt v (euler) or out = v  (layers.py:70-74; integrators.py:106).  `y` holds the updated residual rows (accumulator image =
+// row image); sc / sh: the final layer's scale / shift chunks in LDS; wfin: 24 fragments (one 32-row tile, rows >= D zero, kappa K
+// order); bfin [32].  D[feature][token]: lane (n, hh) ends with features 8 a + 4 hh + i of its token in register 4 a + i.
+__device__ __forceinline__ void rows_final_tail(const f32x16 (&y)[12], int tok, const float* sc, const float* sh,
+                                                const bf16x8* __restrict__ wfin, const float* __restrict__ bfin, int D, int euler,
+                                                float dt, float* __restrict__ x, float* __restrict__ out, bf16x8 (&xf)[24]) {
+    const int lane = lane_id(), hh = lane >> 5;
+    const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
+    // the state values and the bias are requested first; the weight tile (24 KiB, L2) once the row image is dead (192 + 96 registers
+    // do not fit beside it)
+    f32x4 b4[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) b4[a] = *reinterpret_cast<const f32x4*>(bfin + 8 * a + 4 * hh);
+    float xv[16];
+    float* xp = (euler ? x : out) + (size_t)tokc * (unsigned)D;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = 8 * (r >> 2) + 4 * hh + (r & 3);
+        xv[r] = euler ? xp[f < D ? f : 0] : 0.f;   // (unconditional, clamped)
+    }
+    f32x4 v[48];
+#pragma unroll
+    for (int i = 0; i < 48; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[i][j]) : "a"(y[i >> 2][4 * (i & 3) + j]));
+    rows_norm_lds(v, tok, sc, sh, 1e-6f, xf);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 wf[24];
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) wf[ks] = wfin[ks * 64 + lane];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b4[r >> 2][r & 3];
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks], acc, 0, 0, 0);
+    const float s = euler ? dt : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = 8 * (r >> 2) + 4 * hh + (r & 3);
+        if (tok >= 0 && f < D) xp[f] = xv[r] + s * acc[r];
+    }
+}
+
 __device__ __forceinline__ void rows_ln(const float* __restrict__ x, int tok, const ModMap mm, int shift_chunk,
                                         int scale_chunk, float eps, bf16x8 (&xf)[24]) {
     f32x4 v[48];

@@ -2616,7 +2616,22 @@ def test_mlp_gate_fold_vs_unfolded_kernel_and_oracle(shape):
             assert v < TOL_FWD, (key, k, v)
         assert (ran.get("mlp@fold") == nl and "mlp" not in ran and ran.get("fold_pack") == 1) if fold else \
             (ran.get("mlp") == nl and "mlp@fold" not in ran and "fold_pack" not in ran), ran
-        assert torch.equal(m.forward(**dkw), out), key
+        # without a residual-stream trace the folded form also runs the FinalLayer as the last MLP launch's tail (option mlp_tail):
+        # the same bits call to call, the traced call's values to fp32 summation order (+ a bf16 rounding flip now and then)
+        m.profile(True)
+        o2 = m.forward(**dkw)
+        ran2 = {k: v["count"] for k, v in m.profile_report().items()}
+        m.profile(False)
+        assert torch.equal(m.forward(**dkw), o2), key
+        assert (ran2.get("mlp@fold+final") == 1 and ran2.get("mlp@fold") == nl - 1 and "final_euler" not in ran2) if fold else \
+            (ran2.get("final_euler") == 1 and ran2.get("mlp") == nl), ran2
+        e2 = rel_l2(o2.cpu(), out.cpu())
+        print(shape, key, f"untraced call (FinalLayer as the MLP's tail: {bool(fold)}) vs traced call: {e2:.2e}; vs oracle {rel_l2(o2.cpu(), ref):.2e}")
+        assert e2 < 2e-3 and rel_l2(o2.cpu(), ref) < TOL_FWD
+        if fold:
+            m.set_option("mlp_tail", 0)
+            o3 = m.forward(**dkw)
+            assert torch.equal(o3, out), "mlp_tail 0 is the separate k_final launch"
         outs[key] = (out.cpu(), tr[f"h{nl}"].cpu())
         del m
     e_out, e_h = rel_l2(outs["fold"][0], outs["unfolded"][0]), rel_l2(outs["fold"][1], outs["unfolded"][1])
@@ -2632,7 +2647,8 @@ def test_mlp_gate_fold_in_the_euler_rollout():
     cfg, sd, kw, dkw = _fwd_case(3, 300, 4, 0, 1777)
     ekw = _euler_kw(dkw)
     res = {}
-    for key, opts in (("fold", {}), ("fold, one stream", {"streams": 1}), ("unfolded", {"mlp_fold": 0})):
+    for key, opts in (("fold", {}), ("fold, one stream", {"streams": 1}), ("fold, separate final layer", {"mlp_tail": 0}),
+                      ("unfolded", {"mlp_fold": 0})):
         m = LatentMDGenModel(cfg)
         m.load_state_dict(sd)
         for k, v in dict({"mlp_path": 2, "fuse_proj": 0, "streams": 2}, **opts).items():
@@ -2645,10 +2661,17 @@ def test_mlp_gate_fold_in_the_euler_rollout():
         m.sample_euler(dkw["x"], 3, use_graph=False, **ekw)
         ran = {k: v["count"] for k, v in m.profile_report().items()}
         m.profile(False)
-        assert (ran.get("mlp@fold") == 3 * cfg.num_layers) == (key != "unfolded"), ran
+        nl = cfg.num_layers
+        want = {"unfolded": {"mlp": 3 * nl, "final_euler": 3}, "fold, separate final layer": {"mlp@fold": 3 * nl, "final_euler": 3}}.get(
+            key, {"mlp@fold": 3 * (nl - 1), "mlp@fold+final": 3})
+        for k in ("mlp", "mlp@fold", "mlp@fold+final", "final_euler"):
+            assert ran.get(k, 0) == want.get(k, 0), (key, k, ran)
         res[key] = a.cpu()
         del m
     assert torch.equal(res["fold"], res["fold, one stream"])
+    e = rel_l2(res["fold"], res["fold, separate final layer"])
+    print(f"3 Euler steps, FinalLayer as the last MLP launch's tail vs k_final: {e:.2e}")
+    assert e < 1e-3
     e = rel_l2(res["fold"], res["unfolded"])
     print(f"3 Euler steps, folded vs unfolded MLP kernel: {e:.2e}")
     assert e < 3e-3
@@ -2660,7 +2683,8 @@ def test_headline_kernel_mix_at_B8_T1000_vs_oracle():
     from the profile report that the launches took the headline's own kernels: k_flash_proj8 (`flash_proj_T@q128`), k_mlp_rows
     (`mlp` / `mlp@fold`), k_ln_qkv<false, false> (`ln_qkv_T`), k_ln_qkv_attn4<true> (`attn_L_fused`).  (a) `forward` (per-sample t
     path: the unfolded row-owner MLP) at t = 0; (b) ONE Euler step of size 1 through `sample_euler` -- x1 - x0 = v(x0, t = 0), the
-    shared-t path: the gate-folded MLP -- against the same oracle evaluation."""
+    shared-t path: the gate-folded MLP, the last layer's launch with the FinalLayer + Euler update as its tail (`mlp@fold+final`) --
+    against the same oracle evaluation."""
     from oracle import mdgen_oracle as O
     from mdgen_amd.model import LatentMDGenModel
     B, T, L = 8, 1000, 4
@@ -2689,10 +2713,10 @@ def test_headline_kernel_mix_at_B8_T1000_vs_oracle():
     x1 = m.sample_euler(dkw["x"], 1, use_graph=False, **ekw)
     ran = {k: v["count"] for k, v in m.profile_report().items()}
     m.profile(False)
-    want = {"flash_proj_T@q128": nl, "mlp@fold": nl, "ln_qkv_T": nl, "attn_L_fused": nl, "fold_pack": 1}
+    want = {"flash_proj_T@q128": nl, "mlp@fold": nl - 1, "mlp@fold+final": 1, "ln_qkv_T": nl, "attn_L_fused": nl, "fold_pack": 1}
     for k, n in want.items():
         assert ran.get(k) == n, (k, ran)
-    assert "mlp" not in ran, ran
+    assert "mlp" not in ran and "final_euler" not in ran, ran
     xg = m.sample_euler(dkw["x"], 1, use_graph=True, **ekw)
     assert torch.equal(x1, xg)
     v = (xg - dkw["x"]).cpu()
@@ -2720,3 +2744,102 @@ def test_sample_euler_B16_graph_eager_and_stream_counts_agree():
         assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(b, c), ns
         res[ns] = a
     assert torch.equal(res[1], res[2])
+
+
+def _registry_cases():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dispatch_registry import CASES
+    return [c for c in CASES if c["covered_by"] is None]
+
+
+@pytest.mark.parametrize("case", _registry_cases(), ids=lambda c: c["name"])
+def test_dispatch_registry_case_vs_oracle(case):
+    """tests/dispatch_registry.py: every combination of kernel forms the dispatch logic can produce for the shapes the entry points
+    are used with must be compared with the CPU oracle somewhere.  This test runs the registry's own cases (the combinations no
+    older test reaches), DEFAULT options, 0xFF-filled workspace: (1) the kernel classes that ran == `mdgen_debug_dispatch_plan`'s
+    prediction for the same call (the plan is the library's own orchestration code in a mode that skips every HIP call: here it is
+    held against the real thing); (2) forward: every trace and the velocity against the oracle; euler: one Euler step of size 1,
+    x1 - x0 against the oracle's velocity at t = 0 (the shared-t path: gate-folded MLP, FinalLayer as its tail)."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd._lib import dispatch_plan
+    from mdgen_amd.model import LatentMDGenModel
+    B, T, L, n_pad = case["B"], case["T"], case["L"], case["n_pad"]
+    cfg, sd, kw, dkw = _fwd_case(B, T, L, n_pad, 3100 + 7 * T + L, weights_seed=11)
+    euler = case["mode"] == "euler"
+    if euler:
+        kw["t"] = torch.zeros(B)
+        dkw["t"] = kw["t"].to(dkw["x"].device)
+    ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
+    m = LatentMDGenModel(cfg)
+    m.load_state_dict(sd)
+    m.forward(**dkw)   # (workspace of the shape)
+    nl = cfg.num_layers
+    info = None
+    if not euler:
+        out, tr, ran = _profiled_forward(m, dkw)
+        info = m.context_info
+        rep = {k: rel_l2(tr[k].cpu(), rtr[k]) for k in ["ipa_out"] + [f"h{i}" for i in range(nl + 1)]}
+        rep["out"] = rel_l2(out.cpu(), ref)
+        want = dispatch_plan(B, T, L, mode=3, ncu=info["ncu"], xcd_round_robin=bool(info["xcd_round_robin"]))
+    else:
+        ekw = _euler_kw(dkw)
+        m.sample_euler(dkw["x"], 1, use_graph=False, **ekw)
+        for ws in m._ws.values():
+            ws.view(torch.uint8).fill_(0xFF)
+        m.profile(True)
+        x1 = m.sample_euler(dkw["x"], 1, use_graph=False, **ekw)
+        ran = {k: v["count"] for k, v in m.profile_report().items()}
+        info = m.context_info
+        m.profile(False)
+        xg = m.sample_euler(dkw["x"], 1, use_graph=True, **ekw)   # the product's path: graph, sub-batch streams
+        v = (xg - dkw["x"]).cpu()
+        rep = {"velocity": rel_l2(v, ref), "eager": rel_l2((x1 - dkw["x"]).cpu(), ref)}
+        want = dispatch_plan(B, T, L, n_steps=1, mode=2, ncu=info["ncu"], xcd_round_robin=bool(info["xcd_round_robin"]))
+    planned = dict(want["prepare"])
+    for vw in want["views"]:
+        for k, n in vw["classes"].items():
+            planned[k] = planned.get(k, 0) + n
+    print(case["name"], {k: f"{e:.2e}" for k, e in rep.items()}, ran)
+    assert ran == planned, (case["name"], ran, planned)
+    for k, e in rep.items():
+        assert e < TOL_FWD, (case["name"], k, e)
+
+
+@pytest.mark.parametrize("shape", [(1, 256, 16, 49), (32, 4, 0, 49)], ids=["ATLAS_L256_S49", "shard_B32_L4_S49"])
+def test_ipa_table_of_all_steps_vs_oracle(shape):
+    """The IPA stack runs ONCE per call for all S steps (S * B * L rows per launch: ATLAS 12 544 rows = 196 panels, cfg-3's shard 6 272
+    = 98 -- the eight-wave, unsplit forms `ipa.mlp@p8` / `ipa.ln_qkv@p8` that no single forward reaches).  Its output does not depend
+    on T or x (latent_model.py:175-210: aatype, frames, t), so the table a T = 2 rollout leaves in the workspace is compared, step
+    by step, with the oracle's `ipa_out` trace of a forward at that step's t; the report must name the forms the plan predicts."""
+    from oracle import mdgen_oracle as O
+    from mdgen_amd._lib import dispatch_plan
+    from mdgen_amd.model import LatentMDGenModel
+    B, L, n_pad, S = shape
+    T = 2
+    cfg, sd, kw, dkw = _fwd_case(B, T, L, n_pad, 5100 + L, weights_seed=13)
+    m = LatentMDGenModel(cfg)
+    m.load_state_dict(sd)
+    ekw = _euler_kw(dkw)
+    m.profile(True)
+    x = m.sample_euler(dkw["x"], S, use_graph=False, **ekw)
+    ran = {k: v["count"] for k, v in m.profile_report().items() if k.startswith("ipa.")}
+    info = m.context_info
+    m.profile(False)
+    assert torch.isfinite(x).all()
+    want = dispatch_plan(B, T, L, n_steps=S, mode=2, ncu=info["ncu"], xcd_round_robin=bool(info["xcd_round_robin"]))
+    assert ran == {k: v for k, v in want["prepare"].items() if k.startswith("ipa.")}, (ran, want["prepare"])
+    # ... and the bench shapes' IPA launches have the same forms (the signature depends on S * B * L only)
+    full = dispatch_plan(B, 250 if L == 256 else 100, L, n_steps=S, mode=0, ncu=info["ncu"], xcd_round_robin=bool(info["xcd_round_robin"]))
+    assert set(ran) == {k for k in full["prepare"] if k.startswith("ipa.")}, (ran, full["prepare"])
+    lay = m.workspace_layout(B, T, L, S, True)
+    ws = m._ws[(B, T, L, S, 1)]
+    C_ = cfg.embed_dim
+    tab = ws[lay.ipa_out:lay.ipa_out + S * B * L * C_ * 4].view(torch.float32).view(S, B, L, C_).cpu()
+    tg = torch.linspace(0, 1, S + 1)[:S]
+    worst = 0.0
+    for s in range(0, S, 6):   # every sixth step (9 oracle evaluations)
+        _, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **dict(kw, t=torch.full((B,), float(tg[s]))))
+        valid = kw["mask"][:, 0].bool()                       # padded residues' rows are not defined
+        worst = max(worst, rel_l2(tab[s][valid], rtr["ipa_out"][valid]))
+    print(shape, f"IPA table of {S} steps, forms {sorted(ran)}: worst step rel-L2 vs the oracle {worst:.2e}")
+    assert worst < TOL_FWD
