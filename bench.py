@@ -336,6 +336,32 @@ def self_launch(n, argv, script=None, extra_env=None):
     return subprocess.call(cmd, env=env)
 
 
+def dist_selftest(dev):
+    """`--dist-selftest` (round-5 verdict, item 8): on a one-GPU box the N > 1 code of this file never runs -- so run it with ONE rank:
+    RCCL process-group initialisation on a 127.0.0.1 store with the device bound, barrier, the three reductions of the multi-rank
+    path on DEVICE tensors (forced: a group of one skips them otherwise), teardown.  Prints one JSON line."""
+    import socket
+    import torch.distributed as dist
+    from mdgen_amd.sharding import gather_over_ranks, max_over_ranks, sum_over_ranks
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.perf_counter()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+    dist.barrier()
+    torch.cuda.synchronize()
+    res = {"dist_selftest": "ok", "backend": dist.get_backend(), "world": dist.get_world_size(),
+           "max": max_over_ranks(1.25, dist, dev, force=True), "sum": sum_over_ranks(2.5, dist, dev, force=True),
+           "gather": gather_over_ranks(3.75, dist, dev, force=True)}
+    dist.barrier()
+    dist.destroy_process_group()
+    res["seconds"] = round(time.perf_counter() - t0, 2)
+    assert res["max"] == 1.25 and res["sum"] == 2.5 and res["gather"] == [3.75], res
+    print(json.dumps(res))
+
+
 def timed_region(step, steps, warmup, dist, sync):
     """The contract's timed region: W untimed warm-up steps, then exactly K steps bracketed by a barrier + device
     synchronisation on both sides.  Returns (last output, seconds incl. the wait for the slowest rank, this rank's own seconds)."""
@@ -410,6 +436,7 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="library run-time option (mdgen_ctx_set_option), e.g. mlp_path=1; repeatable")
     ap.add_argument("--fake-sampler", action="store_true", help=argparse.SUPPRESS)   # test hook, see fake_sampler_main
+    ap.add_argument("--dist-selftest", action="store_true", help=argparse.SUPPRESS)  # one-rank RCCL self-test, see dist_selftest
     a = ap.parse_args()
     options = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.option}
 
@@ -427,6 +454,8 @@ def main():
     torch.set_grad_enabled(False)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if a.dist_selftest:
+        return dist_selftest(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist_

@@ -82,6 +82,8 @@ typedef struct mdgen_ws_layout {
     size_t fold;       /* option "mlp_fold": per (step, trunk layer) the MLP weight stream with that step's gate folded into fc2
                           [S][layers][2304 KiB bf16 fragments] | gate * fc2.bias [S][layers][384] fp32 (0 bytes unless t_shared and
                           the trunk's MLP launches take the row-owner kernel)                    */
+    size_t embase;     /* option "mlp_tail": the x-independent part of the token embedding per (step, b, l), [S][B*L][384] fp32, for the
+                          steps whose embedding is computed by the previous step's last MLP launch (0 bytes unless `fold` and S > 1) */
 } mdgen_ws_layout;
 
 const char* mdgen_last_error(void);
@@ -126,11 +128,17 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      "accumulators start at h + b2', accumulate W2' u, store": the row-owner kernel reads the residual rows once
  *                      instead of twice.  Same values to the bf16 rounding of gate * w instead of w.  Workspace: mdgen_ws_layout.fold
  *                      (S x layers x 2.36 MB); the report tags such launches "mlp@fold".
- *   "mlp_tail"         1 (default) / 0: with mlp_fold, the FinalLayer (layers.py:57-74: LN + modulate, Linear C -> D) and the Euler update of x
+ *   "mlp_tail"         2 (default) / 1 / 0: with mlp_fold, the FinalLayer (layers.py:57-74: LN + modulate, Linear C -> D) and the Euler update of x
  *                      (integrators.py:106) run inside the LAST trunk layer's folded MLP kernel, on the updated rows while they are in
  *                      registers; that kernel then does not store its rows (nothing reads the residual stream after the last layer) and
  *                      there is no k_final launch: 196 MB less HBM traffic per network evaluation.  Not with trace_h.  Same values to
- *                      fp32 summation order; the report tags the launch "mlp@fold+final".
+ *                      fp32 summation order; the report tags the launch "mlp@fold+final".  In a rollout the same launch goes on to
+ *                      compute the NEXT step's token embedding (latent_model.py:233-246) from the state it has just updated and
+ *                      writes it as that step's residual stream ("mlp@fold+final+embed"): steps 1 .. S-1 launch no k_embed (value 2;
+ *                      1: the FinalLayer + Euler update only; workspace: mdgen_ws_layout.embase).
+ *   "embed_split"      1 (default) / 0: the products of that embedding tail (W_l x, W_c x_cond: K = 21 / 28) on the bf16 MFMA with each operand
+ *                      split into a bf16 pair hi + lo (16 mantissa bits per side, the lo x lo term dropped: 2^-17 of a product)
+ *                      instead of v_mfma_f32_32x32x2_f32, which runs at a quarter of its nominal rate on gfx950.  0: the exact fp32 form.
  *   "fuse_proj"        the temporal attention's out-projection + gated residual (mha.py:397, latent_model.py:476) inside the
  *                      MLP kernel, ahead of the MLP: 0 off / 1 inside the row-owner kernel / 2 as a prologue phase of the
  *                      64-row panel kernel (k_mlp<3, true>; selects the panel kernel) / 3 (default) as 2 where the launch

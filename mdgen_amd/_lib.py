@@ -39,7 +39,7 @@ class Shape(C.Structure):
 class WsLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "total_bytes", "h", "qf", "kf", "vf", "obuf", "mod", "silu_t", "ipa_out", "h_ipa", "ipa_proj",
-        "ipa_feat", "mask_bl", "rel7", "tgrid", "f32_scratch", "split", "fold")]
+        "ipa_feat", "mask_bl", "rel7", "tgrid", "f32_scratch", "split", "fold", "embase")]
 
 
 class ResidueTables(C.Structure):

@@ -113,6 +113,10 @@ struct mdgen_ctx {
     // fp32 small weights
     float *wl = nullptr, *bl = nullptr, *wc = nullptr, *bc = nullptr, *mask_emb = nullptr, *aa_emb = nullptr;
     float *wl_pack = nullptr, *wc_pack = nullptr;   // latent_to_emb / cond_to_emb in k_embed's operand order (launch_pack_embed)
+    float *wl_rows = nullptr, *wc_rows = nullptr;   // ... and in rows_embed_gemm's (the embedding as the tail of the last layer's MLP kernel)
+    float* mask_delta = nullptr;                    // mask_to_emb[1] - mask_to_emb[0]
+    bf16x8 *wl_hi = nullptr, *wl_lo = nullptr, *wc_hi = nullptr, *wc_lo = nullptr;   // ... as bf16 pairs, K padded to 32 in kappa order
+    int opt_embed_split = 1;    // the embedding tail's products on the bf16 MFMA with hi + lo operand pairs (0: fp32 MFMA, exact)
     float *pos_embed = nullptr, *t_w0 = nullptr, *t_b0 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
     float *wf7 = nullptr, *bf7 = nullptr, *wr7 = nullptr, *br7 = nullptr;
     float *ada_w = nullptr, *ada_b = nullptr;
@@ -166,7 +170,7 @@ struct mdgen_ctx {
     size_t train_ev_next = 0;
     int opt_mlp_fold = 1;       // sampling (t shared by the batch): the MLP gate folded into per-(step, layer) fc2 streams, k_mlp_rows starts its
                                 // accumulators from the residual rows and only stores (one HBM read of the rows instead of two)
-    int opt_mlp_tail = 1;       // ... and the FinalLayer + Euler update run inside the last layer's (folded) MLP kernel, which then does not store
+    int opt_mlp_tail = 2;       // ... and the FinalLayer + Euler update run inside the last layer's (folded) MLP kernel, which then does not store
                                 // its rows: no k_final launch, 196 MB less traffic per network evaluation
     int opt_residue_l4 = 2;     // residue axis, L == 4: 0 general L <= 8 path, 1 attention fused, 2 whole sub-layer fused
     std::vector<void*> milestone_events;          // mdgen_train_set_milestone_events (hipEvent_t handles, caller-owned)
@@ -477,6 +481,10 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     TRY(c->dalloc(&c->wl, (size_t)kC * D));
     TRY(c->dalloc(&c->wl_pack, (size_t)kEmbPackFloats));
     TRY(c->dalloc(&c->wc_pack, (size_t)kEmbPackFloats));
+    TRY(c->dalloc(&c->wl_rows, (size_t)kEmbRowsFloats));
+    TRY(c->dalloc(&c->wc_rows, (size_t)kEmbRowsFloats));
+    TRY(c->dalloc(&c->mask_delta, (size_t)kC));
+    for (bf16x8** q : {&c->wl_hi, &c->wl_lo, &c->wc_hi, &c->wc_lo}) TRY(c->dalloc(q, (size_t)12 * 2 * 64));
     TRY(c->dalloc(&c->bl, (size_t)kC));
     TRY(c->dalloc(&c->wc, (size_t)kC * D));
     TRY(c->dalloc(&c->bc, (size_t)kC));
@@ -509,11 +517,13 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
     TRY(c->dalloc(&c->bfin, (size_t)32));
     TRYHIP(hipMemset(c->bfin, 0, 32 * sizeof(float)));
 #undef TRYHIP
-    SETTER("latent_to_emb.weight", { WANT(kC, c->D); if (int r = copy_f32(c->wl, data, (size_t)kC * c->D, s)) return r; launch_pack_embed(c->wl, c->D, c->wl_pack, s); });
+    SETTER("latent_to_emb.weight", { WANT(kC, c->D); if (int r = copy_f32(c->wl, data, (size_t)kC * c->D, s)) return r; launch_pack_embed(c->wl, c->D, c->wl_pack, s); launch_pack_embed_rows(c->wl, c->D, c->wl_rows, s);
+        launch_pack_rows(c->wl, c->D, c->map_nat, 12, 2, 1.f, c->wl_hi, s, 1, 0); launch_pack_rows(c->wl, c->D, c->map_nat, 12, 2, 1.f, c->wl_lo, s, 1, 1); });
     SETTER("latent_to_emb.bias", { WANT(kC); if (int r = copy_f32(c->bl, data, kC, s)) return r; });
-    SETTER("cond_to_emb.weight", { WANT(kC, c->D); if (int r = copy_f32(c->wc, data, (size_t)kC * c->D, s)) return r; launch_pack_embed(c->wc, c->D, c->wc_pack, s); });
+    SETTER("cond_to_emb.weight", { WANT(kC, c->D); if (int r = copy_f32(c->wc, data, (size_t)kC * c->D, s)) return r; launch_pack_embed(c->wc, c->D, c->wc_pack, s); launch_pack_embed_rows(c->wc, c->D, c->wc_rows, s);
+        launch_pack_rows(c->wc, c->D, c->map_nat, 12, 2, 1.f, c->wc_hi, s, 1, 0); launch_pack_rows(c->wc, c->D, c->map_nat, 12, 2, 1.f, c->wc_lo, s, 1, 1); });
     SETTER("cond_to_emb.bias", { WANT(kC); if (int r = copy_f32(c->bc, data, kC, s)) return r; });
-    SETTER("mask_to_emb.weight", { WANT(2, kC); if (int r = copy_f32(c->mask_emb, data, 2 * kC, s)) return r; });
+    SETTER("mask_to_emb.weight", { WANT(2, kC); if (int r = copy_f32(c->mask_emb, data, 2 * kC, s)) return r; launch_sub_f32(c->mask_emb + kC, c->mask_emb, c->mask_delta, kC, s); });
     SETTER("aatype_to_emb.weight", { WANT(21, kC); if (int r = copy_f32(c->aa_emb, data, 21 * kC, s)) return r; });
     SETTER("t_embedder.mlp.0.weight", { WANT(kC, 256); if (int r = copy_f32(c->t_w0, data, (size_t)kC * 256, s)) return r; });
     SETTER("t_embedder.mlp.0.bias", { WANT(kC); if (int r = copy_f32(c->t_b0, data, kC, s)) return r; });
@@ -717,8 +727,11 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "mlp_fold") {
         if (value != 0 && value != 1) return fail(-2, "mlp_fold must be 0 or 1");
         c->opt_mlp_fold = value;
+    } else if (n == "embed_split") {
+        if (value != 0 && value != 1) return fail(-2, "embed_split must be 0 or 1");
+        c->opt_embed_split = value;
     } else if (n == "mlp_tail") {
-        if (value != 0 && value != 1) return fail(-2, "mlp_tail must be 0 or 1");
+        if (value < 0 || value > 2) return fail(-2, "mlp_tail must be 0 (off), 1 (FinalLayer + Euler update) or 2 (... + the next step's token embedding)");
         c->opt_mlp_tail = value;
     } else if (n == "residue_l4_path") {
         if (value < 0 || value > 2) return fail(-2, "residue_l4_path must be 0, 1 or 2");
@@ -839,6 +852,8 @@ extern "C" int32_t mdgen_workspace_layout(const mdgen_ctx* c, const mdgen_shape*
     o->split = take(split_bytes(split_panels(maxrows)));
     // per-(step, layer) gate-folded MLP streams [S][nl][2304 KiB] | b2' [S][nl][384] fp32 (0 bytes unless fold_on)
     o->fold = take(fold_on(c, N, t_shared) ? fold_bytes(c, S) : 0);
+    // base rows of the token embedding per (step, b, l) for the embedding-as-tail form [S][B*L][384] fp32 (0 bytes unless fold and S > 1)
+    o->embase = take(fold_on(c, N, t_shared) && c->opt_mlp_tail == 2 && S > 1 ? (size_t)Mp * kC * 4 : 0);
     o->total_bytes = off;
     return 0;
 }
@@ -873,6 +888,9 @@ struct Run {
     unsigned char* fold_streams;
     float* fold_b2g;
     bool fold_ready;   // prepare() has packed them for this call (its views' MLP launches take the row-owner kernel)
+    // embedding-as-tail: base rows [S][B*L][384] (step 0, first batch element of this view), null when off; floats between steps
+    const float* embase_p;
+    long embase_step_stride;
     float* h() const { return hp; }
     float* mod() const { return modp; }
 };
@@ -903,6 +921,7 @@ static Run sub_run(const Run& r, int b0, int Bs, hipStream_t stream) {
     v.vfp = r.vfp + (size_t)b0 * per_b_kv;
     v.modp = r.modp + (long)b0 * r.mod_group_stride;
     v.ipa_out_p = r.ipa_out_p + (long)b0 * r.L * kC;
+    if (r.embase_p) v.embase_p = r.embase_p + (long)b0 * r.L * kC;
     return v;
 }
 
@@ -1135,12 +1154,12 @@ static bool mlp_uses_rows(const mdgen_ctx* c, long nrows) {
 // `tail` (last trunk layer; nullable): the FinalLayer's parameters; *tail_done = true when the launch ran it (folded row-owner form only)
 static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const ModMap& mm, int shift, int scale,
                         int gate, bool trunk, const ProjParams* proj = nullptr, const bf16x8* wo_stream = nullptr, long fold_sl = -1,
-                        const FinalParams* tail = nullptr, bool* tail_done = nullptr) {
+                        const FinalParams* tail = nullptr, bool* tail_done = nullptr, int next_step = -1, bool* next_h0 = nullptr) {
     if (int e = check_launch_rows(nrows)) return e;
     const bool panel_fused = proj && proj->a_bf16 && r.c->opt_fuse_proj >= 2;   // (3: only handed a projection when the panel kernel runs anyway)
     if (!panel_fused && mlp_uses_rows(r.c, nrows)) {
         MlpRowsParams q{};
-        bool tail_on = false;
+        bool tail_on = false, emb_on = false;
         q.h = h;
         q.nrows = nrows;
         q.mm = mm;
@@ -1169,6 +1188,24 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
                 q.tail_x = tail->x;
                 q.tail_out = tail->out;
                 *tail_done = true;
+                if (next_step >= 0 && next_h0 && r.embase_p && tail->euler) {   // ... and the next step's token embedding
+                    q.emb_wl = r.c->wl_rows;
+                    q.emb_wc = r.c->wc_rows;
+                    if (r.c->opt_embed_split) {
+                        q.emb_wl_hi = r.c->wl_hi;
+                        q.emb_wl_lo = r.c->wl_lo;
+                        q.emb_wc_hi = r.c->wc_hi;
+                        q.emb_wc_lo = r.c->wc_lo;
+                    }
+                    q.emb_base = r.embase_p + (long)next_step * r.embase_step_stride;
+                    q.emb_mdelta = r.c->mask_delta;
+                    q.emb_xcond = r.x_cond;
+                    q.emb_cmask = r.x_cond_mask;
+                    q.emb_T = r.T;
+                    q.emb_L = r.L;
+                    emb_on = true;
+                    *next_h0 = true;
+                }
             }
         }
         if (trunk && r.c->phase_trace) {
@@ -1178,7 +1215,7 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
         }
         // (class "mlp@fold": the folded form ran -- tests assert it)
         // ("mlp@fold+final": ... with the FinalLayer + Euler update as its tail)
-        { ProfScope ps(r.c, !trunk ? "ipa.mlp" : q.o ? "proj_mlp" : tail_on ? "mlp@fold+final" : q.b2g ? "mlp@fold" : "mlp", r.s); if (!g_dry) launch_mlp_rows(q, 4, r.s); }
+        { ProfScope ps(r.c, !trunk ? "ipa.mlp" : q.o ? "proj_mlp" : emb_on ? "mlp@fold+final+embed" : tail_on ? "mlp@fold+final" : q.b2g ? "mlp@fold" : "mlp", r.s); if (!g_dry) launch_mlp_rows(q, 4, r.s); }
         LAUNCHCHK();
         return 0;
     }
@@ -1370,11 +1407,22 @@ static int prepare(Run& r, const float* t_dev, const float* t_host, long view_ro
         if (!g_dry) launch_add_inplace(ipa_out, h2, r.Mp * kC, r.s);
         LAUNCHCHK();
     }
+    if (r.fold_ready && c->opt_mlp_tail == 2 && r.S > 1) {
+        // steps 1 .. S-1 take their token embedding from the previous step's last MLP launch (rows_embed_tail): the part of it that does
+        // not depend on x, per (step, b, l)
+        float* eb = (float*)(r.ws + r.lay.embase);
+        { ProfScope ps(c, "embed_base", r.s); if (!g_dry) launch_embed_base(c->bl, c->bc, c->mask_emb, c->d.abs_pos_emb ? c->pos_embed : nullptr, ipa_out, r.S, r.B * r.L, r.L, eb, r.s); }
+        LAUNCHCHK();
+        r.embase_p = eb;
+    }
     return 0;
 }
 
 // One network evaluation at prepared step `step`: x -> velocity (out) or Euler update of x in place.
-static int denoise_step(const Run& r, int step, float* x, float* out, int euler, float dt, float* trace_h) {
+// h0_ready: the previous step's last MLP launch has already written this step's token embedding into h (no k_embed launch);
+// next_h0 (nullable): ask this step to do the same for step + 1; *next_h0 = true when it did.
+static int denoise_step(const Run& r, int step, float* x, float* out, int euler, float dt, float* trace_h, bool h0_ready = false,
+                        bool* next_h0 = nullptr) {
     mdgen_ctx* c = r.c;
     float* h = r.h();
     EmbedParams e{};
@@ -1395,8 +1443,10 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
     e.T = r.T;
     e.L = r.L;
     e.D = r.D;
-    { ProfScope ps(c, "embed", r.s); if (!g_dry) launch_embed(e, r.s); }
-    LAUNCHCHK();
+    if (!h0_ready) {
+        { ProfScope ps(c, "embed", r.s); if (!g_dry) launch_embed(e, r.s); }
+        LAUNCHCHK();
+    }
     const size_t hbytes = (size_t)r.N * kC * 4;
     if (trace_h) HIPCHK(hipMemcpyAsync(trace_h, h, hbytes, hipMemcpyDeviceToDevice, r.s));
     const float* modstep = r.mod() + (long)step * r.mod_step_stride;
@@ -1454,7 +1504,7 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
         // the last layer's MLP may run the FinalLayer as its tail (then h is NOT written: not with a residual-stream trace)
         const bool last = i == c->nl - 1 && !trace_h;
         if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true, &deferred, w.mha_t.wo_stream, (long)step * c->nl + i,
-                                  last ? &f : nullptr, last ? &tail_done : nullptr))
+                                  last ? &f : nullptr, last ? &tail_done : nullptr, next_h0 ? step + 1 : -1, next_h0))
             return er;
         if (trace_h) HIPCHK(hipMemcpyAsync(trace_h + (size_t)(i + 1) * r.N * kC, h, hbytes, hipMemcpyDeviceToDevice, r.s));
     }
@@ -1509,6 +1559,8 @@ static int make_run(Run* r, mdgen_ctx* c, const mdgen_shape* sh, int S, int t_sh
     r->fold_streams = nullptr;
     r->fold_b2g = nullptr;
     r->fold_ready = false;
+    r->embase_p = nullptr;
+    r->embase_step_stride = (long)sh->B * sh->L * kC;
     if (fold_on(c, r->N, t_shared)) {
         r->fold_streams = r->ws + r->lay.fold;
         r->fold_b2g = (float*)(r->fold_streams + (size_t)S * c->nl * kFoldStreamBytes);
@@ -1575,9 +1627,12 @@ static int n_streams(const Run& r) {
 
 static int euler_steps(const Run& v, const std::vector<float>& tg, float* x) {
     if (g_dry) g_dry->push_back("@view");   // plan mode: a sub-batch view's launches start here
+    bool h0_ready = false;
     for (int i = 0; i < v.S; ++i) {
         const float dt = tg[i + 1] - tg[i];
-        if (int e = denoise_step(v, i, x, nullptr, 1, dt, nullptr)) return e;
+        bool next = false;
+        if (int e = denoise_step(v, i, x, nullptr, 1, dt, nullptr, h0_ready, i + 1 < v.S ? &next : nullptr)) return e;
+        h0_ready = next;
     }
     return 0;
 }
@@ -1684,7 +1739,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45 | (uint64_t)c->opt_mlp_tail << 46), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45 | (uint64_t)c->opt_mlp_tail << 46 | (uint64_t)c->opt_embed_split << 48), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1744,7 +1799,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45 | (uint64_t)c->opt_mlp_tail << 46),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45 | (uint64_t)c->opt_mlp_tail << 46 | (uint64_t)c->opt_embed_split << 48),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

@@ -627,15 +627,8 @@ __global__ __launch_bounds__(256, 2) void k_flash_proj(const FlashProjParams p) 
     setup_rows_axis(pr, p.f.ax, seq, qc * kPanel, p.mm);   // read after the barrier below
     FlashPre<NQ> cur;
     flash_prefetch<NQ>(p.f, seq, w, qc, cur);
-#ifdef MDGEN_DEV_FLASH_HWPRIO   // (experiment) the two co-resident workgroups' waves of a SIMD take turns by hardware wave slot parity
-    const int slot = (int)(__builtin_amdgcn_s_getreg((4 << 11) | 4) & 1u);   // HW_REG_HW_ID bits 3:0 = wave slot of the SIMD
-#endif
 #pragma unroll 1
     for (int hg = 0; hg < 4; ++hg) {
-#ifdef MDGEN_DEV_FLASH_HWPRIO
-        if ((hg & 1) ^ slot) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-#endif
         FlashPre<NQ> nxt;
         flash_prefetch<NQ>(p.f, seq, 4 * (hg < 3 ? hg + 1 : 3) + w, qc, nxt);   // in flight while this head's job runs
         __builtin_amdgcn_sched_barrier(0);
@@ -643,14 +636,12 @@ __global__ __launch_bounds__(256, 2) void k_flash_proj(const FlashProjParams p) 
         cur = nxt;
         FPROJ_STAMP(1 + hg, __builtin_amdgcn_s_memtime());
     }
-#ifdef MDGEN_DEV_FLASH_HWPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     __syncthreads();   // the attention output of all 16 heads is in the panel
     FPROJ_STAMP(5, __builtin_amdgcn_s_memtime());
     const int lane = lane_id();
     f32x16 acc[6];
-#ifdef MDGEN_DEV_FLASH_EARLY64   // (experiment) as k_flash_proj8: the first batch of residual rows requested ahead of the GEMM
+#ifndef MDGEN_DEV_FLASH_NOEARLY   // as k_flash_proj8: the first batch of residual rows requested ahead of the GEMM (ATLAS +0.8 % end to end,
+                                  // profiles/r06_experiments.txt #3)
     EpiPre<8> ep;
     epi_rmw_request<8>(0, 0, pr, 96 * w, p.h, ep);
     __builtin_amdgcn_sched_barrier(0);
@@ -659,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void k_flash_proj(const FlashProjParams p) 
     wave_gemm<2, 3, 24, false>(panel, kC * 2, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     FPROJ_STAMP(6, __builtin_amdgcn_s_memtime());
     __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
-#ifdef MDGEN_DEV_FLASH_EARLY64
+#ifndef MDGEN_DEV_FLASH_NOEARLY
     epilogue_gate_residual_lds_pre<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk, true,
                                       p.h, ep);
 #else

@@ -636,6 +636,8 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     // ---- out-projection + gated residual, as k_proj<0>
     __syncthreads();   // the whole attention output is in the panel
     ATTN4_STAMP(8);
+    // (the epilogue's first batch of residual rows requested ahead of this GEMM, as k_flash_proj does: measured, no gain here -- 130.6
+    // against 128-130 us per launch, 125.9k against 126.4k frames/s; profiles/r06_experiments.txt #6)
     zero_acc<6>(acc);
     wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     ATTN4_STAMP(9);

@@ -387,7 +387,10 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
     // ---- gated residual
     if (TAIL) {
         const float* fmod = reinterpret_cast<const float*>(smem + kRingBytes + 8192 + NW * 6144);   // [shift 512 floats | scale 512]
-        rows_final_tail(m.y, tok, fmod + 512, fmod, p.tail_w, p.tail_b, p.tail_D, p.tail_euler, p.tail_dt, p.tail_x, p.tail_out, xf);
+        float xnew[16];
+        rows_final_tail(m.y, tok, fmod + 512, fmod, p.tail_w, p.tail_b, p.tail_D, p.tail_euler, p.tail_dt, p.tail_x, p.tail_out, xf, xnew);
+        if (p.emb_base)   // (uniform) the next step's token embedding, from the state just updated: that step launches no k_embed
+            rows_embed_tail(m.y, tok, xnew, EmbedTail{p.emb_wl, p.emb_wc, p.emb_wl_hi, p.emb_wl_lo, p.emb_wc_hi, p.emb_wc_lo, p.emb_base, p.emb_mdelta, p.emb_xcond, p.emb_cmask, p.emb_T, p.emb_L, p.tail_D}, p.h);
     } else if (FOLD) {
         rows_store<0, 12>(m.y, tok, p.h);
     } else if (MODLDS) {
@@ -488,6 +491,48 @@ void launch_pack_fold(const float* mod, long mod_step_stride, int S, int nl, con
     p.dst = dst;
     p.b2g = b2g;
     hipLaunchKernelGGL(k_pack_fold, dim3(2304 * 64 / 256, (unsigned)(S * nl)), dim3(256), 0, s, p);
+}
+
+__global__ void k_pack_embed_rows(const float* __restrict__ w, int D, float* __restrict__ pack) {
+    const int i = blockIdx.x * 256 + threadIdx.x;   // < 12 * NK4 * 64
+    const int nk4 = D <= 24 ? 3 : 4;
+    if (i >= 12 * nk4 * 64) return;
+    const int lane = i & 63, q = (i >> 6) % nk4, ft = (i >> 6) / nk4;
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int f = 8 * q + 4 * (lane >> 5) + k;
+        v[k] = f < D ? w[(size_t)(32 * ft + (lane & 31)) * D + f] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(pack)[i] = v;
+}
+__global__ void k_sub_f32(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = a[i] - b[i];
+}
+void launch_sub_f32(const float* a, const float* b, float* dst, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_sub_f32, dim3((n + 255) / 256), dim3(256), 0, s, a, b, dst, n);
+}
+void launch_pack_embed_rows(const float* w, int D, float* pack, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_embed_rows, dim3(12), dim3(256), 0, s, w, D, pack);
+}
+__global__ __launch_bounds__(96) void k_embed_base(const float* __restrict__ bl, const float* __restrict__ bc, const float* __restrict__ mask_emb,
+                                                   const float* __restrict__ pos_embed, const float* __restrict__ ipa_out, int BL, int L,
+                                                   float* __restrict__ base) {
+    const long row = blockIdx.x;            // s * BL + bl
+    const int l = (int)(row % BL) % L, c = threadIdx.x * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(bl + c);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(bc + c), m0 = *reinterpret_cast<const f32x4*>(mask_emb + c),
+                ip = *reinterpret_cast<const f32x4*>(ipa_out + row * kC + c);
+    f32x4 pe = {0.f, 0.f, 0.f, 0.f};
+    if (pos_embed) pe = *reinterpret_cast<const f32x4*>(pos_embed + (size_t)l * kC + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ((v[k] + a[k]) + m0[k]) + (pe[k] + ip[k]);
+    *reinterpret_cast<f32x4*>(base + row * kC + c) = v;
+}
+void launch_embed_base(const float* bl, const float* bc, const float* mask_emb, const float* pos_embed, const float* ipa_out, int S,
+                       int BL, int L, float* base, hipStream_t s) {
+    hipLaunchKernelGGL(k_embed_base, dim3((unsigned)((long)S * BL)), dim3(96), 0, s, bl, bc, mask_emb, pos_embed, ipa_out, BL, L, base);
 }
 
 void launch_pack_stream(const float* w, int ld, int which, const int* tab, int nfrag, float scale, int kappa, bf16x8* dst,

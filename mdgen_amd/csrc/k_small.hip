@@ -84,7 +84,7 @@ __global__ void k_gather_f32(const float* __restrict__ src, const int* __restric
 // kappa == 1: the K slice of a k-step in rows.h's kappa order, k = 16 ks + 8 (j >> 2) + 4 hh + (j & 3) (operands whose B fragments are
 // LayerNorm registers of the row-owner kernels); 0: natural, k = 16 ks + 8 hh + j
 __global__ void k_pack_rows(const float* __restrict__ w, int ld, const int* __restrict__ rowmap, int nft, int ksteps,
-                            float scale, bf16x8* __restrict__ dst, int kappa) {
+                            float scale, bf16x8* __restrict__ dst, int kappa, int part) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)nft * ksteps * 64;
     if (i >= total) return;
@@ -97,7 +97,9 @@ __global__ void k_pack_rows(const float* __restrict__ w, int ld, const int* __re
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = kappa ? ks * 16 + 8 * (j >> 2) + 4 * hh + (j & 3) : ks * 16 + hh * 8 + j;
-        v[j] = (__bf16)(row >= 0 && k < ld ? w[(long)row * ld + k] * scale : 0.f);
+        const float x = row >= 0 && k < ld ? w[(long)row * ld + k] * scale : 0.f;
+        const __bf16 hi = (__bf16)x;
+        v[j] = part ? (__bf16)(x - (float)hi) : hi;
     }
     dst[i] = v;
 }
@@ -657,10 +659,10 @@ void launch_gather_f32(const float* src, const int* idx, float scale, float* dst
     hipLaunchKernelGGL(k_gather_f32, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, scale, dst, n);
 }
 void launch_pack_rows(const float* w, int ld, const int* rowmap, int nft, int ksteps, float scale, bf16x8* dst,
-                      hipStream_t s, int kappa) {
+                      hipStream_t s, int kappa, int part) {
     const long total = (long)nft * ksteps * 64;
     hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, ld, rowmap, nft, ksteps,
-                       scale, dst, kappa);
+                       scale, dst, kappa, part);
 }
 void launch_path_plan(const float* t, const float* x0, const float* x1, float* xt, float* ut, long per_sample, long B,
                       int gvp, hipStream_t s) {

@@ -102,7 +102,21 @@ struct MlpRowsParams {
     float tail_dt;
     float* tail_x;      // euler: state updated in place
     float* tail_out;    // !euler: velocity
+    // ... and (emb_base != null; euler) the NEXT step's token embedding from the updated state (k_embed's work) written to h: see rows.h
+    // rows_embed_tail.  emb_wl / emb_wc: launch_pack_embed_rows; emb_base: the next step's base rows of this view (launch_embed_base)
+    const float *emb_wl, *emb_wc, *emb_base, *emb_mdelta, *emb_xcond;
+    const bf16x8 *emb_wl_hi, *emb_wl_lo, *emb_wc_hi, *emb_wc_lo;   // the weights as bf16 pairs (launch_pack_rows kappa = 1, part 0 / 1); null: exact fp32 form
+    const int64_t* emb_cmask;
+    int emb_T, emb_L;
 };
+// latent_to_emb / cond_to_emb weight [384][D] -> [12 ft][NK4][64 lanes][4]: value (ft, q, lane, i) = W[32 ft + (lane & 31)][8 q + 4 (lane >> 5) + i]
+// (0 past D), NK4 = 3 (D <= 24) or 4: the A operands of rows_embed_gemm
+void launch_pack_embed_rows(const float* w, int D, float* pack, hipStream_t s);
+void launch_sub_f32(const float* a, const float* b, float* dst, int n, hipStream_t s);   // dst = a - b
+constexpr int kEmbRowsFloats = 12 * 4 * 64 * 4;
+// base[s][bl][c] = bl[c] + bc[c] + mask_emb[0][c] + (pos_embed ? pos_embed[l][c] : 0) + ipa_out[s][bl][c]   (S * BL rows)
+void launch_embed_base(const float* bl, const float* bc, const float* mask_emb, const float* pos_embed, const float* ipa_out, int S,
+                       int BL, int L, float* base, hipStream_t s);
 
 struct LnLinearParams {
     const float* h;
@@ -306,8 +320,9 @@ void launch_temb(const float* t_rows, int nrows, float tmul, const float* w0, co
 void launch_adaln(const float* st, int nrows, const float* w, const float* b, int nout, float* mod, hipStream_t s);
 void launch_rope_table(float* rope, const float* inv_freq, int npos, hipStream_t s);
 void launch_gather_f32(const float* src, const int* idx, float scale, float* dst, int n, hipStream_t s);
+// part: 0 the weight rounded to bf16, 1 the bf16 of its rounding error (w - float(bf16(w))): the lo half of a bf16 pair
 void launch_pack_rows(const float* w, int ld, const int* rowmap, int nft, int ksteps, float scale, bf16x8* dst,
-                      hipStream_t s, int kappa = 0);
+                      hipStream_t s, int kappa = 0, int part = 0);
 void launch_ipa_init(const float* aa_emb, const int64_t* aatype, const float* rel7, const float* w7, const float* b7,
                      float* h, int ngroups, int B, int L, hipStream_t s);
 void launch_add_inplace(float* dst, const float* src, long n, hipStream_t s);

@@ -310,7 +310,8 @@ __device__ __forceinline__ void rows_store(const f32x16 (&y)[12], int tok, float
 // order); bfin [32].  D[feature][token]: lane (n, hh) ends with features 8 a + 4 hh + i of its token in register 4 a + i.
 __device__ __forceinline__ void rows_final_tail(const f32x16 (&y)[12], int tok, const float* sc, const float* sh,
                                                 const bf16x8* __restrict__ wfin, const float* __restrict__ bfin, int D, int euler,
-                                                float dt, float* __restrict__ x, float* __restrict__ out, bf16x8 (&xf)[24]) {
+                                                float dt, float* __restrict__ x, float* __restrict__ out, bf16x8 (&xf)[24],
+                                                float (&xnew)[16]) {   // xnew[4 a + i]: the updated state value of feature 8 a + 4 hh + i
     const int lane = lane_id(), hh = lane >> 5;
     const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
     // the state values and the bias are requested first; the weight tile (24 KiB, L2) once the row image is dead (192 + 96 registers
@@ -344,8 +345,136 @@ __device__ __forceinline__ void rows_final_tail(const f32x16 (&y)[12], int tok, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int f = 8 * (r >> 2) + 4 * hh + (r & 3);
-        if (tok >= 0 && f < D) xp[f] = xv[r] + s * acc[r];
+        xnew[r] = f < D ? xv[r] + s * acc[r] : 0.f;
+        if (tok >= 0 && f < D) xp[f] = xnew[r];
     }
+}
+
+// The NEXT step's token embedding from the state the tail has just updated (k_embed's work, latent_model.py:233-246):
+//   h0[tok] = W_l x_new + [W_c x_cond] + (b_l + b_c + mask_to_emb[0] + pos_embed[l] + ipa_out[step + 1][b, l])  + [mask delta]
+// computed transposed on the fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products as k_embed): A = the weight (lane m = output
+// feature of the tile, k = hh), B = the state -- and the B operand of k-step j IS xnew[j]: the weights are packed with their K
+// dimension in the order the FinalLayer's accumulators hold the features (api.hip launch_pack_embed_rows).  The accumulators
+// start from the per-(step, b, l) base row (k_embed_base, once per call) loaded as a row image; result stored as rows of h.
+// wl / wc: [12 ft][NK4][64 lanes][4] floats, NK4 = 3 (D <= 24) or 4; base: rows of 384 floats, row = b * L + l of the launch's view.
+// The same product on the bf16 MFMA with both operands split into a bf16 pair hi + lo (16 mantissa bits each side; the lo x lo
+// term, 2^-18 of the product, is dropped): 3 x 2 v_mfma_f32_32x32x16_bf16 per feature tile instead of 12 v_mfma_f32_32x32x2_f32 --
+// the fp32 MFMA runs at a quarter of its nominal rate on gfx950 (profiles/r06_experiments.txt #5: the 144 of them were 30 us of this
+// launch).  whi / wlo: [12 ft][2 k-steps][64 lanes] bf16x8, K (padded to 32) in kappa order: k-step s of a lane half IS xnew[8 s .. 8 s + 7].
+__device__ __forceinline__ void rows_embed_gemm_split(f32x16 (&y)[12], const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo,
+                                                      const float (&xv)[16]) {
+    const int lane = lane_id();
+    bf16x8 xh[2], xl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const __bf16 h = (__bf16)xv[8 * s + j];
+            xh[s][j] = h;
+            xl[s][j] = (__bf16)(xv[8 * s + j] - (float)h);
+        }
+    bf16x8 wh[2][2], wl[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        wh[0][s] = whi[s * 64 + lane];
+        wl[0][s] = wlo[s * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ft = 0; ft < 12; ++ft) {
+        if (ft + 1 < 12) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                wh[(ft + 1) & 1][s] = whi[((ft + 1) * 2 + s) * 64 + lane];
+                wl[(ft + 1) & 1][s] = wlo[((ft + 1) * 2 + s) * 64 + lane];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            y[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ft & 1][s], xh[s], y[ft], 0, 0, 0);   // small terms first
+            y[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ft & 1][s], xl[s], y[ft], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) y[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ft & 1][s], xh[s], y[ft], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int NK4>
+__device__ __forceinline__ void rows_embed_gemm(f32x16 (&y)[12], const float* __restrict__ wrows, const float (&xv)[16]) {
+    const int lane = lane_id();
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wrows) + lane;
+    f32x4 w[2][NK4];
+#pragma unroll
+    for (int q = 0; q < NK4; ++q) w[0][q] = wp[q * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ft = 0; ft < 12; ++ft) {
+        if (ft + 1 < 12) {
+#pragma unroll
+            for (int q = 0; q < NK4; ++q) w[(ft + 1) & 1][q] = wp[((ft + 1) * NK4 + q) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NK4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[ft & 1][q][i], xv[4 * q + i], y[ft], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+struct EmbedTail {
+    const float *wl, *wc;        // packed latent_to_emb / cond_to_emb weights (rows order, fp32: the exact form)
+    const bf16x8 *wl_hi, *wl_lo, *wc_hi, *wc_lo;   // ... as bf16 pairs for rows_embed_gemm_split (null: the exact form runs)
+    const float* base;           // base rows of the NEXT step for this launch's view: [B_view * L][384]
+    const float* mdelta;         // mask_to_emb[1] - mask_to_emb[0]  [384]
+    const float* x_cond;         // [N][D]
+    const int64_t* x_cond_mask;  // [N]
+    int T, L, D;
+};
+__device__ __forceinline__ void rows_embed_tail(f32x16 (&y)[12], int tok, const float (&xnew)[16], const EmbedTail e,
+                                                float* __restrict__ h) {
+    const int lane = lane_id(), hh = lane >> 5;
+    const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
+    const unsigned row = (tokc / (unsigned)(e.T * e.L)) * (unsigned)e.L + tokc % (unsigned)e.L;
+    // everything requested up front: base row image, the conditioning values and mask of the token
+    const unsigned char* bb = reinterpret_cast<const unsigned char*>(e.base) + (size_t)row * (kC * 4) + hh * 16;
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bb + 32u * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[i >> 2][4 * (i & 3) + j] = b[j];
+    }
+    float xc[16];
+    const float* cp = e.x_cond + (size_t)tokc * (unsigned)e.D;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = 8 * (r >> 2) + 4 * hh + (r & 3);
+        const float v = cp[f < e.D ? f : 0];
+        xc[r] = f < e.D && tok >= 0 ? v : 0.f;
+    }
+    const bool cm = tok >= 0 && e.x_cond_mask[tokc] != 0;
+    if (e.wl_hi) rows_embed_gemm_split(y, e.wl_hi, e.wl_lo, xnew);
+    else if (e.D <= 24) rows_embed_gemm<3>(y, e.wl, xnew);
+    else rows_embed_gemm<4>(y, e.wl, xnew);
+    bool anyc = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) anyc |= xc[r] != 0.f;
+    if (__builtin_amdgcn_ballot_w64(anyc) != 0) {   // some token of the tile is conditioned (k_embed skips the product likewise)
+        if (e.wc_hi) rows_embed_gemm_split(y, e.wc_hi, e.wc_lo, xc);
+        else if (e.D <= 24) rows_embed_gemm<3>(y, e.wc, xc);
+        else rows_embed_gemm<4>(y, e.wc, xc);
+    }
+    if (__builtin_amdgcn_ballot_w64(cm) != 0) {     // mask_to_emb[1] instead of [0] for the tokens whose x_cond_mask is set
+        const unsigned char* mb = reinterpret_cast<const unsigned char*>(e.mdelta) + hh * 16;
+        const float sel = cm ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < 48; ++i) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(mb + 32u * i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[i >> 2][4 * (i & 3) + j] += sel * d[j];
+        }
+    }
+    rows_store<0, 12>(y, tok, h);
 }
 
 __device__ __forceinline__ void rows_ln(const float* __restrict__ x, int tok, const ModMap mm, int shift_chunk,

@@ -192,8 +192,12 @@ class GradBucketer:
     the latency regime of a collective (~50 us at 8 GPUs), small enough that 7 of them overlap with the rest of the
     backward pass."""
 
-    def __init__(self, params: FlatParams, grads: torch.Tensor, dist=None, bucket_bytes: int = 16 << 20):
+    def __init__(self, params: FlatParams, grads: torch.Tensor, dist=None, bucket_bytes: int = 16 << 20,
+                 single_rank_collectives: bool = False):
         self.params, self.grads, self.dist = params, grads, dist
+        # self-test on a one-GPU box: issue every bucket's all-reduce even in a group of ONE rank (an identity), so that the RCCL
+        # path of `launch_on_events` executes where no second device exists
+        self.single_rank_collectives = single_rank_collectives
         names = list(params.shapes)[::-1]
         self.buckets: List[dict] = []
         cur: List[str] = []
@@ -224,12 +228,15 @@ class GradBucketer:
     def world(self) -> int:
         return self.dist.get_world_size() if (self.dist is not None and self.dist.is_initialized()) else 1
 
+    def _reduces(self) -> bool:
+        return self.world() > 1 or (self.single_rank_collectives and self.dist is not None and self.dist.is_initialized())
+
     def mark_ready(self, name: str):
         i = self.bucket_of[name]
         self._pending[i].discard(name)
         if not self._pending[i] and i not in self.launch_order:
             self.launch_order.append(i)
-            if self.world() > 1:
+            if self._reduces():
                 b = self.buckets[i]
                 self._handles.append(self.dist.all_reduce(self.grads[b["lo"]:b["hi"]], op=self.dist.ReduceOp.SUM,
                                                           async_op=True))
@@ -250,7 +257,7 @@ class GradBucketer:
                 view = self.grads[b["lo"]:b["hi"]]
                 if on_bucket is not None:
                     on_bucket(i, view)
-                if self.world() > 1:
+                if self._reduces():
                     self._handles.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, async_op=True))
             self._pending[i] = set()
             self.launch_order.append(i)

@@ -21,9 +21,10 @@ def shard_list(items: Sequence, rank: int, world: int) -> List:
     return list(items[lo:hi])
 
 
-def max_over_ranks(seconds: float, dist=None, device=None) -> float:
-    """Wall time of the slowest rank (what the whole job waited for)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def max_over_ranks(seconds: float, dist=None, device=None, force: bool = False) -> float:
+    """Wall time of the slowest rank (what the whole job waited for).  force: run the collective in a group of one rank too
+    (bench.py --dist-selftest)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return float(seconds)
     import torch
     if device is None and dist.get_backend() == "nccl":
@@ -33,8 +34,8 @@ def max_over_ranks(seconds: float, dist=None, device=None) -> float:
     return float(t.item())
 
 
-def sum_over_ranks(value: float, dist=None, device=None) -> float:
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def sum_over_ranks(value: float, dist=None, device=None, force: bool = False) -> float:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return float(value)
     import torch
     if device is None and dist.get_backend() == "nccl":
@@ -44,9 +45,9 @@ def sum_over_ranks(value: float, dist=None, device=None) -> float:
     return float(t.item())
 
 
-def gather_over_ranks(value: float, dist=None, device=None) -> List[float]:
+def gather_over_ranks(value: float, dist=None, device=None, force: bool = False) -> List[float]:
     """`value` of every rank, in rank order (per-rank timings of a weak-scaling run: stragglers show up here)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return [float(value)]
     import torch
     if device is None and dist.get_backend() == "nccl":

@@ -193,7 +193,7 @@ class Trainer:
     -- what torch DDP / Lightning do -- so that ranks started from different states cannot silently diverge."""
 
     def __init__(self, wrapper, lr: float = 1e-4, adamw: bool = False, grad_clip: Optional[float] = 1.0,
-                 ema_decay: Optional[float] = None, dist=None, state_dict=None):
+                 ema_decay: Optional[float] = None, dist=None, state_dict=None, single_rank_collectives: bool = False):
         self.wrapper = wrapper                    # a NewMDGenWrapper whose .model is replaced by the trainable model's
         # (load_ema_weights caches the trainer's CURRENT weights, not the loaded ones.  A weak reference: wrapper -> trainer ->
         # wrapper would be a cycle, and `__del__` -> `close()`, which detaches the milestone events, would run only at a cyclic GC)
@@ -207,12 +207,13 @@ class Trainer:
         wrapper.model = self.tm.model
         self.opt = Adam(self.tm.params, lr=lr, adamw=adamw, grad_clip=grad_clip)
         self.ema = EMA(self.tm.params, ema_decay, buffers=self.tm._buffers, order=list(sd.keys())) if ema_decay else None
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        # (single_rank_collectives: self-test -- broadcast / all-reduce run in a group of one rank too, see GradBucketer)
+        self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or single_rank_collectives)) else None
         if self.dist is not None:
             for buf in [self.tm.params.data, self.opt.exp_avg, self.opt.exp_avg_sq] + ([self.ema.data] if self.ema else []):
                 self.dist.broadcast(buf, 0)
             self.tm.mark_updated()
-        self.buckets = GradBucketer(self.tm.params, self.tm.grads, dist=self.dist)
+        self.buckets = GradBucketer(self.tm.params, self.tm.grads, dist=self.dist, single_rank_collectives=single_rank_collectives)
         # gradient milestones of the library's backward pass (include/mdgen_amd.h): one event per parameter group, the
         # buckets' all-reduces wait for them on a communication stream of their own
         nl = wrapper.cfg.num_layers

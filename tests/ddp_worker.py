@@ -30,13 +30,15 @@ def run(out_path, steps=2):
     backend = os.environ.get("DDP_BACKEND", "gloo")
     dev = torch.device("cuda", rank if backend == "nccl" and world > 1 else 0)
     torch.cuda.set_device(dev)
-    if world > 1:
+    selftest = os.environ.get("DDP_SELFTEST") == "1"   # one rank, backend nccl: RCCL initialisation + every collective of the step as identities
+    if world > 1 or selftest:
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     B, T, L = 2, 6, 5
     cfg = ModelConfig(crop=L, num_frames=T, num_layers=1, abs_pos_emb=True, sim_condition=True)
     w = NewMDGenWrapper(cfg, device=dev)
     w.load_model_state_dict(synth_state_dict(cfg, 23 if rank == 0 else 999))   # rank 1 starts elsewhere: broadcast must fix it
-    tr = Trainer(w, lr=1e-3, adamw=False, grad_clip=1.0, ema_decay=0.9, dist=dist if world > 1 else None)
+    tr = Trainer(w, lr=1e-3, adamw=False, grad_clip=1.0, ema_decay=0.9, dist=dist if (world > 1 or selftest) else None,
+                 single_rank_collectives=selftest)
     g0 = load_golden("prep_sim")
     batch = {k[3:]: v.to(dev) for k, v in g0.items() if k.startswith("in_")}
     gen = torch.Generator().manual_seed(3)
@@ -52,7 +54,8 @@ def run(out_path, steps=2):
             loss = tr.training_step(batch, t=t, x0=x0)
     torch.cuda.synchronize()
     assert len(launched) == steps * len(tr.buckets.buckets)
-    res = {"params": tr.tm.params.data.cpu(), "ema": tr.ema.data.cpu(), "loss": float(loss), "world": world, "backend": backend}
+    res = {"params": tr.tm.params.data.cpu(), "ema": tr.ema.data.cpu(), "loss": float(loss), "world": world, "backend": backend,
+           "collectives": len(tr.buckets._handles) if hasattr(tr.buckets, "_handles") else 0, "reduces": tr.buckets._reduces()}
     tr.close()
     if os.environ.get("DDP_TIMING") == "1":   # cfg-5's per-GPU shape: how much of the all-reduce is NOT hidden behind the backward pass
         import time
@@ -79,7 +82,7 @@ def run(out_path, steps=2):
         tr5.close()
     if rank == 0:
         torch.save(res, out_path)
-    if world > 1:
+    if world > 1 or selftest:
         dist.barrier()
         dist.destroy_process_group()
 

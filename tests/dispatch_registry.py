@@ -9,7 +9,7 @@ tests/test_dispatch_cpu.py sweeps the shapes the entry points are used with (B =
 cfg-3's shapes; streams 1 / 2 / default) and FAILS when a signature turns up that no entry here produces.
 
 mode: "forward" (mdgen_denoiser_forward, no trace), "forward+trace" (with trace_h: what `return_trace=True` tests run),
-"euler" (mdgen_sample_euler: S steps; the generic GPU test runs S = 1 and compares x1 - x0 with the oracle's velocity at t = 0).
+"euler" (mdgen_sample_euler: the generic GPU test runs S = 2 and compares x2 - x0 with two Euler steps of the oracle).
 """
 
 CASES = [

@@ -33,7 +33,7 @@ def ipa_signature(p):
 def registry_signatures():
     trunk, ipa = {}, {}
     for c in CASES:
-        p = plan(c["B"], c["T"], c["L"], c["mode"], S=c.get("S", 1))
+        p = plan(c["B"], c["T"], c["L"], c["mode"], S=c.get("S", 2))   # (euler cases run two steps: the embedding-as-tail feeds the second)
         if c.get("part") != "ipa":          # (an IPA-table entry's rollout is not compared beyond the table)
             for s in view_signatures(p):
                 trunk.setdefault(s, []).append(c["name"])
@@ -64,12 +64,13 @@ def test_plan_is_available_without_a_gpu_and_names_the_headline_kernels():
     p = plan(16, 1000, 4, "euler", S=49)
     assert p["streams"] == 2 and [v["B"] for v in p["views"]] == [8, 8]
     for v in p["views"]:   # BASELINE.json configs[1]: two sub-batch views of B 8
-        assert v["classes"] == {"attn_L_fused": 245, "embed": 49, "flash_proj_T@q128": 245, "ln_qkv_T": 245, "mlp@fold": 196,
-                                "mlp@fold+final": 49}, v
+        assert v["classes"] == {"attn_L_fused": 245, "embed": 1, "flash_proj_T@q128": 245, "ln_qkv_T": 245, "mlp@fold": 196,
+                                "mlp@fold+final": 1, "mlp@fold+final+embed": 48}, v   # (steps 1 .. 48: no k_embed, no k_final)
     assert p["prepare"]["fold_pack"] == 1 and p["prepare"]["adaln_table"] == 1
     # options reach the plan: without the fold the separate final layer is back
     q = plan(16, 1000, 4, "euler", S=49, options={"mlp_fold": 0})
     assert q["views"][0]["classes"]["mlp"] == 245 and q["views"][0]["classes"]["final_euler"] == 49 and "fold_pack" not in q["prepare"]
+    assert q["views"][0]["classes"]["embed"] == 49
     # under the profiler the rollout is one stream of B 16
     assert [v["B"] for v in plan(16, 1000, 4, "euler_profiled")["views"]] == [16]
 
