@@ -270,7 +270,8 @@ int32_t mdgen_rollout_euler(mdgen_ctx* ctx, const mdgen_shape* shape, int32_t n_
  * `mdgen_profile_report` synchronises `stream`, writes a JSON object
  *   {"<class>": {"count": n, "ms": total_ms}, ...}   into buf (NUL-terminated) and resets the log.  Classes of the 64-row panel
  * kernels that exist in two forms carry "@p4" / "@p8" (four / eight waves per panel; option panel_waves), "@p8x3" / "@p8x2" the split
- * forms, the fused attention "@q64" / "@q128" (k_flash_proj / k_flash_proj8), the gate-folded row-owner MLP "mlp@fold".  One entry is
+ * forms, the fused attention "@q64" / "@q128" (k_flash_proj / k_flash_proj8), the gate-folded row-owner MLP "mlp@fold" ("+final", "+final+embed": its
+ * tails, option mlp_tail).  One entry is
  * not a kernel class: "@context": {"count": split-form MLP launches since the last report, "xcd_round_robin": 0/1 (the placement
  * probe of mdgen_ctx_create: workgroups with equal blockIdx % 8 share an XCD -- where it fails the split MLP form is never picked),
  * "ncu": compute units}. */

@@ -116,6 +116,7 @@ struct mdgen_ctx {
     float *wl_rows = nullptr, *wc_rows = nullptr;   // ... and in rows_embed_gemm's (the embedding as the tail of the last layer's MLP kernel)
     float* mask_delta = nullptr;                    // mask_to_emb[1] - mask_to_emb[0]
     bf16x8 *wl_hi = nullptr, *wl_lo = nullptr, *wc_hi = nullptr, *wc_lo = nullptr;   // ... as bf16 pairs, K padded to 32 in kappa order
+    int opt_trace_tail = 0;     // measurement: mdgen_profile_phase_trace targets the row-owner MLP launch that carries both tails
     int opt_embed_split = 1;    // the embedding tail's products on the bf16 MFMA with hi + lo operand pairs (0: fp32 MFMA, exact)
     float *pos_embed = nullptr, *t_w0 = nullptr, *t_b0 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
     float *wf7 = nullptr, *bf7 = nullptr, *wr7 = nullptr, *br7 = nullptr;
@@ -727,6 +728,8 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "mlp_fold") {
         if (value != 0 && value != 1) return fail(-2, "mlp_fold must be 0 or 1");
         c->opt_mlp_fold = value;
+    } else if (n == "trace_tail") {
+        c->opt_trace_tail = value != 0;
     } else if (n == "embed_split") {
         if (value != 0 && value != 1) return fail(-2, "embed_split must be 0 or 1");
         c->opt_embed_split = value;
@@ -1208,7 +1211,7 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
                 }
             }
         }
-        if (trunk && r.c->phase_trace) {
+        if (trunk && r.c->phase_trace && (!r.c->opt_trace_tail || emb_on)) {   // (trace_tail: the launch with both tails is the one traced)
             q.trace = r.c->phase_trace;
             q.trace_cap = r.c->phase_trace_cap;
             r.c->phase_trace = nullptr;

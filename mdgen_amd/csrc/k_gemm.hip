@@ -6,6 +6,10 @@
 namespace mdg {
 
 constexpr int kRowB = kC * 2;            // panel row bytes at K = 384
+// (Round 6, measured and removed: small-launch forms that request ALL rows of their LayerNorm prologue / residual epilogue at once --
+// k_mlp8, k_ln_qkv8, a k_ln_qkv_attn4 instantiation for <= one workgroup per CU.  B = 1: attn_L_fused 41.0 against 41.7 us, proj_mlp
+// 54.4 against 53.2, 30 627 against 30 495 frames/s; the TPS shard 83 869 against 84 367: nothing -- hipcc already hoists the batched
+// requests of an unrolled prologue as far as the registers allow.  profiles/r06_experiments.txt #8.)
 constexpr int kPanelBytes = kPanel * kRowB;
 
 // =================================================================================================

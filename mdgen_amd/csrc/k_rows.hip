@@ -389,8 +389,12 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
         const float* fmod = reinterpret_cast<const float*>(smem + kRingBytes + 8192 + NW * 6144);   // [shift 512 floats | scale 512]
         float xnew[16];
         rows_final_tail(m.y, tok, fmod + 512, fmod, p.tail_w, p.tail_b, p.tail_D, p.tail_euler, p.tail_dt, p.tail_x, p.tail_out, xf, xnew);
-        if (p.emb_base)   // (uniform) the next step's token embedding, from the state just updated: that step launches no k_embed
-            rows_embed_tail(m.y, tok, xnew, EmbedTail{p.emb_wl, p.emb_wc, p.emb_wl_hi, p.emb_wl_lo, p.emb_wc_hi, p.emb_wc_lo, p.emb_base, p.emb_mdelta, p.emb_xcond, p.emb_cmask, p.emb_T, p.emb_L, p.tail_D}, p.h);
+        ROWS_STAMP(6);
+        if (p.emb_base) {   // (uniform) the next step's token embedding, from the state just updated: that step launches no k_embed
+            rows_embed_tail(m.y, tok, xnew, EmbedTail{p.emb_wl, p.emb_wc, p.emb_wl_hi, p.emb_wl_lo, p.emb_wc_hi, p.emb_wc_lo, p.emb_base, p.emb_mdelta, p.emb_xcond, p.emb_cmask, p.emb_T, p.emb_L, p.tail_D});
+            ROWS_STAMP(7);
+            rows_store<0, 12>(m.y, tok, p.h);
+        }
     } else if (FOLD) {
         rows_store<0, 12>(m.y, tok, p.h);
     } else if (MODLDS) {

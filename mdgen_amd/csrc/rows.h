@@ -431,8 +431,8 @@ struct EmbedTail {
     const int64_t* x_cond_mask;  // [N]
     int T, L, D;
 };
-__device__ __forceinline__ void rows_embed_tail(f32x16 (&y)[12], int tok, const float (&xnew)[16], const EmbedTail e,
-                                                float* __restrict__ h) {
+// (computes into y; the caller stores the rows: rows_store)
+__device__ __forceinline__ void rows_embed_tail(f32x16 (&y)[12], int tok, const float (&xnew)[16], const EmbedTail e) {
     const int lane = lane_id(), hh = lane >> 5;
     const unsigned tokc = tok < 0 ? 0u : (unsigned)tok;
     const unsigned row = (tokc / (unsigned)(e.T * e.L)) * (unsigned)e.L + tokc % (unsigned)e.L;
@@ -474,7 +474,6 @@ __device__ __forceinline__ void rows_embed_tail(f32x16 (&y)[12], int tok, const 
             for (int j = 0; j < 4; ++j) y[i >> 2][4 * (i & 3) + j] += sel * d[j];
         }
     }
-    rows_store<0, 12>(y, tok, h);
 }
 
 __device__ __forceinline__ void rows_ln(const float* __restrict__ x, int tok, const ModMap mm, int shift_chunk,

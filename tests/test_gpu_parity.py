@@ -2934,6 +2934,7 @@ def test_small_split_hand_over_stress_200_graph_replays():
     for i in range(200):
         again, _ = w.inference(batch, zs=zs, num_steps=49, use_graph=True)
         assert torch.equal(again, first), i
+    w.model.profile_report()   # (resets the split-launch counter: it also counted the launches the graph capture enqueued)
     w.model.profile(True)
     w.inference(batch, zs=zs, num_steps=49, use_graph=False)
     ran = {k: v["count"] for k, v in w.model.profile_report().items()}
