@@ -762,11 +762,12 @@ static size_t split_bytes(long panels) { return kSplitCounterBytes + 2 * (size_t
 // Gate fold (option mlp_fold): per (step, trunk layer) one MLP weight stream with that step's gate folded into fc2, and b2' = gate * b2.
 // Carved when the call shares t across the batch and its trunk launches can take the row-owner kernel.
 static bool mlp_uses_rows(const mdgen_ctx* c, long nrows);
-static bool fold_on(const mdgen_ctx* c, long N, int t_shared) {
-    return t_shared && c->opt_mlp_fold && c->opt_precision == 16 && mlp_uses_rows(c, N);
-}
 constexpr size_t kFoldStreamBytes = (size_t)kMlpFrags * 1024;
+constexpr size_t kFoldMaxBytes = (size_t)8 << 30;   // a call with so many steps that its streams would pass 8 GiB keeps the unfolded kernel
 static size_t fold_bytes(const mdgen_ctx* c, int S) { return (size_t)S * c->nl * (kFoldStreamBytes + (size_t)kC * 4); }
+static bool fold_on(const mdgen_ctx* c, long N, int t_shared, int S) {
+    return t_shared && c->opt_mlp_fold && c->opt_precision == 16 && mlp_uses_rows(c, N) && fold_bytes(c, S) <= kFoldMaxBytes;
+}
 
 static size_t frag_bytes(long nseq, int len) { return (size_t)nseq * kH * (len / 32 + 1) * kFragBytes; }
 
@@ -854,9 +855,9 @@ extern "C" int32_t mdgen_workspace_layout(const mdgen_ctx* c, const mdgen_shape*
     // the latter two [panels][kMlpSplit][64][384] fp32 each
     o->split = take(split_bytes(split_panels(maxrows)));
     // per-(step, layer) gate-folded MLP streams [S][nl][2304 KiB] | b2' [S][nl][384] fp32 (0 bytes unless fold_on)
-    o->fold = take(fold_on(c, N, t_shared) ? fold_bytes(c, S) : 0);
+    o->fold = take(fold_on(c, N, t_shared, S) ? fold_bytes(c, S) : 0);
     // base rows of the token embedding per (step, b, l) for the embedding-as-tail form [S][B*L][384] fp32 (0 bytes unless fold and S > 1)
-    o->embase = take(fold_on(c, N, t_shared) && c->opt_mlp_tail == 2 && S > 1 ? (size_t)Mp * kC * 4 : 0);
+    o->embase = take(fold_on(c, N, t_shared, S) && c->opt_mlp_tail == 2 && S > 1 ? (size_t)Mp * kC * 4 : 0);
     o->total_bytes = off;
     return 0;
 }
@@ -1564,7 +1565,7 @@ static int make_run(Run* r, mdgen_ctx* c, const mdgen_shape* sh, int S, int t_sh
     r->fold_ready = false;
     r->embase_p = nullptr;
     r->embase_step_stride = (long)sh->B * sh->L * kC;
-    if (fold_on(c, r->N, t_shared)) {
+    if (fold_on(c, r->N, t_shared, S)) {
         r->fold_streams = r->ws + r->lay.fold;
         r->fold_b2g = (float*)(r->fold_streams + (size_t)S * c->nl * kFoldStreamBytes);
     }

@@ -23,6 +23,7 @@ CASES = [
     dict(name="B6_T1024_L4_euler", mode="euler", B=6, T=1024, L=4, n_pad=0, covered_by=None),          # row-owner MLP, but < 512 fused-attention jobs: k_flash + k_proj<0>
     dict(name="B6_T1024_L4_fwd", mode="forward+trace", B=6, T=1024, L=4, n_pad=0, covered_by=None),
     dict(name="B64_T100_L4_euler", mode="euler", B=64, T=100, L=4, n_pad=0, covered_by=None),          # cfg-3's batch on few GPUs: 64-query fused attention on short sequences
+    dict(name="tps_B64_T100_L4_euler", mode="euler", B=64, T=100, L=4, n_pad=0, tps=True, covered_by=None),   # the two-sided model (D = 28) through the folded MLP and both tails
     # ---- longer chains (tiled residue axis), T = 250 unless a smaller shape has the same signature
     dict(name="B1_T250_L8", mode="forward+trace", B=1, T=250, L=8, n_pad=1, covered_by=None),          # 4 < L <= 8: micro-attention in k_proj<2>
     dict(name="B1_T250_L16", mode="forward+trace", B=1, T=250, L=16, n_pad=2, covered_by=None),        # <= 85 panels: split forms with the tiled residue axis

@@ -2310,12 +2310,14 @@ def test_validation_on_ema_weights_leaves_the_master_parameters_alone(tmp_path):
 
 
 # ---- round 5: k_flash_proj, the 257..383-panel window, four- vs eight-wave panel kernels ---------------------------------------
-def _fwd_case(B, T, L, n_pad, seed, weights_seed=5):
-    """(cfg, sd, host kwargs, device kwargs) of one synthetic forward call (forward-simulation model, crop max(L, 4))."""
+def _fwd_case(B, T, L, n_pad, seed, weights_seed=5, tps=False):
+    """(cfg, sd, host kwargs, device kwargs) of one synthetic forward call (forward-simulation model, crop max(L, 4); tps: the
+    two-sided model, D = 28)."""
     from mdgen_amd.config import ModelConfig
     from mdgen_amd.synthetic import synth_forward_inputs, synth_state_dict
     dev = _cuda()
-    cfg = ModelConfig.forward_sim(num_frames=T, crop=max(L, 4))
+    cfg = ModelConfig(crop=max(L, 4), num_frames=T, abs_pos_emb=True, sim_condition=False, tps_condition=True) if tps else \
+        ModelConfig.forward_sim(num_frames=T, crop=max(L, 4))
     sd = synth_state_dict(cfg, weights_seed)
     inp = synth_forward_inputs(cfg, B, T, L, n_pad, seed)
     kw = dict(x=inp["x"], t=inp["t"], mask=inp["mask"], start_frames=(inp["start_rot"], inp["start_trans"]),
@@ -2586,16 +2588,16 @@ def test_two_stream_views_in_the_panel_window_match_one_stream():
 
 
 # ---- round 6: the gate-folded row-owner MLP, the headline's own kernel mix against the oracle ------------------------------------
-def _euler_kw(dkw):
-    return {k: v for k, v in dkw.items() if k not in ("x", "t", "end_frames")}
+def _euler_kw(dkw, tps=False):
+    return {k: v for k, v in dkw.items() if k not in (("x", "t") if tps else ("x", "t", "end_frames"))}
 
 
-def _oracle_two_euler_steps(sd, cfg, kw, v0=None):
+def _oracle_two_euler_steps(sd, cfg, kw, v0=None, cd=None):
     """x2 of the fixed-grid Euler rollout with S = 2 (t = 0, 0.5; integrators.py:95-114) from the CPU oracle; v0: the oracle's velocity
     at (x0, t = 0) when the caller has it already."""
     from oracle import mdgen_oracle as O
     B = kw["x"].shape[0]
-    cd = O.cfg_dict(cfg)
+    cd = cd if cd is not None else O.cfg_dict(cfg)
     if v0 is None:
         v0 = O.forward(sd, cd, **dict(kw, t=torch.zeros(B)))
     x1 = kw["x"] + 0.5 * v0
@@ -2799,13 +2801,15 @@ def test_dispatch_registry_case_vs_oracle(case):
     from oracle import mdgen_oracle as O
     from mdgen_amd._lib import dispatch_plan
     from mdgen_amd.model import LatentMDGenModel
-    B, T, L, n_pad = case["B"], case["T"], case["L"], case["n_pad"]
-    cfg, sd, kw, dkw = _fwd_case(B, T, L, n_pad, 3100 + 7 * T + L, weights_seed=11)
+    B, T, L, n_pad, tps = case["B"], case["T"], case["L"], case["n_pad"], case.get("tps", False)
+    cfg, sd, kw, dkw = _fwd_case(B, T, L, n_pad, 3100 + 7 * T + L, weights_seed=11, tps=tps)
     euler = case["mode"] == "euler"
     if euler:
         kw["t"] = torch.zeros(B)
         dkw["t"] = kw["t"].to(dkw["x"].device)
-    ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
+    # (two-sided model: the library's relative-frame quaternions carry w >= 0; the oracle is told to do the same)
+    cd = dict(O.cfg_dict(cfg), quat_sign="w_nonneg") if tps else O.cfg_dict(cfg)
+    ref, rtr = O.forward(sd, cd, return_trace=True, **kw)
     m = LatentMDGenModel(cfg)
     m.load_state_dict(sd)
     m.forward(**dkw)   # (workspace of the shape)
@@ -2816,9 +2820,9 @@ def test_dispatch_registry_case_vs_oracle(case):
         info = m.context_info
         rep = {k: rel_l2(tr[k].cpu(), rtr[k]) for k in ["ipa_out"] + [f"h{i}" for i in range(nl + 1)]}
         rep["out"] = rel_l2(out.cpu(), ref)
-        want = dispatch_plan(B, T, L, mode=3, ncu=info["ncu"], xcd_round_robin=bool(info["xcd_round_robin"]))
+        want = dispatch_plan(B, T, L, mode=3, tps=tps, ncu=info["ncu"], xcd_round_robin=bool(info["xcd_round_robin"]))
     else:
-        ekw = _euler_kw(dkw)
+        ekw = _euler_kw(dkw, tps)
         m.sample_euler(dkw["x"], 2, use_graph=False, **ekw)
         for ws in m._ws.values():
             ws.view(torch.uint8).fill_(0xFF)
@@ -2828,9 +2832,9 @@ def test_dispatch_registry_case_vs_oracle(case):
         info = m.context_info
         m.profile(False)
         xg = m.sample_euler(dkw["x"], 2, use_graph=True, **ekw)   # the product's path: graph, sub-batch streams
-        d_ref = _oracle_two_euler_steps(sd, cfg, kw, v0=ref) - kw["x"]
+        d_ref = _oracle_two_euler_steps(sd, cfg, kw, v0=ref, cd=cd) - kw["x"]
         rep = {"x2 - x0": rel_l2((xg - dkw["x"]).cpu(), d_ref), "eager": rel_l2((x2 - dkw["x"]).cpu(), d_ref)}
-        want = dispatch_plan(B, T, L, n_steps=2, mode=2, ncu=info["ncu"], xcd_round_robin=bool(info["xcd_round_robin"]))
+        want = dispatch_plan(B, T, L, n_steps=2, mode=2, tps=tps, ncu=info["ncu"], xcd_round_robin=bool(info["xcd_round_robin"]))
     planned = dict(want["prepare"])
     for vw in want["views"]:
         for k, n in vw["classes"].items():
