@@ -313,7 +313,7 @@ def extra_legs(dev, options):
         except Exception as e:   # an extra leg must never take the headline number down with it
             ex[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
     run("box_probe", lambda: box_probe(dev))
-    run("atlas_crop256_T250_B1", lambda: sampler_leg("atlas_crop256_T250_B1", dev, 2, 1, 49, options, roofline=True))
+    run("atlas_crop256_T250_B1", lambda: sampler_leg("atlas_crop256_T250_B1", dev, 4, 2, 49, options, roofline=True))
     # (the two small shapes: 40 ms per call, so five timed calls behind two warm-up calls cost nothing and settle the clocks)
     run("tetrapeptide_tps_crop4_T100_B32", lambda: sampler_leg("tetrapeptide_tps_crop4_T100_B32", dev, 5, 2, 49, options))
     run("tetrapeptide_fwdsim_crop4_T1000_B1", lambda: sampler_leg("tetrapeptide_fwdsim_crop4_T1000_B1", dev, 5, 2, 49, options))

@@ -162,7 +162,7 @@ struct mdgen_ctx {
                                    // positions whose launch gives every CU such a workgroup (cfg-2), else k_flash_proj (four waves, 64-row
                                    // panel; ATLAS); 4 / 8: one form always
     int opt_flash_proj = 1;     // tiled attention + its out-projection + gated residual in ONE launch (k_flash_proj): 0 off (k_flash, then
-                                // k_proj<0> or a deferred projection), 1 (default) when the launch has >= kFlashProjMinJobs workgroups
+                                // k_proj<0> or a deferred projection), 1 (default) when the launch has >= 2 x CUs workgroups
                                 // of (sequence, 64 queries), 2 always
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_train_streams = 2;      // training step: 2 = weight / bias gradients of the linear layers on a second stream (train.inc)
@@ -750,10 +750,12 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
 // ---------------------------------------------------------------------------------------------
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// panels the split scratch of a call covers, and its bytes (counters first: make_run zeroes them in every call)
-static long split_panels(long maxrows) {
-    const long pn = (maxrows + kPanel - 1) / kPanel;
-    return pn < kMlpSplitMaxPanels ? pn : kMlpSplitMaxPanels;
+// panels the split scratch of a call covers, and its bytes (counters first: make_run zeroes them in every call): the largest launch that
+// can take the split form has ncu / kMlpSplit panels; nothing but the counter block when the option is off
+static long split_panels(const mdgen_ctx* c, long maxrows) {
+    if (!c->opt_small_split) return 0;
+    const long pn = (maxrows + kPanel - 1) / kPanel, cap = c->ncu / kMlpSplit < kMlpSplitMaxPanels ? c->ncu / kMlpSplit : kMlpSplitMaxPanels;
+    return pn < cap ? pn : cap;
 }
 constexpr size_t kSplitCounterBytes = 1024;   // kMlpSplitMaxPanels counters, padded
 static_assert(kMlpSplitMaxPanels * sizeof(unsigned) <= kSplitCounterBytes, "counter block");
@@ -853,7 +855,7 @@ extern "C" int32_t mdgen_workspace_layout(const mdgen_ctx* c, const mdgen_shape*
     o->f32_scratch = take(c->opt_keep_fp32 ? (size_t)maxrows * (kC + 3 * kC + kC + kF) * 4 + (size_t)Mp * kIpaFeat * 4 : 0);
     // k_mlp8's split form (launches of <= ncu / kMlpSplit panels): counters [kMlpSplitMaxPanels] | fc2 partials | private residual rows,
     // the latter two [panels][kMlpSplit][64][384] fp32 each
-    o->split = take(split_bytes(split_panels(maxrows)));
+    o->split = take(split_bytes(split_panels(c, maxrows)));
     // per-(step, layer) gate-folded MLP streams [S][nl][2304 KiB] | b2' [S][nl][384] fp32 (0 bytes unless fold_on)
     o->fold = take(fold_on(c, N, t_shared, S) ? fold_bytes(c, S) : 0);
     // base rows of the token embedding per (step, b, l) for the embedding-as-tail form [S][B*L][384] fp32 (0 bytes unless fold and S > 1)
@@ -1000,9 +1002,9 @@ static int check_launch_rows(long nrows) {
 // k_flash_proj owns a (sequence, 64-query chunk) for all 16 heads: four times the work of a k_flash workgroup, a quarter of the
 // workgroups.  It pays where those still fill the chip (cfg-2: 1024 per launch, ATLAS: 1000 / 1024); small launches (B = 1: 64,
 // the IPA stack) keep the finer-grained k_flash + projection.
-constexpr long kFlashProjMinJobs = 512;
+// (two such workgroups per CU: 512 on the 256-CU part)
 static bool flash_proj_on(const mdgen_ctx* c, const AxisMap& ax) {
-    return c->opt_precision == 16 && (c->opt_flash_proj == 2 || (c->opt_flash_proj == 1 && flash_proj_jobs(ax) >= kFlashProjMinJobs));
+    return c->opt_precision == 16 && (c->opt_flash_proj == 2 || (c->opt_flash_proj == 1 && flash_proj_jobs(ax) >= 2L * c->ncu));
 }
 
 // `defer`: when non-null and the sub-layer takes the tiled-attention path, its out-projection is NOT launched; *defer receives
@@ -1150,7 +1152,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
 // chip; smaller launches (IPA stack, B = 1 tetrapeptides) stay on the 64-row panel kernel.
 static bool mlp_uses_rows(const mdgen_ctx* c, long nrows) {
     const long tiles = (nrows + 31) / 32;
-    return c->opt_mlp_path == 2 || (c->opt_mlp_path == 1 && tiles >= 4 * 192);
+    return c->opt_mlp_path == 2 || (c->opt_mlp_path == 1 && tiles >= 3L * c->ncu);   // (768 row tiles = 192 four-wave workgroups on the 256-CU part)
 }
 
 // `proj`: a deferred out-projection (attn_sublayer) to run inside the MLP kernel, ahead of the MLP
@@ -1552,7 +1554,7 @@ static int make_run(Run* r, mdgen_ctx* c, const mdgen_shape* sh, int S, int t_sh
     r->ipa_step_stride = (long)sh->B * sh->L * kC;
     {
         const long maxrows = r->N > r->Mp ? r->N : r->Mp;
-        r->split_cap = split_panels(maxrows);
+        r->split_cap = split_panels(c, maxrows);
         r->split_counters = (unsigned*)(r->ws + r->lay.split);
         r->split_part = (float*)(r->ws + r->lay.split + kSplitCounterBytes);
         r->split_hupd = r->split_part + (size_t)r->split_cap * kMlpSplit * kPanel * kC;

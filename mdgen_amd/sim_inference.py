@@ -108,22 +108,22 @@ def sample_group(model, batch, args):
     return torch.cat(out, 1)
 
 
-_XTC_WARNED = False
+def require_xtc_writer():
+    """`--xtc` is the reference's mdtraj post-processing (sim_inference.py:121-125).  A pipeline that asks for `{name}.xtc` must not
+    find out after hours of sampling that none was written: without mdtraj the command is refused BEFORE anything is sampled
+    (exit status 2); drop `--xtc` to get the multi-model PDB, which holds every frame."""
+    try:
+        import mdtraj  # noqa: F401
+    except ImportError:
+        print("error: --xtc needs mdtraj (the reference's dependency for the XTC file), which is not installed; "
+              "run without --xtc to get the multi-model PDB with all frames", file=sys.stderr)
+        raise SystemExit(2)
 
 
 def write_xtc(pdb_path, xtc_path):
     """`--xtc` (sim_inference.py:121-125): superpose the sampled trajectory on its first frame, save it as XTC and cut the PDB to
-    that frame.  mdtraj is the reference's dependency for this and is not part of the hot path; without it the multi-model PDB
-    (which holds every frame) is left as written and a warning is printed once.  Returns True if the XTC was written."""
-    global _XTC_WARNED
-    try:
-        import mdtraj
-    except ImportError:
-        if not _XTC_WARNED:
-            print("warning: --xtc needs mdtraj, which is not installed: keeping the multi-model PDB (all frames) and writing no .xtc",
-                  file=sys.stderr)
-            _XTC_WARNED = True
-        return False
+    that frame (mdtraj: checked by require_xtc_writer before sampling starts)."""
+    import mdtraj
     traj = mdtraj.load(pdb_path)
     traj.superpose(traj)
     traj.save(xtc_path)
@@ -141,6 +141,8 @@ def run(args, model, device, names_seqres, rank=0, world=1, batch_fn=make_group_
     from .pdb import atom14_to_pdb
     from .sharding import max_over_ranks, sum_over_ranks
     sync = sync or (lambda: None)
+    if getattr(args, "xtc", False):
+        require_xtc_writer()
     names = select_names(list(names_seqres), args.pdb_id, args.chunk_idx, args.n_chunks, rank, world)
     seqres = {n: names_seqres[n] for n in names}
     os.makedirs(args.out_dir, exist_ok=True)

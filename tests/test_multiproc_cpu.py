@@ -3,6 +3,8 @@ once, the job time is the max over ranks, and no collective touches sample data.
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -249,8 +251,9 @@ def test_bench_self_launches_its_ranks_when_run_without_a_launcher():
 
 def test_cli_accepts_the_readme_flags_incl_xtc(tmp_path, capsys):
     """The reference README's forward-simulation command line (README.md:72: `--num_rollouts 10 --num_frames 1000 --xtc`) must
-    run in the drop-in CLI: `--xtc` is accepted, the multi-model PDB is written, and the XTC (sim_inference.py:121-125, mdtraj)
-    is written where mdtraj imports -- here it does not, so a warning is printed once and the PDB keeps every frame."""
+    run in the drop-in CLI: `--xtc` is accepted and, where mdtraj imports, the XTC is written and the PDB cut to one frame
+    (sim_inference.py:121-125).  Where it does not (this image), the command is refused with exit status 2 BEFORE anything is sampled
+    -- a pipeline that consumes `{name}.xtc` must fail at the command, not later; without `--xtc` the multi-model PDB is written."""
     import numpy as np
     from mdgen_amd import sim_inference as cli
     from mdgen_amd.geometry import restype_order
@@ -265,12 +268,20 @@ def test_cli_accepts_the_readme_flags_incl_xtc(tmp_path, capsys):
     def batch_fn(names, arrs, seqres, device):
         return {"seqres": torch.tensor([[restype_order[c] for c in seqres[n]] for n in names]),
                 "tag": torch.tensor([float(ord(n[1])) for n in names])}
-    res = cli.run(args, _FakeSampler(), "cpu", {"pA": "FLRH"}, batch_fn=batch_fn)
-    assert res["frames"] == 6
-    pdb = open(out / "pA.pdb").read()
     try:
         import mdtraj  # noqa: F401
-        assert (out / "pA.xtc").exists() and pdb.count("MODEL") <= 1
+        have = True
     except ImportError:
-        assert pdb.count("MODEL") == 6 and not (out / "pA.xtc").exists()
-        assert "mdtraj" in capsys.readouterr().err
+        have = False
+    if have:
+        res = cli.run(args, _FakeSampler(), "cpu", {"pA": "FLRH"}, batch_fn=batch_fn)
+        assert res["frames"] == 6
+        assert (out / "pA.xtc").exists() and open(out / "pA.pdb").read().count("MODEL") <= 1
+    else:
+        with pytest.raises(SystemExit) as ei:
+            cli.run(args, _FakeSampler(), "cpu", {"pA": "FLRH"}, batch_fn=batch_fn)
+        assert ei.value.code == 2 and "mdtraj" in capsys.readouterr().err
+        assert not out.exists() or not list(out.iterdir())            # nothing was sampled or written
+        args.xtc = False
+        res = cli.run(args, _FakeSampler(), "cpu", {"pA": "FLRH"}, batch_fn=batch_fn)
+        assert res["frames"] == 6 and open(out / "pA.pdb").read().count("MODEL") == 6
