@@ -1068,11 +1068,11 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
 // PRIVATE copy p.hupd of the panel's updated residual rows -- nobody writes h while another workgroup may still read it), writes its
 // fp32 partial of the fc2 product to p.part and bumps the panel's counter; the LAST ARRIVER adds the S partials in the order of s
 // (the same bits whoever is last) and runs the gated residual epilogue from its private rows into h.
-// Nobody waits for anybody.  Memory ordering: producer: s_waitcnt vmcnt(0), barrier, agent-scope RELEASE atomic add (L2 write-back);
-// consumer: agent-scope acquire fence (drops stale lines of its vector cache and of its L2), ordinary loads -- a release / acquire
-// pair at agent scope, correct for any placement.  The S workgroups of a panel are nevertheless placed on ONE XCD (equal
-// blockIdx % 8; the context's placement probe checks the residue -> XCD rule and the launcher only picks the form where it holds):
-// that is where the form pays -- the partials then meet in one L2.
+// Nobody waits for anybody.  Memory ordering: the partials are written and read with agent-scope atomic accesses (sc1: coherent across
+// the XCDs' L2s element by element); producer: s_waitcnt vmcnt(0) on every wave, barrier, agent-scope atomic add; consumer: the
+// same atomic add tells it that it is last, then agent-scope atomic loads.  Correct for any placement.  The S workgroups of a panel
+// are nevertheless placed on ONE XCD (equal blockIdx % 8; the context's placement probe checks the residue -> XCD rule and the
+// launcher only picks the form where it holds): that is where the form pays.
 template <bool PRE, int S = 1>
 __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
     static_assert(kNChunk % (2 * S) == 0, "whole chunks per group");
@@ -1192,23 +1192,24 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
 #pragma unroll
         for (int f = 0; f < 3; ++f)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mine[(f * 16 + r) * 64] = z[f][r];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's partial stores are acknowledged by this XCD's L2
+            for (int r = 0; r < 16; ++r)   // agent-scope atomic stores (global_store_dword ... sc1): written THROUGH this XCD's L2
+                __hip_atomic_store(&mine[(f * 16 + r) * 64], z[f][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's partial stores have completed at agent scope
         __syncthreads();                                    // (also: exchange area read)
         if (threadIdx.x == 0) {
             unsigned* c = p.counters + pn;
-            // RELEASE at agent scope (round 6): the arrival writes this XCD's dirty L2 lines back (buffer_wbl2) before the counter
-            // moves, so the hand-over is correct under the HIP memory model wherever the S workgroups of a panel run; the
-            // placement rule (one XCD per panel) is a performance hint only -- the partials then never leave that L2's reach.
-            // The stores of the OTHER waves are covered: they were acknowledged (vmcnt(0)) before the barrier above, and the
-            // write-back is of the whole L2, not of this wave's lines.
-            const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            // Round 6: the hand-over no longer rests on where the S workgroups of a panel run.  The partials are written and read
+            // with AGENT-scope atomic accesses (sc1: write-through stores, loads that bypass non-coherent cache lines), so they are
+            // coherent across the XCDs' L2s element by element; every wave has waited for its stores (vmcnt(0)) before the barrier
+            // above, and only then does the arrival counter move (agent-scope RMW).  A release fence instead (first form of this
+            // round: __ATOMIC_ACQ_REL on the counter = buffer_wbl2, a write-back of the WHOLE L2) cost 4 us per launch at B = 1
+            // (k_mlp8<true, 3> 45.3 -> 49.2 us, profiles/r06_experiments.txt #10).  The one-XCD placement stays a performance hint.
+            const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = old == (unsigned)(S - 1);
             if (old == (unsigned)(S - 1)) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
         __syncthreads();
         if (!s_last) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // no stale copy of the others' partials in this CU's vector cache
         f32x16 zt[3];
 #pragma unroll
         for (int f = 0; f < 3; ++f)
@@ -1220,7 +1221,8 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
 #pragma unroll
             for (int f = 0; f < 3; ++f)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) zt[f][r] += src[(f * 16 + r) * 64];
+                for (int r = 0; r < 16; ++r)   // agent-scope atomic loads (sc1): never a stale line of this CU's L1 or this XCD's L2
+                    zt[f][r] += __hip_atomic_load(&src[(f * 16 + r) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int f = 0; f < 3; ++f) z[f] = zt[f];
