@@ -726,7 +726,7 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
         if (value != 1 && value != 2) return fail(-2, "train_streams must be 1 (one stream) or 2 (weight gradients on a second stream)");
         c->opt_train_streams = value;
     } else if (n == "mlp_fold") {
-        if (value < 0 || value > 2) return fail(-2, "mlp_fold must be 0, 1 or 2");
+        if (value != 0 && value != 1) return fail(-2, "mlp_fold must be 0 or 1");
         c->opt_mlp_fold = value;
     } else if (n == "trace_tail") {
         c->opt_trace_tail = value != 0;
@@ -1183,7 +1183,6 @@ static int mlp_sublayer(const Run& r, const FfnW& f, float* h, long nrows, const
         } else if (fold_sl >= 0 && r.fold_ready && mm.group_stride == 0 && mm.step_stride == 0) {
             q.wstream = r.fold_streams + (size_t)fold_sl * kFoldStreamBytes;
             q.b2g = r.fold_b2g + (size_t)fold_sl * kC;
-            q.h16 = r.c->opt_mlp_fold == 2;
             if (tail && tail_done && r.c->opt_mlp_tail && tail->mm.group_stride == 0 && tail->mm.step_stride == 0) {
                 tail_on = true;
                 q.tail_w = r.c->wfin_k;
@@ -1383,7 +1382,7 @@ static int prepare(Run& r, const float* t_dev, const float* t_host, long view_ro
             b2[i] = c->trunk[i].ffn.b2;
             base[i] = c->trunk[i].ffn.wstream;
         }
-        { ProfScope ps(c, "fold_pack", r.s); if (!g_dry) launch_pack_fold(r.mod(), r.mod_step_stride, r.S, c->nl, goff, w2, b2, base, c->mlp_tab, (bf16x8*)r.fold_streams, r.fold_b2g, c->opt_mlp_fold == 2, r.s); }
+        { ProfScope ps(c, "fold_pack", r.s); if (!g_dry) launch_pack_fold(r.mod(), r.mod_step_stride, r.S, c->nl, goff, w2, b2, base, c->mlp_tab, (bf16x8*)r.fold_streams, r.fold_b2g, r.s); }
         LAUNCHCHK();
     }
     // mask_bl[b][l] = mask[b][0][l]  (latent_model.py:246 passes mask[:,0])
@@ -1746,7 +1745,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)(c->opt_mlp_fold & 1) << 45 | (uint64_t)c->opt_mlp_tail << 46 | (uint64_t)c->opt_embed_split << 48 | (uint64_t)(c->opt_mlp_fold >> 1) << 49), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45 | (uint64_t)c->opt_mlp_tail << 46 | (uint64_t)c->opt_embed_split << 48), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1806,7 +1805,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)(c->opt_mlp_fold & 1) << 45 | (uint64_t)c->opt_mlp_tail << 46 | (uint64_t)c->opt_embed_split << 48 | (uint64_t)(c->opt_mlp_fold >> 1) << 49),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45 | (uint64_t)c->opt_mlp_tail << 46 | (uint64_t)c->opt_embed_split << 48),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

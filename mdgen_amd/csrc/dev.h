@@ -13,23 +13,16 @@
 //   MDGEN_DEV_QKV_STAMPS        k_ln_qkv / k_ln_qkv_attn4: phase stamps         (scripts/micro/qkv_stamps.py, scripts/r05/attn4_stamps.py)
 //   MDGEN_DEV_MLP_STAMPX        k_mlp: stamp inside one fc1 stage              (scripts/micro/mlp_stampx.py)
 //   MDGEN_DEV_ROWS_NOGELU       k_mlp_rows: main loop without its VALU work, timing only (values wrong)
-//   MDGEN_DEV_ROWS_NOREARM / _NOACCREAD / _NOPOLY   k_mlp_rows (round 6): the GELU groups without their accumulator re-arm (v_accvgpr_write) / without
-//                               their accumulator reads (v_accvgpr_read) / the f16 form without five of its Horner steps, timing only (values wrong)
 //   MDGEN_DEV_ROWS_COALESCED    k_mlp_rows: row loads as coalesced 1 KiB requests, timing only (values wrong)
 //   MDGEN_DEV_ATTN16_NOEXP / _NOSTAGE / _NOMMA / _NOBAR   k16_attn*: one ingredient of the chunk loop left out, timing only (values wrong)
 //   MDGEN_DEV_WIDE_STAMPS       k16_linear_wide: s_memtime stamps per k-step phase (scripts/micro/wide_stamps.py)
 //   MDGEN_DEV_WIDE_NOLOAD / _NOMMA / _NOSTORE   k16_linear_wide: one phase of the k-step left out, timing only (values wrong)
 #pragma once
 
-#ifdef MDGEN_DEV_ROWS_NOACC   // both accumulator-file switches together
-#define MDGEN_DEV_ROWS_NOREARM 1
-#define MDGEN_DEV_ROWS_NOACCREAD 1
-#endif
-
 #if defined(MDGEN_DEV_FLASH_TRUNC) || defined(MDGEN_DEV_FLASH_NOPRIO) || defined(MDGEN_DEV_FLASH_NOEARLY) || \
     defined(MDGEN_DEV_FLASH_STAMPS) || defined(MDGEN_DEV_FLASH_NOLOAD) || defined(MDGEN_DEV_FLASH_NOFALLBACK) || \
     defined(MDGEN_DEV_QKV_STAMPS) ||  defined(MDGEN_DEV_MLP_STAMPX) || defined(MDGEN_DEV_ROWS_NOGELU) ||           \
-    defined(MDGEN_DEV_ROWS_COALESCED) || defined(MDGEN_DEV_ROWS_NOREARM) || defined(MDGEN_DEV_ROWS_NOACCREAD) || defined(MDGEN_DEV_ROWS_NOPOLY) ||  defined(MDGEN_DEV_WIDE_NOLOAD) || defined(MDGEN_DEV_WIDE_NOMMA) ||        \
+    defined(MDGEN_DEV_ROWS_COALESCED) || defined(MDGEN_DEV_WIDE_NOLOAD) || defined(MDGEN_DEV_WIDE_NOMMA) ||        \
     defined(MDGEN_DEV_WIDE_NOSTORE) || defined(MDGEN_DEV_WIDE_STAMPS) || \
     defined(MDGEN_DEV_ATTN16_NOEXP) || defined(MDGEN_DEV_ATTN16_NOSTAGE) ||         \
     defined(MDGEN_DEV_ATTN16_NOMMA) || defined(MDGEN_DEV_ATTN16_NOBAR)

@@ -20,21 +20,13 @@ namespace mdg {
 // 2304 fragments = 96 ring slots; one iteration = 96 fragments = the whole ring, so every LDS address in the loop
 // body is a compile-time constant.
 // =================================================================================================
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// H16 (round 6, the folded form with option mlp_fold 2): the hidden activations are IEEE half instead of bf16 -- hf holds f16 bit
-// patterns, the fc2 fragments of the stream are f16 (k_pack_fold) and stage Y runs v_mfma_f32_32x32x16_f16 -- so that the GELU can be
-// evaluated two values per instruction on the packed-f16 VALU ops (gelu16_stage).
-template <bool H16>
-struct MlpPipeT {
-    static constexpr bool kH16 = H16;
+struct MlpPipe {
     f32x16 y[12];
     f32x16 a1[2][2];
     bf16x8 hf[2][4];
     bf16x8 wr[kWRing];
     f32x4 bias;       // fc1 bias (LDS copy of b1) the accumulator registers of the GELU group in flight are re-armed with
     float gx[4], gp[4], gq[4];   // GELU state of the four values of the group in flight
-    f16x2 hx[2], hz[2], hr[2], hl[2];   // ... of the packed-f16 form (two values per register)
 };
 
 // GELU of group g (0..7) of a chunk = hidden tile g >> 2, accumulator registers 4 (g & 3) .. + 3 -> half of the fragment
@@ -45,9 +37,6 @@ struct MlpPipeT {
 // matrix pipe hides ~5, MI355X_MICROARCH "one wave per SIMD").  The fc1 bias is not added here: the accumulators
 // START from it -- stages 7, 10, 11 re-arm the four registers with the bias of the chunk two further on (REARM).
 __device__ __forceinline__ void acc_rearm(f32x16& t, int r, float b) {
-#ifdef MDGEN_DEV_ROWS_NOREARM   // (experiment build, timing only: no accumulator re-arm -- the fc1 bias is lost)
-    return;
-#endif
     float z;
     asm("v_accvgpr_write_b32 %0, %1" : "=a"(z) : "v"(b));
     t[r] = z;
@@ -57,17 +46,13 @@ __device__ __forceinline__ void acc_rearm(f32x16& t, int r, float b) {
 // coefficient has the wrong sign for large |x|, hence the clamp of x^2 at 64 (|x| > 8: Phi is 0 or 1 in fp32 anyway).
 // Constants carry the factor -log2(e): the exponential is a bare v_exp_f32.
 constexpr float kGelu3C0 = -2.301208258e+00f, kGelu3C1 = -1.066924557e-01f, kGelu3C2 = 1.000115648e-03f;
-template <int ST, bool REARM, class MP>
-__device__ __forceinline__ void gelu_stage(MP& m, f32x16 (&a1r)[2], int g, bf16x8 (&hfw)[4]) {
+template <int ST, bool REARM>
+__device__ __forceinline__ void gelu_stage(MlpPipe& m, f32x16 (&a1r)[2], int g, bf16x8 (&hfw)[4]) {
     const int tile = g >> 2, a = g & 3;
     if (ST == 0) {
         // explicit accumulator-file reads: left to hipcc, the whole 16-register tuple is copied to VGPRs at its first use
 #pragma unroll
-#ifdef MDGEN_DEV_ROWS_NOACCREAD   // (experiment build, timing only: the group's inputs are not the accumulators)
-        for (int j = 0; j < 4; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(m.gx[j]) : "v"(m.bias[j]));
-#else
         for (int j = 0; j < 4; ++j) asm("v_accvgpr_read_b32 %0, %1" : "=v"(m.gx[j]) : "a"(a1r[tile][4 * a + j]));
-#endif
     } else if (ST == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) m.gq[j] = m.gx[j] * m.gx[j];
@@ -120,77 +105,9 @@ __device__ __forceinline__ void gelu_stage(MP& m, f32x16 (&a1r)[2], int g, bf16x
         hfw[kk][e0 + 3] = (__bf16)m.gx[3];
     }
 }
-// The packed-f16 form (H16): gelu(x) = max(x, 0) - h(min(|x|, 4)),  h(a) = a Phi(-a)  (exact identity for the erf GELU, layers.py:77-84;
-// h <= 0.17, h(4) = 1.3e-4: both tails are exact by construction, no cancellation anywhere), h as a degree-7 polynomial in
-// z = a / 2 - 1 in [-1, 1] (coefficients of order 0.1: Horner is stable in half precision).  Two values per instruction
-// (v_pk_{max,min,add,fma}_f16), no transcendental: 34 VALU instructions per group of four values where the fp32 form issues 46, eight of
-// them quarter-rate.  Error of the result against the exact GELU, evaluated in emulated f16 (scripts/fit_gelu.py --f16): rms 2.8e-4
-// for N(0, 1) pre-activations -- the bf16 rounding the fp32 form's result receives is 1.1e-3 -- and 2^-11 relative for large x
-// (the f16 rounding of x itself; bf16: 2^-9).  Pre-activations beyond the f16 range (|x| > 65504) become inf.
-// Twelve stages as gelu_stage; the result registers ARE two of the four dwords of the fc2 B-operand fragment.
-constexpr float kG16C[8] = {4.535109900e-02f, -1.715763697e-01f, 2.218589398e-01f, 1.425205394e-02f,
-                            -3.257676889e-01f, 2.390770075e-01f, 5.842357391e-02f, -8.168925724e-02f};
-__device__ __forceinline__ f16x2 h2c(float v) { return f16x2{(_Float16)v, (_Float16)v}; }
-template <int ST, bool REARM, class MP>
-__device__ __forceinline__ void gelu16_stage(MP& m, f32x16 (&a1r)[2], int g, bf16x8 (&hfw)[4]) {
-    const int tile = g >> 2, a = g & 3;
-    if (ST == 0) {
-#pragma unroll
-#ifdef MDGEN_DEV_ROWS_NOACCREAD   // (experiment build, timing only: the group's inputs are not the accumulators)
-        for (int j = 0; j < 4; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(m.gx[j]) : "v"(m.bias[j]));
-#else
-        for (int j = 0; j < 4; ++j) asm("v_accvgpr_read_b32 %0, %1" : "=v"(m.gx[j]) : "a"(a1r[tile][4 * a + j]));
-#endif
-    } else if (ST == 1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const f32x2 v = {m.gx[2 * i], m.gx[2 * i + 1]};
-            m.hx[i] = __builtin_convertvector(v, f16x2);   // v_cvt_pk_f16_f32 (round to nearest even)
-        }
-    } else if (ST == 2) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) m.hz[i] = __builtin_elementwise_max(m.hx[i], -m.hx[i]);   // |x|
-    } else if (ST == 3) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            m.hz[i] = __builtin_elementwise_min(m.hz[i], h2c(4.0f));
-            m.hl[i] = __builtin_elementwise_max(m.hx[i], h2c(0.0f));
-        }
-    } else if (ST == 4) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            m.hz[i] = m.hz[i] * h2c(0.5f) + h2c(-1.0f);
-            m.hl[i] = m.hl[i] - h2c(kG16C[0]);
-        }
-    } else if (ST == 5) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) m.hr[i] = h2c(kG16C[7]) * m.hz[i] + h2c(kG16C[6]);
-    } else if (ST >= 6 && ST <= 10) {
-#ifndef MDGEN_DEV_ROWS_NOPOLY   // (experiment build, timing only: five of the seven Horner steps left out)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) m.hr[i] = m.hr[i] * m.hz[i] + h2c(kG16C[11 - ST]);
-#endif
-        if (REARM && ST == 6) {
-            acc_rearm(a1r[tile], 4 * a + 0, m.bias[0]);
-            acc_rearm(a1r[tile], 4 * a + 1, m.bias[1]);
-        }
-        if (REARM && ST == 10) {
-            acc_rearm(a1r[tile], 4 * a + 2, m.bias[2]);
-            acc_rearm(a1r[tile], 4 * a + 3, m.bias[3]);
-        }
-    } else {
-        const int kk = 2 * tile + (a >> 1), e0 = 2 * (a & 1);
-        u32x4 t = __builtin_bit_cast(u32x4, hfw[kk]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) t[e0 + i] = __builtin_bit_cast(uint32_t, (f16x2)(m.hl[i] - m.hr[i] * m.hz[i]));
-        hfw[kk] = __builtin_bit_cast(bf16x8, t);
-    }
-}
-template <bool REARM, int ST = 0, class MP>
-__device__ __forceinline__ void gelu_stages_from(MP& m, f32x16 (&a1r)[2], int g, bf16x8 (&hfw)[4]) {
-    if constexpr (MP::kH16) gelu16_stage<ST, REARM>(m, a1r, g, hfw);
-    else gelu_stage<ST, REARM>(m, a1r, g, hfw);
+template <bool REARM, int ST = 0>
+__device__ __forceinline__ void gelu_stages_from(MlpPipe& m, f32x16 (&a1r)[2], int g, bf16x8 (&hfw)[4]) {
+    gelu_stage<ST, REARM>(m, a1r, g, hfw);
     if constexpr (ST < 11) gelu_stages_from<REARM, ST + 1>(m, a1r, g, hfw);
 }
 // The four accumulator registers a GELU group has consumed start their next accumulation (the chunk two further on, which
@@ -225,26 +142,21 @@ __device__ __forceinline__ void issue_q(const WS& ws, long slot, int q) {
     }
 }
 
-template <bool REARM, int ST, class MP>
-__device__ __forceinline__ void gelu_stage_any(MP& m, f32x16 (&a1r)[2], int g, bf16x8 (&hfw)[4]) {
-    if constexpr (MP::kH16) gelu16_stage<ST, REARM>(m, a1r, g, hfw);
-    else gelu_stage<ST, REARM>(m, a1r, g, hfw);
-}
-template <bool REARM, class MP>
-__device__ __forceinline__ void gelu_stage_q(MP& m, f32x16 (&a1r)[2], int g, int q, bf16x8 (&hfw)[4]) {
+template <bool REARM>
+__device__ __forceinline__ void gelu_stage_q(MlpPipe& m, f32x16 (&a1r)[2], int g, int q, bf16x8 (&hfw)[4]) {
     switch (q) {   // q is a constant after unrolling
-        case 0: gelu_stage_any<REARM, 0>(m, a1r, g, hfw); break;
-        case 1: gelu_stage_any<REARM, 1>(m, a1r, g, hfw); break;
-        case 2: gelu_stage_any<REARM, 2>(m, a1r, g, hfw); break;
-        case 3: gelu_stage_any<REARM, 3>(m, a1r, g, hfw); break;
-        case 4: gelu_stage_any<REARM, 4>(m, a1r, g, hfw); break;
-        case 5: gelu_stage_any<REARM, 5>(m, a1r, g, hfw); break;
-        case 6: gelu_stage_any<REARM, 6>(m, a1r, g, hfw); break;
-        case 7: gelu_stage_any<REARM, 7>(m, a1r, g, hfw); break;
-        case 8: gelu_stage_any<REARM, 8>(m, a1r, g, hfw); break;
-        case 9: gelu_stage_any<REARM, 9>(m, a1r, g, hfw); break;
-        case 10: gelu_stage_any<REARM, 10>(m, a1r, g, hfw); break;
-        default: gelu_stage_any<REARM, 11>(m, a1r, g, hfw); break;
+        case 0: gelu_stage<0, REARM>(m, a1r, g, hfw); break;
+        case 1: gelu_stage<1, REARM>(m, a1r, g, hfw); break;
+        case 2: gelu_stage<2, REARM>(m, a1r, g, hfw); break;
+        case 3: gelu_stage<3, REARM>(m, a1r, g, hfw); break;
+        case 4: gelu_stage<4, REARM>(m, a1r, g, hfw); break;
+        case 5: gelu_stage<5, REARM>(m, a1r, g, hfw); break;
+        case 6: gelu_stage<6, REARM>(m, a1r, g, hfw); break;
+        case 7: gelu_stage<7, REARM>(m, a1r, g, hfw); break;
+        case 8: gelu_stage<8, REARM>(m, a1r, g, hfw); break;
+        case 9: gelu_stage<9, REARM>(m, a1r, g, hfw); break;
+        case 10: gelu_stage<10, REARM>(m, a1r, g, hfw); break;
+        default: gelu_stage<11, REARM>(m, a1r, g, hfw); break;
     }
 }
 
@@ -258,8 +170,8 @@ __device__ __forceinline__ void gelu_stage_q(MP& m, f32x16 (&a1r)[2], int g, int
 //   BARVM >= 0: the block opens a ring slot: barrier with that vmcnt first
 //   FILL  issue this wave's DMAs of slot `fill_slot` (half of them per block: a slot is two blocks)
 //   NLOOK look-ahead reads are issued for the first NLOOK fragments only (end of the stream)
-template <int NW, int I0, int KIND, int KI, int GG, bool REARM, int BARVM, bool FILL, int NLOOK = 12, class WS, class MP>
-__device__ __forceinline__ void pipe_block(MP& m, const bf16x8 (&xf)[24], f32x16 (&a1w)[2], f32x16 (&a1r)[2],
+template <int NW, int I0, int KIND, int KI, int GG, bool REARM, int BARVM, bool FILL, int NLOOK = 12, class WS>
+__device__ __forceinline__ void pipe_block(MlpPipe& m, const bf16x8 (&xf)[24], f32x16 (&a1w)[2], f32x16 (&a1r)[2],
                                            bf16x8 (&hfw)[4], const bf16x8 (&hfr)[4], const float* b1n,
                                            const unsigned char* ring_lane, const WS& ws, long fill_slot) {
     constexpr int FPW = WS::FPW, DPB = FPW / 2, STRIDE = 12 / DPB;
@@ -275,10 +187,7 @@ __device__ __forceinline__ void pipe_block(MP& m, const bf16x8 (&xf)[24], f32x16
             const int ks = 6 * KI + (q >> 1), tile = q & 1;
             a1w[tile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], xf[ks], a1w[tile], 0, 0, 0);
         } else if (KIND == 1) {
-            if constexpr (MP::kH16)
-                m.y[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, m.wr[I % kWRing]), __builtin_bit_cast(f16x8, hfr[KI]), m.y[q], 0, 0, 0);
-            else
-                m.y[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], hfr[KI], m.y[q], 0, 0, 0);
+            m.y[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], hfr[KI], m.y[q], 0, 0, 0);
         } else {   // KIND 2: out-projection, k-step KI of the attention output rows (xf), 12 feature tiles
             m.y[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m.wr[I % kWRing], xf[KI], m.y[q], 0, 0, 0);
         }
@@ -290,8 +199,8 @@ __device__ __forceinline__ void pipe_block(MP& m, const bf16x8 (&xf)[24], f32x16
 }
 
 // a whole GELU group without MFMAs beside it (pipeline fill / drain only)
-template <bool REARM, class MP>
-__device__ __forceinline__ void gelu_group_plain(MP& m, f32x16 (&a1r)[2], const float* b1n, int g, bf16x8 (&hfw)[4]) {
+template <bool REARM>
+__device__ __forceinline__ void gelu_group_plain(MlpPipe& m, f32x16 (&a1r)[2], const float* b1n, int g, bf16x8 (&hfw)[4]) {
     if (REARM) m.bias = *reinterpret_cast<const f32x4*>(b1n + 32 * (g >> 2) + 8 * (g & 3));
     gelu_stages_from<REARM>(m, a1r, g, hfw);
 }
@@ -305,8 +214,8 @@ __device__ __forceinline__ void gelu_group_plain(MP& m, f32x16 (&a1r)[2], const 
 
 // out-projection blocks KS .. 23 of the fused form (one block = one k-step of the attention output rows x 12 feature tiles;
 // two blocks per ring slot, slot s = global slot: barrier + refill of slot s + 3)
-template <int NW, int KS, class WS, class MP>
-__device__ __forceinline__ void proj_blocks(MP& m, const bf16x8 (&xf)[24], const unsigned char* ring_lane, const WS& ws) {
+template <int NW, int KS, class WS>
+__device__ __forceinline__ void proj_blocks(MlpPipe& m, const bf16x8 (&xf)[24], const unsigned char* ring_lane, const WS& ws) {
     constexpr int FPW = WS::FPW;
     pipe_block<NW, (12 * KS) % kRingFrags, 2, KS, -1, false, (KS & 1) == 0 ? FPW : -1, true>(
         m, xf, m.a1[0], m.a1[1], m.hf[0], m.hf[1], nullptr, ring_lane, ws, KS / 2 + 3);
@@ -326,13 +235,10 @@ __device__ __forceinline__ void proj_blocks(MP& m, const bf16x8 (&xf)[24], const
 // TAIL (with FOLD; the trunk's last layer in a sampling call): the FinalLayer -- LN + modulate, Linear C -> D, Euler update of x
 // (layers.py:57-74, integrators.py:106; k_final's work) -- runs on the updated rows straight from the accumulators (the row image is
 // the LayerNorm image) and the rows are never stored.
-// H16 (with FOLD; option mlp_fold 2): hidden activations and the stream's fc2 fragments in IEEE half, GELU on the packed-f16 VALU ops
-// (gelu16_stage).
-template <int NW, bool PROJ, bool MODLDS, bool FOLD = false, bool TAIL = false, bool H16 = false>
+template <int NW, bool PROJ, bool MODLDS, bool FOLD = false, bool TAIL = false>
 __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) {
     static_assert(!FOLD || (MODLDS && !PROJ), "the folded form: one modulation group per launch, no fused out-projection");
     static_assert(!TAIL || FOLD, "the tail runs on the folded form's accumulators");
-    static_assert(!H16 || FOLD, "f16 fc2 fragments exist only in the per-call folded streams");
     // ring | fc1 bias | slack: the last re-arm reads the (non-existent) chunk 24 | per wave: scale, shift, gate chunks (2 KiB slots)
     // | TAIL: the final layer's shift, scale chunks (2 KiB slots, shared by the waves)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kRingBytes + 8192 + NW * 6144 + (TAIL ? 4096 : 0)];
@@ -383,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_rows(const MlpRowsParams p) 
     ws.issue_slot(2);
     float* b1s = reinterpret_cast<float*>(smem + kRingBytes);
     bf16x8 xf[24];
-    MlpPipeT<H16> m;
+    MlpPipe m;
     const unsigned char* ring_lane = smem + lane * 16;
     if (PROJ) {
         rows_load_bf16(p.o, tok, xf);
@@ -547,7 +453,6 @@ struct PackFoldParams {
     const int* tab;
     bf16x8* dst;                 // [S * nl][kMlpFrags * 64]
     float* b2g;                  // [S * nl][384]
-    int h16;                     // fc2 fragments as IEEE half bit patterns (k_mlp_rows<.., H16>) instead of bf16
 };
 __global__ __launch_bounds__(256) void k_pack_fold(const PackFoldParams p) {
     const int sl = blockIdx.y, s = sl / p.nl, l = sl % p.nl;
@@ -566,28 +471,17 @@ __global__ __launch_bounds__(256) void k_pack_fold(const PackFoldParams p) {
         const float g = gate[row];
         const float* wr = p.w2[l] + (size_t)row * kF + 16 * ks + 4 * hh;   // kappa: cols 16 ks + 8 (j >> 2) + 4 hh + (j & 3)
         const f32x4 a = *reinterpret_cast<const f32x4*>(wr), b = *reinterpret_cast<const f32x4*>(wr + 8);
-        if (p.h16) {
-            f16x8 hv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {   // (clamped to the finite f16 range; values below 6e-8 flush to zero)
-                hv[j] = (_Float16)fminf(fmaxf(a[j] * g, -65504.f), 65504.f);
-                hv[4 + j] = (_Float16)fminf(fmaxf(b[j] * g, -65504.f), 65504.f);
-            }
-            v = __builtin_bit_cast(bf16x8, hv);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = (__bf16)(a[j] * g);
-                v[4 + j] = (__bf16)(b[j] * g);
-            }
+        for (int j = 0; j < 4; ++j) {
+            v[j] = (__bf16)(a[j] * g);
+            v[4 + j] = (__bf16)(b[j] * g);
         }
     }
     p.dst[(size_t)sl * (2304 * 64) + i] = v;
 }
 void launch_pack_fold(const float* mod, long mod_step_stride, int S, int nl, const int* goff, const float* const* w2,
-                      const float* const* b2, const bf16x8* const* base, const int* tab, bf16x8* dst, float* b2g, int h16, hipStream_t s) {
+                      const float* const* b2, const bf16x8* const* base, const int* tab, bf16x8* dst, float* b2g, hipStream_t s) {
     PackFoldParams p{};
-    p.h16 = h16;
     p.mod = mod;
     p.mod_step_stride = mod_step_stride;
     p.nl = nl;
@@ -662,9 +556,7 @@ static void launch_mlp_rows_nw(const MlpRowsParams& p, long tiles, hipStream_t s
         if (uni) hipLaunchKernelGGL((k_mlp_rows<NW, true, true>), g, b, 0, s, p);
         else hipLaunchKernelGGL((k_mlp_rows<NW, true, false>), g, b, 0, s, p);
     } else {
-        if (p.b2g && p.h16 && p.tail_w) hipLaunchKernelGGL((k_mlp_rows<NW, false, true, true, true, true>), g, b, 0, s, p);
-        else if (p.b2g && p.h16) hipLaunchKernelGGL((k_mlp_rows<NW, false, true, true, false, true>), g, b, 0, s, p);
-        else if (p.b2g && p.tail_w) hipLaunchKernelGGL((k_mlp_rows<NW, false, true, true, true>), g, b, 0, s, p);
+        if (p.b2g && p.tail_w) hipLaunchKernelGGL((k_mlp_rows<NW, false, true, true, true>), g, b, 0, s, p);
         else if (p.b2g) hipLaunchKernelGGL((k_mlp_rows<NW, false, true, true>), g, b, 0, s, p);   // (the caller has checked: one modulation group)
         else if (uni) hipLaunchKernelGGL((k_mlp_rows<NW, false, true>), g, b, 0, s, p);
         else hipLaunchKernelGGL((k_mlp_rows<NW, false, false>), g, b, 0, s, p);

@@ -91,7 +91,6 @@ struct MlpRowsParams {
     // gate fold (non-null; o == null, every row of the launch shares the modulation row): `wstream` is the (step, layer) stream with
     // the gate folded into fc2 and b2g = gate * b2 (launch_pack_fold): accumulators start from the residual rows, store-only epilogue
     const float* b2g;
-    int h16;   // ... and the stream's fc2 fragments are IEEE half: the hidden activations are computed and multiplied in f16 (option mlp_fold 2)
     // tail (with b2g, the trunk's LAST layer): FinalLayer + Euler update (layers.py:57-74, integrators.py:106) run on the updated rows while
     // they are still in registers, and the rows are NOT stored (nothing reads the residual stream after the last layer): k_final's
     // launch, its 98 MB read and this kernel's 98 MB write are gone.  tail_w: emb_to_latent.linear.weight as 24 fragments in kappa
@@ -223,7 +222,7 @@ void launch_mlp_rows(const MlpRowsParams& p, int nw, hipStream_t s);
 constexpr int kMlpStreamFrags = 2304;   // 1 KiB fragments of one MLP weight stream (api.hip mlp_stream_table)
 // per-(step, layer) MLP streams with the step's gate folded into fc2 (+ b2g = gate * b2); S * nl streams, nl <= 8
 void launch_pack_fold(const float* mod, long mod_step_stride, int S, int nl, const int* goff, const float* const* w2,
-                      const float* const* b2, const bf16x8* const* base, const int* tab, bf16x8* dst, float* b2g, int h16, hipStream_t s);
+                      const float* const* b2, const bf16x8* const* base, const int* tab, bf16x8* dst, float* b2g, hipStream_t s);
 // rowmap (nullable): source row of packed row r (a permutation of the matrix's rows); kappa: K order inside a k-step -- 0
 // natural, 1 rows.h kappa (operand = LayerNorm / GELU registers)
 void launch_pack_stream(const float* w, int ld, int which, const int* tab, int nfrag, float scale, int kappa, bf16x8* dst,
