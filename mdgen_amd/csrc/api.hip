@@ -1055,10 +1055,7 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
             q.wo = m.wo;
             q.bo = m.bo;
             q.gate_chunk = gate;
-            // launches of at most one workgroup per CU: eight waves per panel (k_ln_qkv_attn4<true, true>; tag "@p8")
-            const int pw = panel_waves_for((nrows + kPanel - 1) / kPanel, r.c->opt_panel_waves, r.c->ncu);
-            const std::string cls = std::string(residue_axis && trunk ? "attn_L_fused" : c_qkv) + (pw == 8 ? "@p8" : "");
-            { ProfScope ps(r.c, r.c->intern(cls), r.s); if (!g_dry) launch_ln_qkv_attn4(q, true, r.s, pw); }
+            { ProfScope ps(r.c, residue_axis && trunk ? "attn_L_fused" : c_qkv, r.s); if (!g_dry) launch_ln_qkv_attn4(q, true, r.s); }
             LAUNCHCHK();
         } else {
             { ProfScope ps(r.c, c_qkv, r.s); if (!g_dry) launch_ln_qkv_attn4(q, false, r.s); }

@@ -224,8 +224,8 @@ extern "C" int mdgen_dev_attn4_stamps(void* host, size_t bytes) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn4_stamps), bytes);
 }
 #define ATTN4_STAMP(slot)                                                                                    \
-    if (lane_id() == 0 && (long)blockIdx.x * (blockDim.x >> 6) + wave_id() < 8192)                             \
-    g_attn4_stamps[((long)blockIdx.x * (blockDim.x >> 6) + wave_id()) * 16 + (slot)] = __builtin_amdgcn_s_memtime()
+    if (lane_id() == 0 && (long)blockIdx.x * 4 + wave_id() < 8192)                                             \
+    g_attn4_stamps[((long)blockIdx.x * 4 + wave_id()) * 16 + (slot)] = __builtin_amdgcn_s_memtime()
 #else
 #define QKV_STAMP(slot)
 #define ATTN4_STAMP(slot)
@@ -336,14 +336,13 @@ __device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// the 12 values a lane holds for head hd of its token (tile tt of the wave's TT) in the transposed QKV accumulators, + bias
-template <int TT = 2>
+// the 12 values a lane holds for head hd of its token (tile tt) in the transposed QKV accumulators, + bias
 __device__ __forceinline__ void head_values(const f32x16* acc, int tt, int hd, const f32x4 (&bq)[3], float (&e)[12]) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) e[4 * c + b] = acc[ft * TT + tt][4 * a + b] + bq[c][b];
+        for (int b = 0; b < 4; ++b) e[4 * c + b] = acc[ft * 2 + tt][4 * a + b] + bq[c][b];
     }
 }
 __device__ __forceinline__ void load_head_bias(const float* bias_perm, int w, int hh, f32x4 (&bq)[4][3]) {
@@ -428,74 +427,57 @@ __global__ __launch_bounds__(512, 1) void k_ln_qkv8(const QkvParams p) {
 // spills (3 / 4) or with 8 more spilled dwords (4 / 4) and change nothing: 129.4-132.8 us per launch at cfg-2 for all four
 // combinations on one box (profiles/r05_experiments.txt #9).
 constexpr int kAttn4KPF = 2, kAttn4VPF = 3;
-#ifdef MDGEN_DEV_ATTN4_DEEP   // (experiment build: the eight-wave form with every weight ring six k-steps deep -- it has the registers)
-constexpr int kAttn4DeepPF = 6;
-#else
-constexpr int kAttn4DeepPF = 0;
-#endif
-// EIGHT (with PROJ; launches of at most one workgroup per CU: B = 1, cfg-3's shard, round 6): the panel goes to EIGHT waves -- wave
-// w8 = head group w8 & 3 of the 32-token tile w8 >> 2 -- so a wave's chain (three QKV products, the 5-key attention, the out-projection,
-// the residual epilogue) is half as long; a weight fragment then feeds one MFMA instead of two, which a launch that leaves CUs idle can
-// afford (the same trade was slower for the chip-filling q | k | v kernel: r04 #17).  With one tile per wave q and P stay in registers
-// (no stash), and every wave has its own 12 KiB epilogue slab (8 x 12 KiB: the panel region is sized for them).
-template <bool PROJ, bool EIGHT = false>
-__global__ __launch_bounds__(EIGHT ? 512 : 256, EIGHT ? 1 : 2) void k_ln_qkv_attn4(const QkvParams p) {
-    static_assert(!EIGHT || PROJ, "the eight-wave form is the whole sub-layer");
-    constexpr int TT = EIGHT ? 1 : 2;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + (EIGHT ? 8 * 32 * 96 * 4 : kPanelBytes)];
+template <bool PROJ>
+__global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
     // q of the second 32-token tile waits in LDS while the K GEMM runs ([wave][value][lane]: conflict-free): with
     // all 48 packed q registers live across that GEMM hipcc spilled ~90 registers per lane -- 180 MB of scratch
     // traffic per launch, more than the q/k/v stores this kernel exists to avoid.
-    __shared__ uint32_t qstash[EIGHT ? 1 : 4][24][64];
+    __shared__ uint32_t qstash[4][24][64];
     PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
     unsigned char* panel = smem + sizeof(PanelRows);
     ATTN4_STAMP(0);
     setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
     __syncthreads();
-    const int w8 = __builtin_amdgcn_readfirstlane(wave_id()), w = EIGHT ? w8 & 3 : w8, t0 = EIGHT ? w8 >> 2 : 0;
-    if (!EIGHT) prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
-    else if (t0 == 0) prologue_ln<false, 0, 2>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane_id());
-    else prologue_ln<false, 2, 4>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane_id());
+    prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
     __syncthreads();
     ATTN4_STAMP(1);
-    const int lane = lane_id(), hh = lane >> 5, tk = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id(), hh = lane >> 5, tk = lane & 31;
     constexpr int L = 4;
     // per-token constants: token id, key validity of the own token; the rotary factors (position = token % 4)
     // are re-read from the (L2-resident) table after each GEMM rather than held across it
-    int tok[TT];
-    float mval[TT];
+    int tok[2];
+    float mval[2];
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-        tok[tt] = pr->tok[(t0 + tt) * 32 + tk];
+    for (int tt = 0; tt < 2; ++tt) {
+        tok[tt] = pr->tok[tt * 32 + tk];
         mval[tt] = p.mk.at(tok[tt] < 0 ? 0 : tok[tt]);
     }
-    auto load_rope = [&](f32x4 (&rq)[TT][4]) {
+    auto load_rope = [&](f32x4 (&rq)[2][4]) {
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) {
+        for (int tt = 0; tt < 2; ++tt) {
             const int tc = tok[tt] < 0 ? 0 : tok[tt];
             const f32x4* rc = reinterpret_cast<const f32x4*>(p.rope + (long)(tc & (L - 1)) * kRopeRow + 16 * hh);
 #pragma unroll
             for (int i = 0; i < 4; ++i) rq[tt][i] = rc[i];
         }
     };
-    f32x16 acc[3 * TT];
+    f32x16 acc[6];
     f32x4 bb[4][3];
-    f32x4 rq[TT][4];
+    f32x4 rq[2][4];
     // ---- Q (heads 4w..4w+3): RoPE, keep as bf16 pairs (48 registers)
-    zero_acc<3 * TT>(acc);
-    constexpr int QPF = EIGHT && kAttn4DeepPF ? kAttn4DeepPF : 4, KPF = EIGHT && kAttn4DeepPF ? kAttn4DeepPF : kAttn4KPF,
-                  VPF = EIGHT && kAttn4DeepPF ? kAttn4DeepPF : kAttn4VPF;
-    wave_gemm<TT, 3, 24, true, QPF>(panel, kRowB, t0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     ATTN4_STAMP(2);
     load_head_bias(p.bq, w, hh, bb);
     load_rope(rq);
-    uint32_t qp[TT][4][6];
+    uint32_t qp[2][4][6];
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int hd = 0; hd < 4; ++hd) {
             float e[12];
-            head_values<TT>(acc, tt, hd, bb[hd], e);
+            head_values(acc, tt, hd, bb[hd], e);
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 const float c = rq[tt][q >> 2][q & 3], sn = rq[tt][2 + (q >> 2)][q & 3];
@@ -503,27 +485,25 @@ __global__ __launch_bounds__(EIGHT ? 512 : 256, EIGHT ? 1 : 2) void k_ln_qkv_att
                 qp[tt][hd][q] = pack_bf16(x1 * c - x2 * sn, x2 * c + x1 * sn);
             }
         }
-    if constexpr (!EIGHT) {
 #pragma unroll
-        for (int hd = 0; hd < 4; ++hd)
+    for (int hd = 0; hd < 4; ++hd)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) qstash[w][hd * 6 + q][lane] = qp[TT - 1][hd][q];
-    }
+        for (int q = 0; q < 6; ++q) qstash[w][hd * 6 + q][lane] = qp[1][hd][q];
     ATTN4_STAMP(3);
     __builtin_amdgcn_sched_barrier(0);
     // ---- K: RoPE in place, then the scores of the 4 keys of the quad + the bias key; softmax -> P (40 registers)
-    zero_acc<3 * TT>(acc);
-    wave_gemm<TT, 3, 24, true, KPF>(panel, kRowB, t0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);   // (q is live)
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, 24, true, kAttn4KPF>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);   // (q is live)
     ATTN4_STAMP(4);
     load_head_bias(p.bk, w, hh, bb);
     load_rope(rq);
     // pass 1: bias + RoPE IN PLACE in the accumulators (frees the bias / rotary registers before the scores)
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int hd = 0; hd < 4; ++hd) {
             float k[12];
-            head_values<TT>(acc, tt, hd, bb[hd], k);
+            head_values(acc, tt, hd, bb[hd], k);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
@@ -532,15 +512,15 @@ __global__ __launch_bounds__(EIGHT ? 512 : 256, EIGHT ? 1 : 2) void k_ln_qkv_att
                     const int q = 2 * c + b2;
                     const float cs = rq[tt][q >> 2][q & 3], sn = rq[tt][2 + (q >> 2)][q & 3];
                     const float x1 = k[2 * q], x2 = k[2 * q + 1];
-                    acc[ft * TT + tt][4 * a + 2 * b2] = x1 * cs - x2 * sn;
-                    acc[ft * TT + tt][4 * a + 2 * b2 + 1] = x2 * cs + x1 * sn;
+                    acc[ft * 2 + tt][4 * a + 2 * b2] = x1 * cs - x2 * sn;
+                    acc[ft * 2 + tt][4 * a + 2 * b2 + 1] = x2 * cs + x1 * sn;
                 }
             }
         }
     ATTN4_STAMP(5);
     __builtin_amdgcn_sched_barrier(0);
     // pass 2: scores against the 4 keys of the quad + the bias key, softmax -> P (40 registers)
-    float P[TT][4][5];
+    float P[2][4][5];
     {
         // learned bias key (mha.py:265-268), rotated at position L like every key (:356-357), rounded to bf16
         const float* rcL = p.rope + (long)L * kRopeRow + 16 * hh;
@@ -556,17 +536,17 @@ __global__ __launch_bounds__(EIGHT ? 512 : 256, EIGHT ? 1 : 2) void k_ln_qkv_att
                 kb[2 * q + 1] = bf16_lo(pack_bf16(x2 * c + x1 * sn, 0.f));
             }
 #pragma unroll
-            for (int tt = 0; tt < TT; ++tt) {
+            for (int tt = 0; tt < 2; ++tt) {
                 float k[12], qf[12];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
 #pragma unroll
-                    for (int b2 = 0; b2 < 4; ++b2) k[4 * c + b2] = acc[ft * TT + tt][4 * a + b2];
+                    for (int b2 = 0; b2 < 4; ++b2) k[4 * c + b2] = acc[ft * 2 + tt][4 * a + b2];
                 }
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
-                    const uint32_t u = (EIGHT || tt == 0) ? qp[tt][hd][q] : qstash[w][hd * 6 + q][lane];
+                    const uint32_t u = tt == 0 ? qp[0][hd][q] : qstash[w][hd * 6 + q][lane];
                     qf[2 * q] = bf16_lo(u);
                     qf[2 * q + 1] = bf16_hi(u);
                 }
@@ -604,28 +584,22 @@ __global__ __launch_bounds__(EIGHT ? 512 : 256, EIGHT ? 1 : 2) void k_ln_qkv_att
     ATTN4_STAMP(6);
     // the 40 attention weights of this lane wait in the (now free) q stash as 20 bf16 pairs while the V GEMM runs
     // (bf16 weights: what the streaming kernel feeds its PV MFMA as well)
-    // (the eight-wave form: 20 weights as 10 packed registers, rounded to bf16 alike, held across the GEMM)
-    uint32_t Pk[10];
-    if constexpr (EIGHT) {
-        const float* Pf = &P[0][0][0];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) Pk[i] = pack_bf16(Pf[2 * i], Pf[2 * i + 1]);
-    } else {
+    {
         const float* Pf = &P[0][0][0];
 #pragma unroll
         for (int i = 0; i < 20; ++i) qstash[w][i][lane] = pack_bf16(Pf[2 * i], Pf[2 * i + 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- V (transposed as well: a lane holds features 12 hh .. 12 hh + 11 of each head of its token)
-    zero_acc<3 * TT>(acc);
-    wave_gemm<TT, 3, 24, true, VPF>(panel, kRowB, t0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, 24, true, kAttn4VPF>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     ATTN4_STAMP(7);
     load_head_bias(p.bv, w, hh, bb);
     {
         float* Pf = &P[0][0][0];
 #pragma unroll
-        for (int i = 0; i < 10 * TT; ++i) {
-            const uint32_t u = EIGHT ? Pk[i % 10] : qstash[w][i][lane];
+        for (int i = 0; i < 20; ++i) {
+            const uint32_t u = qstash[w][i][lane];
             Pf[2 * i] = bf16_lo(u);
             Pf[2 * i + 1] = bf16_hi(u);
         }
@@ -640,9 +614,9 @@ __global__ __launch_bounds__(EIGHT ? 512 : 256, EIGHT ? 1 : 2) void k_ln_qkv_att
 #pragma unroll
         for (int i = 0; i < 12; ++i) bvv[i] = bf16_lo(pack_bf16(p.bias_v[head * kDH + 12 * hh + i], 0.f));
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) {
+        for (int tt = 0; tt < 2; ++tt) {
             float v[12], o[12];
-            head_values<TT>(acc, tt, hd, bb[hd], v);
+            head_values(acc, tt, hd, bb[hd], v);
 #pragma unroll
             for (int i = 0; i < 12; ++i)
                 o[i] = P[tt][hd][0] * quad_bcast<0>(v[i]) + P[tt][hd][1] * quad_bcast<1>(v[i]) +
@@ -651,7 +625,7 @@ __global__ __launch_bounds__(EIGHT ? 512 : 256, EIGHT ? 1 : 2) void k_ln_qkv_att
                 const bool ok = tok[tt] >= 0;   // padding rows enter the GEMM as zeros
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
-                    *reinterpret_cast<u32x2*>(panel + panel_off((t0 + tt) * 32 + tk, head * 48 + hh * 24 + 8 * i, kRowB)) =
+                    *reinterpret_cast<u32x2*>(panel + panel_off(tt * 32 + tk, head * 48 + hh * 24 + 8 * i, kRowB)) =
                         u32x2{ok ? pack_bf16(o[4 * i], o[4 * i + 1]) : 0u, ok ? pack_bf16(o[4 * i + 2], o[4 * i + 3]) : 0u};
             } else if (tok[tt] >= 0) {
                 u32x2* d = reinterpret_cast<u32x2*>(p.obuf + (long)tok[tt] * kC + head * kDH + hh * 12);
@@ -668,18 +642,12 @@ __global__ __launch_bounds__(EIGHT ? 512 : 256, EIGHT ? 1 : 2) void k_ln_qkv_att
     ATTN4_STAMP(8);
     // (the epilogue's first batch of residual rows requested ahead of this GEMM, as k_flash_proj does: measured, no gain here -- 130.6
     // against 128-130 us per launch, 125.9k against 126.4k frames/s; profiles/r06_experiments.txt #6)
-    zero_acc<3 * TT>(acc);
-    wave_gemm<TT, 3, 24, false, QPF>(panel, kRowB, t0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    zero_acc<6>(acc);
+    wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     ATTN4_STAMP(9);
-    __syncthreads();   // every wave is done reading the panel: reuse it as four (eight) 12 KiB staging slabs
-    if constexpr (EIGHT) {
-        float* stage = reinterpret_cast<float*>(panel) + w8 * (32 * 96);
-        epi_stage(acc, stage);
-        epi_rmw<8>(t0, pr, stage, 96 * w, p.bo, p.mm, p.gate_chunk, true, p.h_rw);
-    } else {
-        epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk,
-                                      true, p.h_rw);
-    }
+    __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
+    epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk,
+                                  true, p.h_rw);
     ATTN4_STAMP(10);
 }
 
@@ -1370,16 +1338,9 @@ __global__ void k_xcc_probe(int* out) {
 }
 void launch_xcc_probe(int* out, int nblocks, hipStream_t s) { hipLaunchKernelGGL(k_xcc_probe, dim3(nblocks), dim3(64), 0, s, out); }
 
-void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s, int waves) {
+void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-#ifdef MDGEN_DEV_ATTN4_FOUR   // (experiment build, A/B of the eight-wave form: every launch takes the four-wave kernel, whatever the tag says)
-    waves = 4;
-#endif
-#ifdef MDGEN_DEV_ATTN4_EIGHT  // (... every launch takes the eight-wave kernel: the chip-filling launches of cfg-2 too)
-    waves = 8;
-#endif
-    if (fuse_proj && waves == 8) hipLaunchKernelGGL((k_ln_qkv_attn4<true, true>), dim3(grid), dim3(512), 0, s, p);
-    else if (fuse_proj) hipLaunchKernelGGL((k_ln_qkv_attn4<true>), dim3(grid), dim3(256), 0, s, p);
+    if (fuse_proj) hipLaunchKernelGGL((k_ln_qkv_attn4<true>), dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_ln_qkv_attn4<false>), dim3(grid), dim3(256), 0, s, p);
 }
 void launch_proj(const ProjParams& p, int mode, hipStream_t s) {
