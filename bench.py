@@ -125,7 +125,7 @@ def cpu_baseline(cfg, sd, B, T, L, S, n_pad, budget_s=20.0):
 # kernel class (hipEvent profile name) -> substring of the rocprof kernel name
 _KERNEL_OF_CLASS = {"mlp": "k_mlp", "proj_mlp": "k_mlp_rows", "flash_T": "k_flash<", "flash_L": "k_flash<", "ln_qkv_T": "k_ln_qkv<false",
                     "ln_qkv_L": "k_ln_qkv<true", "proj_T": "k_proj<0>", "proj_L": "k_proj<2>",
-                    "attn_L_fused": "k_ln_qkv_attn4<true>", "flash_proj_T": "k_flash_proj", "flash_proj_L": "k_flash_proj",
+                    "attn_L_fused": "k_ln_qkv_attn4<true, false>", "attn_L_fused@h32": "k_ln_qkv_attn4<true, true>", "flash_proj_T": "k_flash_proj", "flash_proj_L": "k_flash_proj",
                     "projL_qkvT": "k_ln_qkv<false, true>",
                     # tagged classes name ONE kernel form (looked up before the untagged base class)
                     "mlp@fold": "k_mlp_rows<4, false, true, true>", "mlp@p4": "k_mlp<3, false>", "mlp@p8": "k_mlp8<false>",

@@ -223,12 +223,22 @@ __device__ unsigned long long g_attn4_stamps[8192 * 16];
 extern "C" int mdgen_dev_attn4_stamps(void* host, size_t bytes) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn4_stamps), bytes);
 }
-#define ATTN4_STAMP(slot)                                                                                    \
-    if (lane_id() == 0 && (long)blockIdx.x * 4 + wave_id() < 8192)                                             \
-    g_attn4_stamps[((long)blockIdx.x * 4 + wave_id()) * 16 + (slot)] = __builtin_amdgcn_s_memtime()
+// (round 6: the stamps are held in SGPRs and written by ONE branch at the end of the kernel -- a store under `if (lane == 0)` per stamp
+// splits the kernel into basic blocks around which hipcc spilled 60-190 registers, and a spilled kernel's phases are not the product's)
+#define ATTN4_STAMP_DECL unsigned long long a4st[11] = {}
+#define ATTN4_STAMP(slot)                          \
+    a4st[slot] = __builtin_amdgcn_s_memtime();     \
+    __builtin_amdgcn_sched_barrier(0)
+#define ATTN4_STAMP_FLUSH                                                                                   \
+    if (lane_id() == 0 && (long)blockIdx.x * 4 + wave_id() < 8192) {                                          \
+        _Pragma("unroll") for (int k = 0; k < 11; ++k)                                                        \
+            g_attn4_stamps[((long)blockIdx.x * 4 + wave_id()) * 16 + k] = a4st[k];                            \
+    }
 #else
 #define QKV_STAMP(slot)
+#define ATTN4_STAMP_DECL
 #define ATTN4_STAMP(slot)
+#define ATTN4_STAMP_FLUSH
 #endif
 
 // PRE (FLASH layout only): the panel first runs the PREVIOUS sub-layer's out-projection + gated residual for its 64 tokens
@@ -336,13 +346,14 @@ __device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// the 12 values a lane holds for head hd of its token (tile tt) in the transposed QKV accumulators, + bias
+// the 12 values a lane holds for head hd of its token (tile tt of the wave's TT) in the transposed QKV accumulators, + bias
+template <int TT = 2>
 __device__ __forceinline__ void head_values(const f32x16* acc, int tt, int hd, const f32x4 (&bq)[3], float (&e)[12]) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) e[4 * c + b] = acc[ft * 2 + tt][4 * a + b] + bq[c][b];
+        for (int b = 0; b < 4; ++b) e[4 * c + b] = acc[ft * TT + tt][4 * a + b] + bq[c][b];
     }
 }
 __device__ __forceinline__ void load_head_bias(const float* bias_perm, int w, int hh, f32x4 (&bq)[4][3]) {
@@ -427,57 +438,72 @@ __global__ __launch_bounds__(512, 1) void k_ln_qkv8(const QkvParams p) {
 // spills (3 / 4) or with 8 more spilled dwords (4 / 4) and change nothing: 129.4-132.8 us per launch at cfg-2 for all four
 // combinations on one box (profiles/r05_experiments.txt #9).
 constexpr int kAttn4KPF = 2, kAttn4VPF = 3;
-template <bool PROJ>
+// HALF (with PROJ; launches of at most HALF a workgroup per CU: B = 1; round 6): a workgroup takes 32 rows instead of 64 -- the panel's
+// upper half stays empty, every wave computes ONE 32-token tile (TT = 1) -- so the launch has twice the workgroups on twice the CUs and
+// every SIMD half the work: a small launch lasts as long as one wave's chain (profiles/r06_experiments.txt #14: 87k cycles per wave at
+// B = 1 and at cfg-3's shard alike), and the chain is LN prologue + four products + the 5-key attention + the residual epilogue of the
+// rows the SIMD owns.  (Eight waves on the same 64 rows -- r06 #13 -- only put two waves on every SIMD: the same work per SIMD, a tie.)
+// A weight fragment then feeds one MFMA instead of two, which only a launch that leaves CUs idle can afford.  q and P stay in registers.
+template <bool PROJ, bool HALF = false>
 __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
+    static_assert(!HALF || PROJ, "the half-panel form is the whole sub-layer");
+    constexpr int TT = HALF ? 1 : 2, kRows = HALF ? 32 : kPanel;
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
     // q of the second 32-token tile waits in LDS while the K GEMM runs ([wave][value][lane]: conflict-free): with
     // all 48 packed q registers live across that GEMM hipcc spilled ~90 registers per lane -- 180 MB of scratch
     // traffic per launch, more than the q/k/v stores this kernel exists to avoid.
-    __shared__ uint32_t qstash[4][24][64];
+    __shared__ uint32_t qstash[HALF ? 1 : 4][24][64];
     PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
     unsigned char* panel = smem + sizeof(PanelRows);
+    ATTN4_STAMP_DECL;
     ATTN4_STAMP(0);
-    setup_rows_linear(pr, (long)blockIdx.x * kPanel, p.nrows, p.mm);
+    {
+        const long row0 = (long)blockIdx.x * kRows, rend = row0 + kRows;
+        setup_rows_linear(pr, row0, rend < p.nrows ? rend : p.nrows, p.mm);   // (HALF: rows 32 .. 63 of the panel are padding rows)
+    }
     __syncthreads();
-    prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
+    const int w = __builtin_amdgcn_readfirstlane(wave_id());
+    constexpr int t0 = 0;
+    if (HALF) prologue_ln<false, 0, 2>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane_id());
+    else prologue_ln<false>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f);
     __syncthreads();
     ATTN4_STAMP(1);
-    const int w = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id(), hh = lane >> 5, tk = lane & 31;
+    const int lane = lane_id(), hh = lane >> 5, tk = lane & 31;
     constexpr int L = 4;
     // per-token constants: token id, key validity of the own token; the rotary factors (position = token % 4)
     // are re-read from the (L2-resident) table after each GEMM rather than held across it
-    int tok[2];
-    float mval[2];
+    int tok[TT];
+    float mval[TT];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        tok[tt] = pr->tok[tt * 32 + tk];
+    for (int tt = 0; tt < TT; ++tt) {
+        tok[tt] = pr->tok[(t0 + tt) * 32 + tk];
         mval[tt] = p.mk.at(tok[tt] < 0 ? 0 : tok[tt]);
     }
-    auto load_rope = [&](f32x4 (&rq)[2][4]) {
+    auto load_rope = [&](f32x4 (&rq)[TT][4]) {
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
             const int tc = tok[tt] < 0 ? 0 : tok[tt];
             const f32x4* rc = reinterpret_cast<const f32x4*>(p.rope + (long)(tc & (L - 1)) * kRopeRow + 16 * hh);
 #pragma unroll
             for (int i = 0; i < 4; ++i) rq[tt][i] = rc[i];
         }
     };
-    f32x16 acc[6];
+    f32x16 acc[3 * TT];
     f32x4 bb[4][3];
-    f32x4 rq[2][4];
+    f32x4 rq[TT][4];
     // ---- Q (heads 4w..4w+3): RoPE, keep as bf16 pairs (48 registers)
-    zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    zero_acc<3 * TT>(acc);
+    wave_gemm<TT, 3, 24, true>(panel, kRowB, t0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     ATTN4_STAMP(2);
     load_head_bias(p.bq, w, hh, bb);
     load_rope(rq);
-    uint32_t qp[2][4][6];
+    uint32_t qp[TT][4][6];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
         for (int hd = 0; hd < 4; ++hd) {
             float e[12];
-            head_values(acc, tt, hd, bb[hd], e);
+            head_values<TT>(acc, tt, hd, bb[hd], e);
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 const float c = rq[tt][q >> 2][q & 3], sn = rq[tt][2 + (q >> 2)][q & 3];
@@ -485,25 +511,27 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
                 qp[tt][hd][q] = pack_bf16(x1 * c - x2 * sn, x2 * c + x1 * sn);
             }
         }
+    if constexpr (!HALF) {
 #pragma unroll
-    for (int hd = 0; hd < 4; ++hd)
+        for (int hd = 0; hd < 4; ++hd)
 #pragma unroll
-        for (int q = 0; q < 6; ++q) qstash[w][hd * 6 + q][lane] = qp[1][hd][q];
+            for (int q = 0; q < 6; ++q) qstash[w][hd * 6 + q][lane] = qp[TT - 1][hd][q];
+    }
     ATTN4_STAMP(3);
     __builtin_amdgcn_sched_barrier(0);
     // ---- K: RoPE in place, then the scores of the 4 keys of the quad + the bias key; softmax -> P (40 registers)
-    zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, true, kAttn4KPF>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);   // (q is live)
+    zero_acc<3 * TT>(acc);
+    wave_gemm<TT, 3, 24, true, HALF ? 4 : kAttn4KPF>(panel, kRowB, t0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);   // (q is live)
     ATTN4_STAMP(4);
     load_head_bias(p.bk, w, hh, bb);
     load_rope(rq);
     // pass 1: bias + RoPE IN PLACE in the accumulators (frees the bias / rotary registers before the scores)
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
         for (int hd = 0; hd < 4; ++hd) {
             float k[12];
-            head_values(acc, tt, hd, bb[hd], k);
+            head_values<TT>(acc, tt, hd, bb[hd], k);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
@@ -512,15 +540,15 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
                     const int q = 2 * c + b2;
                     const float cs = rq[tt][q >> 2][q & 3], sn = rq[tt][2 + (q >> 2)][q & 3];
                     const float x1 = k[2 * q], x2 = k[2 * q + 1];
-                    acc[ft * 2 + tt][4 * a + 2 * b2] = x1 * cs - x2 * sn;
-                    acc[ft * 2 + tt][4 * a + 2 * b2 + 1] = x2 * cs + x1 * sn;
+                    acc[ft * TT + tt][4 * a + 2 * b2] = x1 * cs - x2 * sn;
+                    acc[ft * TT + tt][4 * a + 2 * b2 + 1] = x2 * cs + x1 * sn;
                 }
             }
         }
     ATTN4_STAMP(5);
     __builtin_amdgcn_sched_barrier(0);
     // pass 2: scores against the 4 keys of the quad + the bias key, softmax -> P (40 registers)
-    float P[2][4][5];
+    float P[TT][4][5];
     {
         // learned bias key (mha.py:265-268), rotated at position L like every key (:356-357), rounded to bf16
         const float* rcL = p.rope + (long)L * kRopeRow + 16 * hh;
@@ -536,17 +564,17 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
                 kb[2 * q + 1] = bf16_lo(pack_bf16(x2 * c + x1 * sn, 0.f));
             }
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
+            for (int tt = 0; tt < TT; ++tt) {
                 float k[12], qf[12];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
 #pragma unroll
-                    for (int b2 = 0; b2 < 4; ++b2) k[4 * c + b2] = acc[ft * 2 + tt][4 * a + b2];
+                    for (int b2 = 0; b2 < 4; ++b2) k[4 * c + b2] = acc[ft * TT + tt][4 * a + b2];
                 }
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
-                    const uint32_t u = tt == 0 ? qp[0][hd][q] : qstash[w][hd * 6 + q][lane];
+                    const uint32_t u = (HALF || tt == 0) ? qp[tt][hd][q] : qstash[w][hd * 6 + q][lane];
                     qf[2 * q] = bf16_lo(u);
                     qf[2 * q + 1] = bf16_hi(u);
                 }
@@ -584,22 +612,28 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     ATTN4_STAMP(6);
     // the 40 attention weights of this lane wait in the (now free) q stash as 20 bf16 pairs while the V GEMM runs
     // (bf16 weights: what the streaming kernel feeds its PV MFMA as well)
-    {
+    // (the half-panel form: 20 weights as 10 packed registers, rounded to bf16 alike, held across the GEMM)
+    uint32_t Pk[10];
+    if constexpr (HALF) {
+        const float* Pf = &P[0][0][0];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) Pk[i] = pack_bf16(Pf[2 * i], Pf[2 * i + 1]);
+    } else {
         const float* Pf = &P[0][0][0];
 #pragma unroll
         for (int i = 0; i < 20; ++i) qstash[w][i][lane] = pack_bf16(Pf[2 * i], Pf[2 * i + 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- V (transposed as well: a lane holds features 12 hh .. 12 hh + 11 of each head of its token)
-    zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, true, kAttn4VPF>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    zero_acc<3 * TT>(acc);
+    wave_gemm<TT, 3, 24, true, HALF ? 4 : kAttn4VPF>(panel, kRowB, t0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     ATTN4_STAMP(7);
     load_head_bias(p.bv, w, hh, bb);
     {
         float* Pf = &P[0][0][0];
 #pragma unroll
-        for (int i = 0; i < 20; ++i) {
-            const uint32_t u = qstash[w][i][lane];
+        for (int i = 0; i < 10 * TT; ++i) {
+            const uint32_t u = HALF ? Pk[i % 10] : qstash[w][i][lane];
             Pf[2 * i] = bf16_lo(u);
             Pf[2 * i + 1] = bf16_hi(u);
         }
@@ -614,9 +648,9 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) bvv[i] = bf16_lo(pack_bf16(p.bias_v[head * kDH + 12 * hh + i], 0.f));
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
             float v[12], o[12];
-            head_values(acc, tt, hd, bb[hd], v);
+            head_values<TT>(acc, tt, hd, bb[hd], v);
 #pragma unroll
             for (int i = 0; i < 12; ++i)
                 o[i] = P[tt][hd][0] * quad_bcast<0>(v[i]) + P[tt][hd][1] * quad_bcast<1>(v[i]) +
@@ -625,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
                 const bool ok = tok[tt] >= 0;   // padding rows enter the GEMM as zeros
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
-                    *reinterpret_cast<u32x2*>(panel + panel_off(tt * 32 + tk, head * 48 + hh * 24 + 8 * i, kRowB)) =
+                    *reinterpret_cast<u32x2*>(panel + panel_off((t0 + tt) * 32 + tk, head * 48 + hh * 24 + 8 * i, kRowB)) =
                         u32x2{ok ? pack_bf16(o[4 * i], o[4 * i + 1]) : 0u, ok ? pack_bf16(o[4 * i + 2], o[4 * i + 3]) : 0u};
             } else if (tok[tt] >= 0) {
                 u32x2* d = reinterpret_cast<u32x2*>(p.obuf + (long)tok[tt] * kC + head * kDH + hh * 12);
@@ -642,13 +676,20 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_attn4(const QkvParams p) {
     ATTN4_STAMP(8);
     // (the epilogue's first batch of residual rows requested ahead of this GEMM, as k_flash_proj does: measured, no gain here -- 130.6
     // against 128-130 us per launch, 125.9k against 126.4k frames/s; profiles/r06_experiments.txt #6)
-    zero_acc<6>(acc);
-    wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+    zero_acc<3 * TT>(acc);
+    wave_gemm<TT, 3, 24, false>(panel, kRowB, t0, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
     ATTN4_STAMP(9);
     __syncthreads();   // every wave is done reading the panel: reuse it as four 12 KiB staging slabs
-    epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk,
-                                  true, p.h_rw);
+    if constexpr (HALF) {
+        float* stage = reinterpret_cast<float*>(panel) + w * (32 * 96);
+        epi_stage(acc, stage);
+        epi_rmw<8>(0, pr, stage, 96 * w, p.bo, p.mm, p.gate_chunk, true, p.h_rw);
+    } else {
+        epilogue_gate_residual_lds<3>(acc, pr, reinterpret_cast<float*>(panel) + w * (32 * 96), 96 * w, p.bo, p.mm, p.gate_chunk,
+                                      true, p.h_rw);
+    }
     ATTN4_STAMP(10);
+    ATTN4_STAMP_FLUSH
 }
 
 // =================================================================================================
@@ -1338,9 +1379,13 @@ __global__ void k_xcc_probe(int* out) {
 }
 void launch_xcc_probe(int* out, int nblocks, hipStream_t s) { hipLaunchKernelGGL(k_xcc_probe, dim3(nblocks), dim3(64), 0, s, out); }
 
-void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s) {
+void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s, bool half) {
     const int grid = (int)((p.nrows + kPanel - 1) / kPanel);
-    if (fuse_proj) hipLaunchKernelGGL((k_ln_qkv_attn4<true>), dim3(grid), dim3(256), 0, s, p);
+#ifdef MDGEN_DEV_ATTN4_FULL   // (experiment build, A/B of the half-panel form: every launch takes 64-row panels, whatever the tag says)
+    half = false;
+#endif
+    if (fuse_proj && half) hipLaunchKernelGGL((k_ln_qkv_attn4<true, true>), dim3((unsigned)((p.nrows + 31) / 32)), dim3(256), 0, s, p);
+    else if (fuse_proj) hipLaunchKernelGGL((k_ln_qkv_attn4<true>), dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_ln_qkv_attn4<false>), dim3(grid), dim3(256), 0, s, p);
 }
 void launch_proj(const ProjParams& p, int mode, hipStream_t s) {

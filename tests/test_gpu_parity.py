@@ -662,7 +662,8 @@ def test_forward_headline_regime_vs_reference_and_oracle(name):
     ref, rtr = O.forward(sd, O.cfg_dict(cfg), return_trace=True, **kw)
     # third pass (round 6): the reference's own T = 1000 golden through the HEADLINE's kernels, forced -- by shape this B 2 call takes
     # k_flash + the eight-wave panel kernels; the bench line's B 8 views take k_flash_proj8 / k_mlp_rows / k_ln_qkv<false, false>
-    forced = {"flash_proj": 2, "flash_proj_form": 8, "mlp_path": 2, "panel_waves": 4}
+    # (small_split 0: at B 2 the L = 4 sub-layer kernel would otherwise take its 32-row form, "attn_L_fused@h32")
+    forced = {"flash_proj": 2, "flash_proj_form": 8, "mlp_path": 2, "panel_waves": 4, "small_split": 0}
     for prec, tol in (("bf16", TOL_FWD), ("fp32", 1e-5), ("bf16 headline kernels", TOL_FWD)):
         hk = prec == "bf16 headline kernels"
         if hk and T < 512:
