@@ -151,12 +151,6 @@ struct mdgen_ctx {
     int opt_panel_waves = 0;    // 64-row panel kernels with a four- and an eight-wave form (k_mlp / k_mlp8, k_ln_qkv<false> / k_ln_qkv8): 0 (default)
                                 // eight waves where a launch is at most one workgroup per CU, 4 / 8 force one form (tests, A/B runs)
     int ncu = 256;              // compute units of the device the context was created on (hipDeviceAttributeMultiprocessorCount)
-    int opt_l2_warm = 0;        // small launches (one stream, at most one 32-row workgroup per CU): the NEXT kernel's weights are touched from every XCD
-                                // by a side-stream launch beside the current kernel (k_l2_warm): a hint, same results bit for bit
-    unsigned* warm_sink = nullptr;
-    hipEvent_t ev_warm = nullptr;
-    bool warm_live = false;     // the call being recorded / run qualifies (set by the entry point, cleared when it joins the side stream)
-    bool warm_used = false;     // ... and has launched a warmer on side[0]: join before the call returns / the capture ends
     int opt_small_split = 1;    // launches far below one workgroup per CU (B = 1, the IPA stack): a panel's work over several workgroups --
                                 // k_mlp8<., kMlpSplit> (hidden chunks over 3 workgroups, last arriver finishes; panels <= ncu / 3) and
                                 // k_ln_qkv8<true> (q, k | v over 2 workgroups; panels <= ncu / 2).  0 off, 1 (default) on
@@ -519,8 +513,6 @@ extern "C" int32_t mdgen_ctx_create(mdgen_ctx** out, const mdgen_model_desc* d) 
         TRYHIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
     TRYHIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    TRYHIP(hipEventCreateWithFlags(&c->ev_warm, hipEventDisableTiming));
-    TRY(c->dalloc(&c->warm_sink, 64));
     TRY(c->dalloc(&c->wfin, (size_t)kKS * 64));
     TRY(c->dalloc(&c->wfin_k, (size_t)kKS * 64));
     TRY(c->dalloc(&c->bfin, (size_t)32));
@@ -624,7 +616,6 @@ extern "C" int32_t mdgen_ctx_destroy(mdgen_ctx* c) {
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_warm) (void)hipEventDestroy(c->ev_warm);
     for (hipEvent_t e : c->train_ev) (void)hipEventDestroy(e);
     if (c->train_side) (void)hipStreamDestroy(c->train_side);
     for (int i = 0; i < mdgen_ctx::kMaxSide; ++i) {
@@ -710,9 +701,6 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "fuse_proj_qkv") {
         if (value != 0 && value != 1) return fail(-2, "fuse_proj_qkv must be 0 or 1");
         c->opt_fuse_proj_qkv = value;
-    } else if (n == "l2_warm") {
-        if (value != 0 && value != 1) return fail(-2, "l2_warm must be 0 or 1");
-        c->opt_l2_warm = value;
     } else if (n == "small_split") {
         if (value != 0 && value != 1) return fail(-2, "small_split must be 0 or 1");
         c->opt_small_split = value;
@@ -1443,41 +1431,6 @@ static int prepare(Run& r, const float* t_dev, const float* t_host, long view_ro
 // One network evaluation at prepared step `step`: x -> velocity (out) or Euler update of x in place.
 // h0_ready: the previous step's last MLP launch has already written this step's token embedding into h (no k_embed launch);
 // next_h0 (nullable): ask this step to do the same for step + 1; *next_h0 = true when it did.
-// L2 warmer (option l2_warm; k_small.hip k_l2_warm): touch `ranges` from every XCD on side[0], ordered behind everything enqueued on
-// r.s so far -- i.e. BESIDE the next launch on r.s -- so that the launch after that one finds its weights in L2.  Small single-stream
-// calls only (warm_begin); a hint: it reads, the results are the same bits with and without it.
-static bool warm_qualifies(const mdgen_ctx* c, long N) {
-    return c->opt_l2_warm && c->opt_precision == 16 && c->xcd_round_robin && N <= (long)c->ncu * kPanel;
-}
-static int warm_ahead(const Run& r, std::initializer_list<std::pair<const void*, size_t>> ranges) {
-    mdgen_ctx* c = r.c;
-    if (!c->warm_live || g_dry) return 0;
-    WarmParams q{};
-    for (const auto& x : ranges)
-        if (x.first && q.n < 6) {
-            q.p[q.n] = x.first;
-            q.bytes[q.n] = (unsigned)x.second;
-            ++q.n;
-        }
-    if (q.n == 0) return 0;
-    HIPCHK(hipEventRecord(c->ev_warm, r.s));
-    HIPCHK(hipStreamWaitEvent(c->side[0], c->ev_warm, 0));
-    launch_l2_warm(q, c->warm_sink, c->side[0]);
-    LAUNCHCHK();
-    c->warm_used = true;
-    return 0;
-}
-static int warm_join(const Run& r) {   // (also ends the qualification: every entry point that sets warm_live calls this on its way out)
-    mdgen_ctx* c = r.c;
-    c->warm_live = false;
-    if (!c->warm_used) return 0;
-    c->warm_used = false;
-    HIPCHK(hipEventRecord(c->ev_join[0], c->side[0]));
-    HIPCHK(hipStreamWaitEvent(r.s, c->ev_join[0], 0));
-    return 0;
-}
-constexpr size_t kPackCCBytes = kPackCC * sizeof(bf16x8);
-
 static int denoise_step(const Run& r, int step, float* x, float* out, int euler, float dt, float* trace_h, bool h0_ready = false,
                         bool* next_h0 = nullptr) {
     mdgen_ctx* c = r.c;
@@ -1550,24 +1503,14 @@ static int denoise_step(const Run& r, int step, float* x, float* out, int euler,
         ProjParams def_l{};
         {
             const bool fuse_lt = c->opt_fuse_proj_qkv && r.L > 8 && r.T > 8;
-            // (beside the residue-axis sub-layer: the temporal q / k / v weights)
-            if (int er = warm_ahead(r, {{w.mha_t.wq, kPackCCBytes}, {w.mha_t.wk, kPackCCBytes}, {w.mha_t.wv_flash, kPackCCBytes}})) return er;
             if (int er = attn_sublayer(r, w.mha_l, h, r.N, axL, mm, 0, 1, 2, mk, true, true, fuse_lt ? &def_l : nullptr)) return er;
         }
         ProjParams deferred{};
         const bool fuse = c->opt_fuse_proj == 2 || (c->opt_fuse_proj == 1 && mlp_uses_rows(c, r.N)) ||
                           (c->opt_fuse_proj == 3 && !mlp_uses_rows(c, r.N));
-        // (beside the temporal q / k / v kernel: the MLP block's weights and the temporal out-projection)
-        if (int er = warm_ahead(r, {{w.ffn.w1, 4 * kPackCCBytes}, {w.ffn.w2, 4 * kPackCCBytes}, {w.mha_t.wo, kPackCCBytes}})) return er;
         if (int er = attn_sublayer(r, w.mha_t, h, r.N, axT, mm, 3, 4, 5, mk, false, true, fuse ? &deferred : nullptr,
                                    def_l.a_bf16 ? &def_l : nullptr))
             return er;
-        {   // (beside the MLP kernel: the next layer's -- or the next step's first layer's -- residue-axis weights)
-            const MhaW& nx = c->trunk[(i + 1) % c->nl].mha_l;
-            if (int er = warm_ahead(r, {{nx.wq, kPackCCBytes}, {nx.wk, kPackCCBytes}, {r.L <= 8 ? nx.wv_small : nx.wv_flash, kPackCCBytes},
-                                        {nx.wo, kPackCCBytes}}))
-                return er;
-        }
         // the last layer's MLP may run the FinalLayer as its tail (then h is NOT written: not with a residual-stream trace)
         const bool last = i == c->nl - 1 && !trace_h;
         if (int er = mlp_sublayer(r, w.ffn, h, r.N, mm, 6, 7, 8, true, &deferred, w.mha_t.wo_stream, (long)step * c->nl + i,
@@ -1713,12 +1656,7 @@ static int euler_body(const Run& r_in, const std::vector<float>& tg, float* x) {
     if (nv == 0) return fail(-2, "sample too large for one launch");
     if (int e = prepare(r, nullptr, tg.data(), (long)((r.B + nv - 1) / nv) * r.T * r.L)) return e;
     r.c->live_streams = 1;
-    if (nv == 1) {
-        r.c->warm_live = warm_qualifies(r.c, r.N);
-        const int e = euler_steps(r, tg, x);
-        const int ej = warm_join(r);
-        return e ? e : ej;
-    }
+    if (nv == 1) return euler_steps(r, tg, x);
     struct Live {   // the views below run on ns streams at once: kernels that use context-owned scratch stay off meanwhile
         mdgen_ctx* c;
         ~Live() { c->live_streams = 1; }
@@ -1811,7 +1749,7 @@ extern "C" int32_t mdgen_sample_euler(mdgen_ctx* c, const mdgen_shape* sh, int32
     std::vector<uint64_t> key = {0u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)x,
                                  (uint64_t)mask, (uint64_t)start_rot, (uint64_t)start_trans, (uint64_t)end_rot,
                                  (uint64_t)end_trans, (uint64_t)x_cond, (uint64_t)x_cond_mask, (uint64_t)aatype,
-                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45 | (uint64_t)c->opt_mlp_tail << 46 | (uint64_t)c->opt_embed_split << 48 | (uint64_t)c->opt_l2_warm << 49), (uint64_t)c->opt_precision,
+                                 (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45 | (uint64_t)c->opt_mlp_tail << 46 | (uint64_t)c->opt_embed_split << 48), (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path, (uint64_t)rel7};
     return replay_or_capture(c, key, r.s, [&]() { return euler_body(r, tg, x); });
 }
@@ -1871,7 +1809,7 @@ extern "C" int32_t mdgen_rollout_euler(mdgen_ctx* c, const mdgen_shape* sh, int3
     std::vector<uint64_t> key = {1u, (uint64_t)sh->B, (uint64_t)sh->T, (uint64_t)sh->L, (uint64_t)S, (uint64_t)n_blocks,
                                  (uint64_t)zs, (uint64_t)mask, (uint64_t)cond_rots, (uint64_t)cond_trans,
                                  (uint64_t)cond_torsions, (uint64_t)seqres, (uint64_t)x_cond, (uint64_t)x_cond_mask,
-                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45 | (uint64_t)c->opt_mlp_tail << 46 | (uint64_t)c->opt_embed_split << 48 | (uint64_t)c->opt_l2_warm << 49),
+                                 (uint64_t)atom14, (uint64_t)ws, (uint64_t)n_streams(r), (uint64_t)(c->opt_residue_l4 | c->opt_mlp_path << 8 | c->opt_fuse_proj << 12 | c->opt_fuse_proj_qkv << 20 | c->opt_flash_proj << 24 | (uint64_t)c->opt_panel_waves << 32 | (uint64_t)c->opt_flash_rotate << 36 | (uint64_t)c->opt_flash_proj_form << 40 | (uint64_t)c->opt_small_split << 44 | (uint64_t)c->opt_mlp_fold << 45 | (uint64_t)c->opt_mlp_tail << 46 | (uint64_t)c->opt_embed_split << 48),
                                  (uint64_t)t.default_frames, (uint64_t)t.atom37_to_atom14, (uint64_t)c->opt_precision,
                                  (uint64_t)c->opt_attn_path};
     return replay_or_capture(c, key, r.s, body);

@@ -793,27 +793,4 @@ void launch_ipa_attn(const IpaAttnParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_ipa_attn, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
 }
 
-// ---- L2 warmer (round 6; option l2_warm) ---------------------------------------------------------------------------------------
-// A small launch (B = 1: 63-125 workgroups) runs its workgroups in lock step: every one of them asks for the SAME weight fragment at
-// the same moment, and since a layer's 4.7 MB of packed weights x 5 layers do not stay in an XCD's 4 MB L2 from one network
-// evaluation to the next, each k-step of each GEMM waits for a fetch from beyond L2 (stamps: 270 cycles per k-step with four k-steps
-// of weights in flight, profiles/r06_experiments.txt #15).  This kernel runs on a side stream BESIDE kernel k and touches the weights of
-// kernel k + 1: workgroups with equal blockIdx % 8 share an XCD (the dispatcher's round robin, probed at mdgen_ctx_create), and every
-// XCD's group reads one word of every 128-byte line of every range.  A hint only: it reads; the one conditional store
-// (into a scratch word of the context, when the XOR of a thread's words happens to equal a constant) exists to keep the loads alive.
-__global__ __launch_bounds__(256) void k_l2_warm(const WarmParams q, unsigned* sink) {
-    const unsigned part = blockIdx.x >> 3, nparts = gridDim.x >> 3;
-    unsigned acc = 0;
-    for (int i = 0; i < q.n; ++i) {
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(q.p[i]);
-        const unsigned nline = q.bytes[i] >> 7;
-        for (unsigned j = part * 256 + threadIdx.x; j < nline; j += nparts * 256)
-            acc ^= *reinterpret_cast<const unsigned*>(src + (size_t)j * 128);
-    }
-    if (acc == 0x9e3779b9u) *sink = acc;
-}
-void launch_l2_warm(const WarmParams& q, unsigned* sink, hipStream_t s) {
-    hipLaunchKernelGGL(k_l2_warm, dim3(8 * 8), dim3(256), 0, s, q, sink);
-}
-
 }  // namespace mdg

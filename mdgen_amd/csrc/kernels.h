@@ -215,13 +215,6 @@ struct FloatChunk {
 int panel_waves_for(long grid, int forced, int ncu);   // 4 or 8 waves per 64-row panel for a launch of `grid` panels
 void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre = false, int waves = 4, bool split = false);
 void launch_xcc_probe(int* out, int nblocks, hipStream_t s);
-// L2 warmer (k_small.hip): touch every 128-byte line of up to six ranges from every XCD (64 workgroups); reads only
-struct WarmParams {
-    const void* p[6];
-    unsigned bytes[6];
-    int n;
-};
-void launch_l2_warm(const WarmParams& q, unsigned* sink, hipStream_t s);
 void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s, bool half = false);   // half: 32-row workgroups (fuse_proj only)
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);
 void launch_mlp(const MlpParams& p, hipStream_t s, int waves = 4);
