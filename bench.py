@@ -130,7 +130,7 @@ _KERNEL_OF_CLASS = {"mlp": "k_mlp", "proj_mlp": "k_mlp_rows", "flash_T": "k_flas
                     # tagged classes name ONE kernel form (looked up before the untagged base class)
                     "mlp@fold": "k_mlp_rows<4, false, true, true>", "mlp@p4": "k_mlp<3, false>", "mlp@p8": "k_mlp8<false>",
                     "mlp@p8x3": "k_mlp8<false, 3>", "proj_mlp@p4": "k_mlp<3, true>", "proj_mlp@p8": "k_mlp8<true>",
-                    "proj_mlp@p8x3": "k_mlp8<true, 3>", "ln_qkv_T@p8": "k_ln_qkv8<false>", "ln_qkv_T@p8x2": "k_ln_qkv8<true>",
+                    "proj_mlp@p8x3": "k_mlp8<true, 3>", "ln_qkv_T@p8": "k_ln_qkv8<false, false>", "ln_qkv_T@p8x2": "k_ln_qkv8<true, false>", "ln_qkv_T@h32x2": "k_ln_qkv8<true, true>",
                     "flash_proj_T@q128": "k_flash_proj8", "flash_proj_T@q64": "k_flash_proj(", "flash_proj_L@q64": "k_flash_proj(",
                     "flash_proj_L@q128": "k_flash_proj8"}
 

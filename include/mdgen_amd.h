@@ -172,6 +172,11 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      waits) and q, k | v of the temporal LN -> q, k, v kernel to two (k_ln_qkv8<true>, <= CUs / 2 panels).
  *                      Scratch: mdgen_ws_layout.split.  Same values to fp32 rounding (a three-term instead of a two-term sum);
  *                      the report tags such launches "@p8x3" / "@p8x2".  Off while a call runs sub-batch streams.
+ *                      Round 6: ... and give the L = 4 residue sub-layer kernel and the split q, k | v kernel 32-ROW workgroups where
+ *                      even those fit one per CU (k_ln_qkv_attn4<true, true>: B <= 2 at T 1000, the IPA stack; k_ln_qkv8<true, true>:
+ *                      B = 1 at T 1000): twice the workgroups on twice the CUs, half the rows per SIMD -- a small launch lasts as long
+ *                      as one wave's chain of work.  Same arithmetic per row; tags "@h32" / "@h32x2"; no scratch, so these two stay
+ *                      on while a call runs sub-batch streams.
  *   "train_precision"  operands of the matrix products of mdgen_train_forward_backward (linear layers, weight gradients,
  *                      the attention's q k^T / p v and their backward): 32 (default) fp32, the exact mode; 16 rounded to
  *                      bf16 on the MFMA, fp32 accumulation, fp32 master weights and activations (train.py:13

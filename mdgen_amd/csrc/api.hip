@@ -1103,8 +1103,12 @@ static int attn_sublayer(const Run& r, const MhaW& m, float* h, long nrows, cons
             // (profile class "...@p8": the eight-wave form ran -- tests assert which kernel a launch took)
             const int pw = panel_waves_for((long)ax.nseq * q.panels_per_seq, r.c->opt_panel_waves, r.c->ncu);
             const bool split = pw == 8 && r.c->opt_small_split && 2L * ax.nseq * q.panels_per_seq <= r.c->ncu;
-            const std::string cls = std::string(c_qkv) + (split ? "@p8x2" : pw == 8 ? "@p8" : "");
-            { ProfScope ps(r.c, r.c->intern(cls), r.s); if (!g_dry) launch_ln_qkv(q, false, r.s, false, pw, split); }
+            // ... and 32 positions per workgroup pair where even those fit one per CU (B = 1 at T 1000: 256; tag "@h32x2")
+            const int pps32 = (ax.len + 31) / 32;
+            const bool half = split && 2L * ax.nseq * pps32 <= r.c->ncu;
+            if (half) q.panels_per_seq = pps32;
+            const std::string cls = std::string(c_qkv) + (half ? "@h32x2" : split ? "@p8x2" : pw == 8 ? "@p8" : "");
+            { ProfScope ps(r.c, r.c->intern(cls), r.s); if (!g_dry) launch_ln_qkv(q, false, r.s, false, pw, split, half); }
             LAUNCHCHK();
         }
         FlashParams f{};

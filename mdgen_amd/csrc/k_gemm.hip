@@ -21,8 +21,8 @@ constexpr int kPanelBytes = kPanel * kRowB;
 // holds, for its token, 12 features of each head = six rotary pairs (i, i+12): RoPE is lane-local
 // and the accumulators ARE the attention MFMA fragments (DESIGN.md "fragment layout").
 // =================================================================================================
-template <bool ROPE>
-__device__ __forceinline__ void epilogue_heads_T(const f32x16* acc /*[3 ft][2 tt]*/, const PanelRows* pr, int w,
+template <bool ROPE, int TT = 2>
+__device__ __forceinline__ void epilogue_heads_T(const f32x16* acc /*[3 ft][TT]*/, const PanelRows* pr, int w,
                                                  const float* __restrict__ bias_perm, const float* __restrict__ rope,
                                                  bool small, int pos0, int len, int seq, int ntile, int tile0,
                                                  unsigned char* __restrict__ frag, __bf16* __restrict__ small_dst,
@@ -38,10 +38,10 @@ __device__ __forceinline__ void epilogue_heads_T(const f32x16* acc /*[3 ft][2 tt
 #pragma unroll
             for (int c = 0; c < 3; ++c) bq[hd][c] = bp[hd * 3 + c];
     }
-    int tokv[2], posv[2];
-    f32x4 rq[2][4];
+    int tokv[TT], posv[TT];
+    f32x4 rq[TT][4];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < TT; ++tt) {
         const int row = tt * 32 + tk;
         tokv[tt] = pr->tok[row];
         int pos = small ? (tokv[tt] >= 0 ? tokv[tt] % len : 0) : pos0 + row;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void epilogue_heads_T(const f32x16* acc /*[3 ft][2 tt
         }
     }
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < TT; ++tt) {
         const int token = tokv[tt];
         const bool valid = token >= 0;
         float cs[6], sn[6];
@@ -73,7 +73,7 @@ __device__ __forceinline__ void epilogue_heads_T(const f32x16* acc /*[3 ft][2 tt
             for (int c = 0; c < 3; ++c) {
                 const int ap = 3 * hd + c, ft = ap >> 2, a = ap & 3;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) e[4 * c + b] = acc[ft * 2 + tt][4 * a + b] + bq[hd][c][b];
+                for (int b = 0; b < 4; ++b) e[4 * c + b] = acc[ft * TT + tt][4 * a + b] + bq[hd][c][b];
             }
             if (ROPE) {
 #pragma unroll
@@ -111,7 +111,8 @@ __device__ __forceinline__ void epilogue_heads_T(const f32x16* acc /*[3 ft][2 tt
 
 // V for the FLASH layout: non-transposed D[token][feature]; the accumulators are the V^T
 // fragments of the P.V MFMA (lane = (d, half), register r = key slot) -- no data movement.
-__device__ __forceinline__ void epilogue_v_flash(const f32x16* acc /*[2 tt][3 ft]*/, int w,
+template <int TT = 2>
+__device__ __forceinline__ void epilogue_v_flash(const f32x16* acc /*[TT][3 ft]*/, int w,
                                                  const float* __restrict__ bias_perm, int seq, int ntile, int tile0,
                                                  unsigned char* __restrict__ vf) {
     const int lane = lane_id(), hh = lane >> 5, n = lane & 31;
@@ -122,7 +123,7 @@ __device__ __forceinline__ void epilogue_v_flash(const f32x16* acc /*[2 tt][3 ft
         const float b = bias_perm[w * 96 + col];
         const int head = 4 * w + hd;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TT; ++tt) {
             const int tile = tile0 + tt;
             if (tile < ntile) {
                 unsigned char* base = vf + ((long)(seq * kH + head) * ntile + tile) * kFragV + hh * 400 + d * 16;
@@ -138,7 +139,7 @@ __device__ __forceinline__ void epilogue_v_flash(const f32x16* acc /*[2 tt][3 ft
     if (lane < 32) {   // row 24 of every fragment this wave owns: 4 heads x 2 tiles x 2 key halves x 2 k-steps, all ones
         const int hd = lane & 3, tt = (lane >> 2) & 1, h2 = (lane >> 3) & 1, ks = lane >> 4;
         const int tile = tile0 + tt;
-        if (tile < ntile)
+        if (tt < TT && tile < ntile)
             *reinterpret_cast<u32x4*>(vf + ((long)(seq * kH + 4 * w + hd) * ntile + tile) * kFragV + ks * 800 + h2 * 400 + kDH * 16) =
                 u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     }
@@ -150,11 +151,12 @@ __device__ __forceinline__ void epilogue_v_flash(const f32x16* acc /*[2 tt][3 ft
 // 4w..4w+3, AFTER the same wave's K / V epilogues (which may have stored padding-row values into that slot: same wave,
 // same address, program order).  The attention kernel then needs no special case for it.
 // do_k / do_v: the K / V^T half only (k_ln_qkv8: the two halves are written by different waves).
-__device__ __forceinline__ void write_bias_slots(const QkvParams& p, int seq, int w, bool do_k = true, bool do_v = true) {
+// tpp: 32-position tiles per panel (2; 1 for the 32-row workgroups of k_ln_qkv8<true, true>)
+__device__ __forceinline__ void write_bias_slots(const QkvParams& p, int seq, int w, bool do_k = true, bool do_v = true, int tpp = 2) {
     const int lane = lane_id();
     const int len = p.ax.len, nt = p.ax.ntile();
     const int kt = len >> 5, sl = len & 31;
-    if (kt >= 2 * p.panels_per_seq) {
+    if (kt >= tpp * p.panels_per_seq) {
         // len is a multiple of 64: the bias key starts a tile of its own, which no panel epilogue has touched.  Its
         // other 31 key slots are masked, but the PV MFMA still multiplies their V^T entries by P = 0 -- stale bytes
         // that decode to NaN / inf would poison the sum -- and the all-ones row 24 must exist for the bias key's own P
@@ -373,61 +375,70 @@ __device__ __forceinline__ void load_head_bias(const float* bias_perm, int w, in
 // 0..3 q, waves 4..7 k (and the key-validity words); blockIdx 2 n + 1: waves 0..3 v, waves 4..7 leave after their share of the
 // LayerNorm prologue (which both workgroups run in full) -- so the longest chain of a launch is one product instead of two.  The
 // two workgroups write disjoint fragments; nothing is exchanged.
-template <bool SPLIT>
+// HALF (with SPLIT; launches of at most one such workgroup per CU: B = 1; round 6, profiles/r06_experiments.txt #14 / #16): 32 positions per
+// workgroup pair -- the panel's upper half stays empty, every wave computes one 32-token tile -- twice the workgroups, half the rows per SIMD.
+template <bool SPLIT, bool HALF = false>
 __global__ __launch_bounds__(512, 1) void k_ln_qkv8(const QkvParams p) {
+    static_assert(!HALF || SPLIT, "32-row workgroups exist in the split form only");
+    constexpr int TT = HALF ? 1 : 2, kRows = 32 * TT;
     __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(PanelRows) + kPanelBytes];
     PanelRows* pr = reinterpret_cast<PanelRows*>(smem);
     unsigned char* panel = smem + sizeof(PanelRows);
     const int blk = SPLIT ? blockIdx.x >> 1 : blockIdx.x, half = SPLIT ? blockIdx.x & 1 : 0;
     const int seq = blk / p.panels_per_seq;
     const int pn = blk - seq * p.panels_per_seq;
-    const int pos0 = pn * kPanel, tile0 = pn * 2;
-    setup_rows_axis(pr, p.ax, seq, pos0, p.mm);
-    if (wave_id() == 0 && half == 0) {   // key-validity words of this panel's two tiles (as k_ln_qkv<false>)
+    const int pos0 = pn * kRows, tile0 = pn * TT;
+    setup_rows_axis(pr, p.ax, seq, pos0, p.mm, kRows);
+    if (wave_id() == 0 && half == 0) {   // key-validity words of this panel's tiles (as k_ln_qkv<false>)
         const int lane = lane_id(), len = p.ax.len, pos = pos0 + lane;
         const float mv = p.mk.at(p.ax.token(seq, pos < len ? pos : len - 1));
         const unsigned long long bal = __ballot(pos == len || (pos < len && mv != 0.f));
         uint32_t* vm = p.vmask + (long)seq * p.vmask_stride;
-        if (lane < 2) vm[tile0 + lane] = (uint32_t)(bal >> (32 * lane));
+        if (lane < TT) vm[tile0 + lane] = (uint32_t)(bal >> (32 * lane));
         if (pn == p.panels_per_seq - 1) {
-            const int idx = tile0 + 2 + lane;
+            const int idx = tile0 + TT + lane;
             if (idx < p.vmask_stride) vm[idx] = idx == (len >> 5) ? 1u << (len & 31) : 0u;
             if (idx + 64 < p.vmask_stride) vm[idx + 64] = 0u;
         }
     }
     __syncthreads();
     const int w8 = __builtin_amdgcn_readfirstlane(wave_id()), g = w8 >> 2, w = w8 & 3, lane = lane_id();
-    if (g == 0) prologue_ln<false, 0, 2>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
-    else prologue_ln<false, 2, 4>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
+    if (HALF) {   // 32 rows: one batch of sixteen per wave group
+        if (g == 0) prologue_ln<false, 0, 1>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
+        else prologue_ln<false, 1, 2>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
+    } else {
+        if (g == 0) prologue_ln<false, 0, 2>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
+        else prologue_ln<false, 2, 4>(panel, pr, p.h, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
+    }
     __syncthreads();
     const int ntile = p.ax.ntile(), len = p.ax.len;
     const bool last = pn == p.panels_per_seq - 1;
-    f32x16 acc[6];
+    f32x16 acc[3 * TT];
     // which products this wave group computes: q and k (do_q, do_k) or v
     const bool do_q = SPLIT ? half == 0 && g == 0 : g == 0, do_k = SPLIT ? half == 0 && g == 1 : g == 0;
     const bool do_v = SPLIT ? half == 1 && g == 0 : g == 1;
     if (do_q) {
-        zero_acc<6>(acc);
-        wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
-        epilogue_heads_T<true>(acc, pr, w, p.bq, p.rope, false, pos0, len, seq, ntile, tile0, p.qf, p.qkv_small, 0);
+        zero_acc<3 * TT>(acc);
+        wave_gemm<TT, 3, 24, true>(panel, kRowB, 0, 0, p.wq + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        epilogue_heads_T<true, TT>(acc, pr, w, p.bq, p.rope, false, pos0, len, seq, ntile, tile0, p.qf, p.qkv_small, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
     if (do_k) {
-        zero_acc<6>(acc);
-        wave_gemm<2, 3, 24, true>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
-        epilogue_heads_T<true>(acc, pr, w, p.bk, p.rope, false, pos0, len, seq, ntile, tile0, p.kf, p.qkv_small, 1);
+        zero_acc<3 * TT>(acc);
+        wave_gemm<TT, 3, 24, true>(panel, kRowB, 0, 0, p.wk + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        epilogue_heads_T<true, TT>(acc, pr, w, p.bk, p.rope, false, pos0, len, seq, ntile, tile0, p.kf, p.qkv_small, 1);
         if (last) {   // the learned bias key, after this wave's own K stores
             __builtin_amdgcn_sched_barrier(0);
-            write_bias_slots(p, seq, w, true, false);
+            write_bias_slots(p, seq, w, true, false, TT);
         }
     }
     if (do_v) {
-        zero_acc<6>(acc);
-        wave_gemm<2, 3, 24, false>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
-        epilogue_v_flash(acc, w, p.bv, seq, ntile, tile0, p.vf);
+        zero_acc<3 * TT>(acc);
+        wave_gemm<TT, 3, 24, false>(panel, kRowB, 0, 0, p.wv + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
+        epilogue_v_flash<TT>(acc, w, p.bv, seq, ntile, tile0, p.vf);
         if (last) {   // the learned bias value, after this wave's own V^T stores
             __builtin_amdgcn_sched_barrier(0);
-            write_bias_slots(p, seq, w, false, true);
+            write_bias_slots(p, seq, w, false, true, TT);
         }
     }
 }
@@ -1357,7 +1368,7 @@ __global__ __launch_bounds__(256, 2) void k_final(const FinalParams p) {
 // workgroup per CU, unless the caller forces one form (option panel_waves: 4 / 8).
 int panel_waves_for(long grid, int forced, int ncu) { return forced == 4 || forced == 8 ? forced : (grid <= ncu ? 8 : 4); }
 
-void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre, int waves, bool split) {
+void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre, int waves, bool split, bool half) {
     if (pre) {
         const int grid = p.ax.nseq * p.panels_per_seq;
         hipLaunchKernelGGL((k_ln_qkv<false, true>), dim3(grid), dim3(256), 0, s, p);
@@ -1368,7 +1379,9 @@ void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre, int 
         hipLaunchKernelGGL(k_ln_qkv<true>, dim3(grid), dim3(256), 0, s, p);
     } else {
         const int grid = p.ax.nseq * p.panels_per_seq;
-        if (waves == 8 && split) hipLaunchKernelGGL(k_ln_qkv8<true>, dim3(2 * grid), dim3(512), 0, s, p);
+        // (half: p.panels_per_seq counts 32-position panels)
+        if (waves == 8 && split && half) hipLaunchKernelGGL((k_ln_qkv8<true, true>), dim3(2 * grid), dim3(512), 0, s, p);
+        else if (waves == 8 && split) hipLaunchKernelGGL(k_ln_qkv8<true>, dim3(2 * grid), dim3(512), 0, s, p);
         else if (waves == 8) hipLaunchKernelGGL(k_ln_qkv8<false>, dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL(k_ln_qkv<false>, dim3(grid), dim3(256), 0, s, p);
     }

@@ -213,7 +213,7 @@ struct FloatChunk {
 };
 
 int panel_waves_for(long grid, int forced, int ncu);   // 4 or 8 waves per 64-row panel for a launch of `grid` panels
-void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre = false, int waves = 4, bool split = false);
+void launch_ln_qkv(const QkvParams& p, bool small, hipStream_t s, bool pre = false, int waves = 4, bool split = false, bool half = false);
 void launch_xcc_probe(int* out, int nblocks, hipStream_t s);
 void launch_ln_qkv_attn4(const QkvParams& p, bool fuse_proj, hipStream_t s, bool half = false);   // half: 32-row workgroups (fuse_proj only)
 void launch_proj(const ProjParams& p, int mode, hipStream_t s);

@@ -115,11 +115,12 @@ __device__ __forceinline__ void set_uniform(PanelRows* pr, int tid, long t, long
 }
 
 // rows = positions pos0 .. pos0+63 of sequence `seq` along an attention axis
-__device__ __forceinline__ void setup_rows_axis(PanelRows* pr, const AxisMap ax, int seq, int pos0, const ModMap mm) {
+// (nrows < 64: the panel's rows from nrows on are padding rows -- the 32-row workgroups of the small launches)
+__device__ __forceinline__ void setup_rows_axis(PanelRows* pr, const AxisMap ax, int seq, int pos0, const ModMap mm, int nrows = kPanel) {
     if (threadIdx.x < kPanel) {
         const int pos = pos0 + threadIdx.x;
         long t = -1, mo = 0;
-        if (pos < ax.len) {
+        if (pos < ax.len && (int)threadIdx.x < nrows) {
             t = ax.token(seq, pos);
             mo = mm.row_off(t);
         }

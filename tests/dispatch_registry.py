@@ -10,12 +10,14 @@ cfg-3's shapes; streams 1 / 2 / default) and FAILS when a signature turns up tha
 
 mode: "forward" (mdgen_denoiser_forward, no trace), "forward+trace" (with trace_h: what `return_trace=True` tests run),
 "euler" (mdgen_sample_euler: the generic GPU test runs S = 2 and compares x2 - x0 with two Euler steps of the oracle).
+options: library options the case sets (default: none) -- e.g. `streams` 2 where the default stream count would not produce the combination.
 """
 
 CASES = [
     # ---- tetrapeptides (L = 4: the residue axis is k_ln_qkv_attn4<true>), by launch size
     dict(name="B1_T1000_L4", mode="forward+trace", B=1, T=1000, L=4, n_pad=0, covered_by="test_small_launches_split_a_panel_over_workgroups_vs_oracle"),
     dict(name="B2_T1000_L4", mode="forward+trace", B=2, T=1000, L=4, n_pad=0, covered_by="test_forward_headline_regime_vs_reference_and_oracle"),
+    dict(name="B2_T1000_L4_euler_2streams", mode="euler", B=2, T=1000, L=4, n_pad=0, options={"streams": 2}, covered_by=None),   # two one-sample views on two streams: 32-row L = 4 / q, k | v forms beside the UNSPLIT eight-wave MLP (its scratch serves one stream)
     dict(name="B3_T700_L4", mode="forward+trace", B=3, T=700, L=4, n_pad=0, covered_by=None),          # 129..256 panels: eight-wave forms, unsplit
     dict(name="B5_T1000_L4", mode="forward+trace", B=5, T=1000, L=4, n_pad=0, covered_by="test_panel_kernels_257_to_383_panels_vs_oracle"),
     dict(name="B8_T1000_L4_fwd", mode="forward+trace", B=8, T=1000, L=4, n_pad=0, covered_by="test_headline_kernel_mix_at_B8_T1000_vs_oracle"),

@@ -33,7 +33,7 @@ def ipa_signature(p):
 def registry_signatures():
     trunk, ipa = {}, {}
     for c in CASES:
-        p = plan(c["B"], c["T"], c["L"], c["mode"], S=c.get("S", 2), tps=c.get("tps", False))   # (euler cases run two steps: the embedding-as-tail feeds the second)
+        p = plan(c["B"], c["T"], c["L"], c["mode"], S=c.get("S", 2), tps=c.get("tps", False), options=c.get("options"))   # (euler cases run two steps: the embedding-as-tail feeds the second)
         if c.get("part") != "ipa":          # (an IPA-table entry's rollout is not compared beyond the table)
             for s in view_signatures(p):
                 trunk.setdefault(s, []).append(c["name"])
