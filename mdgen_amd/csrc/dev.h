@@ -12,6 +12,7 @@
 //                               the residual rows requested ahead of the out-projection GEMM (both product since round 6)
 //   MDGEN_DEV_QKV_STAMPS        k_ln_qkv / k_ln_qkv_attn4: phase stamps         (scripts/micro/qkv_stamps.py, scripts/r05/attn4_stamps.py)
 //   MDGEN_DEV_ATTN4_FULL        k_ln_qkv_attn4: small launches keep 64-row workgroups (round 6 A/B of the half-panel form)
+//   MDGEN_DEV_MLP8_STAMPS       k_mlp8: per-wave phase stamps held in SGPRs (scripts/r06/mlp8_stamps.py)
 //   MDGEN_DEV_MLP_STAMPX        k_mlp: stamp inside one fc1 stage              (scripts/micro/mlp_stampx.py)
 //   MDGEN_DEV_ROWS_NOGELU       k_mlp_rows: main loop without its VALU work, timing only (values wrong)
 //   MDGEN_DEV_ROWS_COALESCED    k_mlp_rows: row loads as coalesced 1 KiB requests, timing only (values wrong)
@@ -21,9 +22,10 @@
 #pragma once
 
 
+
 #if defined(MDGEN_DEV_FLASH_TRUNC) || defined(MDGEN_DEV_FLASH_NOPRIO) || defined(MDGEN_DEV_FLASH_NOEARLY) || \
     defined(MDGEN_DEV_FLASH_STAMPS) || defined(MDGEN_DEV_FLASH_NOLOAD) || defined(MDGEN_DEV_FLASH_NOFALLBACK) || \
-    defined(MDGEN_DEV_QKV_STAMPS) || defined(MDGEN_DEV_ATTN4_FULL) ||  defined(MDGEN_DEV_MLP_STAMPX) || defined(MDGEN_DEV_ROWS_NOGELU) ||           \
+    defined(MDGEN_DEV_QKV_STAMPS) || defined(MDGEN_DEV_MLP8_STAMPS) || defined(MDGEN_DEV_ATTN4_FULL) ||  defined(MDGEN_DEV_MLP_STAMPX) || defined(MDGEN_DEV_ROWS_NOGELU) ||           \
     defined(MDGEN_DEV_ROWS_COALESCED) || defined(MDGEN_DEV_WIDE_NOLOAD) || defined(MDGEN_DEV_WIDE_NOMMA) ||        \
     defined(MDGEN_DEV_WIDE_NOSTORE) || defined(MDGEN_DEV_WIDE_STAMPS) || \
     defined(MDGEN_DEV_ATTN16_NOEXP) || defined(MDGEN_DEV_ATTN16_NOSTAGE) ||         \

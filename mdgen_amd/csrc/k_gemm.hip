@@ -366,6 +366,10 @@ __device__ __forceinline__ void load_head_bias(const float* bias_perm, int w, in
         for (int c = 0; c < 3; ++c) bq[hd][c] = bp[hd * 3 + c];
 }
 
+// (Weight-ring depth of the small launches' one-tile-per-wave GEMMs: 8 or 12 k-steps in flight instead of 4 change nothing -- they are
+// bound by the 64 B/clk at which a CU's vector memory path returns data: 3 KiB per wave and k-step for 96 cycles of matrix-pipe time;
+// profiles/r06_experiments.txt #17.)
+
 // ---- LN -> q, k, v (FLASH layout) for launches of at most one workgroup per CU: eight waves per panel ------------------------------
 // (see k_mlp8.)  The split keeps 64 rows per wave -- with one row tile per wave every weight fragment feeds one MFMA instead of two and
 // the launch gets slower (profiles/r04_experiments.txt #17) -- and divides the three products instead: waves 0..3 compute q and k,
@@ -1125,6 +1129,23 @@ __global__ __launch_bounds__(256, 2) void k_mlp(const MlpParams p) {
 // same atomic add tells it that it is last, then agent-scope atomic loads.  Correct for any placement.  The S workgroups of a panel
 // are nevertheless placed on ONE XCD (equal blockIdx % 8; the context's placement probe checks the residue -> XCD rule and the
 // launcher only picks the form where it holds): that is where the form pays.
+#ifdef MDGEN_DEV_MLP8_STAMPS   // (experiment build, scripts/r06/mlp8_stamps.py: per-wave s_memtime stamps of k_mlp8, held in SGPRs, one store branch)
+__device__ unsigned long long g_mlp8_stamps[8192 * 16];
+extern "C" int mdgen_dev_mlp8_stamps(void* host, size_t bytes) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mlp8_stamps), bytes); }
+#define MLP8_STAMP_DECL unsigned long long m8st[12] = {}
+#define MLP8_STAMP(slot)                         \
+    m8st[slot] = __builtin_amdgcn_s_memtime();   \
+    __builtin_amdgcn_sched_barrier(0)
+#define MLP8_STAMP_FLUSH                                                                      \
+    if (lane_id() == 0 && (long)blockIdx.x * 8 + wave_id() < 8192) {                            \
+        _Pragma("unroll") for (int k = 0; k < 12; ++k)                                          \
+            g_mlp8_stamps[((long)blockIdx.x * 8 + wave_id()) * 16 + k] = m8st[k];               \
+    }
+#else
+#define MLP8_STAMP_DECL
+#define MLP8_STAMP(slot)
+#define MLP8_STAMP_FLUSH
+#endif
 template <bool PRE, int S = 1>
 __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
     static_assert(kNChunk % (2 * S) == 0, "whole chunks per group");
@@ -1148,6 +1169,8 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
         if ((long)pn * kPanel >= p.nrows) return;
     }
     const int slot = pn * S + sp;   // this workgroup's slot in p.part / p.hupd
+    MLP8_STAMP_DECL;
+    MLP8_STAMP(0);
     setup_rows_linear(pr, (long)pn * kPanel, p.nrows, p.mm);
     constexpr bool PRIV = PRE && S > 1;   // residual rows come from / go to the private copy
     if (PRIV) {
@@ -1158,20 +1181,24 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
     if (PRE) {
         if (threadIdx.x < 256) prologue_bf16<kC>(panel, pr, p.o);
         __syncthreads();
+        MLP8_STAMP(1);
         f32x16 acc[3];
         zero_acc<3>(acc);
         wave_gemm<1, 3, 24, false>(panel, kRowB, g, 0, p.wo + (size_t)(3 * w) * 24 * 64 + lane, 24 * 64, acc);
         __syncthreads();   // every wave is done reading the panel
+        MLP8_STAMP(2);
         epi_stage(acc, slab);
         if (PRIV) epi_rmw<8>(g, pr, slab, 96 * w, p.bo, p.mm, p.gate_chunk_o, true, p.h, &prs2, p.hupd);
         else epi_rmw<8>(g, pr, slab, 96 * w, p.bo, p.mm, p.gate_chunk_o, true, p.h);
         __syncthreads();   // (vmcnt(0) + barrier) the updated rows are in L2; the slabs are free
     }
+    MLP8_STAMP(3);
     const PanelRows* prx = PRIV ? &prs2 : pr;          // where the MLP's input rows (and the residual of its epilogue) are read
     const float* hx = PRIV ? p.hupd : p.h;
     if (g == 0) prologue_ln<false, 0, 2>(panel, prx, hx, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
     else prologue_ln<false, 2, 4>(panel, prx, hx, p.mm, p.shift_chunk, p.scale_chunk, 1e-6f, w, lane);
     __syncthreads();
+    MLP8_STAMP(4);
     const bf16x8* w1l = p.w1 + (size_t)w * 24 * 64 + lane;
     const bf16x8* w2l = p.w2 + (size_t)(3 * w) * 96 * 64 + lane;
     const float* b1l = p.b1 + 32 * w + 4 * hh;
@@ -1205,6 +1232,7 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
         for (int q = 0; q < 8; ++q) gelu_group(a1, b4[q >> 1], hb0, q, w, hh, tk);
     }
     lds_barrier();
+    MLP8_STAMP(5);
 #pragma unroll 1
     for (int i = 1; i < NC; ++i) {
         const int c = c0 + i;
@@ -1216,8 +1244,10 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
         stage_y<true>(hr, w2l + (size_t)8 * (c - 1) * 64, yp, y, a1, b0, b1l + c * kHC, hw, w, hh, tk, panel, w1l + (size_t)cn * W1C, xp);
         lds_barrier();
     }
+    MLP8_STAMP(6);
     wave_gemm<2, 3, 8, false, 3>((NC & 1) ? hb0 : hb1, kHRowB, 0, 0, w2l + (size_t)8 * (c0 + NC - 1) * 64, kW2S, y);
     __syncthreads();   // panel and hidden buffers are dead: exchange area
+    MLP8_STAMP(7);
     {   // this group's partial of the row tile the OTHER group finishes
         float* dst = reinterpret_cast<float*>(smem) + (size_t)(g * 4 + w) * (3 * 16 * 64);
 #pragma unroll
@@ -1238,6 +1268,7 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
                 z[f][r] = lo + hi;
             }
     }
+    MLP8_STAMP(8);
     if (S > 1) {
         // this workgroup's partial: [slot][wave][3 tiles x 16 registers][lane] -- 256-byte runs per store
         float* mine = p.part + ((size_t)slot * 8 + w8) * (3 * 16 * 64) + lane;
@@ -1261,7 +1292,11 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
             if (old == (unsigned)(S - 1)) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
         __syncthreads();
-        if (!s_last) return;
+        MLP8_STAMP(9);
+        if (!s_last) {
+            MLP8_STAMP_FLUSH
+            return;
+        }
         f32x16 zt[3];
 #pragma unroll
         for (int f = 0; f < 3; ++f)
@@ -1281,9 +1316,12 @@ __global__ __launch_bounds__(512, 1) void k_mlp8(const MlpParams p) {
     } else {
         __syncthreads();   // exchange area read: the slabs may overwrite it
     }
+    MLP8_STAMP(10);
     epi_stage(z, slab);
     if (PRIV) epi_rmw<8>(g, &prs2, slab, 96 * w, p.b2, p.mm, p.gate_chunk, true, p.hupd, pr, p.h);
     else epi_rmw<8>(g, pr, slab, 96 * w, p.b2, p.mm, p.gate_chunk, true, p.h);
+    MLP8_STAMP(11);
+    MLP8_STAMP_FLUSH
 }
 
 // =================================================================================================
