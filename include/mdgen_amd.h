@@ -181,6 +181,11 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      the attention's q k^T / p v and their backward): 32 (default) fp32, the exact mode; 16 rounded to
  *                      bf16 on the MFMA, fp32 accumulation, fp32 master weights and activations (train.py:13
  *                      set_float32_matmul_precision('medium')); softmax, LayerNorm, reductions stay fp32, GELU to 5e-6.
+ *   "train_attn_form"  1 (default) / 0: with train_precision 16, attention axes of 129 .. 256 positions (the ATLAS training shapes)
+ *                      run their backward pass in ONE launch of one workgroup per (sequence, head) that converts the sequence's
+ *                      q, k, v, dO to bf16 tiles in LDS once and runs the query pass and the key pass out of LDS
+ *                      (k16_attn_bwd_seq) instead of the chunked pair k16_attn_bwd_q / _kv; the forward likewise
+ *                      (k16_attn_seq).  Same products and operand rounding; 0 keeps the chunked kernels for every length.
  *   "train_streams"    2 (default) / 1: mdgen_train_forward_backward launches the weight / bias gradients (nothing reads them
  *                      before the optimiser) on a second stream of the context, beside the backward pass's critical path on the
  *                      caller's stream; it joins the caller's stream before the call returns, and milestone events are recorded
@@ -341,7 +346,8 @@ int32_t mdgen_debug_train_dw(int32_t precision, const float* dy, int32_t ldy, co
  *   bias_k, bias_v[384]: the learned bias key / value (rotated at position len by the kernels); inv_freq[12].
  * Forward: out[ntok][384], lse[ntok][16].  Backward from dout[ntok][384]: dqkv[ntok][1152] = (d q, d k taken back through RoPE,
  * d q also through the q scale; d v), dbias[nseq][768] = per-sequence (d bias_k | d bias_v); stats[ntok][16][2] scratch.
- * precision 32: k32_attn* + k32_rope_bwd; 16: k16_attn* (bf16 operands on the MFMA, inverse RoPE in the store stage). */
+ * precision 32: k32_attn* + k32_rope_bwd; 16: k16_attn* (bf16 operands on the MFMA, inverse RoPE in the store stage) as the training
+ * step dispatches them; 160: the chunked k16 kernels for every length (the A/B of option "train_attn_form"). */
 int32_t mdgen_debug_train_attention(int32_t precision, const float* qkv, int64_t ntok, int32_t nseq, int32_t len, int32_t inner,
                                     int32_t outer_stride, int32_t inner_stride, int32_t pos_stride, const float* mask,
                                     const float* bias_k, const float* bias_v, const float* inv_freq, const float* dout,

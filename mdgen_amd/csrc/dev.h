@@ -17,6 +17,8 @@
 //   MDGEN_DEV_ROWS_NOGELU       k_mlp_rows: main loop without its VALU work, timing only (values wrong)
 //   MDGEN_DEV_ROWS_COALESCED    k_mlp_rows: row loads as coalesced 1 KiB requests, timing only (values wrong)
 //   MDGEN_DEV_ATTN16_NOEXP / _NOSTAGE / _NOMMA / _NOBAR   k16_attn*: one ingredient of the chunk loop left out, timing only (values wrong)
+//   MDGEN_DEV_ATTN16_SEQNOLOAD / _SEQNOLOOP / _SEQNOSTORE   k16_attn_bwd_seq (round 6): the fill's global loads / all but one tile of each pass /
+//                               the result stores left out, timing only (values wrong)
 //   MDGEN_DEV_WIDE_STAMPS       k16_linear_wide: s_memtime stamps per k-step phase (scripts/micro/wide_stamps.py)
 //   MDGEN_DEV_WIDE_NOLOAD / _NOMMA / _NOSTORE   k16_linear_wide: one phase of the k-step left out, timing only (values wrong)
 #pragma once
@@ -29,7 +31,8 @@
     defined(MDGEN_DEV_ROWS_COALESCED) || defined(MDGEN_DEV_WIDE_NOLOAD) || defined(MDGEN_DEV_WIDE_NOMMA) ||        \
     defined(MDGEN_DEV_WIDE_NOSTORE) || defined(MDGEN_DEV_WIDE_STAMPS) || \
     defined(MDGEN_DEV_ATTN16_NOEXP) || defined(MDGEN_DEV_ATTN16_NOSTAGE) ||         \
-    defined(MDGEN_DEV_ATTN16_NOMMA) || defined(MDGEN_DEV_ATTN16_NOBAR)
+    defined(MDGEN_DEV_ATTN16_NOMMA) || defined(MDGEN_DEV_ATTN16_NOBAR) || defined(MDGEN_DEV_ATTN16_SEQNOLOAD) ||     \
+    defined(MDGEN_DEV_ATTN16_SEQNOLOOP) || defined(MDGEN_DEV_ATTN16_SEQNOSTORE)
 #ifndef MDGEN_DEV_BUILD
 #error "an MDGEN_DEV_* experiment switch is set without -DMDGEN_DEV_BUILD: product libraries are built with none of them"
 #endif

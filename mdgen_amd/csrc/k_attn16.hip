@@ -46,6 +46,21 @@ constexpr float kMasked = -3.0e38f;
 #else
 #define A16_BARRIER() __syncthreads()
 #endif
+#ifdef MDGEN_DEV_ATTN16_SEQNOLOAD   // k16_attn_bwd_seq: the fill's global loads / all but one tile of each pass / the result stores left out
+#define A16_SEQ_NOLOAD true
+#else
+#define A16_SEQ_NOLOAD false
+#endif
+#ifdef MDGEN_DEV_ATTN16_SEQNOLOOP
+#define A16_SEQ_NOLOOP true
+#else
+#define A16_SEQ_NOLOOP false
+#endif
+#ifdef MDGEN_DEV_ATTN16_SEQNOSTORE
+#define A16_SEQ_NOSTORE true
+#else
+#define A16_SEQ_NOSTORE false
+#endif
 #ifdef MDGEN_DEV_ATTN16_NOSTAGE
 #define A16_STAGE(c0) ((c0) == 0)
 #else
@@ -86,7 +101,7 @@ struct Own {   // one owned row as an MFMA B operand: features 8 hh .. 8 hh + 7 
 };
 // `row` points at the row's 24 floats (global or LDS); null: a zero row
 template <typename P>
-__device__ __forceinline__ Own own_row(P row, int hh, float* part_dot = nullptr, const float* other = nullptr) {
+__device__ __forceinline__ Own own_row(P row, int hh, float* part_dot = nullptr, const float* other = nullptr, float scale = 1.0f) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a, c = a, d = a;
     if (row) {
         a = *reinterpret_cast<const f32x4*>(row + 8 * hh);
@@ -107,6 +122,10 @@ __device__ __forceinline__ Own own_row(P row, int hh, float* part_dot = nullptr,
             for (int i = 0; i < 4; ++i) s += c[i] * oc[i] + d[i] * od[i];
         }
         *part_dot = s;
+    }
+    if (scale != 1.0f) {   // (compile-time constant at every call site)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] *= scale; b[i] *= scale; c[i] *= scale; d[i] *= scale; }
     }
     Own o;
     o.f0 = __builtin_bit_cast(bf16x8, u32x4{pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(b[0], b[1]), pack_bf16(b[2], b[3])});
@@ -550,13 +569,466 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k16_attn_bwd_kv(cons
     }
 }
 
+// ---- backward, one workgroup per (sequence, head) and pass --------------------------------------------------------------
+// Axes of 129 .. 256 positions (the ATLAS training shapes: 250 frames x 256 residues): the chunked kernels above stage the
+// other side of every 128-row block through LDS again (five fills of the sequence per (sequence, head) over the two passes,
+// two barriers per 64-row chunk, global loads inside the loop).  Here a workgroup of eight waves owns ALL rows of one
+// (sequence, head) -- queries in k16_attn_bwd_seq_q, keys in k16_attn_bwd_seq_kv, one 32-row tile per wave -- and converts the
+// whole other side ONCE: k, v row-major + k transposed (288 rows: the bias key may open a ninth tile; 66 KB), or q, dO
+// row-major + transposed (256 rows; 78 KB); after that one fill the pass runs out of LDS alone (no barrier, no global load in the
+// loop, the next tile's score MFMAs issued beside the current tile's exponentials), two workgroups per CU so that one's
+// fill / result stores overlap the other's pass.  (A first form kept both sides in one 147 KB workgroup: its fill, its passes
+// and its stores each took a third of the launch and nothing overlapped them: profiles/r06_experiments.txt #18.)
+// Same products, the same chained-accumulator layout as the kernels above; what differs:
+//   * scores in log2 units: q is multiplied by log2(e) BEFORE it is rounded to bf16 (forward k16_attn_seq rounds the same
+//     product), so p = 2^s needs no multiply; dk is multiplied by ln 2 in its store stage;
+//   * per-row addends ride in the padding features 24 .. 27 of the operands (d = 24 of 32): -lse2 and -delta as three bf16
+//     each in the own q / dO operand against 1.0 in every K / V row (query pass), key validity 0 / -3e38 in the own k operand
+//     against 1.0 in every Q row (key pass): the exponent's argument comes out of the MFMA as it is;
+//   * a bias key that opens a tile of its own (len = 256) is shared out: wave w takes query tile w against it and the eight
+//     partial (dk | dv) rows are summed in wave order (deterministic).
+namespace {
+constexpr int kSeqQ = 256, kSeqK = 288;
+constexpr int kTrQB = kSeqQ * 2 + 16, kTrKB = kSeqK * 2 + 16;   // bytes of one feature row of a transposed (Q | K) image
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr int kSeqLds = 2 * kSeqQ * kRowB + 2 * 32 * kTrQB + (2 * kSeqQ + 2 * kDH + 8 * 2 * kDH) * 4;   // the key pass's images: 78 528 B, two workgroups per CU
+
+__device__ __forceinline__ void put_tr(unsigned char* img, int stride, int rho, int quad, const f32x4& a, const f32x4& b) {
+    const int col = (rho >> 5) * 64 + perm_pos(rho & 31) * 2;   // rows rho, rho + 1 (rho even) are neighbours in the permuted order
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint32_t*>(img + (4 * quad + i) * stride + col) = pack_bf16(a[i], b[i]);
+}
+__device__ __forceinline__ void put_rm(unsigned char* img, int row, int quad, const f32x4& v) {
+    *reinterpret_cast<u32x2*>(img + row * kRowB + quad * 8) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+}
+// x as three bf16 (24 significant bits) in features 24, 25, 26 of an own operand's k-step 1 (lanes hh == 1): against 1.0 in the
+// other operand's rows the MFMA adds x to every product of the lane's column
+__device__ __forceinline__ float round_bf16_(float x) { return __uint_as_float(pack_bf16(x, 0.f) << 16); }
+__device__ __forceinline__ void ride3(bf16x8& f, float x) {
+    const float hi = round_bf16_(x), mid = round_bf16_(x - hi), lo = round_bf16_(x - hi - mid);
+    f[0] = (__bf16)hi;
+    f[1] = (__bf16)mid;
+    f[2] = (__bf16)lo;
+}
+// unrope() with the hardware sine / cosine (input in revolutions): 3e-5 rad at position 256, far inside the bf16 operands' error
+__device__ __forceinline__ void unrope_fast(f32x16& v, int pos, const float* __restrict__ inv_freq, int hh, float scale) {
+    float recv[3][4];
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) recv[e][i] = __shfl_xor(hh ? v[4 * ((e + 1) % 3) + i] : v[4 * e + i], 32, 64);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int base = e == 0 ? 0 : e == 1 ? 8 : 4;
+        const int grp = hh ? (e + 1) % 3 : e;
+        const bool lower = hh ? e == 2 : e < 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float rev = __builtin_amdgcn_fractf((float)pos * (inv_freq[base + i] * 0.15915494309189535f));
+            const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+            const float own = v[4 * grp + i], oth = recv[e][i];
+            v[4 * grp + i] = (lower ? own * c + oth * sn : own * c - oth * sn) * scale;
+        }
+    }
+}
+// the 16 bytes of padding features 24 .. 31 of every row of a row-major image
+__device__ __forceinline__ void pad_rows(unsigned char* img, int nrows, u32x4 v) {
+    for (int e = threadIdx.x; e < nrows; e += 512) *reinterpret_cast<u32x4*>(img + e * kRowB + 48) = v;
+}
+__device__ __forceinline__ void zero_tr_tail(unsigned char* img, int stride) {   // feature rows 24 .. 31 of a transposed image
+    for (int e = threadIdx.x; e < 8 * (stride / 16); e += 512) *reinterpret_cast<u32x4*>(img + 24 * stride + e * 16) = u32x4{0, 0, 0, 0};
+}
+}  // namespace
+
+// query pass: dq (taken back through RoPE and the q scale) into dqkv[:, 0:384]
+__device__ __forceinline__ void attn_bwd_seq_q(unsigned char* lds, const Wg g, const float* __restrict__ qkv, int ld, const AxisMap& ax,
+                                               const MaskMap& mk, const float* __restrict__ bias_k, const float* __restrict__ bias_v,
+                                               const float* __restrict__ inv_freq, const float* __restrict__ o,
+                                               const float* __restrict__ dout, float* __restrict__ dqkv,
+                                               const float* __restrict__ lse_in) {
+    unsigned char *sK = lds, *sV = sK + kSeqK * kRowB, *sKt = sV + kSeqK * kRowB;
+    float *sM = reinterpret_cast<float*>(sKt + 32 * kTrKB), *sB = sM + kSeqK;
+    static_assert(2 * kSeqK * kRowB + 32 * kTrKB + (kSeqK + 2 * kDH) * 4 <= kSeqLds, "query pass: LDS");
+    const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5, w = wave_id();
+    const int nkt = len / 32 + 1, nqt = (len + 31) / 32;   // key tiles incl. the bias key's, query tiles
+    const long tok0 = ax.token(g.seq, 0);
+    const long pstr = ax.pos_stride;
+    fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
+    pad_rows(sK, 32 * nkt, u32x4{0x3F803F80u, 0x00003F80u, 0, 0});   // 1.0 in features 24, 25, 26: -lse2 rides against them
+    pad_rows(sV, 32 * nkt, u32x4{0x3F803F80u, 0x00003F80u, 0, 0});   //                             -delta
+    zero_tr_tail(sKt, kTrKB);
+    for (int r = tid; r < 32 * nkt; r += 512)
+        sM[r] = r < len ? (mk.at(tok0 + (long)r * pstr) != 0.f ? 0.f : kMasked) : (r == len ? 0.f : kMasked);
+    // own rows straight from global memory (fp32 -> bf16 in registers), delta = dO . O on the way
+    const int own = 32 * w + l31;
+    const long qtok = tok0 + (long)(own < len ? own : len - 1) * pstr;
+    Own q, dO;
+    float delta = 0.f, lse2 = -kMasked;
+    if (w < nqt) {
+        q = own_row(qkv + qtok * ld + g.hd * kDH, hh, nullptr, nullptr, kLog2e);   // scores in log2 units
+        dO = own_row(dout + qtok * kC + g.hd * kDH, hh, &delta, o + qtok * kC + g.hd * kDH);
+        delta = half_sum(delta);
+        if (own < len) lse2 = kLog2e * lse_in[qtok * kH + g.hd];   // beyond len: p = 2^-inf = 0
+        if (hh) {   // features 24 .. 31 of the own operands: -lse2 and -delta ride against the 1.0s of the K / V rows
+            ride3(q.f1, -lse2);
+            ride3(dO.f1, -delta);
+        }
+    }
+    __syncthreads();   // sB
+    for (int e = tid; e < 16 * nkt * 6; e += 512) {   // the (row pair, feature quad) items of the key side
+        const int pair = e / 6, quad = e - 6 * pair, r0 = 2 * pair;
+        f32x4 kf[2], vf[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int r = r0 + x;
+            kf[x] = vf[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < len && !A16_SEQ_NOLOAD) {
+                const float* row = qkv + (tok0 + (long)r * pstr) * ld + g.hd * kDH + 4 * quad;
+                kf[x] = *reinterpret_cast<const f32x4*>(row + kC);
+                vf[x] = *reinterpret_cast<const f32x4*>(row + 2 * kC);
+            } else if (r == len) {
+                kf[x] = *reinterpret_cast<const f32x4*>(sB + 4 * quad);
+                vf[x] = *reinterpret_cast<const f32x4*>(sB + kDH + 4 * quad);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            put_rm(sK, r0 + x, quad, kf[x]);
+            put_rm(sV, r0 + x, quad, vf[x]);
+        }
+        put_tr(sKt, kTrKB, r0, quad, kf[0], kf[1]);
+    }
+    __syncthreads();
+    if (w >= nqt) return;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = opaque_zero();
+    // software pipeline over the key tiles: the block of tile t issues the score / dP MFMAs of tile t + 1 beside its own
+    // exponentials, then its dq MFMAs (the last block recomputes its own scores: discarded)
+    auto scores = [&](int t, f32x16& s, f32x16& dp) {
+        s = rows_from(sM + 32 * t, hh, 1.0f);
+        const unsigned char* kr = sK + (32 * t + l31) * kRowB + hh * 16;
+        const unsigned char* vr = sV + (32 * t + l31) * kRowB + hh * 16;
+        const bf16x8 k0 = lds_frag(kr), k1 = lds_frag(kr + 32), v0 = lds_frag(vr), v1 = lds_frag(vr + 32);
+        s = A16_MMA(k0, q.f0, s);
+        dp = A16_MMA(v0, dO.f0, zero);
+        s = A16_MMA(k1, q.f1, s);
+        dp = A16_MMA(v1, dO.f1, dp);
+        asm volatile("" ::"v"(v0), "v"(v1), "v"(dO.f0), "v"(dO.f1));   // sources outlive the inline-constant-C MFMA (common.h opaque_zero)
+    };
+    f32x16 s, dp;
+    scores(0, s, dp);
+    for (int t = 0; t < (A16_SEQ_NOLOOP ? 1 : nkt); ++t) {
+        const unsigned char* tr = sKt + l31 * kTrKB + 64 * t + hh * 16;
+        const bf16x8 t0 = lds_frag(tr), t1 = lds_frag(tr + 32);
+        f32x16 sn, dpn;
+        scores(t + 1 < nkt ? t + 1 : t, sn, dpn);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = A16_EXP2(s[r]) * dp[r];   // p = 2^(s2 - lse2),  d s = p (d p - delta)
+        bf16x8 d0, d1;
+        chain(s, d0, d1);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x402, 10, 0);  // ten VALU / transcendental
+        }
+        dq = A16_MMA(t0, d0, dq);
+        dq = A16_MMA(t1, d1, dq);
+        s = sn;
+        dp = dpn;
+    }
+    unrope_fast(dq, own < len ? own : len - 1, inv_freq, hh, 0.20412414523193151f);   // back through RoPE and the q scale 24^-1/2
+    if (own < len && !A16_SEQ_NOSTORE) {
+        float* dst = dqkv + qtok * ld + g.hd * kDH + 4 * hh;
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq)
+            *reinterpret_cast<f32x4*>(dst + 8 * gq) = f32x4{dq[4 * gq], dq[4 * gq + 1], dq[4 * gq + 2], dq[4 * gq + 3]};
+    }
+}
+
+// key pass: real keys write dqkv[:, 384:1152] (dk taken back through RoPE); the bias key writes dbias[seq][dk rotated back | dv]
+__device__ __forceinline__ void attn_bwd_seq_kv(unsigned char* lds, const Wg g, const float* __restrict__ qkv, int ld, const AxisMap& ax,
+                                                const MaskMap& mk, const float* __restrict__ bias_k, const float* __restrict__ bias_v,
+                                                const float* __restrict__ inv_freq, const float* __restrict__ o,
+                                                const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                float* __restrict__ dbias, const float* __restrict__ lse_in) {
+    unsigned char *sQ = lds, *sdO = sQ + kSeqQ * kRowB, *sQt = sdO + kSeqQ * kRowB, *sdOt = sQt + 32 * kTrQB;
+    float *sLse = reinterpret_cast<float*>(sdOt + 32 * kTrQB), *sDel = sLse + kSeqQ, *sB = sDel + kSeqQ, *sRed = sB + 2 * kDH;
+    const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5, w = wave_id();
+    const int nkt = len / 32 + 1, nqt = (len + 31) / 32;
+    const long tok0 = ax.token(g.seq, 0);
+    const long pstr = ax.pos_stride;
+    fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
+    pad_rows(sQ, 32 * nqt, u32x4{0, 0x3F800000u, 0, 0});   // 1.0 in feature 27: the own key's validity rides against it
+    pad_rows(sdO, 32 * nqt, u32x4{0, 0, 0, 0});
+    zero_tr_tail(sQt, kTrQB);
+    zero_tr_tail(sdOt, kTrQB);
+    if (tid < 8 * 2 * kDH) sRed[tid] = 0.f;
+    // per query row: -lse2 and -delta = -(dO . O)  (one thread per row; its 24 + 24 floats are lines the fill below reads too)
+    if (tid < 32 * nqt) {
+        float nl = kMasked, nd = 0.f;   // beyond len: p = 2^-inf = 0
+        if (tid < len && !A16_SEQ_NOLOAD) {
+            const long t = tok0 + (long)tid * pstr;
+            nl = -kLog2e * lse_in[t * kH + g.hd];
+            const float* dr = dout + t * kC + g.hd * kDH;
+            const float* orow = o + t * kC + g.hd * kDH;
+            float acc[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(dr + 4 * c), b = *reinterpret_cast<const f32x4*>(orow + 4 * c);
+                acc[c] = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+            }
+            nd = -(((acc[0] + acc[1]) + (acc[2] + acc[3])) + (acc[4] + acc[5]));
+        }
+        sLse[tid] = nl;
+        sDel[tid] = nd;
+    }
+    for (int e = tid; e < 16 * nqt * 6; e += 512) {   // the (row pair, feature quad) items of the query side
+        const int pair = e / 6, quad = e - 6 * pair, r0 = 2 * pair;
+        f32x4 qf[2], df[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int r = r0 + x;
+            qf[x] = df[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < len && !A16_SEQ_NOLOAD) {
+                const long t = tok0 + (long)r * pstr;
+                qf[x] = *reinterpret_cast<const f32x4*>(qkv + t * ld + g.hd * kDH + 4 * quad);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qf[x][i] *= kLog2e;   // scores in log2 units (k16_attn_seq rounds the same product)
+                df[x] = *reinterpret_cast<const f32x4*>(dout + t * kC + g.hd * kDH + 4 * quad);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            put_rm(sQ, r0 + x, quad, qf[x]);
+            put_rm(sdO, r0 + x, quad, df[x]);
+        }
+        put_tr(sQt, kTrQB, r0, quad, qf[0], qf[1]);
+        put_tr(sdOt, kTrQB, r0, quad, df[0], df[1]);
+    }
+    __syncthreads();
+    // (dk, dv) of key tile jt over the query tiles t0 .. t1 - 1
+    auto key_pass = [&](int jt, int t0, int t1, f32x16& dk, f32x16& dv) {
+        const int j = 32 * jt + l31;
+        Own k, v;
+        bool valid;
+        if (j < len) {
+            const long ktok = tok0 + (long)j * pstr;
+            k = own_row(qkv + ktok * ld + kC + g.hd * kDH, hh);
+            v = own_row(qkv + ktok * ld + 2 * kC + g.hd * kDH, hh);
+            valid = mk.at(ktok) != 0.f;
+        } else if (j == len) {
+            k = own_row((const float*)sB, hh);
+            v = own_row((const float*)(sB + kDH), hh);
+            valid = true;
+        } else {
+            k = own_row((const float*)nullptr, hh);
+            v = k;
+            valid = false;
+        }
+        if (hh) k.f1[3] = (__bf16)(valid ? 0.f : kMasked);   // feature 27, against the 1.0 of the Q rows: a padded key's scores are -3e38
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[r] = dv[r] = opaque_zero();
+        auto scores = [&](int t, f32x16& s, f32x16& dp) {
+            s = rows_from(sLse + 32 * t, hh, 1.0f);    // -lse2 of the tile's queries
+            dp = rows_from(sDel + 32 * t, hh, 1.0f);   // -delta
+            const unsigned char* qr = sQ + (32 * t + l31) * kRowB + hh * 16;
+            const unsigned char* dr = sdO + (32 * t + l31) * kRowB + hh * 16;
+            const bf16x8 q0 = lds_frag(qr), q1 = lds_frag(qr + 32), e0 = lds_frag(dr), e1 = lds_frag(dr + 32);
+            s = A16_MMA(q0, k.f0, s);
+            dp = A16_MMA(e0, v.f0, dp);
+            s = A16_MMA(q1, k.f1, s);
+            dp = A16_MMA(e1, v.f1, dp);
+        };
+        // (not software-pipelined: with the next tile's scores in flight the kernel needs 132 registers, one workgroup per CU; at
+        // 128 the second workgroup's waves fill this wave's waits)
+        for (int t = t0; t < (A16_SEQ_NOLOOP ? t0 + 1 : t1); ++t) {
+            f32x16 s, dp;
+            scores(t, s, dp);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = A16_EXP2(s[r]);
+                dp[r] *= s[r];
+            }
+            bf16x8 p0, p1, d0, d1;
+            chain(s, p0, p1);
+            chain(dp, d0, d1);
+            const unsigned char* dt = sdOt + l31 * kTrQB + 64 * t + hh * 16;
+            const unsigned char* qt = sQt + l31 * kTrQB + 64 * t + hh * 16;
+            const bf16x8 a0 = lds_frag(dt), a1 = lds_frag(dt + 32), b0 = lds_frag(qt), b1 = lds_frag(qt + 32);
+            dv = A16_MMA(a0, p0, dv);
+            dk = A16_MMA(b0, d0, dk);
+            dv = A16_MMA(a1, p1, dv);
+            dk = A16_MMA(b1, d1, dk);
+        }
+    };
+    auto bias_row = [&](float* slot, const f32x16& dk, const f32x16& dv) {   // the bias key's two lanes: raw (dk | dv) into a slot
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                slot[8 * gq + 4 * hh + i] = dk[4 * gq + i] * kLn2;   // (the Q images carry q log2(e))
+                slot[kDH + 8 * gq + 4 * hh + i] = dv[4 * gq + i];
+            }
+    };
+    const int own = 32 * w + l31;
+    if (w < nkt && w < 8) {
+        f32x16 dk, dv;
+        key_pass(w, 0, nqt, dk, dv);
+        if (own == len) bias_row(sRed, dk, dv);
+        unrope_fast(dk, own < len ? own : 0, inv_freq, hh, kLn2);   // the Q images carry q log2(e)
+        if (own < len && !A16_SEQ_NOSTORE) {
+            float* dst = dqkv + (tok0 + (long)own * pstr) * ld + kC + g.hd * kDH + 4 * hh;
+#pragma unroll
+            for (int gq = 0; gq < 3; ++gq) {
+                *reinterpret_cast<f32x4*>(dst + 8 * gq) = f32x4{dk[4 * gq], dk[4 * gq + 1], dk[4 * gq + 2], dk[4 * gq + 3]};
+                *reinterpret_cast<f32x4*>(dst + kC + 8 * gq) = f32x4{dv[4 * gq], dv[4 * gq + 1], dv[4 * gq + 2], dv[4 * gq + 3]};
+            }
+        }
+    }
+    if (nkt == 9 && w < nqt) {   // len = 256: the bias key's tile, one query tile per wave
+        f32x16 dk, dv;
+        key_pass(8, w, w + 1, dk, dv);
+        if (l31 == 0) bias_row(sRed + w * 2 * kDH, dk, dv);
+    }
+    __syncthreads();
+    // the bias key: partial rows summed in wave order, dk back through its rotation (position len), one row per sequence
+    float* dst = dbias + (long)g.seq * 2 * kC + g.hd * kDH;
+    auto red = [&](int i) {
+        float a = 0.f;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) a += sRed[x * 2 * kDH + i];
+        return a;
+    };
+    if (tid < 12) {
+        const float ang = (float)len * inv_freq[tid];
+        const float c = cosf(ang), sn = sinf(ang);
+        const float y1 = red(tid), y2 = red(tid + 12);
+        dst[tid] = y1 * c + y2 * sn;            // R(-theta): d x1 = d y1 c + d y2 s
+        dst[tid + 12] = y2 * c - y1 * sn;       //            d x2 = d y2 c - d y1 s
+    } else if (tid >= 32 && tid < 32 + kDH) {
+        dst[kC + tid - 32] = red(kDH + tid - 32);
+    }
+}
+
+// Workgroup b: sequence (b / 32 / 8) * 8 + b % 8 (all 32 workgroups of a sequence on ONE XCD, see wg_of), pass (b / 8 / 16) % 2,
+// head (b / 8) % 16: the two passes of a sequence are dispatched back to back, so the key pass finds the rows the query pass read
+// in its XCD's L2 (64 resident workgroups = two sequences = 3.8 MB of rows).
+__global__ __launch_bounds__(512, 2) void k16_attn_bwd_seq(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
+                                                           const float* __restrict__ bias_k, const float* __restrict__ bias_v,
+                                                           const float* __restrict__ inv_freq, const float* __restrict__ o,
+                                                           const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                           float* __restrict__ dbias, const float* __restrict__ lse_in) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kSeqLds];
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3, within = rest % (2 * kH);
+    const Wg g{(rest / (2 * kH)) * 8 + xcd, within % kH, 0};
+    if (g.seq >= ax.nseq) return;
+    if (within < kH) attn_bwd_seq_q(lds, g, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout, dqkv, lse_in);
+    else attn_bwd_seq_kv(lds, g, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout, dqkv, dbias, lse_in);
+}
+
+// ---- forward, one workgroup per (sequence, head): the same idea for the forward pass (k: 288 row-major rows, v transposed, the
+// key-validity addends: 43 KB, filled once; no barrier and no global load inside the key loop).  Tile order and arithmetic are
+// those of k16_attn, except that q is multiplied by log2(e) BEFORE it is rounded to bf16 (scores in log2 units: no multiply in
+// front of the exponentials, here and in k16_attn_bwd_seq, which rounds the same product): the two forms agree to bf16 rounding.
+__global__ __launch_bounds__(512, 2) void k16_attn_seq(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
+                                                       const float* __restrict__ bias_k, const float* __restrict__ bias_v,
+                                                       const float* __restrict__ inv_freq, float* __restrict__ out,
+                                                       float* __restrict__ lse_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK[kSeqK * kRowB];
+    __shared__ __attribute__((aligned(16))) unsigned char sVt[32 * kTrKB];
+    __shared__ __attribute__((aligned(16))) float sM[kSeqK];
+    __shared__ __attribute__((aligned(16))) float sB[2 * kDH];
+    const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5, w = wave_id();
+    const Wg g = wg_of(1);
+    if (g.seq >= ax.nseq) return;
+    const int nkt = len / 32 + 1, nqt = (len + 31) / 32;
+    const long tok0 = ax.token(g.seq, 0);
+    const long pstr = ax.pos_stride;
+    fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
+    for (int e = tid; e < kSeqK; e += 512) *reinterpret_cast<u32x4*>(sK + e * kRowB + 48) = u32x4{0, 0, 0, 0};
+    for (int e = tid; e < 8 * (kTrKB / 16); e += 512) *reinterpret_cast<u32x4*>(sVt + 24 * kTrKB + e * 16) = u32x4{0, 0, 0, 0};
+    for (int r = tid; r < 32 * nkt; r += 512)
+        sM[r] = r < len ? (mk.at(tok0 + (long)r * pstr) != 0.f ? 0.f : kMasked) : (r == len ? 0.f : kMasked);
+    const int qi = 32 * w + l31;
+    const long qtok = tok0 + (long)(qi < len ? qi : len - 1) * pstr;
+    const Own q = own_row(qkv + qtok * ld + g.hd * kDH, hh, nullptr, nullptr, kLog2e);   // scores in log2 units
+    __syncthreads();   // sB
+    for (int e = tid; e < 16 * nkt * 6; e += 512) {
+        const int pair = e / 6, quad = e - 6 * pair, r0 = 2 * pair;
+        f32x4 kf[2], vf[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int r = r0 + x;
+            kf[x] = vf[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < len) {
+                const float* row = qkv + (tok0 + (long)r * pstr) * ld + g.hd * kDH + 4 * quad;
+                kf[x] = *reinterpret_cast<const f32x4*>(row + kC);
+                vf[x] = *reinterpret_cast<const f32x4*>(row + 2 * kC);
+            } else if (r == len) {
+                kf[x] = *reinterpret_cast<const f32x4*>(sB + 4 * quad);
+                vf[x] = *reinterpret_cast<const f32x4*>(sB + kDH + 4 * quad);
+            }
+            put_rm(sK, r, quad, kf[x]);
+        }
+        put_tr(sVt, kTrKB, r0, quad, vf[0], vf[1]);
+    }
+    __syncthreads();
+    if (w >= nqt) return;
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = opaque_zero();
+    float mrun = kMasked, den = 0.f;
+#pragma unroll 3
+    for (int t = 0; t < nkt; ++t) {
+        f32x16 s = rows_from(sM + 32 * t, hh, 1.0f);
+        const unsigned char* kr = sK + (32 * t + l31) * kRowB + hh * 16;
+        s = A16_MMA(lds_frag(kr), q.f0, s);
+        s = A16_MMA(lds_frag(kr + 32), q.f1, s);
+        float tmax = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+        const float mnew = fmaxf(mrun, half_max(tmax));
+        const float alpha = A16_EXP2(mrun - mnew);
+        mrun = mnew;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = A16_EXP2(s[r] - mnew);
+            sum += s[r];
+            o[r] *= alpha;
+        }
+        den = den * alpha + sum;
+        bf16x8 p0, p1;
+        chain(s, p0, p1);
+        const unsigned char* vr = sVt + l31 * kTrKB + 64 * t + hh * 16;
+        o = A16_MMA(lds_frag(vr), p0, o);
+        o = A16_MMA(lds_frag(vr + 32), p1, o);
+    }
+    den = half_sum(den);
+    if (qi >= len) return;
+    const float inv = 1.0f / den;
+    float* dst = out + qtok * kC + g.hd * kDH + 4 * hh;
+#pragma unroll
+    for (int gq = 0; gq < 3; ++gq)
+        *reinterpret_cast<f32x4*>(dst + 8 * gq) = f32x4{o[4 * gq] * inv, o[4 * gq + 1] * inv, o[4 * gq + 2] * inv, o[4 * gq + 3] * inv};
+    if (lse_out && hh == 0) lse_out[qtok * kH + g.hd] = mrun * 0.6931471805599453f + logf(den);
+}
+
+// 1 (default): axes of 129 .. 256 positions take the sequence-resident backward kernel; 0: the chunked pair for every length
+// (context option "train_attn_form"; mdgen_debug_train_attention: precision 160)
+thread_local int g_k16_attn_form = 1;
+
 static unsigned wg_grid(int nseq, int nblk) { return (unsigned)((long)((nseq + 7) / 8) * 8 * kH * nblk); }   // see wg_of
 
 // Forward: 256 queries per workgroup (eight waves) once an axis is longer than 128 -- K / V are then staged once per
 // (sequence, head) at the ATLAS lengths instead of once per 128-query block (124 -> 104 us); four waves below that.
 void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
                    const float* inv_freq, float* out, hipStream_t s, float* lse_out) {
-    if (ax.len > 128) {
+    if (g_k16_attn_form && ax.len > 128 && ax.len <= kSeqQ) {
+        hipLaunchKernelGGL(k16_attn_seq, dim3(wg_grid(ax.nseq, 1)), dim3(512), 0, s, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, out, lse_out);
+    } else if (ax.len > 128) {
         const int nqb = (ax.len + 255) / 256;
         hipLaunchKernelGGL(k16_attn<8>, dim3(wg_grid(ax.nseq, nqb)), dim3(512), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
                            inv_freq, out, lse_out);
@@ -570,6 +1042,11 @@ void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& m
 void launch16_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
                        const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
                        float* stats, float* dbias, hipStream_t s, const float* lse_in) {
+    if (g_k16_attn_form && ax.len > 128 && ax.len <= kSeqQ) {   // one workgroup per (sequence, head) and pass, the other side resident in LDS
+        hipLaunchKernelGGL(k16_attn_bwd_seq, dim3(2 * wg_grid(ax.nseq, 1)), dim3(512), 0, s, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout,
+                           dqkv, dbias, lse_in);
+        return;
+    }
     const int nqb = (ax.len + 127) / 128, nkb = (ax.len + 128) / 128;
     hipLaunchKernelGGL(k16_attn_bwd_q<4>, dim3(wg_grid(ax.nseq, nqb)), dim3(256), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
                        inv_freq, o, dout, dqkv, stats, lse_in);

@@ -242,6 +242,7 @@ void launch_masked_mse(const float* pred, const float* target, const float* mask
 void launch_ipa_attn(const IpaAttnParams& p, hipStream_t s);
 
 // fp32-operand path (k_fp32.hip)
+extern thread_local int g_k16_attn_form;       // k_attn16.hip: 1 = sequence-resident attention backward for axes of 129 .. 256 positions
 extern thread_local int g_k32_bf16_operands;   // 1: k32_linear / k32_dw multiply bf16-rounded operands (training option train_precision = 16)
 extern thread_local const char* g_k32_launch_error;   // set by a launcher that refused a shape (nothing launched)
 const char* k32_take_launch_error();                  // ... and cleared by the entry point that reports it

@@ -17,10 +17,11 @@ g = dict(qkv=d(qkv), mask=d(mask), bk=d(torch.randn(384, generator=gen)), bv=d(t
 out = torch.empty(ntok, 384, device=dev); lse = torch.empty(ntok, 16, device=dev); dqkv = torch.empty(ntok, 1152, device=dev)
 dbias = torch.empty(256, 768, device=dev); stats = torch.empty(ntok, 16, 2, device=dev)
 s = L.stream_ptr()
+PREC = int(sys.argv[2]) if len(sys.argv) > 2 else 16   # 16: the training step's dispatch; 160: the chunked kernels for every length
 axes = {"residue": (T, Lr, T, 0, Lr, 1), "temporal": (Lr, T, Lr, T * Lr, 1, Lr)}   # (nseq, len, inner, outer_stride, inner_stride, pos_stride)
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     for name, ax in axes.items():
-        L.check(L.lib.mdgen_debug_train_attention(16, L.ptr(g["qkv"]), ntok, *ax, L.ptr(g["mask"]), L.ptr(g["bk"]), L.ptr(g["bv"]),
+        L.check(L.lib.mdgen_debug_train_attention(PREC, L.ptr(g["qkv"]), ntok, *ax, L.ptr(g["mask"]), L.ptr(g["bk"]), L.ptr(g["bv"]),
                                                   L.ptr(g["f"]), L.ptr(g["dout"]), L.ptr(out), L.ptr(lse), L.ptr(dqkv), L.ptr(dbias),
                                                   L.ptr(stats), s))
 torch.cuda.synchronize()
