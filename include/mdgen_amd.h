@@ -184,8 +184,12 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *   "train_attn_form"  1 (default) / 0: with train_precision 16, attention axes of 129 .. 256 positions (the ATLAS training shapes)
  *                      run their backward pass in ONE launch of one workgroup per (sequence, head) that converts the sequence's
  *                      q, k, v, dO to bf16 tiles in LDS once and runs the query pass and the key pass out of LDS
- *                      (k16_attn_bwd_seq) instead of the chunked pair k16_attn_bwd_q / _kv; the forward likewise
- *                      (k16_attn_seq).  Same products and operand rounding; 0 keeps the chunked kernels for every length.
+ *                      (k16_attn_bwd_seq: the query pass and the key pass of a sequence as neighbouring workgroups of one XCD, each
+ *                      with the other side's rows resident) instead of the chunked pair k16_attn_bwd_q / _kv; the forward likewise
+ *                      (k16_attn_seq); these kernels apply RoPE to q, k while they convert them, so no RoPE pass is launched for
+ *                      such an axis.  Same products; q is rounded to bf16 after the factor log2(e) (scores in log2 units), the
+ *                      rotation uses the hardware sine / cosine (3e-5 rad); 0 keeps the chunked kernels for every length.
+ *                      586 -> 419 us per backward launch, 28.9 -> 27.4 ms per step at cfg-5's per-GPU size.
  *   "train_streams"    2 (default) / 1: mdgen_train_forward_backward launches the weight / bias gradients (nothing reads them
  *                      before the optimiser) on a second stream of the context, beside the backward pass's critical path on the
  *                      caller's stream; it joins the caller's stream before the call returns, and milestone events are recorded
@@ -347,7 +351,9 @@ int32_t mdgen_debug_train_dw(int32_t precision, const float* dy, int32_t ldy, co
  * Forward: out[ntok][384], lse[ntok][16].  Backward from dout[ntok][384]: dqkv[ntok][1152] = (d q, d k taken back through RoPE,
  * d q also through the q scale; d v), dbias[nseq][768] = per-sequence (d bias_k | d bias_v); stats[ntok][16][2] scratch.
  * precision 32: k32_attn* + k32_rope_bwd; 16: k16_attn* (bf16 operands on the MFMA, inverse RoPE in the store stage) as the training
- * step dispatches them; 160: the chunked k16 kernels for every length (the A/B of option "train_attn_form"). */
+ * step dispatches them; 160: the chunked k16 kernels for every length (the A/B of option "train_attn_form"); 161 (len 129 .. 256
+ * only): q, k of `qkv` are given UNROTATED (q scaled) and the sequence-resident kernels rotate them while they convert them,
+ * as the training step runs them (it launches no RoPE pass for such an axis). */
 int32_t mdgen_debug_train_attention(int32_t precision, const float* qkv, int64_t ntok, int32_t nseq, int32_t len, int32_t inner,
                                     int32_t outer_stride, int32_t inner_stride, int32_t pos_stride, const float* mask,
                                     const float* bias_k, const float* bias_v, const float* inv_freq, const float* dout,

@@ -591,7 +591,7 @@ namespace {
 constexpr int kSeqQ = 256, kSeqK = 288;
 constexpr int kTrQB = kSeqQ * 2 + 16, kTrKB = kSeqK * 2 + 16;   // bytes of one feature row of a transposed (Q | K) image
 constexpr float kLn2 = 0.6931471805599453f;
-constexpr int kSeqLds = 2 * kSeqQ * kRowB + 2 * 32 * kTrQB + (2 * kSeqQ + 2 * kDH + 8 * 2 * kDH) * 4;   // the key pass's images: 78 528 B, two workgroups per CU
+constexpr int kSeqLds = 2 * kSeqQ * kRowB + 2 * 32 * kTrQB + (2 * kSeqQ + 2 * kDH + 8 * 2 * kDH + 12) * 4;   // the key pass's images: 78 576 B, two workgroups per CU
 
 __device__ __forceinline__ void put_tr(unsigned char* img, int stride, int rho, int quad, const f32x4& a, const f32x4& b) {
     const int col = (rho >> 5) * 64 + perm_pos(rho & 31) * 2;   // rows rho, rho + 1 (rho even) are neighbours in the permuted order
@@ -635,6 +635,49 @@ __device__ __forceinline__ void unrope_fast(f32x16& v, int pos, const float* __r
 __device__ __forceinline__ void pad_rows(unsigned char* img, int nrows, u32x4 v) {
     for (int e = threadIdx.x; e < nrows; e += 512) *reinterpret_cast<u32x4*>(img + e * kRowB + 48) = v;
 }
+// RoPE inside the kernels (launch argument `rope`: q, k arrive unrotated and k32_rope is not launched; mha.py:356-357).  sF = the
+// twelve frequencies in revolutions per position; hardware sine / cosine as in unrope_fast.
+// One row's features 4 qq .. 4 qq + 3 (lo) and 12 + 4 qq .. (hi): the two halves of four rotation pairs.
+__device__ __forceinline__ void rope_pair(f32x4& lo, f32x4& hi, int pos, int qq, const float* sF) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float rev = __builtin_amdgcn_fractf((float)pos * sF[4 * qq + c]);
+        const float cs = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+        const float x1 = lo[c], x2 = hi[c];
+        lo[c] = x1 * cs - x2 * sn;
+        hi[c] = x2 * cs + x1 * sn;
+    }
+}
+// An own row (24 floats in global memory) rotated at `pos`, scaled, as an MFMA B operand.
+__device__ __forceinline__ Own own_row_rope(const float* row, int pos, int hh, const float* sF, float scale) {
+    float x[24], y[24];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[4 * c + i] = v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const float rev = __builtin_amdgcn_fractf((float)pos * sF[i]);
+        const float cs = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+        y[i] = (x[i] * cs - x[i + 12] * sn) * scale;
+        y[i + 12] = (x[i + 12] * cs + x[i] * sn) * scale;
+    }
+    float a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = hh ? y[8 + i] : y[i];
+        b[i] = hh ? 0.f : y[16 + i];
+    }
+    Own o;
+    o.f0 = __builtin_bit_cast(bf16x8, u32x4{pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(a[4], a[5]), pack_bf16(a[6], a[7])});
+    o.f1 = __builtin_bit_cast(bf16x8, u32x4{pack_bf16(b[0], b[1]), pack_bf16(b[2], b[3]), pack_bf16(b[4], b[5]), pack_bf16(b[6], b[7])});
+    return o;
+}
+__device__ __forceinline__ void fill_freq(float* sF, const float* __restrict__ inv_freq) {
+    if (threadIdx.x >= 64 && threadIdx.x < 76) sF[threadIdx.x - 64] = inv_freq[threadIdx.x - 64] * 0.15915494309189535f;
+}
 __device__ __forceinline__ void zero_tr_tail(unsigned char* img, int stride) {   // feature rows 24 .. 31 of a transposed image
     for (int e = threadIdx.x; e < 8 * (stride / 16); e += 512) *reinterpret_cast<u32x4*>(img + 24 * stride + e * 16) = u32x4{0, 0, 0, 0};
 }
@@ -645,15 +688,16 @@ __device__ __forceinline__ void attn_bwd_seq_q(unsigned char* lds, const Wg g, c
                                                const MaskMap& mk, const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                const float* __restrict__ inv_freq, const float* __restrict__ o,
                                                const float* __restrict__ dout, float* __restrict__ dqkv,
-                                               const float* __restrict__ lse_in) {
+                                               const float* __restrict__ lse_in, bool rope) {
     unsigned char *sK = lds, *sV = sK + kSeqK * kRowB, *sKt = sV + kSeqK * kRowB;
-    float *sM = reinterpret_cast<float*>(sKt + 32 * kTrKB), *sB = sM + kSeqK;
-    static_assert(2 * kSeqK * kRowB + 32 * kTrKB + (kSeqK + 2 * kDH) * 4 <= kSeqLds, "query pass: LDS");
+    float *sM = reinterpret_cast<float*>(sKt + 32 * kTrKB), *sB = sM + kSeqK, *sF = sB + 2 * kDH;
+    static_assert(2 * kSeqK * kRowB + 32 * kTrKB + (kSeqK + 2 * kDH + 12) * 4 <= kSeqLds, "query pass: LDS");
     const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5, w = wave_id();
     const int nkt = len / 32 + 1, nqt = (len + 31) / 32;   // key tiles incl. the bias key's, query tiles
     const long tok0 = ax.token(g.seq, 0);
     const long pstr = ax.pos_stride;
     fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
+    fill_freq(sF, inv_freq);
     pad_rows(sK, 32 * nkt, u32x4{0x3F803F80u, 0x00003F80u, 0, 0});   // 1.0 in features 24, 25, 26: -lse2 rides against them
     pad_rows(sV, 32 * nkt, u32x4{0x3F803F80u, 0x00003F80u, 0, 0});   //                             -delta
     zero_tr_tail(sKt, kTrKB);
@@ -665,38 +709,53 @@ __device__ __forceinline__ void attn_bwd_seq_q(unsigned char* lds, const Wg g, c
     Own q, dO;
     float delta = 0.f, lse2 = -kMasked;
     if (w < nqt) {
-        q = own_row(qkv + qtok * ld + g.hd * kDH, hh, nullptr, nullptr, kLog2e);   // scores in log2 units
+        if (!rope) q = own_row(qkv + qtok * ld + g.hd * kDH, hh, nullptr, nullptr, kLog2e);   // scores in log2 units
         dO = own_row(dout + qtok * kC + g.hd * kDH, hh, &delta, o + qtok * kC + g.hd * kDH);
         delta = half_sum(delta);
         if (own < len) lse2 = kLog2e * lse_in[qtok * kH + g.hd];   // beyond len: p = 2^-inf = 0
+    }
+    __syncthreads();   // sB, sF
+    if (w < nqt) {
+        if (rope) q = own_row_rope(qkv + qtok * ld + g.hd * kDH, own < len ? own : len - 1, hh, sF, kLog2e);
         if (hh) {   // features 24 .. 31 of the own operands: -lse2 and -delta ride against the 1.0s of the K / V rows
             ride3(q.f1, -lse2);
             ride3(dO.f1, -delta);
         }
     }
-    __syncthreads();   // sB
-    for (int e = tid; e < 16 * nkt * 6; e += 512) {   // the (row pair, feature quad) items of the key side
-        const int pair = e / 6, quad = e - 6 * pair, r0 = 2 * pair;
-        f32x4 kf[2], vf[2];
+    // the fill: item = (row pair, feature quads qq and qq + 3) -- both halves of its rotation pairs in one thread, two neighbouring
+    // rows for the packed transposed stores; 16 nkt * 3 <= 432 items
+    if (tid < 16 * nkt * 3) {
+        const int pair = tid / 3, qq = tid - 3 * pair, r0 = 2 * pair;
+        f32x4 kf[2][2], vf[2][2];
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const int r = r0 + x;
-            kf[x] = vf[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kf[x][0] = kf[x][1] = vf[x][0] = vf[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (r < len && !A16_SEQ_NOLOAD) {
-                const float* row = qkv + (tok0 + (long)r * pstr) * ld + g.hd * kDH + 4 * quad;
-                kf[x] = *reinterpret_cast<const f32x4*>(row + kC);
-                vf[x] = *reinterpret_cast<const f32x4*>(row + 2 * kC);
+                const float* row = qkv + (tok0 + (long)r * pstr) * ld + g.hd * kDH + 4 * qq;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    kf[x][h] = *reinterpret_cast<const f32x4*>(row + kC + 12 * h);
+                    vf[x][h] = *reinterpret_cast<const f32x4*>(row + 2 * kC + 12 * h);
+                }
+                if (rope) rope_pair(kf[x][0], kf[x][1], r, qq, sF);
             } else if (r == len) {
-                kf[x] = *reinterpret_cast<const f32x4*>(sB + 4 * quad);
-                vf[x] = *reinterpret_cast<const f32x4*>(sB + kDH + 4 * quad);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    kf[x][h] = *reinterpret_cast<const f32x4*>(sB + 4 * qq + 12 * h);
+                    vf[x][h] = *reinterpret_cast<const f32x4*>(sB + kDH + 4 * qq + 12 * h);
+                }
             }
         }
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            put_rm(sK, r0 + x, quad, kf[x]);
-            put_rm(sV, r0 + x, quad, vf[x]);
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                put_rm(sK, r0 + x, qq + 3 * h, kf[x][h]);
+                put_rm(sV, r0 + x, qq + 3 * h, vf[x][h]);
+            }
+            put_tr(sKt, kTrKB, r0, qq + 3 * h, kf[0][h], kf[1][h]);
         }
-        put_tr(sKt, kTrKB, r0, quad, kf[0], kf[1]);
     }
     __syncthreads();
     if (w >= nqt) return;
@@ -752,14 +811,16 @@ __device__ __forceinline__ void attn_bwd_seq_kv(unsigned char* lds, const Wg g, 
                                                 const MaskMap& mk, const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                 const float* __restrict__ inv_freq, const float* __restrict__ o,
                                                 const float* __restrict__ dout, float* __restrict__ dqkv,
-                                                float* __restrict__ dbias, const float* __restrict__ lse_in) {
+                                                float* __restrict__ dbias, const float* __restrict__ lse_in, bool rope) {
     unsigned char *sQ = lds, *sdO = sQ + kSeqQ * kRowB, *sQt = sdO + kSeqQ * kRowB, *sdOt = sQt + 32 * kTrQB;
-    float *sLse = reinterpret_cast<float*>(sdOt + 32 * kTrQB), *sDel = sLse + kSeqQ, *sB = sDel + kSeqQ, *sRed = sB + 2 * kDH;
+    float *sLse = reinterpret_cast<float*>(sdOt + 32 * kTrQB), *sDel = sLse + kSeqQ, *sB = sDel + kSeqQ, *sRed = sB + 2 * kDH,
+          *sF = sRed + 8 * 2 * kDH;
     const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5, w = wave_id();
     const int nkt = len / 32 + 1, nqt = (len + 31) / 32;
     const long tok0 = ax.token(g.seq, 0);
     const long pstr = ax.pos_stride;
     fill_bias(sB, bias_k, bias_v, inv_freq, g.hd, len);
+    fill_freq(sF, inv_freq);
     pad_rows(sQ, 32 * nqt, u32x4{0, 0x3F800000u, 0, 0});   // 1.0 in feature 27: the own key's validity rides against it
     pad_rows(sdO, 32 * nqt, u32x4{0, 0, 0, 0});
     zero_tr_tail(sQt, kTrQB);
@@ -784,28 +845,39 @@ __device__ __forceinline__ void attn_bwd_seq_kv(unsigned char* lds, const Wg g, 
         sLse[tid] = nl;
         sDel[tid] = nd;
     }
-    for (int e = tid; e < 16 * nqt * 6; e += 512) {   // the (row pair, feature quad) items of the query side
-        const int pair = e / 6, quad = e - 6 * pair, r0 = 2 * pair;
-        f32x4 qf[2], df[2];
+    if (rope) __syncthreads();   // sF
+    if (tid < 16 * nqt * 3) {   // the fill: (row pair, feature quads qq and qq + 3) items of the query side (see the query pass)
+        const int pair = tid / 3, qq = tid - 3 * pair, r0 = 2 * pair;
+        f32x4 qf[2][2], df[2][2];
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const int r = r0 + x;
-            qf[x] = df[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+            qf[x][0] = qf[x][1] = df[x][0] = df[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (r < len && !A16_SEQ_NOLOAD) {
                 const long t = tok0 + (long)r * pstr;
-                qf[x] = *reinterpret_cast<const f32x4*>(qkv + t * ld + g.hd * kDH + 4 * quad);
+                const float* row = qkv + t * ld + g.hd * kDH + 4 * qq;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) qf[x][i] *= kLog2e;   // scores in log2 units (k16_attn_seq rounds the same product)
-                df[x] = *reinterpret_cast<const f32x4*>(dout + t * kC + g.hd * kDH + 4 * quad);
+                for (int h = 0; h < 2; ++h) {
+                    qf[x][h] = *reinterpret_cast<const f32x4*>(row + 12 * h);
+                    df[x][h] = *reinterpret_cast<const f32x4*>(dout + t * kC + g.hd * kDH + 4 * qq + 12 * h);
+                }
+                if (rope) rope_pair(qf[x][0], qf[x][1], r, qq, sF);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) qf[x][h][i] *= kLog2e;   // scores in log2 units (k16_attn_seq rounds the same product)
             }
         }
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            put_rm(sQ, r0 + x, quad, qf[x]);
-            put_rm(sdO, r0 + x, quad, df[x]);
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                put_rm(sQ, r0 + x, qq + 3 * h, qf[x][h]);
+                put_rm(sdO, r0 + x, qq + 3 * h, df[x][h]);
+            }
+            put_tr(sQt, kTrQB, r0, qq + 3 * h, qf[0][h], qf[1][h]);
+            put_tr(sdOt, kTrQB, r0, qq + 3 * h, df[0][h], df[1][h]);
         }
-        put_tr(sQt, kTrQB, r0, quad, qf[0], qf[1]);
-        put_tr(sdOt, kTrQB, r0, quad, df[0], df[1]);
     }
     __syncthreads();
     // (dk, dv) of key tile jt over the query tiles t0 .. t1 - 1
@@ -815,7 +887,7 @@ __device__ __forceinline__ void attn_bwd_seq_kv(unsigned char* lds, const Wg g, 
         bool valid;
         if (j < len) {
             const long ktok = tok0 + (long)j * pstr;
-            k = own_row(qkv + ktok * ld + kC + g.hd * kDH, hh);
+            k = rope ? own_row_rope(qkv + ktok * ld + kC + g.hd * kDH, j, hh, sF, 1.0f) : own_row(qkv + ktok * ld + kC + g.hd * kDH, hh);
             v = own_row(qkv + ktok * ld + 2 * kC + g.hd * kDH, hh);
             valid = mk.at(ktok) != 0.f;
         } else if (j == len) {
@@ -919,13 +991,13 @@ __global__ __launch_bounds__(512, 2) void k16_attn_bwd_seq(const float* __restri
                                                            const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                            const float* __restrict__ inv_freq, const float* __restrict__ o,
                                                            const float* __restrict__ dout, float* __restrict__ dqkv,
-                                                           float* __restrict__ dbias, const float* __restrict__ lse_in) {
+                                                           float* __restrict__ dbias, const float* __restrict__ lse_in, bool rope) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kSeqLds];
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3, within = rest % (2 * kH);
     const Wg g{(rest / (2 * kH)) * 8 + xcd, within % kH, 0};
     if (g.seq >= ax.nseq) return;
-    if (within < kH) attn_bwd_seq_q(lds, g, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout, dqkv, lse_in);
-    else attn_bwd_seq_kv(lds, g, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout, dqkv, dbias, lse_in);
+    if (within < kH) attn_bwd_seq_q(lds, g, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout, dqkv, lse_in, rope);
+    else attn_bwd_seq_kv(lds, g, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout, dqkv, dbias, lse_in, rope);
 }
 
 // ---- forward, one workgroup per (sequence, head): the same idea for the forward pass (k: 288 row-major rows, v transposed, the
@@ -935,11 +1007,12 @@ __global__ __launch_bounds__(512, 2) void k16_attn_bwd_seq(const float* __restri
 __global__ __launch_bounds__(512, 2) void k16_attn_seq(const float* __restrict__ qkv, int ld, AxisMap ax, MaskMap mk,
                                                        const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                        const float* __restrict__ inv_freq, float* __restrict__ out,
-                                                       float* __restrict__ lse_out) {
+                                                       float* __restrict__ lse_out, bool rope) {
     __shared__ __attribute__((aligned(16))) unsigned char sK[kSeqK * kRowB];
     __shared__ __attribute__((aligned(16))) unsigned char sVt[32 * kTrKB];
     __shared__ __attribute__((aligned(16))) float sM[kSeqK];
     __shared__ __attribute__((aligned(16))) float sB[2 * kDH];
+    __shared__ __attribute__((aligned(16))) float sF[12];
     const int len = ax.len, tid = threadIdx.x, lane = lane_id(), l31 = lane & 31, hh = lane >> 5, w = wave_id();
     const Wg g = wg_of(1);
     if (g.seq >= ax.nseq) return;
@@ -953,26 +1026,40 @@ __global__ __launch_bounds__(512, 2) void k16_attn_seq(const float* __restrict__
         sM[r] = r < len ? (mk.at(tok0 + (long)r * pstr) != 0.f ? 0.f : kMasked) : (r == len ? 0.f : kMasked);
     const int qi = 32 * w + l31;
     const long qtok = tok0 + (long)(qi < len ? qi : len - 1) * pstr;
-    const Own q = own_row(qkv + qtok * ld + g.hd * kDH, hh, nullptr, nullptr, kLog2e);   // scores in log2 units
-    __syncthreads();   // sB
-    for (int e = tid; e < 16 * nkt * 6; e += 512) {
-        const int pair = e / 6, quad = e - 6 * pair, r0 = 2 * pair;
-        f32x4 kf[2], vf[2];
+    fill_freq(sF, inv_freq);
+    Own q;
+    if (!rope) q = own_row(qkv + qtok * ld + g.hd * kDH, hh, nullptr, nullptr, kLog2e);   // scores in log2 units
+    __syncthreads();   // sB, sF
+    if (rope) q = own_row_rope(qkv + qtok * ld + g.hd * kDH, qi < len ? qi : len - 1, hh, sF, kLog2e);
+    if (tid < 16 * nkt * 3) {   // the fill: (row pair, feature quads qq and qq + 3) items (see k16_attn_bwd_seq's query pass)
+        const int pair = tid / 3, qq = tid - 3 * pair, r0 = 2 * pair;
+        f32x4 kf[2][2], vf[2][2];
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const int r = r0 + x;
-            kf[x] = vf[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kf[x][0] = kf[x][1] = vf[x][0] = vf[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (r < len) {
-                const float* row = qkv + (tok0 + (long)r * pstr) * ld + g.hd * kDH + 4 * quad;
-                kf[x] = *reinterpret_cast<const f32x4*>(row + kC);
-                vf[x] = *reinterpret_cast<const f32x4*>(row + 2 * kC);
+                const float* row = qkv + (tok0 + (long)r * pstr) * ld + g.hd * kDH + 4 * qq;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    kf[x][h] = *reinterpret_cast<const f32x4*>(row + kC + 12 * h);
+                    vf[x][h] = *reinterpret_cast<const f32x4*>(row + 2 * kC + 12 * h);
+                }
+                if (rope) rope_pair(kf[x][0], kf[x][1], r, qq, sF);
             } else if (r == len) {
-                kf[x] = *reinterpret_cast<const f32x4*>(sB + 4 * quad);
-                vf[x] = *reinterpret_cast<const f32x4*>(sB + kDH + 4 * quad);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    kf[x][h] = *reinterpret_cast<const f32x4*>(sB + 4 * qq + 12 * h);
+                    vf[x][h] = *reinterpret_cast<const f32x4*>(sB + kDH + 4 * qq + 12 * h);
+                }
             }
-            put_rm(sK, r, quad, kf[x]);
         }
-        put_tr(sVt, kTrKB, r0, quad, vf[0], vf[1]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) put_rm(sK, r0 + x, qq + 3 * h, kf[x][h]);
+            put_tr(sVt, kTrKB, r0, qq + 3 * h, vf[0][h], vf[1][h]);
+        }
     }
     __syncthreads();
     if (w >= nqt) return;
@@ -1024,10 +1111,13 @@ static unsigned wg_grid(int nseq, int nblk) { return (unsigned)((long)((nseq + 7
 
 // Forward: 256 queries per workgroup (eight waves) once an axis is longer than 128 -- K / V are then staged once per
 // (sequence, head) at the ATLAS lengths instead of once per 128-query block (124 -> 104 us); four waves below that.
+bool attn16_seq_form(const AxisMap& ax) { return g_k16_attn_form && ax.len > 128 && ax.len <= kSeqQ; }
+
 void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
-                   const float* inv_freq, float* out, hipStream_t s, float* lse_out) {
-    if (g_k16_attn_form && ax.len > 128 && ax.len <= kSeqQ) {
-        hipLaunchKernelGGL(k16_attn_seq, dim3(wg_grid(ax.nseq, 1)), dim3(512), 0, s, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, out, lse_out);
+                   const float* inv_freq, float* out, hipStream_t s, float* lse_out, bool rope_inside) {
+    if (attn16_seq_form(ax)) {
+        hipLaunchKernelGGL(k16_attn_seq, dim3(wg_grid(ax.nseq, 1)), dim3(512), 0, s, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, out, lse_out,
+                           rope_inside);
     } else if (ax.len > 128) {
         const int nqb = (ax.len + 255) / 256;
         hipLaunchKernelGGL(k16_attn<8>, dim3(wg_grid(ax.nseq, nqb)), dim3(512), 0, s, qkv, ld, ax, mk, bias_k, bias_v,
@@ -1041,10 +1131,10 @@ void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& m
 // threads -- the query pass went 168 -> 186 us and the key pass 172 -> 221 us at the ATLAS lengths)
 void launch16_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
                        const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
-                       float* stats, float* dbias, hipStream_t s, const float* lse_in) {
-    if (g_k16_attn_form && ax.len > 128 && ax.len <= kSeqQ) {   // one workgroup per (sequence, head) and pass, the other side resident in LDS
+                       float* stats, float* dbias, hipStream_t s, const float* lse_in, bool rope_inside) {
+    if (attn16_seq_form(ax)) {   // one workgroup per (sequence, head) and pass, the other side resident in LDS
         hipLaunchKernelGGL(k16_attn_bwd_seq, dim3(2 * wg_grid(ax.nseq, 1)), dim3(512), 0, s, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout,
-                           dqkv, dbias, lse_in);
+                           dqkv, dbias, lse_in, rope_inside);
         return;
     }
     const int nqb = (ax.len + 127) / 128, nkb = (ax.len + 128) / 128;

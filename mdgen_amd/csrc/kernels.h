@@ -300,11 +300,14 @@ bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ld
 bool launch16_pack_wstream(const float* const* src, int nsrc, int seg, int ld, long n, int m, int k, int turned, void* out, hipStream_t s);
 // bf16-operand (MFMA) attention of the training step, k_attn16.hip: same arguments as launch32_attn / launch32_attn_bwd; the
 // backward needs the forward's log-sum-exp tape (lse_in != nullptr).
+// rope_inside (only where attn16_seq_form(ax): the sequence-resident kernels): q, k of `qkv` are NOT rotated yet -- the kernels
+// rotate them while they convert them (no k32_rope pass); forward and backward of a sub-layer must agree on it
+bool attn16_seq_form(const AxisMap& ax);
 void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
-                   const float* inv_freq, float* out, hipStream_t s, float* lse_out = nullptr);
+                   const float* inv_freq, float* out, hipStream_t s, float* lse_out = nullptr, bool rope_inside = false);
 void launch16_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
                        const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
-                       float* stats, float* dbias, hipStream_t s, const float* lse_in);
+                       float* stats, float* dbias, hipStream_t s, const float* lse_in, bool rope_inside = false);
 void launch32_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
                    const float* inv_freq, float* out, hipStream_t s, float* lse_out = nullptr);
 

@@ -2165,10 +2165,20 @@ def test_training_attention_kernels_unit(ln, layout):
     inv_freq = 1.0 / (10000.0 ** (torch.arange(0, 24, 2).float() / 24))
     dout = torch.randn(ntok, 384, generator=gen)
     r_out, r_lse, r_dqkv, r_dbias = _attn_axis_reference(qkv, mask, bias_k, bias_v, inv_freq, dout, tok)
+    # precision 161: q, k handed over UNROTATED, the kernels apply RoPE themselves (what the training step does on such an axis)
+    pos_of = torch.empty(ntok, dtype=torch.long)
+    pos_of[tok.reshape(-1)] = torch.arange(ln).repeat(nseq)
+    ang = pos_of[:, None].float() * inv_freq[None, :]                      # [ntok][12]
+    co, si = torch.cos(ang)[:, None, :], torch.sin(ang)[:, None, :]
+    def unrot(x):                                                          # inverse of y1 = x1 c - x2 s, y2 = x2 c + x1 s, per head
+        y = x.view(ntok, 16, 24)
+        y1, y2 = y[..., :12], y[..., 12:]
+        return torch.cat([y1 * co + y2 * si, y2 * co - y1 * si], -1).reshape(ntok, 384)
+    qkv_raw = torch.cat([unrot(qkv[:, :384]), unrot(qkv[:, 384:768]), qkv[:, 768:]], 1)
     d = lambda t: t.to(dev).contiguous()
-    g = dict(qkv=d(qkv), mask=d(mask), bk=d(bias_k), bv=d(bias_v), f=d(inv_freq), dout=d(dout))
+    g = dict(qkv=d(qkv), qkv_raw=d(qkv_raw), mask=d(mask), bk=d(bias_k), bv=d(bias_v), f=d(inv_freq), dout=d(dout))
     s = L.stream_ptr()
-    legs = ((32, 2e-5, 2e-5), (16, 1e-2, 3e-2)) + (((160, 1e-2, 3e-2),) if 128 < ln <= 256 else ())
+    legs = ((32, 2e-5, 2e-5), (16, 1e-2, 3e-2)) + (((160, 1e-2, 3e-2), (161, 1e-2, 3e-2)) if 128 < ln <= 256 else ())
     seen = {}
     for prec, tol_o, tol_g in legs:
         out = torch.full((ntok, 384), float("nan"), device=dev)
@@ -2176,7 +2186,7 @@ def test_training_attention_kernels_unit(ln, layout):
         dqkv = torch.full((ntok, 1152), float("nan"), device=dev)
         dbias = torch.full((nseq, 768), float("nan"), device=dev)
         stats = torch.empty(ntok, 16, 2, device=dev)
-        L.check(L.lib.mdgen_debug_train_attention(prec, L.ptr(g["qkv"]), ntok, *ax, L.ptr(g["mask"]), L.ptr(g["bk"]), L.ptr(g["bv"]),
+        L.check(L.lib.mdgen_debug_train_attention(prec, L.ptr(g["qkv_raw" if prec == 161 else "qkv"]), ntok, *ax, L.ptr(g["mask"]), L.ptr(g["bk"]), L.ptr(g["bv"]),
                                                   L.ptr(g["f"]), L.ptr(g["dout"]), L.ptr(out), L.ptr(lse), L.ptr(dqkv), L.ptr(dbias),
                                                   L.ptr(stats), s))
         torch.cuda.synchronize()
@@ -2194,9 +2204,10 @@ def test_training_attention_kernels_unit(ln, layout):
             seen[(prec, name)] = got.double().cpu()
     if 128 < ln <= 256:   # the two bf16-operand forms: same products, same operand rounding, different summation grouping
         for name in ("out", "lse", "dq", "dk", "dv", "dbias_k", "dbias_v"):
-            a, b = seen[(16, name)], seen[(160, name)]
-            e = float((a - b).norm() / (b.norm() + 1e-300))
-            assert e < (3e-2 if name == "dbias_k" else 1e-2), (ln, layout, name, e)
+            for leg in (16, 161):
+                a, b = seen[(leg, name)], seen[(160, name)]
+                e = float((a - b).norm() / (b.norm() + 1e-300))
+                assert e < (3e-2 if name == "dbias_k" else 1e-2), (ln, layout, leg, name, e)
 
 
 def test_row_owner_mlp_paths_agree():
