@@ -166,6 +166,7 @@ struct mdgen_ctx {
                                 // of (sequence, 64 queries), 2 always
     int opt_train_precision = 32;   // operands of the training step's linear layers / weight gradients: 32 exact fp32, 16 bf16 MFMA
     int opt_train_attn_form = 1;    // training step, bf16 operands: 1 = axes of 129 .. 256 positions take the sequence-resident attention kernels (k_attn16.hip)
+    int opt_train_defer_gate = 1;   // training step, trunk forward: 1 = a sub-layer's gated residual update is formed by the next sub-layer's LayerNorm launch
     int opt_train_streams = 2;      // training step: 2 = weight / bias gradients of the linear layers on a second stream (train.inc)
     hipStream_t train_side = nullptr;   // that stream (created on first use, default priority)
     std::vector<hipEvent_t> train_ev;   // event pool of that fork / join traffic (created on first use, round-robin)
@@ -726,6 +727,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "train_attn_form") {
         if (value != 0 && value != 1) return fail(-2, "train_attn_form must be 0 (chunked attention kernels) or 1 (sequence-resident for axes of 129 .. 256 positions)");
         c->opt_train_attn_form = value;
+    } else if (n == "train_defer_gate") {
+        if (value != 0 && value != 1) return fail(-2, "train_defer_gate must be 0 or 1");
+        c->opt_train_defer_gate = value;
     } else if (n == "train_streams") {
         if (value != 1 && value != 2) return fail(-2, "train_streams must be 1 (one stream) or 2 (weight gradients on a second stream)");
         c->opt_train_streams = value;

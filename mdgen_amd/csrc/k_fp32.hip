@@ -60,6 +60,42 @@ __global__ __launch_bounds__(256) void k32_ln_mod(const float* __restrict__ x, l
     }
 }
 
+// The same with the PREVIOUS sub-layer's gated residual update in front (training step, trunk): x = xp + gate * up is formed in
+// registers, written to `keep` (the tape's copy of the residual stream, which is also where the next update reads it) and
+// normalised -- the stream is neither updated in place nor read back (one launch and two passes over the stream less per
+// sub-layer boundary than k32_gated_add + k32_ln_mod; same arithmetic per element).
+__global__ __launch_bounds__(256) void k32_gate_ln_mod(const float* __restrict__ xp, const float* __restrict__ up, long nrows, ModMap gm,
+                                                       int gate_chunk, ModMap mm, int shift_chunk, int scale_chunk, float eps,
+                                                       float* __restrict__ y, float* __restrict__ keep) {
+    const long row = (long)blockIdx.x * 4 + wave_id();
+    if (row >= nrows) return;
+    const int lane = lane_id();
+    const float* gate = gm.mod + gm.row_off(row) + gate_chunk * kC;
+    float v[6];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = xp[row * kC + c] + gate[c] * up[row * kC + c];
+        s += v[i];
+        keep[row * kC + c] = v[i];
+    }
+    const float mean = wave_sum(s) * (1.0f / kC);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v[i] -= mean;
+        q += v[i] * v[i];
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / kC) + eps);
+    const float* mod = mm.mod + mm.row_off(row);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = lane + 64 * i;
+        y[row * kC + c] = v[i] * rstd * (1.0f + mod[scale_chunk * kC + c]) + mod[shift_chunk * kC + c];
+    }
+}
+
 // Operand precision of the training step's linear layers / weight gradients: 0 = fp32 products (k32_linear / k32_dw on
 // v_mfma_f32_32x32x2_f32, the exact mode), 1 = k16_linear / k16_dw: operands rounded
 // to bf16 on their way into LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- what the reference
@@ -603,6 +639,11 @@ void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chu
                      float* y, hipStream_t s, float* keep) {
     hipLaunchKernelGGL(k32_ln_mod, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, x, nrows, mm, shift_chunk, scale_chunk,
                        affine, eps, y, keep);
+}
+void launch32_gate_ln_mod(const float* xp, const float* up, long nrows, const ModMap& gm, int gate_chunk, const ModMap& mm,
+                          int shift_chunk, int scale_chunk, float eps, float* y, float* keep, hipStream_t s) {
+    hipLaunchKernelGGL(k32_gate_ln_mod, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, xp, up, nrows, gm, gate_chunk, mm, shift_chunk,
+                       scale_chunk, eps, y, keep);
 }
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,

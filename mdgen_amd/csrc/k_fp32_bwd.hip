@@ -1036,6 +1036,19 @@ __global__ void k32_gated_add(float* __restrict__ h, const float* __restrict__ u
     const float g = gated ? mm.mod[mm.row_off(t) + gate_chunk * kC + c] : 1.0f;
     h[i] += g * u[i];
 }
+// h[t][c] = x[t][c] + gate[g(t)][c] * u[t][c]   (the deferred update of the training step's trunk, materialised: train.inc Pending)
+__global__ void k32_gated_sum(float* __restrict__ h, const float* __restrict__ x, const float* __restrict__ u, long nrows, ModMap mm,
+                              int gate_chunk) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * kC) return;
+    const long t = i / kC;
+    const int c = (int)(i % kC);
+    h[i] = x[i] + mm.mod[mm.row_off(t) + gate_chunk * kC + c] * u[i];
+}
+void launch32_gated_sum(float* h, const float* x, const float* u, long nrows, const ModMap& mm, int gate_chunk, hipStream_t s) {
+    const long n = nrows * kC;
+    hipLaunchKernelGGL(k32_gated_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h, x, u, nrows, mm, gate_chunk);
+}
 void launch32_gated_add(float* h, const float* u, long nrows, const ModMap& mm, int gate_chunk, int gated, hipStream_t s) {
     const long n = nrows * kC;
     hipLaunchKernelGGL(k32_gated_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h, u, nrows, mm, gate_chunk, gated);

@@ -277,6 +277,9 @@ void launch32_sum_frames(const float* a, int B, int T, int L, float* out, hipStr
 void launch32_ipa_bwd(const IpaAttnParams& f, const float* dfeat, float* dproj, float* dhw, float* qrec, float* dheadw,
                       hipStream_t s, float* part = nullptr, size_t part_floats = 0);   // part: scratch for the sliced form
 void launch32_gated_add(float* h, const float* u, long nrows, const ModMap& mm, int gate_chunk, int gated, hipStream_t s);
+void launch32_gated_sum(float* h, const float* x, const float* u, long nrows, const ModMap& mm, int gate_chunk, hipStream_t s);
+void launch32_gate_ln_mod(const float* xp, const float* up, long nrows, const ModMap& gm, int gate_chunk, const ModMap& mm,
+                          int shift_chunk, int scale_chunk, float eps, float* y, float* keep, hipStream_t s);
 void launch32_indicator(const int64_t* cm, long n, float* ind0, float* ind1, hipStream_t s);
 void launch32_embed_rows_bwd(const float* dx0, const int64_t* aatype, int ngroups, int B, int L, float* dw, hipStream_t s);
 void launch32_temb_bwd(const float* t_rows, int nrows, float tmul, const float* w0, const float* b0, const float* w2,
