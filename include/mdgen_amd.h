@@ -190,6 +190,10 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      such an axis.  Same products; q is rounded to bf16 after the factor log2(e) (scores in log2 units), the
  *                      rotation uses the hardware sine / cosine (3e-5 rad); 0 keeps the chunked kernels for every length.
  *                      586 -> 419 us per backward launch, 28.9 -> 27.4 ms per step at cfg-5's per-GPU size.
+ *   "train_defer_gate" 1 (default) / 0: forward pass of mdgen_train_forward_backward, trunk layers: a sub-layer does not apply its gated
+ *                      residual update h += gate * u in a pass of its own; the next sub-layer's LayerNorm launch forms x + gate * u in
+ *                      registers, writes it to the tape and normalises it (k32_gate_ln_mod); the stream is materialised once, after
+ *                      the last layer.  Same arithmetic per element; 26.9 -> 25.9 ms per step at cfg-5's per-GPU size.
  *   "train_streams"    2 (default) / 1: mdgen_train_forward_backward launches the weight / bias gradients (nothing reads them
  *                      before the optimiser) on a second stream of the context, beside the backward pass's critical path on the
  *                      caller's stream; it joins the caller's stream before the call returns, and milestone events are recorded
