@@ -1889,14 +1889,62 @@ def test_training_gradients_bf16_operands_vs_reference_fixture():
     tm.model.set_option("train_precision", 32)
 
 
-@pytest.mark.parametrize("shape", [(1, 24, 203, 37), (1, 300, 5, 1)], ids=["T24_L203", "T300_L5"])
+def test_training_round6_options_agree():
+    """Options `train_defer_gate` (the trunk's gated residual updates formed by the next sub-layer's LayerNorm launch) and
+    `train_attn_form` (sequence-resident attention kernels, RoPE inside, for axes of 129 .. 256 positions), each against its off
+    value on one step of 160 frames x 130 residues with bf16 operands: deferring the update changes no arithmetic -- loss and every
+    gradient bit-identical; the attention forms round q at a different point (q log2 e instead of q) -- loss to 2e-3, every
+    gradient above the noise floor to rel-L2 2e-2."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict, synth_forward_inputs
+    from mdgen_amd.train import TrainableModel
+    dev = _cuda()
+    B, T, L, npad = 1, 160, 130, 9
+    cfg = ModelConfig.atlas(num_frames=T, crop=L)
+    sd = synth_state_dict(cfg, 11)
+    inp = synth_forward_inputs(cfg, B, T, L, npad, 5)
+    gen = torch.Generator().manual_seed(9)
+    ut = torch.randn(B, T, L, cfg.latent_dim, generator=gen)
+    lm = (torch.rand(B, T, L, cfg.latent_dim, generator=gen) > 0.1).float() * inp["mask"][..., None]
+    args = (inp["x"].to(dev), inp["t"].to(dev), ut.to(dev), lm.to(dev), inp["mask"].to(dev),
+            (inp["start_rot"].to(dev), inp["start_trans"].to(dev)), inp["x_cond"].to(dev), inp["x_cond_mask"].to(dev),
+            inp["aatype"].to(dev))
+    res = {}
+    for name, opts in (("default", {}), ("gate_now", {"train_defer_gate": 0}), ("chunked", {"train_attn_form": 0})):
+        tm = TrainableModel(cfg, dev).load_state_dict(sd)
+        tm.model.set_option("train_precision", 16)
+        for k, v in opts.items():
+            tm.model.set_option(k, v)
+        tm.zero_grad()
+        loss, _ = tm.forward_backward(*args)
+        torch.cuda.synchronize()
+        res[name] = (float(loss), {k: v.detach().float().cpu().clone() for k, v in tm.params.state_dict(tm.grads).items()})
+        tm.model.set_option("train_precision", 32)
+    l0, g0 = res["default"]
+    l1, g1 = res["gate_now"]
+    assert l0 == l1, (l0, l1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    l2, g2 = res["chunked"]
+    assert abs(l0 - l2) <= 2e-3 * abs(l2), (l0, l2)
+    gmax = max(float(v.norm()) for v in g2.values())
+    for k, ref in g2.items():
+        if float(ref.norm()) < 1e-4 * gmax:
+            continue
+        e = float((g0[k].double() - ref.double()).norm() / ref.double().norm())
+        assert e < 2e-2, (k, e)
+
+
+@pytest.mark.parametrize("shape", [(1, 24, 203, 37), (1, 300, 5, 1), (1, 160, 130, 9)], ids=["T24_L203", "T300_L5", "T160_L130"])
 def test_training_bf16_operand_kernels_vs_exact_mode_at_tile_sizes(shape):
     """The golden-fixture gradient tests above run shapes of a few dozen tokens, which the launchers route to the general
     kernels.  This one is sized for the kernels the real workload runs -- the 128 x 384-tile linear layer and weight gradient
     (k_wide16.hip: >= 1024 / 4096 token rows, with row tails), the one-pass q|k|v forms, the MFMA attention forward and its
     two backward passes (k_attn16.hip) on both axes with ragged tiles (24 frames, 203 residues: partial 32-row tiles, the bias
     key inside a tile; 300 frames: three 128-query blocks, five 64-key chunks; 5 residues: one partial tile) and key padding,
-    the bf16-stored GELU output (>= 4096 rows) -- and compares train_precision 16 against the exact fp32 mode (itself gated against
+    the bf16-stored GELU output (>= 4096 rows); (round 6) 203 residues and 160 frames x 130 residues: axes of 129 .. 256 positions
+    take the sequence-resident attention kernels with RoPE inside (no rotation pass; `train_attn_form`), and every trunk sub-layer's gated
+    update rides in the next LayerNorm launch (`train_defer_gate`) -- and compares train_precision 16 against the exact fp32 mode (itself gated against
     the reference's autograd above) on identical inputs: loss to 1e-2 relative, every parameter's gradient to rel-L2 5e-2 and
     cosine 0.999 (gradients at the noise floor excepted)."""
     from mdgen_amd.config import ModelConfig
