@@ -1935,7 +1935,8 @@ def test_training_round6_options_agree():
         assert e < 2e-2, (k, e)
 
 
-@pytest.mark.parametrize("shape", [(1, 24, 203, 37), (1, 300, 5, 1), (1, 160, 130, 9)], ids=["T24_L203", "T300_L5", "T160_L130"])
+@pytest.mark.parametrize("shape", [(1, 24, 203, 37), (1, 300, 5, 1), (1, 160, 130, 9), (1, 250, 256, 16)],
+                         ids=["T24_L203", "T300_L5", "T160_L130", "T250_L256_bench_shape"])
 def test_training_bf16_operand_kernels_vs_exact_mode_at_tile_sizes(shape):
     """The golden-fixture gradient tests above run shapes of a few dozen tokens, which the launchers route to the general
     kernels.  This one is sized for the kernels the real workload runs -- the 128 x 384-tile linear layer and weight gradient
@@ -1944,7 +1945,8 @@ def test_training_bf16_operand_kernels_vs_exact_mode_at_tile_sizes(shape):
     key inside a tile; 300 frames: three 128-query blocks, five 64-key chunks; 5 residues: one partial tile) and key padding,
     the bf16-stored GELU output (>= 4096 rows); (round 6) 203 residues and 160 frames x 130 residues: axes of 129 .. 256 positions
     take the sequence-resident attention kernels with RoPE inside (no rotation pass; `train_attn_form`), and every trunk sub-layer's gated
-    update rides in the next LayerNorm launch (`train_defer_gate`) -- and compares train_precision 16 against the exact fp32 mode (itself gated against
+    update rides in the next LayerNorm launch (`train_defer_gate`); 250 frames x 256 residues = the shape bench.py's training leg
+    times (len 256: the bias key opens a ninth key tile) -- and compares train_precision 16 against the exact fp32 mode (itself gated against
     the reference's autograd above) on identical inputs: loss to 1e-2 relative, every parameter's gradient to rel-L2 5e-2 and
     cosine 0.999 (gradients at the noise floor excepted)."""
     from mdgen_amd.config import ModelConfig
