@@ -19,6 +19,11 @@
 //
 // The learned bias key / value (rotated at position len, mha.py:359-366) is row `len` of the key side; key padding is
 // an additive -3e38 that the score accumulators start from (forward, query pass) or a per-lane flag (key pass).
+//
+// Round 6: axes of 129 .. 256 positions (the ATLAS training shapes) take the SEQUENCE-RESIDENT forms further down --
+// k16_attn_seq / k16_attn_bwd_seq: eight waves own all rows of one (sequence, head), the other side is converted into LDS once,
+// scores in log2 units, per-row addends in the padding features of the operands, RoPE applied while converting (option
+// train_attn_form; launch16_attn / launch16_attn_bwd choose).  The kernels right below remain for every other length.
 #include "common.h"
 #include "kernels.h"
 
