@@ -169,6 +169,14 @@ struct mdgen_ctx {
     int opt_train_defer_gate = 1;   // training step, trunk forward: 1 = a sub-layer's gated residual update is formed by the next sub-layer's LayerNorm launch
     int opt_train_streams = 2;      // training step: 2 = weight / bias gradients of the linear layers on a second stream (train.inc)
     hipStream_t train_side = nullptr;   // that stream (created on first use, default priority)
+    // Turned weights of the small launches' dX products (train.inc `turned`): the requests of one call in order, their images in
+    // tr_buf, computed on the second stream at the start of the next call with the same requests
+    struct TurnReq { const float* w[3]; int nseg, rows, cols; size_t off; };
+    std::vector<TurnReq> tr_plan;
+    float* tr_buf = nullptr;
+    size_t tr_buf_floats = 0;
+    bool tr_plan_ok = false;
+    int opt_train_turn_ahead = 1;       // 1: those images are computed ahead on the second stream (needs train_streams 2)
     std::vector<hipEvent_t> train_ev;   // event pool of that fork / join traffic (created on first use, round-robin)
     size_t train_ev_next = 0;
     int opt_mlp_fold = 1;       // sampling (t shared by the batch): the MLP gate folded into per-(step, layer) fc2 streams, k_mlp_rows starts its
@@ -620,6 +628,7 @@ extern "C" int32_t mdgen_ctx_destroy(mdgen_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (hipEvent_t e : c->train_ev) (void)hipEventDestroy(e);
     if (c->train_side) (void)hipStreamDestroy(c->train_side);
+    if (c->tr_buf) (void)hipFree(c->tr_buf);
     for (int i = 0; i < mdgen_ctx::kMaxSide; ++i) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
@@ -730,6 +739,10 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "train_defer_gate") {
         if (value != 0 && value != 1) return fail(-2, "train_defer_gate must be 0 or 1");
         c->opt_train_defer_gate = value;
+    } else if (n == "train_turn_ahead") {
+        if (value != 0 && value != 1) return fail(-2, "train_turn_ahead must be 0 or 1");
+        c->opt_train_turn_ahead = value;
+        c->tr_plan_ok = false;
     } else if (n == "train_streams") {
         if (value != 1 && value != 2) return fail(-2, "train_streams must be 1 (one stream) or 2 (weight gradients on a second stream)");
         c->opt_train_streams = value;
