@@ -194,6 +194,11 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      residual update h += gate * u in a pass of its own; the next sub-layer's LayerNorm launch forms x + gate * u in
  *                      registers, writes it to the tape and normalises it (k32_gate_ln_mod); the stream is materialised once, after
  *                      the last layer.  Same arithmetic per element; 26.9 -> 25.9 ms per step at cfg-5's per-GPU size.
+ *   "train_turn_ahead" 1 (default) / 0: with train_streams 2 and train_precision 16, the turned weights of the dX products too small
+ *                      for the streamed kernel (W^T through k32_transpose: the IPA stack's 256-row launches, ~50 per step) are
+ *                      computed on the second stream at the START of the call, beside the forward pass, from the list of requests the
+ *                      previous call recorded; a call that asks for something else falls back to a launch in place and records
+ *                      anew.  Same values; 25.6 -> 25.2 ms per step.  (Images live in a context-owned buffer, ~30 MB at cfg-5.)
  *   "train_streams"    2 (default) / 1: mdgen_train_forward_backward launches the weight / bias gradients (nothing reads them
  *                      before the optimiser) on a second stream of the context, beside the backward pass's critical path on the
  *                      caller's stream; it joins the caller's stream before the call returns, and milestone events are recorded
