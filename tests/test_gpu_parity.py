@@ -1889,6 +1889,65 @@ def test_training_gradients_bf16_operands_vs_reference_fixture():
     tm.model.set_option("train_precision", 32)
 
 
+def test_training_turned_weights_ahead_of_time():
+    """Option `train_turn_ahead` (default on): the turned weights of the small launches' dX products are computed on the second stream
+    at the start of a call, from the request list the previous call recorded.  Call 1 records (everything in place), call 2 uses the
+    images, a call at another shape deviates from the list (falls back in place, records anew), the call after that uses the new
+    list: every call's loss and gradients are bit-identical to the same call with the option off -- also after the weights were
+    changed in place between two calls (the images are recomputed every call)."""
+    from mdgen_amd.config import ModelConfig
+    from mdgen_amd.synthetic import synth_state_dict, synth_forward_inputs
+    from mdgen_amd.train import TrainableModel
+    dev = _cuda()
+
+    def make_args(cfg, B, T, L, npad, seed):
+        inp = synth_forward_inputs(cfg, B, T, L, npad, seed)
+        gen = torch.Generator().manual_seed(seed)
+        ut = torch.randn(B, T, L, cfg.latent_dim, generator=gen)
+        lm = (torch.rand(B, T, L, cfg.latent_dim, generator=gen) > 0.1).float() * inp["mask"][..., None]
+        return (inp["x"].to(dev), inp["t"].to(dev), ut.to(dev), lm.to(dev), inp["mask"].to(dev),
+                (inp["start_rot"].to(dev), inp["start_trans"].to(dev)), inp["x_cond"].to(dev), inp["x_cond_mask"].to(dev),
+                inp["aatype"].to(dev))
+
+    results = {}
+    for ahead in (1, 0):
+        out = []
+        tms = {}
+        for T, L in ((12, 40), (6, 24)):        # two models (num_frames is part of the config), sharing nothing
+            cfg = ModelConfig.atlas(num_frames=T, crop=L)
+            tm = TrainableModel(cfg, dev).load_state_dict(synth_state_dict(cfg, 11))
+            tm.model.set_option("train_precision", 16)
+            tm.model.set_option("train_turn_ahead", ahead)
+            tms[(T, L)] = (tm, make_args(cfg, 1, T, L, 3, 5))
+        tm, args = tms[(12, 40)]
+        for call in range(4):
+            if call == 2:                       # the weights change in place (as after an optimiser step)
+                with torch.no_grad():
+                    tm.params.data.mul_(1.001)
+                tm.mark_updated()
+            tm.zero_grad()
+            loss, _ = tm.forward_backward(*args)
+            torch.cuda.synchronize()
+            out.append((float(loss), {k: v.detach().float().cpu().clone() for k, v in tm.params.state_dict(tm.grads).items()}))
+        tm2, args2 = tms[(6, 24)]               # a second context: its own list
+        for call in range(2):
+            tm2.zero_grad()
+            loss, _ = tm2.forward_backward(*args2)
+            torch.cuda.synchronize()
+            out.append((float(loss), {k: v.detach().float().cpu().clone() for k, v in tm2.params.state_dict(tm2.grads).items()}))
+        for tm_, _ in tms.values():
+            tm_.model.set_option("train_precision", 32)
+        results[ahead] = out
+    for i, ((l1, g1), (l0, g0)) in enumerate(zip(results[1], results[0])):
+        assert l1 == l0, (i, l1, l0)
+        for k in g0:
+            assert torch.equal(g1[k], g0[k]), (i, k)
+    # call 1 (recorded in place) against call 2 (images computed ahead): the same inputs, the same bits
+    assert results[1][0][0] == results[1][1][0]
+    for k in results[1][0][1]:
+        assert torch.equal(results[1][0][1][k], results[1][1][1][k]), k
+
+
 def test_training_round6_options_agree():
     """Options `train_defer_gate` (the trunk's gated residual updates formed by the next sub-layer's LayerNorm launch) and
     `train_attn_form` (sequence-resident attention kernels, RoPE inside, for axes of 129 .. 256 positions), each against its off
