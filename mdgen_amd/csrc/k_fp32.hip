@@ -28,9 +28,13 @@ namespace mdg {
 
 // one wave per row; rows in natural token order
 // keep != nullptr: the input rows are also copied there (the training tape's h_in: the row is in registers anyway)
+// y16 != nullptr: y is written THERE, rounded to bf16 (training step, bf16-operand mode: the LayerNorm output of the trunk is only ever
+// a GEMM operand -- the token rows of the q | k | v / fc1 products and X of their weight gradients, which round it to bf16 on their
+// way into LDS anyway: the same values enter the MFMAs, half the bytes cross HBM three times)
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return (unsigned short)(pack_bf16(v, 0.f) & 0xffffu); }
 __global__ __launch_bounds__(256) void k32_ln_mod(const float* __restrict__ x, long nrows, ModMap mm, int shift_chunk,
                                                   int scale_chunk, int affine, float eps, float* __restrict__ y,
-                                                  float* __restrict__ keep) {
+                                                  float* __restrict__ keep, unsigned short* __restrict__ y16) {
     const long row = (long)blockIdx.x * 4 + wave_id();
     if (row >= nrows) return;
     const int lane = lane_id();
@@ -56,7 +60,9 @@ __global__ __launch_bounds__(256) void k32_ln_mod(const float* __restrict__ x, l
     for (int i = 0; i < 6; ++i) {
         const int c = lane + 64 * i;
         const float sc = mod[scale_chunk * kC + c], sh = mod[shift_chunk * kC + c];
-        y[row * kC + c] = v[i] * rstd * (affine ? sc : 1.0f + sc) + sh;
+        const float o = v[i] * rstd * (affine ? sc : 1.0f + sc) + sh;
+        if (y16) y16[row * kC + c] = bf16_bits(o);
+        else y[row * kC + c] = o;
     }
 }
 
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) void k32_ln_mod(const float* __restrict__ x, l
 // sub-layer boundary than k32_gated_add + k32_ln_mod; same arithmetic per element).
 __global__ __launch_bounds__(256) void k32_gate_ln_mod(const float* __restrict__ xp, const float* __restrict__ up, long nrows, ModMap gm,
                                                        int gate_chunk, ModMap mm, int shift_chunk, int scale_chunk, float eps,
-                                                       float* __restrict__ y, float* __restrict__ keep) {
+                                                       float* __restrict__ y, float* __restrict__ keep, unsigned short* __restrict__ y16) {
     const long row = (long)blockIdx.x * 4 + wave_id();
     if (row >= nrows) return;
     const int lane = lane_id();
@@ -92,7 +98,9 @@ __global__ __launch_bounds__(256) void k32_gate_ln_mod(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int c = lane + 64 * i;
-        y[row * kC + c] = v[i] * rstd * (1.0f + mod[scale_chunk * kC + c]) + mod[shift_chunk * kC + c];
+        const float o = v[i] * rstd * (1.0f + mod[scale_chunk * kC + c]) + mod[shift_chunk * kC + c];
+        if (y16) y16[row * kC + c] = bf16_bits(o);
+        else y[row * kC + c] = o;
     }
 }
 
@@ -636,14 +644,14 @@ __global__ __launch_bounds__(256) void k32_attn(const float* __restrict__ qkv, i
 // IPA attention kernels (IpaAttnParams::feat32).
 
 void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chunk, int scale_chunk, int affine, float eps,
-                     float* y, hipStream_t s, float* keep) {
+                     float* y, hipStream_t s, float* keep, bool y_bf16) {
     hipLaunchKernelGGL(k32_ln_mod, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, x, nrows, mm, shift_chunk, scale_chunk,
-                       affine, eps, y, keep);
+                       affine, eps, y, keep, y_bf16 ? reinterpret_cast<unsigned short*>(y) : nullptr);
 }
 void launch32_gate_ln_mod(const float* xp, const float* up, long nrows, const ModMap& gm, int gate_chunk, const ModMap& mm,
-                          int shift_chunk, int scale_chunk, float eps, float* y, float* keep, hipStream_t s) {
+                          int shift_chunk, int scale_chunk, float eps, float* y, float* keep, hipStream_t s, bool y_bf16) {
     hipLaunchKernelGGL(k32_gate_ln_mod, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, xp, up, nrows, gm, gate_chunk, mm, shift_chunk,
-                       scale_chunk, eps, y, keep);
+                       scale_chunk, eps, y, keep, y_bf16 ? reinterpret_cast<unsigned short*>(y) : nullptr);
 }
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
@@ -681,14 +689,18 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
 // q | k | v (three [mseg][k] layers of the same input) in one pass of k16_linear_fast: c[n][col0 + j mseg + i] =
 // (a . w[j][i] + bias[j][i]) * scale[j].  false: shape not eligible (or exact-fp32 mode), nothing launched.
 bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ldw, const float* const* bias, const float* scale,
-                          long n, int mseg, int k, float* c, int ldc, int col0, hipStream_t s, const void* wpack) {
+                          long n, int mseg, int k, float* c, int ldc, int col0, hipStream_t s, const void* wpack, bool a_bf16) {
     const auto al = [](const void* q) { return ((unsigned long long)q & 15) == 0; };
     if (!g_k32_bf16_operands || mseg % 128 || k % 64 || (lda & 3) || (ldw & 3) || !al(a) || !al(w[0]) || !al(w[1]) || !al(w[2]))
         return false;
     LinearParams p{a, lda, w[0], ldw, nullptr, n, 3 * mseg, k, 0, 0, c, ldc, col0, ModMap{nullptr, 1, 1, 0, 0}, 0, 0, 0.f, nullptr,
                    mseg, {w[0], w[1], w[2]}, {bias[0], bias[1], bias[2]}, {scale[0], scale[1], scale[2]},
-                   static_cast<const unsigned char*>(wpack), 1, 0, 0};
+                   static_cast<const unsigned char*>(wpack), 1, a_bf16 ? 1 : 0, 0};
     if (launch16_linear_wide(p, s)) return true;
+    if (a_bf16) {
+        g_k32_launch_error = "launch16_linear_seg3: bf16 token rows need the streamed kernel";
+        return true;
+    }
     if (n <= 2048) {
         hipLaunchKernelGGL(k16_linear_small, dim3((unsigned)(3 * mseg / 32), (unsigned)((n + 31) / 32)), dim3(64), 0, s, p);
         return true;

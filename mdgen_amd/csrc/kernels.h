@@ -247,7 +247,7 @@ extern thread_local int g_k32_bf16_operands;   // 1: k32_linear / k32_dw multipl
 extern thread_local const char* g_k32_launch_error;   // set by a launcher that refused a shape (nothing launched)
 const char* k32_take_launch_error();                  // ... and cleared by the entry point that reports it
 void launch32_ln_mod(const float* x, long nrows, const ModMap& mm, int shift_chunk, int scale_chunk, int affine, float eps,
-                     float* y, hipStream_t s, float* keep = nullptr);   // keep: copy of x (training tape)
+                     float* y, hipStream_t s, float* keep = nullptr, bool y_bf16 = false);   // keep: copy of x (training tape); y_bf16: y holds bf16 rows
 void launch32_linear(const float* a, int lda, const float* w, int ldw, const float* bias, long n, int m, int k, int mode,
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
                      int wtrans = 0, float* c2 = nullptr,
@@ -279,7 +279,7 @@ void launch32_ipa_bwd(const IpaAttnParams& f, const float* dfeat, float* dproj, 
 void launch32_gated_add(float* h, const float* u, long nrows, const ModMap& mm, int gate_chunk, int gated, hipStream_t s);
 void launch32_gated_sum(float* h, const float* x, const float* u, long nrows, const ModMap& mm, int gate_chunk, hipStream_t s);
 void launch32_gate_ln_mod(const float* xp, const float* up, long nrows, const ModMap& gm, int gate_chunk, const ModMap& mm,
-                          int shift_chunk, int scale_chunk, float eps, float* y, float* keep, hipStream_t s);
+                          int shift_chunk, int scale_chunk, float eps, float* y, float* keep, hipStream_t s, bool y_bf16 = false);
 void launch32_indicator(const int64_t* cm, long n, float* ind0, float* ind1, hipStream_t s);
 void launch32_embed_rows_bwd(const float* dx0, const int64_t* aatype, int ngroups, int B, int L, float* dw, hipStream_t s);
 void launch32_temb_bwd(const float* t_rows, int nrows, float tmul, const float* w0, const float* b0, const float* w2,
@@ -295,7 +295,8 @@ bool launch32_gate_bwd_sums(const float* dh, const float* u, long nrows, const M
                             long tokens_per_group, float* out, long ldo, float* part, size_t part_floats, hipStream_t s);
 void launch32_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s, int ldd = 0);   // dst[c][r] (ld ldd, default rows) = src[r][c]
 bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ldw, const float* const* bias, const float* scale,
-                          long n, int mseg, int k, float* c, int ldc, int col0, hipStream_t s, const void* wpack = nullptr);
+                          long n, int mseg, int k, float* c, int ldc, int col0, hipStream_t s, const void* wpack = nullptr,
+                          bool a_bf16 = false);   // a_bf16: `a` holds bf16 rows (lda in elements; the streamed kernel only)
 // bf16 fragment stream of a weight for k16_linear_wdma: W(col, kk), col < m (a multiple of 384), kk < k (a multiple of 64),
 // from nsrc <= 3 fp32 matrices of row stride ld: turned == 0: src[col / seg] is [seg][k] (layers side by side along the
 // columns); turned == 1: src[kk / seg] is [seg][m] (dX = dY W: the contraction runs over the weights' rows).

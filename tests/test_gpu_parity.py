@@ -1952,7 +1952,8 @@ def test_training_round6_options_agree():
     """Options `train_defer_gate` (the trunk's gated residual updates formed by the next sub-layer's LayerNorm launch) and
     `train_attn_form` (sequence-resident attention kernels, RoPE inside, for axes of 129 .. 256 positions), each against its off
     value on one step of 160 frames x 130 residues with bf16 operands: deferring the update changes no arithmetic -- loss and every
-    gradient bit-identical; the attention forms round q at a different point (q log2 e instead of q) -- loss to 2e-3, every
+    gradient bit-identical; `train_y_bf16` (the trunk's taped LayerNorm outputs stored as bf16 rows: the kernels that read them round
+    them to bf16 anyway) likewise bit-identical; the attention forms round q at a different point (q log2 e instead of q) -- loss to 2e-3, every
     gradient above the noise floor to rel-L2 2e-2."""
     from mdgen_amd.config import ModelConfig
     from mdgen_amd.synthetic import synth_state_dict, synth_forward_inputs
@@ -1969,7 +1970,7 @@ def test_training_round6_options_agree():
             (inp["start_rot"].to(dev), inp["start_trans"].to(dev)), inp["x_cond"].to(dev), inp["x_cond_mask"].to(dev),
             inp["aatype"].to(dev))
     res = {}
-    for name, opts in (("default", {}), ("gate_now", {"train_defer_gate": 0}), ("chunked", {"train_attn_form": 0})):
+    for name, opts in (("default", {}), ("gate_now", {"train_defer_gate": 0}), ("y_fp32", {"train_y_bf16": 0}), ("chunked", {"train_attn_form": 0})):
         tm = TrainableModel(cfg, dev).load_state_dict(sd)
         tm.model.set_option("train_precision", 16)
         for k, v in opts.items():
@@ -1980,10 +1981,11 @@ def test_training_round6_options_agree():
         res[name] = (float(loss), {k: v.detach().float().cpu().clone() for k, v in tm.params.state_dict(tm.grads).items()})
         tm.model.set_option("train_precision", 32)
     l0, g0 = res["default"]
-    l1, g1 = res["gate_now"]
-    assert l0 == l1, (l0, l1)
-    for k in g0:
-        assert torch.equal(g0[k], g1[k]), k
+    for other in ("gate_now", "y_fp32"):
+        l1, g1 = res[other]
+        assert l0 == l1, (other, l0, l1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), (other, k)
     l2, g2 = res["chunked"]
     assert abs(l0 - l2) <= 2e-3 * abs(l2), (l0, l2)
     gmax = max(float(v.norm()) for v in g2.values())
