@@ -636,6 +636,21 @@ __device__ __forceinline__ void unrope_fast(f32x16& v, int pos, const float* __r
         }
     }
 }
+// This lane's twelve values of a gradient row (features 8 gq + 4 hh + i in v[4 gq + i]) at element offset e0 of the q | k | v gradient
+// buffer: fp32, or rounded to bf16 (out16: the buffer is bf16 rows -- it is only ever the token operand of the dX product and dY of
+// the weight gradient, which round it to bf16 anyway)
+__device__ __forceinline__ void store_grad(float* base, long e0, const f32x16& v, bool out16) {
+    if (out16) {
+        unsigned short* b16 = reinterpret_cast<unsigned short*>(base);
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq)
+            *reinterpret_cast<u32x2*>(b16 + e0 + 8 * gq) = u32x2{pack_bf16(v[4 * gq], v[4 * gq + 1]), pack_bf16(v[4 * gq + 2], v[4 * gq + 3])};
+    } else {
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq)
+            *reinterpret_cast<f32x4*>(base + e0 + 8 * gq) = f32x4{v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
+    }
+}
 // the 16 bytes of padding features 24 .. 31 of every row of a row-major image
 __device__ __forceinline__ void pad_rows(unsigned char* img, int nrows, u32x4 v) {
     for (int e = threadIdx.x; e < nrows; e += 512) *reinterpret_cast<u32x4*>(img + e * kRowB + 48) = v;
@@ -693,7 +708,7 @@ __device__ __forceinline__ void attn_bwd_seq_q(unsigned char* lds, const Wg g, c
                                                const MaskMap& mk, const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                const float* __restrict__ inv_freq, const float* __restrict__ o,
                                                const float* __restrict__ dout, float* __restrict__ dqkv,
-                                               const float* __restrict__ lse_in, bool rope) {
+                                               const float* __restrict__ lse_in, bool rope, bool out16) {
     unsigned char *sK = lds, *sV = sK + kSeqK * kRowB, *sKt = sV + kSeqK * kRowB;
     float *sM = reinterpret_cast<float*>(sKt + 32 * kTrKB), *sB = sM + kSeqK, *sF = sB + 2 * kDH;
     static_assert(2 * kSeqK * kRowB + 32 * kTrKB + (kSeqK + 2 * kDH + 12) * 4 <= kSeqLds, "query pass: LDS");
@@ -803,12 +818,7 @@ __device__ __forceinline__ void attn_bwd_seq_q(unsigned char* lds, const Wg g, c
         dp = dpn;
     }
     unrope_fast(dq, own < len ? own : len - 1, inv_freq, hh, 0.20412414523193151f);   // back through RoPE and the q scale 24^-1/2
-    if (own < len && !A16_SEQ_NOSTORE) {
-        float* dst = dqkv + qtok * ld + g.hd * kDH + 4 * hh;
-#pragma unroll
-        for (int gq = 0; gq < 3; ++gq)
-            *reinterpret_cast<f32x4*>(dst + 8 * gq) = f32x4{dq[4 * gq], dq[4 * gq + 1], dq[4 * gq + 2], dq[4 * gq + 3]};
-    }
+    if (own < len && !A16_SEQ_NOSTORE) store_grad(dqkv, qtok * ld + g.hd * kDH + 4 * hh, dq, out16);
 }
 
 // key pass: real keys write dqkv[:, 384:1152] (dk taken back through RoPE); the bias key writes dbias[seq][dk rotated back | dv]
@@ -816,7 +826,7 @@ __device__ __forceinline__ void attn_bwd_seq_kv(unsigned char* lds, const Wg g, 
                                                 const MaskMap& mk, const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                 const float* __restrict__ inv_freq, const float* __restrict__ o,
                                                 const float* __restrict__ dout, float* __restrict__ dqkv,
-                                                float* __restrict__ dbias, const float* __restrict__ lse_in, bool rope) {
+                                                float* __restrict__ dbias, const float* __restrict__ lse_in, bool rope, bool out16) {
     unsigned char *sQ = lds, *sdO = sQ + kSeqQ * kRowB, *sQt = sdO + kSeqQ * kRowB, *sdOt = sQt + 32 * kTrQB;
     float *sLse = reinterpret_cast<float*>(sdOt + 32 * kTrQB), *sDel = sLse + kSeqQ, *sB = sDel + kSeqQ, *sRed = sB + 2 * kDH,
           *sF = sRed + 8 * 2 * kDH;
@@ -956,12 +966,9 @@ __device__ __forceinline__ void attn_bwd_seq_kv(unsigned char* lds, const Wg g, 
         if (own == len) bias_row(sRed, dk, dv);
         unrope_fast(dk, own < len ? own : 0, inv_freq, hh, kLn2);   // the Q images carry q log2(e)
         if (own < len && !A16_SEQ_NOSTORE) {
-            float* dst = dqkv + (tok0 + (long)own * pstr) * ld + kC + g.hd * kDH + 4 * hh;
-#pragma unroll
-            for (int gq = 0; gq < 3; ++gq) {
-                *reinterpret_cast<f32x4*>(dst + 8 * gq) = f32x4{dk[4 * gq], dk[4 * gq + 1], dk[4 * gq + 2], dk[4 * gq + 3]};
-                *reinterpret_cast<f32x4*>(dst + kC + 8 * gq) = f32x4{dv[4 * gq], dv[4 * gq + 1], dv[4 * gq + 2], dv[4 * gq + 3]};
-            }
+            const long e0 = (tok0 + (long)own * pstr) * ld + kC + g.hd * kDH + 4 * hh;
+            store_grad(dqkv, e0, dk, out16);
+            store_grad(dqkv, e0 + kC, dv, out16);
         }
     }
     if (nkt == 9 && w < nqt) {   // len = 256: the bias key's tile, one query tile per wave
@@ -996,13 +1003,13 @@ __global__ __launch_bounds__(512, 2) void k16_attn_bwd_seq(const float* __restri
                                                            const float* __restrict__ bias_k, const float* __restrict__ bias_v,
                                                            const float* __restrict__ inv_freq, const float* __restrict__ o,
                                                            const float* __restrict__ dout, float* __restrict__ dqkv,
-                                                           float* __restrict__ dbias, const float* __restrict__ lse_in, bool rope) {
+                                                           float* __restrict__ dbias, const float* __restrict__ lse_in, bool rope, bool out16) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kSeqLds];
     const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3, within = rest % (2 * kH);
     const Wg g{(rest / (2 * kH)) * 8 + xcd, within % kH, 0};
     if (g.seq >= ax.nseq) return;
-    if (within < kH) attn_bwd_seq_q(lds, g, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout, dqkv, lse_in, rope);
-    else attn_bwd_seq_kv(lds, g, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout, dqkv, dbias, lse_in, rope);
+    if (within < kH) attn_bwd_seq_q(lds, g, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout, dqkv, lse_in, rope, out16);
+    else attn_bwd_seq_kv(lds, g, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout, dqkv, dbias, lse_in, rope, out16);
 }
 
 // ---- forward, one workgroup per (sequence, head): the same idea for the forward pass (k: 288 row-major rows, v transposed, the
@@ -1136,10 +1143,10 @@ void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& m
 // threads -- the query pass went 168 -> 186 us and the key pass 172 -> 221 us at the ATLAS lengths)
 void launch16_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
                        const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
-                       float* stats, float* dbias, hipStream_t s, const float* lse_in, bool rope_inside) {
+                       float* stats, float* dbias, hipStream_t s, const float* lse_in, bool rope_inside, bool out_bf16) {
     if (attn16_seq_form(ax)) {   // one workgroup per (sequence, head) and pass, the other side resident in LDS
         hipLaunchKernelGGL(k16_attn_bwd_seq, dim3(2 * wg_grid(ax.nseq, 1)), dim3(512), 0, s, qkv, ld, ax, mk, bias_k, bias_v, inv_freq, o, dout,
-                           dqkv, dbias, lse_in, rope_inside);
+                           dqkv, dbias, lse_in, rope_inside, out_bf16);
         return;
     }
     const int nqb = (ax.len + 127) / 128, nkb = (ax.len + 128) / 128;

@@ -886,9 +886,9 @@ __global__ void k32_sum_frames(const float* __restrict__ a, int B, int T, int L,
 // dW of nseg layers that share the input x and whose dY sit side by side (dy[n][j mseg + i]): one pass over x and dY,
 // m = nseg * mseg.  dw[j] / db[j] may be null.  Returns true if the bias gradients were computed by the same pass.
 int launch16_dw_wide(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* part, size_t part_floats,
-                     bool want_db, float** bpart_out, hipStream_t s, bool x_bf16);   // k_wide16.hip
+                     bool want_db, float** bpart_out, hipStream_t s, bool x_bf16, bool dy_bf16);   // k_wide16.hip
 bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, int mseg, int nseg, int k, float* const* dw,
-                     float* const* db, float* part, size_t part_floats, hipStream_t s, bool x_bf16) {
+                     float* const* db, float* part, size_t part_floats, hipStream_t s, bool x_bf16, bool dy_bf16) {
     const int m = mseg * nseg;
     bool want_db = false;
     for (int j = 0; j < nseg; ++j) want_db = want_db || (db && db[j]);
@@ -905,13 +905,13 @@ bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, 
     };
     if (g_k32_bf16_operands) {   // 128 x 384 tiles (k_wide16.hip): each dY tile read once
         float* bpart = nullptr;
-        if (const int ns = launch16_dw_wide(dy, ldy, x, ldx, n, m, k, part, part_floats, want_db, &bpart, s, x_bf16)) {
+        if (const int ns = launch16_dw_wide(dy, ldy, x, ldx, n, m, k, part, part_floats, want_db, &bpart, s, x_bf16, dy_bf16)) {
             reduce(ns, bpart);
             return bpart != nullptr;
         }
     }
-    if (x_bf16) {
-        g_k32_launch_error = "launch32_dw: bf16 X rows need the wide kernel (bf16-operand mode, n >= 4096)";
+    if (x_bf16 || dy_bf16) {
+        g_k32_launch_error = "launch32_dw: bf16 X / dY rows need the wide kernel (bf16-operand mode, n >= 4096)";
         return false;
     }
     // enough slices to fill the chip ONCE with 128 x 128 tiles at two workgroups per CU (a 384 x 384 weight is only 9 of

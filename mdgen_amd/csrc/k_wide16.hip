@@ -335,8 +335,9 @@ __global__ __launch_bounds__(512) void k16_linear_wdma(const LinearParams p, int
 // token rows of four columns, so that the four token values of a column are one 8-byte LDS store.
 // Tile order: the (row tile, column group) pairs of one n-slice run back to back on one XCD.
 // Requires (launcher): ldy, ldx, m, k multiples of 8, 16-byte aligned operands.
-// XBF: X is stored as bf16 rows (x reinterpreted, ldx in elements): see k16_linear_wdma.
-template <bool XBF>
+// XBF: X is stored as bf16 rows (x reinterpreted, ldx in elements): see k16_linear_wdma.  DYBF: dY likewise (round 6: the q | k | v
+// gradients the sequence-resident attention backward writes as bf16; the bias gradient then sums the rounded values).
+template <bool XBF, bool DYBF>
 __global__ __launch_bounds__(512) void k16_dw_wide(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
                                                    long n, int m, int k, int nsplit, float* __restrict__ part,
                                                    float* __restrict__ bpart) {
@@ -369,12 +370,15 @@ __global__ __launch_bounds__(512) void k16_dw_wide(const float* __restrict__ dy,
     for (int e = 0; e < 3; ++e) kc[e] = k0 + 4 * (pc + 32 * e) < k ? k0 + 4 * (pc + 32 * e) : 0;   // past the end: clamped, never stored
     f32x4 av[4], bv[3][4];
     u32x2 bh[3][4];    // XBF: four bf16 per (piece, token row)
+    u32x2 ah[4];       // DYBF: four bf16 per token row
     const uint16_t* x16 = reinterpret_cast<const uint16_t*>(x);
+    const uint16_t* dy16 = reinterpret_cast<const uint16_t*>(dy);
     auto fetch_quarter = [&](long n0, int r) {   // token row 4 g + r of the step: one dY piece, three X pieces
         {
             const long rw = n0 + 4 * g + r;
             const long row = rw < nhi ? rw : nhi - 1;
-            av[r] = *reinterpret_cast<const f32x4*>(dy + row * ldy + mc);
+            if (DYBF) ah[r] = *reinterpret_cast<const u32x2*>(dy16 + row * ldy + mc);
+            else av[r] = *reinterpret_cast<const f32x4*>(dy + row * ldy + mc);
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
                 if (XBF) bh[e][r] = *reinterpret_cast<const u32x2*>(x16 + row * ldx + kc[e]);
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(512) void k16_dw_wide(const float* __restrict__ dy,
             }
             if (rw >= nhi) {
                 av[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ah[r] = u32x2{0u, 0u};
 #pragma unroll
                 for (int e = 0; e < 3; ++e) {
                     bv[e][r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -401,10 +406,25 @@ __global__ __launch_bounds__(512) void k16_dw_wide(const float* __restrict__ dy,
         unsigned char* Q = P + kWideP;
         if (colsum)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) cs[j] += (av[0][j] + av[1][j]) + (av[2][j] + av[3][j]);
+            for (int j = 0; j < 4; ++j) {
+                if (DYBF) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (j & 1) ? bf16_hi(ah[r][j >> 1]) : bf16_lo(ah[r][j >> 1]);
+                    cs[j] += (v[0] + v[1]) + (v[2] + v[3]);
+                } else {
+                    cs[j] += (av[0][j] + av[1][j]) + (av[2][j] + av[3][j]);
+                }
+            }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<u32x2*>(P + (4 * pc + j) * kWideRowB + 8 * g) = pack4(av[0][j], av[1][j], av[2][j], av[3][j]);
+            if (DYBF) {   // as the XBF gather below
+                const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
+                *reinterpret_cast<u32x2*>(P + (4 * pc + j) * kWideRowB + 8 * g) =
+                    u32x2{__builtin_amdgcn_perm(ah[1][j >> 1], ah[0][j >> 1], sel), __builtin_amdgcn_perm(ah[3][j >> 1], ah[2][j >> 1], sel)};
+            } else {
+                *reinterpret_cast<u32x2*>(P + (4 * pc + j) * kWideRowB + 8 * g) = pack4(av[0][j], av[1][j], av[2][j], av[3][j]);
+            }
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
                 u32x2 q4;
@@ -482,7 +502,7 @@ bool launch16_linear_wide(const LinearParams& p, hipStream_t s) {
 // Same contract as the k16_dw launch inside launch32_dw_seg (k_fp32_bwd.hip): fills part[nsplit][m][k] (and bpart[nsplit][m]).
 // Returns the number of slices used, 0 if the shape is not eligible (nothing launched).
 int launch16_dw_wide(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* part, size_t part_floats,
-                     bool want_db, float** bpart_out, hipStream_t s, bool x_bf16) {
+                     bool want_db, float** bpart_out, hipStream_t s, bool x_bf16, bool dy_bf16) {
     const bool fast = ((ldy | m | ldx | k) & 7) == 0 && (((unsigned long long)dy | (unsigned long long)x) & 15) == 0;
     if (!fast || n < 4096) return 0;
     const int mt = (m + kWideRows - 1) / kWideRows, kg = (k + kWideCols - 1) / kWideCols, nt = mt * kg;
@@ -496,8 +516,10 @@ int launch16_dw_wide(const float* dy, int ldy, const float* x, int ldx, long n, 
     if ((size_t)nsplit * m * (k + 1) > part_floats) return 0;
     float* bpart = want_db ? part + (size_t)nsplit * m * k : nullptr;
     const dim3 grid((unsigned)(8 * ((nsplit + 7) / 8) * nt));
-    if (x_bf16) hipLaunchKernelGGL(k16_dw_wide<true>, grid, dim3(512), 0, s, dy, ldy, x, ldx, n, m, k, nsplit, part, bpart);
-    else hipLaunchKernelGGL(k16_dw_wide<false>, grid, dim3(512), 0, s, dy, ldy, x, ldx, n, m, k, nsplit, part, bpart);
+    if (x_bf16 && dy_bf16) hipLaunchKernelGGL((k16_dw_wide<true, true>), grid, dim3(512), 0, s, dy, ldy, x, ldx, n, m, k, nsplit, part, bpart);
+    else if (x_bf16) hipLaunchKernelGGL((k16_dw_wide<true, false>), grid, dim3(512), 0, s, dy, ldy, x, ldx, n, m, k, nsplit, part, bpart);
+    else if (dy_bf16) hipLaunchKernelGGL((k16_dw_wide<false, true>), grid, dim3(512), 0, s, dy, ldy, x, ldx, n, m, k, nsplit, part, bpart);
+    else hipLaunchKernelGGL((k16_dw_wide<false, false>), grid, dim3(512), 0, s, dy, ldy, x, ldx, n, m, k, nsplit, part, bpart);
     *bpart_out = bpart;
     return nsplit;
 }

@@ -258,7 +258,7 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
 // otherwise the caller runs launch32_colsum)
 bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, int mseg, int nseg, int k, float* const* dw,
                      float* const* db, float* part, size_t part_floats, hipStream_t s,
-                     bool x_bf16 = false);   // nseg layers sharing x, dY side by side
+                     bool x_bf16 = false, bool dy_bf16 = false);   // nseg layers sharing x, dY side by side; *_bf16: stored as bf16 rows (wide kernel only)
 bool launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,
                  size_t part_floats, hipStream_t s, float* db = nullptr, bool x_bf16 = false);   // x_bf16: x is bf16 rows (wide kernel only)
 void launch32_colsum(const float* a, int lda, const float* b, int ldb, const float* roww, int mode, long nrows, int ncols,
@@ -311,7 +311,8 @@ void launch16_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& m
                    const float* inv_freq, float* out, hipStream_t s, float* lse_out = nullptr, bool rope_inside = false);
 void launch16_attn_bwd(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k,
                        const float* bias_v, const float* inv_freq, const float* o, const float* dout, float* dqkv,
-                       float* stats, float* dbias, hipStream_t s, const float* lse_in, bool rope_inside = false);
+                       float* stats, float* dbias, hipStream_t s, const float* lse_in, bool rope_inside = false,
+                       bool out_bf16 = false);   // out_bf16 (sequence-resident form only): dqkv is written as bf16 rows (ld in elements)
 void launch32_attn(const float* qkv, int ld, const AxisMap& ax, const MaskMap& mk, const float* bias_k, const float* bias_v,
                    const float* inv_freq, float* out, hipStream_t s, float* lse_out = nullptr);
 
