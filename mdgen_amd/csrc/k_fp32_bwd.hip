@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void k32_ln_bwd_sums(const float* __restrict__
 // du = gate * dh AND d gate[g] += sum dh * u over the same rows (one pass over dh instead of two); slices as above.
 __global__ __launch_bounds__(256) void k32_gate_bwd_sums(const float* __restrict__ dh, const float* __restrict__ u, long nrows,
                                                          ModMap mm, int gate_chunk, float* __restrict__ du, long tokens_per_group,
-                                                         int rps, int spg, float* __restrict__ partial) {
+                                                         int rps, int spg, float* __restrict__ partial, int du_bf16) {
     __shared__ float red[4][kC];
     const long grp = blockIdx.x / spg;
     const int si = blockIdx.x % spg;
@@ -592,7 +592,9 @@ __global__ __launch_bounds__(256) void k32_gate_bwd_sums(const float* __restrict
             const int c = lane + 64 * i;
             const float d = dh[row * kC + c];
             c1[i] += d * u[row * kC + c];
-            du[row * kC + c] = d * mod[c];
+            // du_bf16: du is stored as bf16 rows (only ever the token operand of a dX product and dY of a weight gradient)
+            if (du_bf16) reinterpret_cast<unsigned short*>(du)[row * kC + c] = (unsigned short)(pack_bf16(d * mod[c], 0.f) & 0xffffu);
+            else du[row * kC + c] = d * mod[c];
         }
     }
 #pragma unroll
@@ -934,8 +936,8 @@ bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, 
     return bpart != nullptr;
 }
 bool launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,
-                 size_t part_floats, hipStream_t s, float* db, bool x_bf16) {
-    return launch32_dw_seg(dy, ldy, x, ldx, n, m, 1, k, &dw, &db, part, part_floats, s, x_bf16);
+                 size_t part_floats, hipStream_t s, float* db, bool x_bf16, bool dy_bf16) {
+    return launch32_dw_seg(dy, ldy, x, ldx, n, m, 1, k, &dw, &db, part, part_floats, s, x_bf16, dy_bf16);
 }
 // out[g][c] (ldo) += sum_{t in group g} a[t][c] * B(t, c); groups of tokens_per_group rows
 void launch32_colsum(const float* a, int lda, const float* b, int ldb, const float* roww, int mode, long nrows, int ncols,
@@ -980,11 +982,11 @@ bool launch32_ln_bwd_sums(const float* x, const float* dy, long nrows, const Mod
 }
 // du = gate * dh; out[g][0:384] += sum dh u
 bool launch32_gate_bwd_sums(const float* dh, const float* u, long nrows, const ModMap& mm, int gate_chunk, float* du,
-                            long tokens_per_group, float* out, long ldo, float* part, size_t part_floats, hipStream_t s) {
+                            long tokens_per_group, float* out, long ldo, float* part, size_t part_floats, hipStream_t s, bool du_bf16) {
     long ng; int rps, spg;
     if (!slice_plan(nrows, tokens_per_group, kC, part_floats, &ng, &rps, &spg)) return false;
     hipLaunchKernelGGL(k32_gate_bwd_sums, dim3((unsigned)(ng * spg)), dim3(256), 0, s, dh, u, nrows, mm, gate_chunk, du, tokens_per_group,
-                       rps, spg, part);
+                       rps, spg, part, du_bf16 ? 1 : 0);
     hipLaunchKernelGGL(k32_colsum_final, dim3((unsigned)(ng * ((kC + 15) / 16))), dim3(256), 0, s, part, (int)ng, spg, kC, out, ldo);
     return true;
 }

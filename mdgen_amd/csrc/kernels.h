@@ -260,7 +260,8 @@ bool launch32_dw_seg(const float* dy, int ldy, const float* x, int ldx, long n, 
                      float* const* db, float* part, size_t part_floats, hipStream_t s,
                      bool x_bf16 = false, bool dy_bf16 = false);   // nseg layers sharing x, dY side by side; *_bf16: stored as bf16 rows (wide kernel only)
 bool launch32_dw(const float* dy, int ldy, const float* x, int ldx, long n, int m, int k, float* dw, float* part,
-                 size_t part_floats, hipStream_t s, float* db = nullptr, bool x_bf16 = false);   // x_bf16: x is bf16 rows (wide kernel only)
+                 size_t part_floats, hipStream_t s, float* db = nullptr, bool x_bf16 = false,
+                 bool dy_bf16 = false);   // x_bf16 / dy_bf16: x / dy are bf16 rows (wide kernel only)
 void launch32_colsum(const float* a, int lda, const float* b, int ldb, const float* roww, int mode, long nrows, int ncols,
                      long tokens_per_group, float eps, float* out, long ldo, float* part, size_t part_floats, hipStream_t s);
 void launch32_ln_bwd(const float* x, const float* dy, long nrows, const ModMap& mm, int scale_chunk, int affine, float eps,
@@ -292,7 +293,8 @@ bool launch32_skinny_wt(const float* x, int ldx, const float* W, int ldw, int nb
 bool launch32_ln_bwd_sums(const float* x, const float* dy, long nrows, const ModMap& mm, int scale_chunk, float eps, float* dx,
                           int accumulate, long tokens_per_group, float* out, long ldo, float* part, size_t part_floats, hipStream_t s);
 bool launch32_gate_bwd_sums(const float* dh, const float* u, long nrows, const ModMap& mm, int gate_chunk, float* du,
-                            long tokens_per_group, float* out, long ldo, float* part, size_t part_floats, hipStream_t s);
+                            long tokens_per_group, float* out, long ldo, float* part, size_t part_floats, hipStream_t s,
+                            bool du_bf16 = false);   // du_bf16: du is written as bf16 rows
 void launch32_transpose(const float* src, int rows, int cols, float* dst, hipStream_t s, int ldd = 0);   // dst[c][r] (ld ldd, default rows) = src[r][c]
 bool launch16_linear_seg3(const float* a, int lda, const float* const* w, int ldw, const float* const* bias, const float* scale,
                           long n, int mseg, int k, float* c, int ldc, int col0, hipStream_t s, const void* wpack = nullptr,
