@@ -1971,7 +1971,7 @@ def test_training_round6_options_agree():
             inp["aatype"].to(dev))
     res = {}
     for name, opts in (("default", {}), ("gate_now", {"train_defer_gate": 0}), ("y_fp32", {"train_y_bf16": 0}),
-                       ("dqkv_fp32", {"train_dqkv_bf16": 0}), ("chunked", {"train_attn_form": 0})):
+                       ("dqkv_fp32", {"train_dqkv_bf16": 0}), ("du_fp32", {"train_du_bf16": 0}), ("chunked", {"train_attn_form": 0})):
         tm = TrainableModel(cfg, dev).load_state_dict(sd)
         tm.model.set_option("train_precision", 16)
         for k, v in opts.items():
@@ -1989,14 +1989,16 @@ def test_training_round6_options_agree():
             assert torch.equal(g0[k], g1[k]), (other, k)
     # `train_dqkv_bf16` (the q | k | v gradients stored as bf16 rows): the dX product and the weight gradient round them to bf16 anyway
     # -- bit-identical -- but the q / k / v BIAS gradients are column sums of the stored values: rounded then, to 5e-3
-    l3, g3 = res["dqkv_fp32"]
-    assert l0 == l3, (l0, l3)
-    for k in g0:
-        if torch.equal(g0[k], g3[k]):
-            continue
-        assert k.endswith(("q_proj.bias", "k_proj.bias", "v_proj.bias")), k
-        e = float((g0[k].double() - g3[k].double()).norm() / (g3[k].double().norm() + 1e-300))
-        assert e < 5e-3, (k, e)
+    # `train_du_bf16` (the gated gradients du = gate * dh) likewise: only the out-projection / fc2 bias gradients may differ
+    for other, biases in (("dqkv_fp32", ("q_proj.bias", "k_proj.bias", "v_proj.bias")), ("du_fp32", ("out_proj.bias", "fc2.bias"))):
+        l3, g3 = res[other]
+        assert l0 == l3, (other, l0, l3)
+        for k in g0:
+            if torch.equal(g0[k], g3[k]):
+                continue
+            assert k.endswith(biases), (other, k)
+            e = float((g0[k].double() - g3[k].double()).norm() / (g3[k].double().norm() + 1e-300))
+            assert e < 5e-3, (other, k, e)
     l2, g2 = res["chunked"]
     assert abs(l0 - l2) <= 2e-3 * abs(l2), (l0, l2)
     gmax = max(float(v.norm()) for v in g2.values())
