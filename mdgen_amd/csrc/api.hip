@@ -170,6 +170,7 @@ struct mdgen_ctx {
     int opt_train_y_bf16 = 1;       // training step, bf16 operands: the trunk's taped LayerNorm outputs are stored as bf16 rows (GEMM operands only)
     int opt_train_dqkv_bf16 = 1;    // training step, bf16 operands: the sequence-resident attention backward writes dq | dk | dv as bf16 rows
     int opt_train_du_bf16 = 1;      // training step, bf16 operands: the gated gradient du = gate * dh of a trunk sub-layer is stored as bf16 rows
+    int opt_train_dhid_bf16 = 1;    // training step, bf16 operands: d pre = d hid * gelu'(pre) of a trunk MLP is stored as bf16 rows
     int opt_train_streams = 2;      // training step: 2 = weight / bias gradients of the linear layers on a second stream (train.inc)
     hipStream_t train_side = nullptr;   // that stream (created on first use, default priority)
     // Turned weights of the small launches' dX products (train.inc `turned`): the requests of one call in order, their images in
@@ -755,6 +756,9 @@ extern "C" int32_t mdgen_ctx_set_option(mdgen_ctx* c, const char* name, int32_t 
     } else if (n == "train_du_bf16") {
         if (value != 0 && value != 1) return fail(-2, "train_du_bf16 must be 0 or 1");
         c->opt_train_du_bf16 = value;
+    } else if (n == "train_dhid_bf16") {
+        if (value != 0 && value != 1) return fail(-2, "train_dhid_bf16 must be 0 or 1");
+        c->opt_train_dhid_bf16 = value;
     } else if (n == "train_streams") {
         if (value != 1 && value != 2) return fail(-2, "train_streams must be 1 (one stream) or 2 (weight gradients on a second stream)");
         c->opt_train_streams = value;

@@ -657,7 +657,11 @@ void launch32_linear(const float* a, int lda, const float* w, int ldw, const flo
                      float* c, int ldc, int col0, const ModMap& mm, int gate_chunk, int gated, float scalar, hipStream_t s,
                      int wtrans, float* c2, const void* wpack, int flags) {
     LinearParams p{a, lda, w, ldw, bias, n, m, k, mode, wtrans, c, ldc, col0, mm, gate_chunk, gated, scalar, c2, 0, {}, {}, {},
-                   static_cast<const unsigned char*>(wpack), g_k32_bf16_operands, flags & 1, (flags >> 1) & 1};
+                   static_cast<const unsigned char*>(wpack), g_k32_bf16_operands, flags & 1, (flags >> 1) & 1, (flags >> 2) & 1};
+    if ((flags & 4) && !(g_k32_bf16_operands && mode == 7)) {   // (fast_gelu turns mode 7 into 17, the only one that stores bf16)
+        g_k32_launch_error = "launch32_linear: a bf16 result is the GELU-derivative epilogue's in the bf16-operand mode only";
+        return;
+    }
     if ((flags & 3) && !(g_k32_bf16_operands && (!(flags & 1) || wpack))) {
         g_k32_launch_error = "launch32_linear: bf16 operand storage outside the streamed bf16-operand kernel";
         return;

@@ -35,6 +35,9 @@ struct LinearParams {
     // storage of two GEMM-only tensors in the bf16-operand mode: a_bf16: the token operand is bf16 rows (k16_linear_wdma<true>
     // only); c2_bf16: the GELU output of mode 6 is written as bf16 (same element indexing as c)
     int a_bf16, c2_bf16;
+    // (round 6) the result of modes 7 / 17 (d pre = d hid * gelu'(pre)) is written as bf16 rows (same element indexing as c): it is
+    // only ever the token operand of fc1's dX product and dY of fc1's weight gradient
+    int c_bf16;
 };
 
 // Phi(x) and x of gelu_erf's fit (see common.h): Phi = 1 / (1 + exp2(x P(x^2)))
@@ -110,7 +113,9 @@ __device__ __forceinline__ void linear_epilogue_mode(const LinearParams& p, cons
                 } else if (MODE == 17) {
                     const float x = old[r];
                     const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
-                    *dst = v * (phi_cdf_fast(x) + x * pdf);
+                    const float dpre = v * (phi_cdf_fast(x) + x * pdf);
+                    if (p.c_bf16) reinterpret_cast<uint16_t*>(p.c)[row * p.ldc + p.col0 + col] = (uint16_t)pack_bf16(dpre, 0.f);
+                    else *dst = dpre;
                 } else {
                     *dst = v;
                     p.c2[row * p.ldc + p.col0 + col] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
