@@ -1971,7 +1971,8 @@ def test_training_round6_options_agree():
             inp["aatype"].to(dev))
     res = {}
     for name, opts in (("default", {}), ("gate_now", {"train_defer_gate": 0}), ("y_fp32", {"train_y_bf16": 0}),
-                       ("dqkv_fp32", {"train_dqkv_bf16": 0}), ("du_fp32", {"train_du_bf16": 0}), ("chunked", {"train_attn_form": 0})):
+                       ("dqkv_fp32", {"train_dqkv_bf16": 0}), ("du_fp32", {"train_du_bf16": 0}), ("dhid_fp32", {"train_dhid_bf16": 0}),
+                       ("chunked", {"train_attn_form": 0})):
         tm = TrainableModel(cfg, dev).load_state_dict(sd)
         tm.model.set_option("train_precision", 16)
         for k, v in opts.items():
@@ -1990,7 +1991,9 @@ def test_training_round6_options_agree():
     # `train_dqkv_bf16` (the q | k | v gradients stored as bf16 rows): the dX product and the weight gradient round them to bf16 anyway
     # -- bit-identical -- but the q / k / v BIAS gradients are column sums of the stored values: rounded then, to 5e-3
     # `train_du_bf16` (the gated gradients du = gate * dh) likewise: only the out-projection / fc2 bias gradients may differ
-    for other, biases in (("dqkv_fp32", ("q_proj.bias", "k_proj.bias", "v_proj.bias")), ("du_fp32", ("out_proj.bias", "fc2.bias"))):
+    # ... and `train_dhid_bf16` (d pre = d hid * gelu'(pre) of the MLPs): only the fc1 bias gradients
+    for other, biases in (("dqkv_fp32", ("q_proj.bias", "k_proj.bias", "v_proj.bias")), ("du_fp32", ("out_proj.bias", "fc2.bias")),
+                          ("dhid_fp32", ("fc1.bias",))):
         l3, g3 = res[other]
         assert l0 == l3, (other, l0, l3)
         for k in g0:
