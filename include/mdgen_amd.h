@@ -199,6 +199,12 @@ int32_t mdgen_ctx_finalize(mdgen_ctx* ctx, void* stream);
  *                      computed on the second stream at the START of the call, beside the forward pass, from the list of requests the
  *                      previous call recorded; a call that asks for something else falls back to a launch in place and records
  *                      anew.  Same values; 25.6 -> 25.2 ms per step.  (Images live in a context-owned buffer, ~30 MB at cfg-5.)
+ *   "train_y_bf16", "train_dqkv_bf16", "train_du_bf16", "train_dhid_bf16"   1 (default) / 0, each: with train_precision 16, a
+ *                      tensor of the training step that is only ever a GEMM operand is stored as bf16 rows by its producer (launches of
+ *                      >= 4096 rows: the trunk) -- the trunk's taped LayerNorm + modulate outputs; dq | dk | dv of the
+ *                      sequence-resident attention backward; du = gate * dh; d pre = d hid * gelu'(pre).  The kernels that read them
+ *                      round them to bf16 anyway: weight and activation gradients are bit-identical, the bias gradients of the
+ *                      layers whose dY is stored rounded differ by ~1e-3 (column sums of the stored values).  25.2 -> 24.2 ms per step.
  *   "train_streams"    2 (default) / 1: mdgen_train_forward_backward launches the weight / bias gradients (nothing reads them
  *                      before the optimiser) on a second stream of the context, beside the backward pass's critical path on the
  *                      caller's stream; it joins the caller's stream before the call returns, and milestone events are recorded
